@@ -1,0 +1,104 @@
+/*
+ * sharp_hip.h -- C ABI of libsharp_hip.so: the MI355X (gfx950) implementation of
+ * SHARP's ensemble random-projection + meta-clustering hot path.
+ *
+ * The reference (shibiaowan/SHARP) is pure R with no FFI (NAMESPACE has no
+ * useDynLib), so the drop-in boundary is the set of exported R functions
+ * (SURVEY.md 8b).  Each entry point below replaces the body of one of them and
+ * cites it; INTEGRATION.md shows the R glue (.C / .Call) and the ctypes binding.
+ *
+ * Conventions
+ *   - plain C, pointers + sizes only; no R, torch or C++ types in any signature.
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from sharp_last_error() (reference convention: stop("..."),
+ *     R/SHARP.R:52-54,171-176; R/get_opt_hclust.R:91-99).  Nothing aborts.
+ *   - the caller owns every host buffer; the library owns device memory and the
+ *     state behind integer handles.
+ *   - matrices: X is genes x cells, COLUMN-major (a cell is a contiguous m-vector),
+ *     exactly R's layout.  E / viE are cells x p ROW-major (= R's p x n column-major
+ *     projmat before the transpose at R/SHARP.R:363,583).  Label matrices (enrp, v)
+ *     are column-major like R.
+ *   - cluster ids are 1-based like R.  "NULL" integer arguments are passed as 0.
+ *   - hmethod codes follow stats::hclust's method table:
+ *       1 ward.D  2 single  3 complete  4 average  5 mcquitty  6 median  7 centroid  8 ward.D2
+ *   - functions ending in _dev take DEVICE pointers (HBM-resident data, e.g. from
+ *     hipMalloc or a torch tensor's data_ptr()) and run on the library's stream.
+ *   - single-threaded callers (R's main thread); the library never calls back.
+ *   - the `sharp_C_*` variants use R's .C() convention (every argument a pointer,
+ *     void return, int* status out) so glue needs no R headers.
+ */
+#ifndef SHARP_HIP_H
+#define SHARP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHARP_OK 0
+#define SHARP_ERR 1          /* generic failure, see sharp_last_error()           */
+#define SHARP_ERR_ARG 2      /* argument rejected (what R's stop() checks reject) */
+#define SHARP_ERR_NO_DEVICE 3
+#define SHARP_WARN_RANGE 16  /* model selection ran off the candidate range (reference quirk 8) */
+#define SHARP_WARN_NA_VOTE 32/* wMetaC single-cluster fallback met a cell with one vote value (quirk 11) */
+
+/* ---- runtime -------------------------------------------------------------- */
+const char *sharp_last_error(void);
+int sharp_version(void);
+int sharp_device_count(int *count);
+/* Select the GPU and create the library's stream/workspace.  Idempotent per device. */
+int sharp_init(int device);
+int sharp_shutdown(void);
+int sharp_synchronize(void);
+/* Per-kernel HIP-event timing on the library's stream (used by bench.py's roofline). */
+int sharp_profile_enable(int on);
+int sharp_profile_reset(void);
+/* name: e.g. "rp_scatter"; returns total milliseconds and launch count since reset. */
+int sharp_profile_get(const char *name, double *total_ms, long long *launches);
+/* writes a '\n'-separated "name total_ms launches" table into buf (NUL-terminated). */
+int sharp_profile_dump(char *buf, int buflen);
+
+/* ---- a1: ranM / ranM2 / projector half of RPmat ---------------------------- */
+/* R/ranM.R:11-33, R/ranM2.R:44-68, R/RPmat.R:82-99.
+ * Builds K sparse ternary projectors R_k (m x p) with R's own RNG stream:
+ * set.seed(seeds[k]); sample(c(sqrt(s),0,-sqrt(s)), m*p, TRUE, c(1/2s,1-1/s,1/2s));
+ * byrow fill.  seeds[k] must be integer-valued (50 + rN.seed + k at the call sites
+ * R/SHARP.R:360,545, R/SHARP_unlimited.R:101); a non-integer seed (the reference's
+ * 0.5 "unseeded" sentinel) draws a seed from the OS entropy source.
+ * The projectors are kept on the device as gene-major packed row lists. */
+int sharp_projector_create(int m, int p, int K, const double *seeds, int *handle);
+int sharp_projector_destroy(int handle);
+int sharp_projector_info(int handle, int *m, int *p, int *K, long long *nnz_total);
+/* ranM() drop-in: the k-th (0-based) projector as COO triplets sorted row-major
+ * (gene, then column): gene[i], col[i] 0-based, sign[i] = +1/-1; value = sign*sqrt(sqrt(m)).
+ * Call with gene == NULL to get *nnz only. */
+int sharp_projector_triplets(int handle, int k, int *gene, int *col, signed char *sign, long long *nnz);
+
+/* ---- a2: RP matmul  E1 = t( 1/sqrt(p) * t(R_k) %*% log2(X+1) ) -------------- */
+/* R/RPmat.R:100, R/SHARP.R:343-345,363,569-571,579-585.
+ * Host variant: X double, m x n column-major with leading dimension ld (>= m).
+ * E: n x (K*p) row-major, component k*p + c = projector k, column c.
+ * X is staged to the device as fp32 (exact for counts < 2^24; otherwise rounded to
+ * fp32 -- see DESIGN.md "Numerics").  log_flag: 1 = log2(x+1) (flag TRUE), 0 = raw. */
+int sharp_project(int proj, const double *X, int m, int n, long long ld, int log_flag, double *E);
+/* Device variant: dX fp32 (m x n, leading dimension ld elements, 16-byte aligned columns
+ * when ld % 4 == 0), dE fp64 n x ldE row-major (ldE >= K*p). */
+int sharp_project_dev(int proj, const float *dX, int m, int n, long long ld, int log_flag,
+                      double *dE, long long ldE);
+
+/* ---- synthetic inputs (bench / tests; not part of the reference) ------------ */
+/* Counter-based generator, value = f(seed, gene, cell): bit-identical to
+ * oracle_synth_value().  Fills dX (fp32, m x ncell column-major, leading dim ld). */
+int sharp_synth_fill_dev(unsigned seed, int m, long long cell0, int ncell, int G, int nmark,
+                         float *dX, long long ld);
+int sharp_synth_labels(unsigned seed, long long cell0, int ncell, int G, int *labels);
+
+/* ---- device memory helpers for non-torch hosts (R glue, tests) -------------- */
+int sharp_dev_alloc(long long bytes, void **dptr);
+int sharp_dev_free(void *dptr);
+int sharp_dev_upload(void *dptr, const void *host, long long bytes);
+int sharp_dev_download(void *host, const void *dptr, long long bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHARP_HIP_H */

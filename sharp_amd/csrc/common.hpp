@@ -1,0 +1,119 @@
+// common.hpp -- runtime plumbing shared by every translation unit of libsharp_hip.so:
+// error reporting across the C ABI, the device context (one HIP stream per process),
+// RAII device buffers and per-kernel HIP-event timing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/sharp_hip.h"
+
+namespace sharp {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+void set_error(const std::string &msg);
+
+#define SHARP_HIP_CHECK(expr)                                                                   \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            throw sharp::Error(SHARP_ERR, std::string(#expr) + ": " + hipGetErrorString(_e) +   \
+                                              " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+
+#define SHARP_REQUIRE(cond, msg)                                  \
+    do {                                                          \
+        if (!(cond)) throw sharp::Error(SHARP_ERR_ARG, (msg));    \
+    } while (0)
+
+#define SHARP_API_BEGIN try {
+#define SHARP_API_END                                        \
+    }                                                        \
+    catch (const sharp::Error &e) {                          \
+        sharp::set_error(e.what());                          \
+        return e.code;                                       \
+    }                                                        \
+    catch (const std::exception &e) {                        \
+        sharp::set_error(e.what());                          \
+        return SHARP_ERR;                                    \
+    }                                                        \
+    return SHARP_OK;
+
+struct KernelStat {
+    double ms = 0;
+    long long launches = 0;
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int num_cu = 256;
+    size_t lds_per_block = 65536;
+    bool profiling = false;
+    std::map<std::string, KernelStat> stats;
+    // pending (start, stop, name) event triples, resolved lazily at sync points
+    struct Pending { hipEvent_t a, b; std::string name; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t get_event();
+    void resolve_pending();
+};
+Ctx &ctx();          // throws SHARP_ERR_NO_DEVICE if sharp_init() has not succeeded
+Ctx &ctx_unchecked();
+
+// Times everything enqueued on the library stream during its lifetime (if profiling is on).
+struct KernelTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    const char *name;
+    explicit KernelTimer(const char *n);
+    ~KernelTimer();
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) SHARP_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+    }
+    void ensure(size_t count) { if (count > n) alloc(count); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void upload(const T *h, size_t count) {
+        SHARP_HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
+    }
+    void download(T *h, size_t count) const {
+        SHARP_HIP_CHECK(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
+        SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    }
+    void zero() { if (n) SHARP_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), ctx().stream)); }
+};
+
+inline void stream_sync() { SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream)); }
+inline void launch_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw Error(SHARP_ERR, std::string("launch of ") + what + " failed: " + hipGetErrorString(e));
+}
+
+}  // namespace sharp

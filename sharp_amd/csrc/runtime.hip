@@ -1,0 +1,187 @@
+// runtime.hip -- context, error string, profiling and device-memory helpers of the C ABI.
+#include <cstring>
+#include <mutex>
+#include <sstream>
+
+#include "common.hpp"
+
+namespace sharp {
+
+static thread_local std::string g_last_error;
+static Ctx g_ctx;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+Ctx &ctx_unchecked() { return g_ctx; }
+Ctx &ctx() {
+    if (!g_ctx.ready)
+        throw Error(SHARP_ERR_NO_DEVICE,
+                    "libsharp_hip: no device context -- call sharp_init(device) first (a MI355X / gfx950 GPU is required; "
+                    "there is no CPU fallback)");
+    return g_ctx;
+}
+
+hipEvent_t Ctx::get_event() {
+    if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    SHARP_HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+void Ctx::resolve_pending() {
+    if (pending.empty()) return;
+    SHARP_HIP_CHECK(hipStreamSynchronize(stream));
+    for (auto &p : pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto &s = stats[p.name];
+            s.ms += ms;
+            s.launches += 1;
+        }
+        event_pool.push_back(p.a);
+        event_pool.push_back(p.b);
+    }
+    pending.clear();
+}
+
+KernelTimer::KernelTimer(const char *n) : name(n) {
+    Ctx &c = ctx();
+    if (!c.profiling) return;
+    a = c.get_event();
+    b = c.get_event();
+    (void)hipEventRecord(a, c.stream);
+}
+KernelTimer::~KernelTimer() {
+    if (!a) return;
+    Ctx &c = ctx_unchecked();
+    (void)hipEventRecord(b, c.stream);
+    c.pending.push_back({a, b, name});
+    if (c.pending.size() > 4096) {
+        try { c.resolve_pending(); } catch (...) {}
+    }
+}
+
+}  // namespace sharp
+
+using namespace sharp;
+
+extern "C" {
+
+const char *sharp_last_error(void) { return g_last_error.c_str(); }
+int sharp_version(void) { return 100; }
+
+int sharp_device_count(int *count) {
+    SHARP_API_BEGIN
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    *count = n;
+    SHARP_API_END
+}
+
+int sharp_init(int device) {
+    SHARP_API_BEGIN
+    Ctx &c = ctx_unchecked();
+    if (c.ready && c.device == device) return SHARP_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        throw Error(SHARP_ERR_NO_DEVICE, "libsharp_hip: no HIP device visible (MI355X / gfx950 required; no CPU fallback)");
+    SHARP_REQUIRE(device >= 0 && device < n, "sharp_init: device index out of range");
+    SHARP_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SHARP_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        throw Error(SHARP_ERR_NO_DEVICE, std::string("libsharp_hip is built for gfx950 only; device reports ") + prop.gcnArchName);
+    if (c.ready && c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
+    SHARP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.device = device;
+    c.num_cu = prop.multiProcessorCount;
+    c.lds_per_block = prop.sharedMemPerBlock;
+    c.ready = true;
+    SHARP_API_END
+}
+
+int sharp_shutdown(void) {
+    SHARP_API_BEGIN
+    Ctx &c = ctx_unchecked();
+    if (c.ready) {
+        (void)hipStreamSynchronize(c.stream);
+        for (auto &p : c.pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        c.pending.clear();
+        for (auto e : c.event_pool) (void)hipEventDestroy(e);
+        c.event_pool.clear();
+        (void)hipStreamDestroy(c.stream);
+        c.stream = nullptr;
+        c.ready = false;
+    }
+    SHARP_API_END
+}
+
+int sharp_synchronize(void) {
+    SHARP_API_BEGIN
+    stream_sync();
+    SHARP_API_END
+}
+
+int sharp_profile_enable(int on) {
+    SHARP_API_BEGIN
+    ctx().profiling = on != 0;
+    SHARP_API_END
+}
+int sharp_profile_reset(void) {
+    SHARP_API_BEGIN
+    Ctx &c = ctx();
+    c.resolve_pending();
+    c.stats.clear();
+    SHARP_API_END
+}
+int sharp_profile_get(const char *name, double *total_ms, long long *launches) {
+    SHARP_API_BEGIN
+    Ctx &c = ctx();
+    c.resolve_pending();
+    auto it = c.stats.find(name);
+    *total_ms = it == c.stats.end() ? 0.0 : it->second.ms;
+    *launches = it == c.stats.end() ? 0 : it->second.launches;
+    SHARP_API_END
+}
+int sharp_profile_dump(char *buf, int buflen) {
+    SHARP_API_BEGIN
+    Ctx &c = ctx();
+    c.resolve_pending();
+    std::ostringstream os;
+    for (auto &kv : c.stats) os << kv.first << ' ' << kv.second.ms << ' ' << kv.second.launches << '\n';
+    std::string s = os.str();
+    SHARP_REQUIRE(buflen > 0, "sharp_profile_dump: empty buffer");
+    size_t n = s.size() < (size_t)buflen - 1 ? s.size() : (size_t)buflen - 1;
+    memcpy(buf, s.data(), n);
+    buf[n] = 0;
+    SHARP_API_END
+}
+
+int sharp_dev_alloc(long long bytes, void **dptr) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(bytes >= 0, "sharp_dev_alloc: negative size");
+    SHARP_HIP_CHECK(hipMalloc(dptr, (size_t)bytes));
+    SHARP_API_END
+}
+int sharp_dev_free(void *dptr) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    SHARP_HIP_CHECK(hipFree(dptr));
+    SHARP_API_END
+}
+int sharp_dev_upload(void *dptr, const void *host, long long bytes) {
+    SHARP_API_BEGIN
+    SHARP_HIP_CHECK(hipMemcpyAsync(dptr, host, (size_t)bytes, hipMemcpyHostToDevice, ctx().stream));
+    stream_sync();
+    SHARP_API_END
+}
+int sharp_dev_download(void *host, const void *dptr, long long bytes) {
+    SHARP_API_BEGIN
+    SHARP_HIP_CHECK(hipMemcpyAsync(host, dptr, (size_t)bytes, hipMemcpyDeviceToHost, ctx().stream));
+    stream_sync();
+    SHARP_API_END
+}
+
+}  // extern "C"

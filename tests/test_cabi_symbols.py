@@ -1,0 +1,74 @@
+"""CPU-side check of the drop-in boundary: libsharp_hip.so loads without a GPU and exports
+every symbol include/sharp_hip.h declares; without a device every compute entry fails loudly."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "sharp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sharp_[A-Za-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def so():
+    import __graft_entry__ as g
+
+    path = os.path.join(ROOT, "sharp_amd", "libsharp_hip.so")
+    if not os.path.exists(path):
+        g.build()
+    return C.CDLL(path)
+
+
+def test_header_declares_the_path():
+    names = _declared()
+    for must in ["sharp_projector_create", "sharp_project", "sharp_project_dev", "sharp_last_error", "sharp_init"]:
+        assert must in names
+
+
+def test_every_declared_symbol_is_exported(so):
+    missing = [n for n in _declared() if not hasattr(so, n)]
+    assert not missing, f"declared in include/sharp_hip.h but not exported: {missing}"
+
+
+def test_no_device_fails_loudly(so):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    so.sharp_last_error.restype = C.c_char_p
+    n = C.c_int(-1)
+    assert so.sharp_device_count(C.byref(n)) == 0 and n.value == 0
+    assert so.sharp_init(0) != 0
+    assert b"no HIP device" in so.sharp_last_error()
+    h = C.c_int()
+    seeds = (C.c_double * 1)(2154.0)
+    assert so.sharp_projector_create(100, 10, 1, seeds, C.byref(h)) != 0  # no context -> error, not a CPU path
+    assert b"no device context" in so.sharp_last_error()
+
+
+def test_python_package_has_no_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import sharp_amd
+
+    with pytest.raises(sharp_amd.SharpError):
+        sharp_amd.ranM2(100, 10, 2154)
+
+
+def test_product_does_not_import_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "sharp_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"(import\s+oracle|from\s+oracle|liboracle|sharp_oracle\.c|oracle/)", txt):
+                    bad.append(f)
+    assert not bad, f"product files referencing the oracle: {bad}"

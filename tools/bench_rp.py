@@ -1,0 +1,47 @@
+"""Scratch micro-benchmark of the RP scatter kernel alone (cfg2/cfg3 shapes)."""
+import ctypes as C
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import sharp_amd
+
+sharp_amd.init(0)
+lib = sharp_amd.lib()
+SEED = 20261003
+CFGS = [(20000, 50000, 15, 391), (20000, 50000, 5, 474), (27000, 40000, 5, 508)]
+if len(sys.argv) > 1:
+    CFGS = [CFGS[int(a)] for a in sys.argv[1:]]
+for (m, n, K, p) in CFGS:
+    t0 = time.time()
+    pr = sharp_amd.Projector(m, p, [50 + 2103 + k for k in range(1, K + 1)])
+    tproj = time.time() - t0
+    dX = torch.empty((n, m), dtype=torch.float32, device="cuda")
+    lib.sharp_synth_fill_dev(C.c_uint(SEED), m, C.c_longlong(0), n, 12, 1000, C.c_void_p(dX.data_ptr()), C.c_longlong(m))
+    lib.sharp_synchronize()
+    dE = torch.zeros((n, K * p), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    lib.sharp_profile_enable(1)
+    for it in range(3):
+        lib.sharp_project_dev(pr.handle, C.c_void_p(dX.data_ptr()), m, n, C.c_longlong(m), 1, C.c_void_p(dE.data_ptr()),
+                              C.c_longlong(K * p))
+    lib.sharp_synchronize()
+    lib.sharp_profile_reset()
+    reps = 10
+    for it in range(reps):
+        lib.sharp_project_dev(pr.handle, C.c_void_p(dX.data_ptr()), m, n, C.c_longlong(m), 1, C.c_void_p(dE.data_ptr()),
+                              C.c_longlong(K * p))
+    lib.sharp_synchronize()
+    ms = C.c_double()
+    cnt = C.c_longlong()
+    lib.sharp_profile_get(b"rp_scatter", C.byref(ms), C.byref(cnt))
+    t = ms.value / cnt.value * 1e-3
+    rd = n * m * 4
+    wr = n * K * p * 8
+    nzfrac = float((dX[:2000] != 0).float().mean())
+    print(f"m={m} n={n} K={K} p={p} nnz={pr.nnz()} proj_build={tproj:.2f}s  rp={t*1e3:.3f} ms  read {rd/t/1e12:.2f} TB/s "
+          f"({rd/t/8e12*100:.1f}% of 8TB/s)  read+write {(rd+wr)/t/1e12:.2f} TB/s  nz={nzfrac:.3f}", flush=True)
+    del dX, dE
