@@ -85,6 +85,28 @@ int sharp_project(int proj, const double *X, int m, int n, long long ld, int log
 int sharp_project_dev(int proj, const float *dX, int m, int n, long long ld, int log_flag,
                       double *dE, long long ldE);
 
+/* ---- a3-a5: get_opt_hclust --------------------------------------------------- */
+/* R/get_opt_hclust.R:33-244.  mat: n x p ROW-major feature rows, or an n x n symmetric similarity
+ * (detected like isSymmetric(): square and all.equal(mat, t(mat), 100*eps)); then d = 1 - mat.
+ * Feature rows: t(scale(t(mat))), d = 1 - cor(t(mat)) (fp64 MFMA), hclust(d, method), cutree for
+ * k = minN..min(maxN, n-1), median silhouette, get_CH(.., "1-corr"), and the reference's choice rule
+ * (middle arg-max of msil; CH when max(msil) <= sil_thre; height gap when CH picks the first k).
+ * N_cluster: 0 = NULL, else a single cutree(k = N_cluster).
+ * Outputs (caller-allocated; any of v, msil, CHind, maxsil, height, optN, nk, branch may be NULL):
+ *   f[n] chosen labels (1-based, numbered by first appearance); v[n * nk] column-major;
+ *   msil[nk], CHind[nk]; height[n-1]; branch: 0 silhouette, 1 CH, 2 height gap.
+ * Returns SHARP_OK, SHARP_WARN_RANGE (choice clamped into the candidate range, reference quirk 8:
+ * R would raise "subscript out of bounds") or an error code. */
+int sharp_get_opt_hclust(const double *mat, int n, int p, int hmethod, int N_cluster, int minN, int maxN,
+                         double sil_thre, double height_Ntimes, int *f, int *v, double *msil, double *CHind,
+                         double *maxsil, double *height, int *optN, int *nk, int *branch);
+
+/* ---- a6: getrowColor ----------------------------------------------------------- */
+/* R/getrowColor.R:17-121.  rowColor[i] in 1..40 is the index into the reference's colorL table
+ * (cluster j > 40 wraps and collides exactly like :59-68); height_Ntimes <= 0 -> 1 (:28-30). */
+int sharp_getrowColor(const double *E, int n, int p, int hmethod, int indN_cluster, int minN, int maxN,
+                      double sil_thre, double height_Ntimes, int *rowColor, double *maxsil);
+
 /* ---- synthetic inputs (bench / tests; not part of the reference) ------------ */
 /* Counter-based generator, value = f(seed, gene, cell): bit-identical to
  * oracle_synth_value().  Fills dX (fp32, m x ncell column-major, leading dim ld). */

@@ -1,0 +1,758 @@
+// hclust.hip -- batched get_opt_hclust on the GPU (R/get_opt_hclust.R:33-244):
+//   a3  distance build      row_prep + fp64-MFMA correlation GEMM (linalg.hip)       :66-74
+//   a4  stats::hclust       one 1024-thread workgroup per task, NN-list algorithm      :76-83
+//   a5  cutree k=min..max, median silhouette, get_CH("1-corr"), model selection        :90-231
+// Third-party algorithms restated (not vendored by the reference): stats::hclust's Fortran NN-list
+// agglomeration with Lance-Williams updates (fp64, same operation order, lowest-index tie-breaks),
+// cutree's first-appearance numbering, cluster::silhouette, clues::get_CH per SURVEY.md App. A.4-A.6.
+#include "hclust.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "linalg.hpp"
+
+namespace sharp {
+
+struct HcMeta {
+    int n, p, nld, kmin, kmax, nk, kpad, method;
+    int symmetric, pad0;
+    long long oD, oD0;        // working distance matrix; pristine copy (symmetric tasks only)
+    long long oCr, oCt, oNrm;
+    long long oM;             // ia / ib / height: n entries per task
+    long long oLab;           // nk * n ints
+    long long oH, oT, oG;     // n * kpad doubles each
+    long long oCSt, oQ;       // p * kpad, kpad * kpad
+    long long oOut;           // msil[nk] then CH[nk]
+};
+
+constexpr int HC_THREADS = 1024;
+constexpr double HC_INF = 1.0e300;
+
+struct MinPair { double v; int i; };
+__device__ __forceinline__ MinPair mp_better(MinPair a, MinPair b) {
+    return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ MinPair mp_wave(MinPair x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        MinPair y;
+        y.v = __shfl_xor(x.v, o);
+        y.i = __shfl_xor(x.i, o);
+        x = mp_better(x, y);
+    }
+    return x;
+}
+// block-wide min; pv/pi: LDS scratch [32]; every thread returns the result.  The caller must have a
+// barrier between two uses of the same scratch (there always is one in the merge loop).
+__device__ __forceinline__ MinPair mp_block(MinPair x, double *pv, int *pi) {
+    x = mp_wave(x);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { pv[w] = x.v; pi[w] = x.i; }
+    __syncthreads();
+    MinPair r; r.v = pv[0]; r.i = pi[0];
+    const int nw = blockDim.x >> 6;
+    for (int q = 1; q < nw; ++q) { MinPair y; y.v = pv[q]; y.i = pi[q]; r = mp_better(r, y); }
+    return r;
+}
+
+__device__ __forceinline__ double lance_williams(int method, double d1, double d2, double d12, double mi, double mj, double mk) {
+    switch (method) {
+        case 1: case 8: {   // ward.D / ward.D2 (squared input)
+            double dn = (mi + mk) * d1 + (mj + mk) * d2 - mk * d12;
+            return dn / (mi + mj + mk);
+        }
+        case 2: return d1 < d2 ? d1 : d2;
+        case 3: return d1 > d2 ? d1 : d2;
+        case 4: return (mi * d1 + mj * d2) / (mi + mj);
+        case 5: return (d1 + d2) / 2;
+        case 6: return ((d1 + d2) - d12 / 2) / 2;
+        default: return (mi * d1 + mj * d2 - mi * mj * d12 / (mi + mj)) / (mi + mj);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a4: agglomeration.  State in LDS: disnn (nearest neighbour to the right), nn, membr, flag.
+// D is the full symmetric matrix in HBM (row reads coalesced; the mirrored column write is strided).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HC_THREADS) void hclust_kernel(const HcMeta *__restrict__ metas, double *__restrict__ Dall,
+                                                            int *__restrict__ ia_all, int *__restrict__ ib_all,
+                                                            double *__restrict__ h_all) {
+    const HcMeta M = metas[blockIdx.x];
+    const int n = M.n, nld = M.nld, method = M.method;
+    double *D = Dall + M.oD;
+    int *ia = ia_all + M.oM, *ib = ib_all + M.oM;
+    double *crit = h_all + M.oM;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int nal = (n + 1) & ~1;
+    double *disnn = reinterpret_cast<double *>(sm);
+    double *pv = disnn + nal;                 // [32]
+    int *nn = reinterpret_cast<int *>(pv + 32);
+    int *membr = nn + nal;
+    int *list = membr + nal;
+    int *pi = list + nal;                     // [32]
+    int *cnt = pi + 32;                       // [2]
+    unsigned char *flag = reinterpret_cast<unsigned char *>(cnt + 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = HC_THREADS / 64;
+
+    if (method == 8) {
+        for (long long q = tid; q < static_cast<long long>(n) * nld; q += HC_THREADS) {
+            const int r = static_cast<int>(q / nld), c = static_cast<int>(q % nld);
+            if (c < n) { const double d = D[static_cast<long long>(r) * nld + c]; D[static_cast<long long>(r) * nld + c] = d * d; }
+        }
+    }
+    for (int i = tid; i < n; i += HC_THREADS) { flag[i] = 1; membr[i] = 1; nn[i] = 0; disnn[i] = HC_INF; }
+    __syncthreads();
+    // initial NN list: nearest neighbour to the RIGHT of i, lowest j on ties
+    for (int i = wave; i < n - 1; i += nwave) {
+        const double *row = D + static_cast<long long>(i) * nld;
+        MinPair b; b.v = HC_INF; b.i = 0x7fffffff;
+        for (int j = i + 1 + lane; j < n; j += 64) { MinPair c; c.v = row[j]; c.i = j; if (c.v < b.v) b = c; }
+        b = mp_wave(b);
+        if (lane == 0) { nn[i] = b.i; disnn[i] = b.v; }
+    }
+    __syncthreads();
+
+    for (int step = 0; step < n - 1; ++step) {
+        // (1) least dissimilarity over the NN list (strict <, lowest index)
+        MinPair b; b.v = HC_INF; b.i = 0x7fffffff;
+        for (int i = tid; i < n - 1; i += HC_THREADS)
+            if (flag[i]) { MinPair c; c.v = disnn[i]; c.i = i; if (c.v < b.v) b = c; }
+        b = mp_block(b, pv, pi);
+        const int im = b.i < n ? b.i : 0;
+        const int jm = nn[im];
+        const int i2 = im < jm ? im : jm, j2 = im < jm ? jm : im;
+        const double d12 = D[static_cast<long long>(i2) * nld + j2];
+        const double mi = membr[i2], mj = membr[j2];
+        __syncthreads();                       // everyone has read nn/membr/pv before they change
+        if (tid == 0) {
+            ia[step] = i2 + 1; ib[step] = j2 + 1;
+            crit[step] = method == 8 ? sqrt(b.v) : b.v;
+            flag[j2] = 0;
+            *cnt = 0;
+        }
+        __syncthreads();
+        // (2) Lance-Williams update of row/column i2; new NN of i2 among k > i2
+        MinPair nb; nb.v = HC_INF; nb.i = 0x7fffffff;
+        const double *ri = D + static_cast<long long>(i2) * nld, *rj = D + static_cast<long long>(j2) * nld;
+        for (int k = tid; k < n; k += HC_THREADS) {
+            if (flag[k] && k != i2) {
+                const double dn = lance_williams(method, ri[k], rj[k], d12, mi, mj, static_cast<double>(membr[k]));
+                D[static_cast<long long>(i2) * nld + k] = dn;
+                D[static_cast<long long>(k) * nld + i2] = dn;
+                if (i2 < k) { if (dn < nb.v) { nb.v = dn; nb.i = k; } }
+                else if (dn < disnn[k]) { disnn[k] = dn; nn[k] = i2; }
+            }
+        }
+        nb = mp_block(nb, pv, pi);
+        __syncthreads();
+        if (tid == 0) {
+            membr[i2] = membr[i2] + membr[j2];
+            disnn[i2] = nb.v;
+            if (nb.i < n) nn[i2] = nb.i;
+        }
+        __syncthreads();
+        // (3) rows whose nearest neighbour was i2 or j2 look again to their right
+        for (int i = tid; i < n - 1; i += HC_THREADS)
+            if (flag[i] && (nn[i] == i2 || nn[i] == j2)) list[atomicAdd(cnt, 1)] = i;
+        __syncthreads();
+        const int nl = *cnt;
+        for (int q = wave; q < nl; q += nwave) {
+            const int i = list[q];
+            const double *row = D + static_cast<long long>(i) * nld;
+            MinPair c; c.v = HC_INF; c.i = 0x7fffffff;
+            for (int j = i + 1 + lane; j < n; j += 64)
+                if (flag[j]) { const double d = row[j]; if (d < c.v) { c.v = d; c.i = j; } }
+            c = mp_wave(c);
+            if (lane == 0) { disnn[i] = c.v; if (c.i < n) nn[i] = c.i; }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a5a: cutree for every level k = kmin..kmax (level index L = k - kmin), ids by first appearance.
+// j2 is absorbed by i2 < j2 at its merge step, so a cluster's representative is its smallest member
+// and "first appearance" order is the order of the representatives.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HC_THREADS) void cutree_kernel(const HcMeta *__restrict__ metas, const int *__restrict__ ia_all,
+                                                            const int *__restrict__ ib_all, int *__restrict__ lab_all) {
+    const HcMeta M = metas[blockIdx.x];
+    const int n = M.n;
+    const int *ia = ia_all + M.oM, *ib = ib_all + M.oM;
+    int *lab = lab_all + M.oLab;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    int *absorbed = reinterpret_cast<int *>(sm);   // merge step at which i stops being a representative
+    int *parent = absorbed + n;
+    int *rank = parent + n;
+    int *wsum = rank + n;                          // [HC_THREADS/64 + 1]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += HC_THREADS) { absorbed[i] = 0x7fffffff; parent[i] = i; }
+    __syncthreads();
+    for (int s = tid; s < n - 1; s += HC_THREADS) { absorbed[ib[s] - 1] = s; parent[ib[s] - 1] = ia[s] - 1; }
+    __syncthreads();
+    const int chunk = (n + HC_THREADS - 1) / HC_THREADS;
+    for (int L = 0; L < M.nk; ++L) {
+        const int k = M.kmin + L;
+        const int nm = n - k;                      // merges applied
+        // exclusive prefix count of representatives -> 1-based id of each representative
+        const int b0 = tid * chunk, b1 = min(n, b0 + chunk);
+        int local = 0;
+        for (int i = b0; i < b1; ++i) local += (absorbed[i] >= nm);
+        int inc = local;
+        const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        if (tid == 0) { int run = 0; for (int q = 0; q < HC_THREADS / 64; ++q) { const int t = wsum[q]; wsum[q] = run; run += t; } }
+        __syncthreads();
+        int run = wsum[w] + inc - local;
+        for (int i = b0; i < b1; ++i) { if (absorbed[i] >= nm) rank[i] = ++run; }
+        __syncthreads();
+        for (int i = tid; i < n; i += HC_THREADS) {
+            int r = i;
+            while (absorbed[r] < nm) r = parent[r];
+            lab[static_cast<long long>(L) * n + i] = rank[r];
+        }
+        __syncthreads();
+    }
+}
+
+// one-hot membership of the finest level (k = kmax): H[i][c] = (label_i == c + 1)
+__global__ void onehot_kernel(const HcMeta *__restrict__ metas, const int *__restrict__ lab_all, double *__restrict__ H_all) {
+    const HcMeta M = metas[blockIdx.y];
+    const int *lab = lab_all + M.oLab + static_cast<long long>(M.nk - 1) * M.n;
+    double *H = H_all + M.oH;
+    const long long tot = static_cast<long long>(M.n) * M.kpad;
+    for (long long q = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; q < tot;
+         q += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const int i = static_cast<int>(q / M.kpad), c = static_cast<int>(q % M.kpad);
+        H[q] = (lab[i] == c + 1) ? 1.0 : 0.0;
+    }
+}
+
+// copy the pristine distances of symmetric tasks (hclust updates D in place)
+__global__ void copy_d_kernel(const HcMeta *__restrict__ metas, const double *__restrict__ Dall, double *__restrict__ D0all) {
+    const HcMeta M = metas[blockIdx.y];
+    if (!M.symmetric) return;
+    const long long tot = static_cast<long long>(M.n) * M.nld;
+    const double *D = Dall + M.oD;
+    double *D0 = D0all + M.oD0;
+    for (long long q = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; q < tot;
+         q += static_cast<long long>(gridDim.x) * blockDim.x)
+        D0[q] = D[q];
+}
+
+// ---------------------------------------------------------------------------------------------
+// a5b: per (task, level): median silhouette (cluster::silhouette semantics) and CH ("1-corr").
+// Everything is derived from finest-level quantities computed by MFMA GEMMs:
+//   T[i][f] = sum_{j in f} d(i,j)   (symmetric tasks: D0 * H;  feature tasks: cnt_f - G[i][f])
+//   G[i][f] = c_i . sum_{j in f} c_j,   Q[f][f'] = (sum_f c) . (sum_f' c)
+// A level-k cluster is a union of finest clusters; its sums add the finest columns in ascending order.
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_THREADS = 512;
+constexpr int ST_MAXK = 512;
+
+__global__ __launch_bounds__(ST_THREADS) void stats_kernel(const HcMeta *__restrict__ metas, const int *__restrict__ lab_all,
+                                                           const double *__restrict__ T_all, const double *__restrict__ G_all,
+                                                           const double *__restrict__ Q_all, const double *__restrict__ nrm_all,
+                                                           double *__restrict__ out_all) {
+    const HcMeta M = metas[blockIdx.y];
+    const int L = blockIdx.x;
+    if (L >= M.nk) return;
+    const int n = M.n, k = M.kmin + L, kf = M.kmax, kpad = M.kpad;
+    const int *lab = lab_all + M.oLab + static_cast<long long>(L) * n;
+    const int *labF = lab_all + M.oLab + static_cast<long long>(M.nk - 1) * n;
+    const double *T = T_all + M.oT, *G = G_all + M.oG, *Q = Q_all + M.oQ, *nrm = nrm_all + M.oNrm;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    int npow2 = 1; while (npow2 < n) npow2 <<= 1;
+    double *sil = reinterpret_cast<double *>(sm);            // npow2
+    double *part = sil + npow2;                              // ST_THREADS
+    double *cn2 = part + ST_THREADS;                         // k  : |sum_c|^2
+    double *ctot = cn2 + ST_MAXK;                            // k  : sum_c . total
+    int *cnt = reinterpret_cast<int *>(ctot + ST_MAXK);      // k
+    int *cntF = cnt + ST_MAXK;                               // kf
+    int *fm = cntF + ST_MAXK;                                // kf : level cluster (0-based) of finest cluster f
+    int *start = fm + ST_MAXK;                               // k + 1
+    int *order = start + ST_MAXK + 1;                        // kf : finest clusters grouped by level cluster
+    const int tid = threadIdx.x;
+    for (int c = tid; c < ST_MAXK; c += ST_THREADS) { cnt[c] = 0; cntF[c] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += ST_THREADS) {
+        atomicAdd(&cnt[lab[i] - 1], 1);
+        atomicAdd(&cntF[labF[i] - 1], 1);
+        fm[labF[i] - 1] = lab[i] - 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < k; ++c) {
+            start[c] = run;
+            for (int f = 0; f < kf; ++f) if (fm[f] == c) order[run++] = f;
+        }
+        start[k] = run;
+    }
+    __syncthreads();
+    double tot2 = 0.0;
+    for (int c = tid; c < k; c += ST_THREADS) {
+        double a = 0.0, b = 0.0;
+        for (int q = start[c]; q < start[c + 1]; ++q) {
+            const double *qr = Q + static_cast<long long>(order[q]) * kpad;
+            for (int q2 = start[c]; q2 < start[c + 1]; ++q2) a += qr[order[q2]];
+            for (int f = 0; f < kf; ++f) b += qr[f];
+        }
+        cn2[c] = a; ctot[c] = b;
+    }
+    __syncthreads();
+    for (int c = 0; c < k; ++c) tot2 += ctot[c];             // |total|^2 (every thread, same order)
+    const bool tfromG = !M.symmetric;
+    double wpart = 0.0;
+    for (int i = tid; i < n; i += ST_THREADS) {
+        const int own = lab[i] - 1;
+        const double *Ti = T + static_cast<long long>(i) * kpad, *Gi = G + static_cast<long long>(i) * kpad;
+        double a = 0.0, bmin = 0.0, gown = 0.0;
+        bool have_b = false;
+        for (int c = 0; c < k; ++c) {
+            double sc = 0.0, gc = 0.0;
+            for (int q = start[c]; q < start[c + 1]; ++q) {
+                const int f = order[q];
+                const double g = Gi[f];
+                sc += tfromG ? (static_cast<double>(cntF[f]) - g) : Ti[f];
+                gc += g;
+            }
+            if (c == own) { a = sc / static_cast<double>(cnt[c] - 1); gown = gc; }
+            else { const double bb = sc / static_cast<double>(cnt[c]); if (!have_b || bmin > bb) { bmin = bb; have_b = true; } }
+        }
+        double s = 0.0;
+        if (cnt[own] > 1 && bmin != a) s = (bmin - a) / fmax(a, bmin);
+        sil[i] = s;
+        double r = gown / (nrm[i] * sqrt(cn2[own]));
+        r = r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);
+        wpart += (1.0 - r) * (1.0 - r);
+    }
+    for (int i = n + tid; i < npow2; i += ST_THREADS) sil[i] = HC_INF;
+    part[tid] = wpart;
+    __syncthreads();
+    // bitonic sort of sil[0..npow2)
+    for (int size = 2; size <= npow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (npow2 >> 1); t += ST_THREADS) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const double x = sil[lo], y = sil[hi];
+                if ((x > y) == up) { sil[lo] = y; sil[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        double W = 0.0;
+        for (int q = 0; q < ST_THREADS; ++q) W += part[q];
+        double B = 0.0;
+        for (int c = 0; c < k; ++c) {
+            double r = ctot[c] / (sqrt(cn2[c]) * sqrt(tot2));
+            r = r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);
+            B += static_cast<double>(cnt[c]) * (1.0 - r) * (1.0 - r);
+        }
+        const double ch = (B / static_cast<double>(k - 1)) / (W / static_cast<double>(n - k));
+        const double med = (n & 1) ? sil[n / 2] : (sil[n / 2 - 1] + sil[n / 2]) / 2;
+        double *out = out_all + M.oOut;
+        out[L] = med;
+        out[M.nk + L] = ch;
+    }
+}
+
+// gather the chosen label column of every task into one contiguous buffer
+__global__ void pack_labels_kernel(const HcMeta *__restrict__ metas, const int *__restrict__ lab_all, const int *__restrict__ chosen,
+                                   const long long *__restrict__ dst_off, int *__restrict__ dst) {
+    const HcMeta M = metas[blockIdx.y];
+    const int *src = lab_all + M.oLab + static_cast<long long>(chosen[blockIdx.y]) * M.n;
+    int *d = dst + dst_off[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M.n; i += gridDim.x * blockDim.x) d[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Workspace {
+    DevBuf<double> D, D0, Cr, Ct, nrm, height, H, T, G, CSt, Q, out;
+    DevBuf<int> ia, ib, lab, chosen, packed;
+    DevBuf<long long> packoff;
+    DevBuf<HcMeta> meta;
+    DevBuf<RowPrepTask> prep;
+    DevBuf<GemmTask> gemm;
+};
+Workspace &ws() { static Workspace w; return w; }
+
+inline long long rup(long long v, long long a) { return (v + a - 1) / a * a; }
+
+// model selection, R/get_opt_hclust.R:162-229
+void select_level(const HcParams &prm, int n, int kmin, int nk, const double *msil, const double *CH, const double *height,
+                  int &oind, int &branch, int &rc) {
+    double mx = msil[0];
+    for (int c = 1; c < nk; ++c) if (msil[c] > mx) mx = msil[c];
+    std::vector<int> ties;
+    for (int c = 0; c < nk; ++c) if (msil[c] == mx) ties.push_back(c);
+    oind = ties.empty() ? 1 : ties[(ties.size() + 1) / 2 - 1] + 1;   // tmp[ceiling(length(tmp)/2)]
+    branch = 0;
+    if (mx <= prm.sil_thre) {
+        branch = 1;
+        int wm = 0;
+        for (int c = 1; c < nk; ++c) if (CH[c] > CH[wm]) wm = c;     // which.max: first maximum
+        oind = wm + 1;
+        if (oind == 1) {
+            const int nh = n - 1, t0 = nh > 10 ? nh - 10 : 0, tl = nh - t0;
+            const double *tmp = height + t0;
+            int pind = -1;
+            for (int i = 0; i + 1 < tl; ++i)
+                if (tmp[i + 1] - tmp[i] > (prm.height_Ntimes - 1) * tmp[i]) { pind = i; break; }
+            if (pind >= 0) {
+                branch = 2;
+                const double opth = (tmp[pind] + tmp[pind + 1]) / 2;
+                int idx = n;                                         // which.max(c(height, Inf) > opth)
+                for (int i = 0; i < n - 1; ++i) if (height[i] > opth) { idx = i + 1; break; }
+                const int kk = n + 1 - idx;
+                oind = kk - 1;                                       // "for consistency": assumes kmin == 2
+            }
+        }
+    }
+    (void)kmin;
+    if (oind < 1 || oind > nk) { rc |= SHARP_WARN_RANGE; oind = oind < 1 ? 1 : nk; }
+}
+
+void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want_v, std::vector<HcResult> &out) {
+    Ctx &c = ctx();
+    Workspace &W = ws();
+    const int T = static_cast<int>(i1 - i0);
+    std::vector<HcMeta> metas(T);
+    long long oD = 0, oD0 = 0, oCr = 0, oCt = 0, oN = 0, oM = 0, oLab = 0, oK = 0, oCS = 0, oQ = 0, oOut = 0;
+    int max_n = 0, max_p = 0, max_nk = 0, max_kpad = 0;
+    bool any_sym = false, any_feat = false;
+    for (int t = 0; t < T; ++t) {
+        const HcTask &tk = tasks[i0 + t];
+        HcMeta &M = metas[t];
+        SHARP_REQUIRE(tk.n >= 3, "get_opt_hclust: need at least 3 observations");
+        SHARP_REQUIRE(tk.n <= kHcMaxN, "get_opt_hclust: more than 7168 observations in one clustering task is not supported");
+        SHARP_REQUIRE(tk.prm.hmethod >= 1 && tk.prm.hmethod <= 8, "get_opt_hclust: unknown agglomeration method");
+        M.n = tk.n; M.p = tk.symmetric ? tk.n : tk.p; M.nld = static_cast<int>(rup(tk.n, 64));
+        M.method = tk.prm.hmethod; M.symmetric = tk.symmetric ? 1 : 0; M.pad0 = 0;
+        if (tk.prm.N_cluster > 0) {
+            SHARP_REQUIRE(tk.prm.N_cluster >= 2, "The given N.cluster is less than 2, which is not suitable for clustering!");
+            SHARP_REQUIRE(tk.prm.N_cluster <= tk.n - 1, "N.cluster must be smaller than the number of observations");
+            M.kmin = M.kmax = tk.prm.N_cluster;
+        } else {
+            M.kmin = tk.prm.minN;
+            M.kmax = std::min(tk.prm.maxN, tk.n - 1);
+            SHARP_REQUIRE(M.kmin >= 2 && M.kmax >= M.kmin, "get_opt_hclust: empty range of cluster numbers (minN.cluster..maxN.cluster)");
+        }
+        SHARP_REQUIRE(M.kmax <= ST_MAXK, "get_opt_hclust: more than 512 candidate clusters is not supported");
+        M.nk = M.kmax - M.kmin + 1;
+        M.kpad = static_cast<int>(rup(M.kmax, 16));
+        M.oD = oD; oD += static_cast<long long>(M.nld) * M.nld;
+        M.oD0 = oD0; if (M.symmetric) oD0 += static_cast<long long>(M.nld) * M.nld;
+        M.oCr = oCr; oCr += static_cast<long long>(M.n) * M.p;
+        M.oCt = oCt; oCt += static_cast<long long>(M.p) * M.nld;
+        M.oNrm = oN; oN += M.n;
+        M.oM = oM; oM += M.n;
+        M.oLab = oLab; oLab += static_cast<long long>(M.nk) * M.n;
+        M.oH = M.oT = M.oG = oK; oK += static_cast<long long>(M.n) * M.kpad;
+        M.oCSt = oCS; oCS += static_cast<long long>(M.p) * M.kpad;
+        M.oQ = oQ; oQ += static_cast<long long>(M.kpad) * M.kpad;
+        M.oOut = oOut; oOut += 2LL * M.nk;
+        max_n = std::max(max_n, M.n); max_p = std::max(max_p, M.p); max_nk = std::max(max_nk, M.nk);
+        max_kpad = std::max(max_kpad, M.kpad);
+        any_sym |= tk.symmetric; any_feat |= !tk.symmetric;
+    }
+    W.D.ensure(oD); W.D0.ensure(std::max<long long>(oD0, 1)); W.Cr.ensure(oCr); W.Ct.ensure(oCt); W.nrm.ensure(oN);
+    W.height.ensure(oM); W.ia.ensure(oM); W.ib.ensure(oM); W.lab.ensure(oLab);
+    W.H.ensure(oK); W.T.ensure(oK); W.G.ensure(oK); W.CSt.ensure(oCS); W.Q.ensure(oQ); W.out.ensure(oOut);
+    W.meta.ensure(T); W.prep.ensure(T); W.gemm.ensure(5 * static_cast<size_t>(T));
+    W.meta.upload(metas.data(), T);
+
+    // a3: rows -> centred/normalised (+ 1 - S for similarity input)
+    std::vector<RowPrepTask> prep(T);
+    for (int t = 0; t < T; ++t) {
+        const HcTask &tk = tasks[i0 + t];
+        const HcMeta &M = metas[t];
+        prep[t] = RowPrepTask{tk.d_mat, tk.ld, M.n, M.p, M.nld, M.symmetric, W.Cr.p + M.oCr, W.Ct.p + M.oCt, W.nrm.p + M.oNrm,
+                              W.D.p + M.oD};
+    }
+    W.prep.upload(prep.data(), T);
+    row_prep_batched(W.prep.p, T, max_n, max_p);
+    std::vector<GemmTask> g;
+    if (any_feat) {   // D = 1 - U U^T
+        g.clear();
+        for (int t = 0; t < T; ++t) {
+            const HcMeta &M = metas[t];
+            if (M.symmetric) continue;
+            g.push_back(GemmTask{W.Ct.p + M.oCt, W.Ct.p + M.oCt, W.D.p + M.oD, M.n, M.n, M.p, M.nld, M.nld, M.nld, 1, 1});
+        }
+        W.gemm.upload(g.data(), g.size());
+        gemm_tn_f64_batched(W.gemm.p, static_cast<int>(g.size()), max_n, max_n, "corr_dist_gemm");
+        stream_sync();   // W.gemm is reused below
+    }
+    if (any_sym) {
+        KernelTimer tm("copy_d");
+        hipLaunchKernelGGL(copy_d_kernel, dim3(64, T), dim3(256), 0, c.stream, W.meta.p, W.D.p, W.D0.p);
+        launch_check("copy_d_kernel");
+    }
+    // a4: agglomeration
+    {
+        const int nal = (max_n + 1) & ~1;
+        const size_t lds = static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16;
+        SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            static_cast<int>(lds)));
+        KernelTimer tm("hclust");
+        hipLaunchKernelGGL(hclust_kernel, dim3(T), dim3(HC_THREADS), lds, c.stream, W.meta.p, W.D.p, W.ia.p, W.ib.p, W.height.p);
+        launch_check("hclust_kernel");
+    }
+    // a5a: labels for every candidate k
+    {
+        const size_t lds = static_cast<size_t>(max_n) * 4 * 3 + (HC_THREADS / 64 + 1) * 4;
+        SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cutree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            static_cast<int>(lds)));
+        KernelTimer tm("cutree");
+        hipLaunchKernelGGL(cutree_kernel, dim3(T), dim3(HC_THREADS), lds, c.stream, W.meta.p, W.ia.p, W.ib.p, W.lab.p);
+        launch_check("cutree_kernel");
+    }
+    {
+        KernelTimer tm("onehot");
+        hipLaunchKernelGGL(onehot_kernel, dim3(64, T), dim3(256), 0, c.stream, W.meta.p, W.lab.p, W.H.p);
+        launch_check("onehot_kernel");
+    }
+    // finest-level sums on the MFMA:  CSt = Cr^T H ; G = C CS^T ; Q = CS CS^T ; (symmetric) T = D0 H
+    auto run_gemms = [&](const char *name, int mM, int mN) {
+        if (g.empty()) return;
+        W.gemm.upload(g.data(), g.size());
+        gemm_tn_f64_batched(W.gemm.p, static_cast<int>(g.size()), mM, mN, name);
+        stream_sync();
+    };
+    g.clear();
+    for (int t = 0; t < T; ++t) {
+        const HcMeta &M = metas[t];
+        g.push_back(GemmTask{W.Cr.p + M.oCr, W.H.p + M.oH, W.CSt.p + M.oCSt, M.p, M.kpad, M.n, M.p, M.kpad, M.kpad, 0, 0});
+    }
+    run_gemms("cluster_sums_gemm", max_p, max_kpad);
+    g.clear();
+    for (int t = 0; t < T; ++t) {
+        const HcMeta &M = metas[t];
+        g.push_back(GemmTask{W.Ct.p + M.oCt, W.CSt.p + M.oCSt, W.G.p + M.oG, M.n, M.kpad, M.p, M.nld, M.kpad, M.kpad, 0, 0});
+    }
+    run_gemms("row_cluster_dot_gemm", max_n, max_kpad);
+    g.clear();
+    for (int t = 0; t < T; ++t) {
+        const HcMeta &M = metas[t];
+        g.push_back(GemmTask{W.CSt.p + M.oCSt, W.CSt.p + M.oCSt, W.Q.p + M.oQ, M.kpad, M.kpad, M.p, M.kpad, M.kpad, M.kpad, 0, 0});
+    }
+    run_gemms("cluster_gram_gemm", max_kpad, max_kpad);
+    if (any_sym) {
+        g.clear();
+        for (int t = 0; t < T; ++t) {
+            const HcMeta &M = metas[t];
+            if (!M.symmetric) continue;
+            g.push_back(GemmTask{W.D0.p + M.oD0, W.H.p + M.oH, W.T.p + M.oT, M.n, M.kpad, M.n, M.nld, M.kpad, M.kpad, 0, 0});
+        }
+        run_gemms("dist_cluster_sums_gemm", max_n, max_kpad);
+    }
+    // a5b: silhouette medians + CH per level
+    {
+        int npow2 = 1; while (npow2 < max_n) npow2 <<= 1;
+        const size_t lds = static_cast<size_t>(npow2) * 8 + ST_THREADS * 8 + 2 * ST_MAXK * 8 + (5 * ST_MAXK + 8) * 4;
+        SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            static_cast<int>(lds)));
+        KernelTimer tm("sil_ch_stats");
+        hipLaunchKernelGGL(stats_kernel, dim3(max_nk, T), dim3(ST_THREADS), lds, c.stream, W.meta.p, W.lab.p, W.T.p, W.G.p, W.Q.p,
+                           W.nrm.p, W.out.p);
+        launch_check("stats_kernel");
+    }
+    std::vector<double> h_out(oOut), h_height(oM);
+    W.out.download(h_out.data(), oOut);
+    W.height.download(h_height.data(), oM);
+    // model selection on the host (a few dozen numbers per task)
+    std::vector<int> chosen(T);
+    std::vector<long long> poff(T);
+    long long ptot = 0;
+    for (int t = 0; t < T; ++t) {
+        const HcTask &tk = tasks[i0 + t];
+        const HcMeta &M = metas[t];
+        HcResult &R = out[i0 + t];
+        R.rc = 0; R.nk = M.nk;
+        R.msil.assign(h_out.begin() + M.oOut, h_out.begin() + M.oOut + M.nk);
+        R.CHind.assign(h_out.begin() + M.oOut + M.nk, h_out.begin() + M.oOut + 2 * M.nk);
+        R.height.assign(h_height.begin() + M.oM, h_height.begin() + M.oM + M.n - 1);
+        int oind = 1;
+        if (tk.prm.N_cluster > 0) {
+            R.branch = 0; R.maxsil = R.msil[0];
+            R.CHind[0] = std::numeric_limits<double>::quiet_NaN();   // intCriteria value: filled by the single-task wrapper
+        } else {
+            select_level(tk.prm, M.n, M.kmin, M.nk, R.msil.data(), R.CHind.data(), R.height.data(), oind, R.branch, R.rc);
+            R.maxsil = *std::max_element(R.msil.begin(), R.msil.end());
+        }
+        chosen[t] = oind - 1;
+        poff[t] = ptot; ptot += M.n;
+    }
+    W.chosen.ensure(T); W.packoff.ensure(T); W.packed.ensure(ptot);
+    W.chosen.upload(chosen.data(), T);
+    W.packoff.upload(poff.data(), T);
+    hipLaunchKernelGGL(pack_labels_kernel, dim3(8, T), dim3(256), 0, c.stream, W.meta.p, W.lab.p, W.chosen.p, W.packoff.p, W.packed.p);
+    launch_check("pack_labels_kernel");
+    std::vector<int> h_packed(ptot);
+    W.packed.download(h_packed.data(), ptot);
+    std::vector<int> h_lab;
+    if (want_v) { h_lab.resize(oLab); W.lab.download(h_lab.data(), oLab); }
+    for (int t = 0; t < T; ++t) {
+        const HcMeta &M = metas[t];
+        HcResult &R = out[i0 + t];
+        R.f.assign(h_packed.begin() + poff[t], h_packed.begin() + poff[t] + M.n);
+        R.optN = *std::max_element(R.f.begin(), R.f.end());
+        if (want_v) R.v.assign(h_lab.begin() + M.oLab, h_lab.begin() + M.oLab + static_cast<long long>(M.nk) * M.n);
+    }
+}
+
+}  // namespace
+
+void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::vector<HcResult> &out) {
+    out.assign(tasks.size(), HcResult());
+    if (tasks.empty()) return;
+    ctx();
+    size_t free_b = 0, total_b = 0;
+    SHARP_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const double budget = std::max(0.5 * static_cast<double>(free_b), 2.0e9);
+    size_t i0 = 0;
+    while (i0 < tasks.size()) {
+        double bytes = 0;
+        size_t i1 = i0;
+        while (i1 < tasks.size()) {
+            const HcTask &t = tasks[i1];
+            const double nld = static_cast<double>(rup(t.n, 64));
+            const double p = t.symmetric ? t.n : t.p;
+            const double b = 8.0 * (nld * nld * (t.symmetric ? 2 : 1) + 2 * nld * p + 4.0 * 64 * t.n) + 4.0 * 64 * t.n;
+            if (i1 > i0 && bytes + b > budget) break;
+            bytes += b;
+            ++i1;
+        }
+        run_chunk(tasks, i0, i1, want_v, out);
+        i0 = i1;
+    }
+}
+
+}  // namespace sharp
+
+using namespace sharp;
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: single-problem wrappers (the reference's exported functions take one matrix at a time)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+bool host_is_symmetric(const double *mat, int n, int p) {   // isSymmetric(): square + all.equal(m, t(m), 100*eps)
+    if (n != p) return false;
+    long double num = 0, den = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            num += fabsl(static_cast<long double>(mat[static_cast<size_t>(i) * n + j]) - mat[static_cast<size_t>(j) * n + i]);
+            den += fabsl(static_cast<long double>(mat[static_cast<size_t>(i) * n + j]));
+        }
+    const double tol = 100 * 2.220446049250313e-16;
+    long double xy = num;
+    if (den > 0 && den / (static_cast<long double>(n) * n) > tol) xy = num / den;
+    return xy < tol;
+}
+
+// clusterCrit::intCriteria(., "Calinski_Harabasz") for the N.cluster-given branch (R/get_opt_hclust.R:105)
+double host_ch_euclid(const double *y, int n, int p, const int *cl, int g) {
+    std::vector<double> cen(static_cast<size_t>(g) * p, 0.0), all(p, 0.0);
+    std::vector<int> cnt(g, 0);
+    for (int i = 0; i < n; ++i) {
+        const int c = cl[i] - 1; cnt[c]++;
+        for (int k = 0; k < p; ++k) { cen[static_cast<size_t>(c) * p + k] += y[static_cast<size_t>(i) * p + k]; all[k] += y[static_cast<size_t>(i) * p + k]; }
+    }
+    for (int c = 0; c < g; ++c) for (int k = 0; k < p; ++k) cen[static_cast<size_t>(c) * p + k] /= cnt[c];
+    for (int k = 0; k < p; ++k) all[k] /= n;
+    double B = 0, W = 0;
+    for (int c = 0; c < g; ++c) for (int k = 0; k < p; ++k) { const double d = cen[static_cast<size_t>(c) * p + k] - all[k]; B += cnt[c] * d * d; }
+    for (int i = 0; i < n; ++i) for (int k = 0; k < p; ++k) { const double d = y[static_cast<size_t>(i) * p + k] - cen[static_cast<size_t>(cl[i] - 1) * p + k]; W += d * d; }
+    return (B / (g - 1)) / (W / (n - g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int sharp_get_opt_hclust(const double *mat, int n, int p, int hmethod, int N_cluster, int minN, int maxN, double sil_thre,
+                         double height_Ntimes, int *f, int *v, double *msil, double *CHind, double *maxsil, double *height,
+                         int *optN, int *nk, int *branch) {
+    int warn = 0;
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(mat && f, "sharp_get_opt_hclust: null argument");
+    SHARP_REQUIRE(n >= 3 && p >= 1, "sharp_get_opt_hclust: need n >= 3 and p >= 1");
+    if (N_cluster != 0) {
+        SHARP_REQUIRE(N_cluster >= 2, "The given N.cluster is less than 2, which is not suitable for clustering!");
+    }
+    HcTask t;
+    t.n = n; t.p = p; t.ld = p;
+    t.symmetric = host_is_symmetric(mat, n, p);
+    t.prm.hmethod = hmethod > 0 ? hmethod : 1;
+    t.prm.N_cluster = N_cluster;
+    t.prm.minN = minN > 0 ? minN : 2;
+    t.prm.maxN = maxN > 0 ? maxN : 40;
+    t.prm.sil_thre = sil_thre;
+    t.prm.height_Ntimes = height_Ntimes > 0 ? height_Ntimes : 2.0;
+    DevBuf<double> dm(static_cast<size_t>(n) * p);
+    dm.upload(mat, static_cast<size_t>(n) * p);
+    t.d_mat = dm.p;
+    std::vector<HcTask> tasks{t};
+    std::vector<HcResult> res;
+    get_opt_hclust_batch(tasks, v != nullptr, res);
+    HcResult &R = res[0];
+    warn = R.rc;
+    std::copy(R.f.begin(), R.f.end(), f);
+    if (v) std::copy(R.v.begin(), R.v.end(), v);
+    if (N_cluster > 0) {
+        // CH of the N.cluster branch is clusterCrit's Euclidean index on the (scaled) matrix
+        std::vector<double> y(mat, mat + static_cast<size_t>(n) * p);
+        if (!t.symmetric) {
+            for (int i = 0; i < n; ++i) {
+                double *r = y.data() + static_cast<size_t>(i) * p;
+                long double s = 0; for (int k = 0; k < p; ++k) s += r[k];
+                const double mean = static_cast<double>(s / p);
+                long double ss = 0; for (int k = 0; k < p; ++k) { r[k] -= mean; ss += static_cast<long double>(r[k] * r[k]); }
+                const double sd = std::sqrt(static_cast<double>(ss) / std::max(1, p - 1));
+                for (int k = 0; k < p; ++k) r[k] /= sd;
+            }
+        }
+        R.CHind[0] = host_ch_euclid(y.data(), n, p, R.f.data(), R.optN);
+        R.optN = N_cluster;
+    }
+    if (msil) std::copy(R.msil.begin(), R.msil.end(), msil);
+    if (CHind) std::copy(R.CHind.begin(), R.CHind.end(), CHind);
+    if (height) std::copy(R.height.begin(), R.height.end(), height);
+    if (maxsil) *maxsil = R.maxsil;
+    if (optN) *optN = R.optN;
+    if (nk) *nk = R.nk;
+    if (branch) *branch = R.branch;
+    }
+    catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
+    catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
+    return warn;
+}
+
+int sharp_getrowColor(const double *E, int n, int p, int hmethod, int indN_cluster, int minN, int maxN, double sil_thre,
+                      double height_Ntimes, int *rowColor, double *maxsil) {
+    std::vector<int> f(static_cast<size_t>(n > 0 ? n : 1));
+    const int rc = sharp_get_opt_hclust(E, n, p, hmethod, indN_cluster, minN, maxN, sil_thre, height_Ntimes > 0 ? height_Ntimes : 1.0,
+                                        f.data(), nullptr, nullptr, nullptr, maxsil, nullptr, nullptr, nullptr, nullptr);
+    if (rc != SHARP_OK && rc != SHARP_WARN_RANGE) return rc;
+    // colorL has 40 names; cluster j > 40 wraps onto colour ((j-1) %% 40) + 1 (R/getrowColor.R:59-68)
+    for (int i = 0; i < n; ++i) rowColor[i] = f[i] > 40 ? ((f[i] - 1) % 40) + 1 : f[i];
+    return rc;
+}
+
+}  // extern "C"

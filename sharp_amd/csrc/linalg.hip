@@ -1,0 +1,178 @@
+// linalg.hip -- batched fp64 kernels: row preparation (scale/centre/normalise), tiled transpose and a
+// TN GEMM on v_mfma_f64_16x16x4_f64.  Used for the correlation distance of get_opt_hclust
+// (R/get_opt_hclust.R:71-72: n_t x n_t x p contraction per task) and for the per-cluster sums behind
+// silhouette / CH (hclust.hip).
+#include "linalg.hpp"
+
+namespace sharp {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// GEMM: 64x64 tile per 256-thread workgroup, each wave a 32x32 quadrant = 2x2 MFMA 16x16 tiles.
+// A/B operand lane map (f64 16x16x4): lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
+// result register r of lane l is D[row = (l>>4) + 4r][col = l&15].
+// LDS tiles are k-major [16][80]: a 32-lane half reads two k rows, 160 dwords apart = 32 banks apart,
+// so ds_read_b64 is conflict-free.
+// ---------------------------------------------------------------------------------------------
+constexpr int GT = 64, GK = 16, GLD = 80;
+
+__global__ __launch_bounds__(256) void gemm_tn_f64_kernel(const GemmTask *__restrict__ tasks) {
+    const GemmTask t = tasks[blockIdx.z];
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    if (m0 >= t.M || n0 >= t.N) return;
+    if (t.symmetric && n0 < m0) return;   // mirrored from the (n0, m0) tile
+    __shared__ double As[GK][GLD];
+    __shared__ double Bs[GK][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int lrow = tid >> 4;          // 0..15  (k within the tile)
+    const int lcol = (tid & 15) * 4;    // 0..60  (4 consecutive m / n)
+    for (int k0 = 0; k0 < t.K; k0 += GK) {
+        const int k = k0 + lrow;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int mm = m0 + lcol + q, nn = n0 + lcol + q;
+            As[lrow][lcol + q] = (k < t.K && mm < t.M) ? t.At[static_cast<long long>(k) * t.lda + mm] : 0.0;
+            Bs[lrow][lcol + q] = (k < t.K && nn < t.N) ? t.Bt[static_cast<long long>(k) * t.ldb + nn] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 4) {
+            const int kr = kk + (lane >> 4);
+            double a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = As[kr][wr + i * 16 + (lane & 15)];
+                b[i] = Bs[kr][wc + i * 16 + (lane & 15)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr + i * 16 + (lane >> 4) + 4 * r;
+                const int col = n0 + wc + j * 16 + (lane & 15);
+                if (row < t.M && col < t.N) {
+                    double v = acc[i][j][r];
+                    if (t.epilogue == 1) {
+                        v = v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v);
+                        v = 1.0 - v;
+                        if (row == col) v = 0.0;
+                    }
+                    t.C[static_cast<long long>(row) * t.ldc + col] = v;
+                    if (t.symmetric && n0 > m0) t.C[static_cast<long long>(col) * t.ldc + row] = v;
+                }
+            }
+}
+
+void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_N, const char *timer_name) {
+    if (count <= 0 || max_M <= 0 || max_N <= 0) return;
+    Ctx &c = ctx();
+    KernelTimer tm(timer_name);
+    for (int z0 = 0; z0 < count; z0 += 65535) {
+        const int nz = std::min(65535, count - z0);
+        hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3((max_N + GT - 1) / GT, (max_M + GT - 1) / GT, nz), dim3(256), 0, c.stream,
+                           d_tasks + z0);
+        launch_check("gemm_tn_f64_kernel");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row preparation: one wave per row.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void row_prep_kernel(const RowPrepTask *__restrict__ tasks) {
+    const RowPrepTask t = tasks[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= t.n) return;
+    const double *x = t.src + static_cast<long long>(row) * t.lds;
+    double *cr = t.Cr + static_cast<long long>(row) * t.p;
+    const int p = t.p;
+    double s = 0.0;
+    for (int q = lane; q < p; q += 64) s += x[q];
+    const double mean = wave_sum(s) / p;
+    if (t.mode == 0) {
+        // t(scale(t(mat))): centre, divide by sd with p-1  (R/get_opt_hclust.R:71)
+        double ss = 0.0;
+        for (int q = lane; q < p; q += 64) { const double c = x[q] - mean; ss += c * c; }
+        const double sd = sqrt(wave_sum(ss) / static_cast<double>(p - 1 > 1 ? p - 1 : 1));
+        // cor(t(mat)) centres again and normalises by the root sum of squares (R/get_opt_hclust.R:72)
+        double s2 = 0.0;
+        for (int q = lane; q < p; q += 64) s2 += (x[q] - mean) / sd;
+        const double mean2 = wave_sum(s2) / p;
+        double n2 = 0.0;
+        for (int q = lane; q < p; q += 64) { const double c = (x[q] - mean) / sd - mean2; n2 += c * c; }
+        const double nr = sqrt(wave_sum(n2));
+        for (int q = lane; q < p; q += 64) cr[q] = ((x[q] - mean) / sd - mean2) / nr;
+        if (lane == 0) t.nrm[row] = 1.0;
+    } else {
+        // symmetric similarity: rows of S are the feature vectors of get_CH (centred, not scaled),
+        // and d = as.dist(1 - S) takes the lower triangle (R/get_opt_hclust.R:66-69)
+        double n2 = 0.0;
+        for (int q = lane; q < p; q += 64) { const double c = x[q] - mean; n2 += c * c; cr[q] = c; }
+        const double nr = sqrt(wave_sum(n2));
+        if (lane == 0) t.nrm[row] = nr;
+        double *drow = t.D + static_cast<long long>(row) * t.nld;
+        for (int q = lane; q < p; q += 64) {
+            double d;
+            if (q == row) d = 0.0;
+            else if (q < row) d = 1.0 - x[q];                                         // S[row][q], row > q
+            else d = 1.0 - t.src[static_cast<long long>(q) * t.lds + row];           // S[q][row], q > row
+            drow[q] = d;
+        }
+    }
+}
+
+// Cr (n x p) -> Ct (p x nld), 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const RowPrepTask *__restrict__ tasks) {
+    const RowPrepTask t = tasks[blockIdx.z];
+    __shared__ double tile[32][33];
+    const int r0 = blockIdx.y * 32, q0 = blockIdx.x * 32;
+    if (r0 >= t.nld || q0 >= t.p) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, q = q0 + tx;
+        tile[j][tx] = (r < t.n && q < t.p) ? t.Cr[static_cast<long long>(r) * t.p + q] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int q = q0 + j, r = r0 + tx;
+        if (q < t.p && r < t.nld) t.Ct[static_cast<long long>(q) * t.nld + r] = (r < t.n) ? tile[tx][j] : 0.0;
+    }
+}
+
+void row_prep_batched(const RowPrepTask *d_tasks, int count, int max_n, int max_p) {
+    if (count <= 0 || max_n <= 0) return;
+    Ctx &c = ctx();
+    KernelTimer tm("row_prep");
+    for (int z0 = 0; z0 < count; z0 += 65535) {
+        const int nz = std::min(65535, count - z0);
+        hipLaunchKernelGGL(row_prep_kernel, dim3((max_n + 3) / 4, nz), dim3(256), 0, c.stream, d_tasks + z0);
+        launch_check("row_prep_kernel");
+        const int nld_max = (max_n + 63) / 64 * 64;
+        hipLaunchKernelGGL(transpose_kernel, dim3((max_p + 31) / 32, (nld_max + 31) / 32, nz), dim3(256), 0, c.stream, d_tasks + z0);
+        launch_check("transpose_kernel");
+    }
+}
+
+}  // namespace sharp

@@ -1,0 +1,42 @@
+// linalg.hpp -- batched fp64 building blocks shared by the clustering stages:
+// row centring/normalisation and a TN GEMM on the f64 MFMA (v_mfma_f64_16x16x4_f64).
+#pragma once
+#include "common.hpp"
+
+namespace sharp {
+
+// One GEMM of a batch:  C[M x N] (row-major, ldc) = sum_k At[k][0..M) * Bt[k][0..N)
+// At is K x M row-major (lda), Bt is K x N row-major (ldb): both operands are "k-major", so tile
+// staging reads contiguous rows.  epilogue: 0 = store v ; 1 = store 1 - clamp(v, -1, 1)
+// symmetric: At == Bt and M == N -> only tiles on/above the diagonal are computed and mirrored.
+struct GemmTask {
+    const double *At;
+    const double *Bt;
+    double *C;
+    int M, N, K;
+    long long lda, ldb, ldc;
+    int epilogue;
+    int symmetric;
+};
+
+// Launch over a device-resident array of `count` GemmTask (max_M/max_N size the grid).
+void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_N, const char *timer_name);
+
+// Row preparation for one matrix of a batch (R/get_opt_hclust.R:66-74 + the centring inside cor()):
+//   mode 0 (feature rows): z = (x - mean)/sd(p-1)  [t(scale(t(mat)))], re-centre as cor() does,
+//                          u = c / ||c||  -> Cr (n x p row-major), Ct (p x nld), nrm = 1
+//   mode 1 (symmetric similarity S): c = x - mean (rows of S as features for get_CH),
+//                          Cr, Ct = centred rows, nrm = ||c||;  D = 1 - S is written as well.
+struct RowPrepTask {
+    const double *src;   // n x p row-major, leading dimension lds
+    long long lds;
+    int n, p, nld;
+    int mode;
+    double *Cr;          // n x p (ld p)
+    double *Ct;          // p x nld
+    double *nrm;         // n
+    double *D;           // nld x nld (mode 1 only)
+};
+void row_prep_batched(const RowPrepTask *d_tasks, int count, int max_n, int max_p);
+
+}  // namespace sharp

@@ -1,0 +1,126 @@
+"""GPU parity tests for rows a3-a6 (get_opt_hclust / getrowColor) through the C ABI, against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20261003
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import sharp_amd
+
+    sharp_amd.init(0)
+    return sharp_amd
+
+
+def _projected(oracle, m, n, G, nm, seed=2154):
+    X = oracle.synth_fill(SEED, m, 0, n, G, nm)
+    p = int(np.ceil(np.log2(n) / 0.04))
+    return oracle.project(X, oracle.ranM(m, p, seed), True)
+
+
+def _compare(res, ref, n, label_exact=True):
+    assert res["optN_cluster"] == ref["optN"]
+    assert res["branch"] == ref["branch"]
+    np.testing.assert_allclose(res["height"], ref["height"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res["msil"], ref["msil"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(res["CHind"], ref["CHind"], rtol=1e-8)
+    assert abs(res["maxsil"] - ref["maxsil"]) < 1e-10
+    if label_exact:
+        assert np.array_equal(res["v"], ref["v"])     # every cutree level identical, ids by first appearance
+        assert np.array_equal(res["f"], ref["f"])
+
+
+@pytest.mark.parametrize("m,n,G,nm", [(2000, 300, 6, 200), (3000, 97, 3, 500), (6000, 700, 8, 500)])
+def test_get_opt_hclust_features_matches_oracle(sa, oracle, m, n, G, nm):
+    E = _projected(oracle, m, n, G, nm)
+    ref = oracle.get_opt_hclust(E)
+    res = sa.get_opt_hclust(E)
+    _compare(res, ref, n)
+
+
+def test_get_opt_hclust_fold_sized_task(sa, oracle):
+    # a full-size fold: n_t = 2000 cells, p = 391 (cfg2's K*T task shape)
+    m, n = 8000, 2000
+    X = oracle.synth_fill(SEED, m, 0, n, 12, 500)
+    E = oracle.project(X, oracle.ranM(m, 391, 2154), True)
+    ref = oracle.get_opt_hclust(E)
+    res = sa.get_opt_hclust(E)
+    _compare(res, ref, n)
+
+
+def test_get_opt_hclust_ch_and_height_branches(sa, oracle):
+    # weak structure -> max median silhouette <= 0.35 -> CH branch (R/get_opt_hclust.R:194-210)
+    rng = np.random.default_rng(7)
+    Y = rng.normal(size=(150, 40))
+    Y[:50, :5] += 0.8
+    ref = oracle.get_opt_hclust(Y)
+    res = sa.get_opt_hclust(Y)
+    assert ref["branch"] >= 1
+    _compare(res, ref, 150)
+    # sil_thre = 0 (testlog's call, R/SHARP.R:907): silhouette branch even for weak structure
+    ref0 = oracle.get_opt_hclust(Y, sil_thre=0.0)
+    res0 = sa.get_opt_hclust(Y, sil_thre=0.0)
+    assert ref0["branch"] == 0
+    _compare(res0, ref0, 150)
+
+
+def test_get_opt_hclust_given_n_cluster(sa, oracle):
+    E = _projected(oracle, 2000, 200, 5, 200)
+    ref = oracle.get_opt_hclust(E, N_cluster=4)
+    res = sa.get_opt_hclust(E, N_cluster=4)
+    assert np.array_equal(res["f"], ref["f"]) and res["optN_cluster"] == 4
+    assert abs(res["msil"][0] - ref["msil"][0]) < 1e-10
+    assert abs(res["CHind"][0] - ref["CHind"][0]) < 1e-8 * abs(ref["CHind"][0])
+    with pytest.raises(sa.SharpError, match="less than 2"):
+        sa.get_opt_hclust(E, N_cluster=1)
+    with pytest.raises(sa.SharpError, match="not an integer"):
+        sa.get_opt_hclust(E, N_cluster=2.5)
+
+
+@pytest.mark.parametrize("method", ["ward.D", "ward.D2", "average", "complete", "single", "mcquitty"])
+def test_get_opt_hclust_other_linkages(sa, oracle, method):
+    E = _projected(oracle, 2000, 120, 4, 300)
+    ref = oracle.get_opt_hclust(E, hmethod=method)
+    res = sa.get_opt_hclust(E, hmethod=method)
+    np.testing.assert_allclose(res["height"], ref["height"], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(res["v"], ref["v"])
+
+
+def test_get_opt_hclust_symmetric_similarity(sa, oracle):
+    # the wMetaC / sMetaC call shape: a similarity matrix with exact ones (R/wMetaC.R:98, R/sMetaC.R:128)
+    rng = np.random.default_rng(8)
+    base = rng.integers(1, 7, 400)
+    cols = [base.copy() for _ in range(5)]
+    for c in cols[1:]:
+        flip = rng.random(400) < 0.05
+        c[flip] = rng.integers(1, 7, flip.sum())
+    w = oracle.wMetaC(np.stack(cols, 1))
+    S = w["S"]
+    ref = oracle.get_opt_hclust(S)
+    res = sa.get_opt_hclust(S)
+    _compare(res, ref, S.shape[0])
+    # saturated case: identical partitions -> silhouettes exactly 1 for several k; the reference breaks
+    # such ties by the middle arg-max with == on doubles (R/get_opt_hclust.R:162-168)
+    w2 = oracle.wMetaC(np.stack([base, base % 6 + 1, base], 1))
+    ref2 = oracle.get_opt_hclust(w2["S"])
+    res2 = sa.get_opt_hclust(w2["S"])
+    assert np.array_equal(res2["msil"] == res2["msil"].max(), ref2["msil"] == ref2["msil"].max())
+    assert np.array_equal(res2["f"], ref2["f"])
+
+
+def test_getrowcolor_names_and_edge_sizes(sa, oracle):
+    E = _projected(oracle, 2000, 60, 3, 300)
+    ref = oracle.getrowColor(E)
+    res = sa.getrowColor(E)
+    assert np.array_equal(res["rowColor_id"], ref["rowColor"])
+    assert res["rowColor"][0] == "red"      # first cluster -> colorL[1]
+    assert abs(res["maxsil"] - ref["maxsil"]) < 1e-10
+    # tiny inputs: n = 3 is the smallest the reference can cluster (k = 2..n-1)
+    E3 = E[:3]
+    r3 = sa.get_opt_hclust(E3)
+    assert np.array_equal(r3["f"], oracle.get_opt_hclust(E3)["f"])
+    with pytest.raises(sa.SharpError):
+        sa.get_opt_hclust(E[:2])
