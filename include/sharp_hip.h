@@ -107,6 +107,66 @@ int sharp_get_opt_hclust(const double *mat, int n, int p, int hmethod, int N_clu
 int sharp_getrowColor(const double *E, int n, int p, int hmethod, int indN_cluster, int minN, int maxN,
                       double sil_thre, double height_Ntimes, int *rowColor, double *maxsil);
 
+/* ---- a9: wMetaC ------------------------------------------------------------------ */
+/* R/wMetaC.R:15-226 (+ getA :242-283, getss :299-311, getnewk :313-320).
+ * nC: N x C column-major integer labels (the reference's strings only ever compare for equality
+ * within a column).  finalC[N]: meta-cluster id per cell (the number R stores as a string; ties in the
+ * vote go to the id whose decimal string sorts first, like names(sort(table(d), decreasing=TRUE)[1])).
+ * x0 (optional): N x *ncl column-major soft matrix (caller buffer of N * min(maxN, allC-1) doubles).
+ * Optional intermediates for stage-wise checks: w1_out[N], S_out[allC*allC], tf_out[allC], *allC_out.
+ * Returns SHARP_OK, or warning bits SHARP_WARN_RANGE / SHARP_WARN_NA_VOTE, or an error code. */
+int sharp_wMetaC(const int *nC, int N, int C, int hmethod, int enN_cluster, int minN, int maxN, double sil_thre,
+                 double height_Ntimes, int *finalC, double *x0, int *ncl, double *w1_out, double *S_out, int *allC_out,
+                 int *tf_out);
+
+/* ---- a10: sMetaC ----------------------------------------------------------------- */
+/* R/sMetaC.R:17-210.  labels[n]: integers, equal <=> same label string; sE1: n x p row-major.
+ * finalColor[n]: meta id per cell; tf_out[nC] (optional): meta id per unique label in
+ * first-appearance order; `folds` is unused by the reference and has no counterpart here. */
+int sharp_sMetaC(const int *labels, const double *sE1, long long n, int p, int hmethod, int finalN_cluster, int minN,
+                 int maxN, double sil_thre, double height_Ntimes, int *finalColor, int *tf_out, int *nC_out);
+
+/* ---- a7, a8, a12: SHARP / SHARP_small / SHARP_large -------------------------------- */
+/* R/SHARP.R:44-318 (front door), :339-454 (SHARP_small), :478-851 (SHARP_large), for a matrix that
+ * already went through the host-side preparation (dedupe, prep, CPM: the Python/R glue does those).
+ * Arguments <= 0 (sil_thre < 0) take the reference defaults: ensize_K 15 (small) / 5 (large),
+ * reduced_ndim ceiling(log2(n)/0.2^2), base_ncells 5000, partition_ncells 2000, hmethod ward.D,
+ * minN 2, maxN max(40, ceiling(n/5000)), sil_thre 0.35, height_Ntimes 2.  *_cluster: 0 = NULL.
+ * log_flag: the `flag` of R/SHARP.R:211-228 (1 = log2(x+1)).  projector: handle of a shared `rM` list
+ * (sharp_projector_create) or 0 to draw it from rN_seed (seeds 50 + rN_seed + k); rN_seed = 0.5 is the
+ * reference's "not reproducible" sentinel.  n < base_ncells runs SHARP_small, else SHARP_large
+ * (with N_cluster given and n < base_ncells the reference's reroute at :181-191 applies).
+ * Outputs: pred[n] (1..*n_pred, numbered by first appearance); viE (optional) n x p row-major;
+ * x0 (optional) n x *x0_cols column-major with room for x0_cap_cols columns; *path 0 small / 1 large. */
+int sharp_SHARP_dev(const float *dX, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells,
+                    int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
+                    double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred,
+                    int *n_pred, double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path);
+/* host matrix: X double, m x n column-major (ld >= m); staged as fp32 */
+int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells,
+                int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
+                double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred,
+                int *n_pred, double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path);
+
+/* ---- a11: SHARP_unlimited ---------------------------------------------------------- */
+/* R/SHARP_unlimited.R:29-242.  Whole call on one GPU: blocks are device (or host) matrices sharing m
+ * genes; p = ceiling(log2(sum ncb)/0.04); shared projectors; per-block SHARP(); cross-block sMetaC on
+ * the per-(block, cluster) centroid means of viE; < 10-cell merge; ids by decreasing size. */
+int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                              int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred,
+                              int *p_used);
+int sharp_SHARP_unlimited(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K,
+                          int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used);
+/* The same split for one-block-per-GPU sharding: every rank runs its blocks through
+ * sharp_unlimited_block_dev (block labels 1..*n_clusters by first appearance, the cluster means of viE,
+ * n_clusters x p row-major into `means` with room for cap_rows rows, and the cluster sizes), the
+ * (means, counts) tables are all-gathered in block order, and every rank calls sharp_unlimited_merge,
+ * which returns the final 1-based id of each gathered (block, cluster) row. */
+int sharp_unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
+                              double rN_seed, int *pred, int *n_clusters, double *means, int cap_rows, long long *counts);
+int sharp_unlimited_merge(const double *means, const long long *counts, int nC, int p, long long ncells, int N_cluster,
+                          int minN, int maxN, int *final_id, int *n_final);
+
 /* ---- synthetic inputs (bench / tests; not part of the reference) ------------ */
 /* Counter-based generator, value = f(seed, gene, cell): bit-identical to
  * oracle_synth_value().  Fills dX (fp32, m x ncell column-major, leading dim ld). */

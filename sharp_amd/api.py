@@ -10,7 +10,8 @@ import numpy as np
 from . import _lib
 from ._lib import SharpError, check, lib
 
-__all__ = ["ranM", "ranM2", "RPmat", "Projector", "SharpError", "get_opt_hclust", "getrowColor", "colorL", "HMETHODS"]
+__all__ = ["ranM", "ranM2", "RPmat", "Projector", "SharpError", "get_opt_hclust", "getrowColor", "colorL", "HMETHODS",
+           "wMetaC", "sMetaC", "SHARP", "SHARP_small", "SHARP_large", "SHARP_unlimited", "testlog", "ARI"]
 
 
 def _dp(a):
@@ -172,3 +173,256 @@ def getrowColor(Emat, hmethod=None, indN_cluster=None, minN_cluster=2, maxN_clus
                                   C.c_double(1.0 if height_Ntimes is None else height_Ntimes), _ip(rc_), C.byref(maxsil)),
           allow=16)
     return {"rowColor": [colorL[j - 1] for j in rc_], "rowColor_id": rc_, "maxsil": maxsil.value, "mat": Emat}
+
+
+def _labels_to_int(col):
+    """R label strings / arbitrary hashables -> ints with equal <=> same label."""
+    col = np.asarray(col)
+    if col.dtype.kind in "iu":
+        return col.astype(np.int32)
+    _, inv = np.unique(col, return_inverse=True)
+    return inv.astype(np.int32)
+
+
+def wMetaC(nC, hmethod=None, enN_cluster=None, minN_cluster=None, maxN_cluster=None, sil_thre=None,
+           height_Ntimes=None, debug=False):
+    """R/wMetaC.R:15-226.  nC: (N, C) labels (ints or strings).  Returns dict(finalC, x0)."""
+    _lib.ensure_init()
+    nC = np.asarray(nC)
+    if nC.ndim != 2:
+        raise SharpError("nC must be an N x C matrix of cluster labels")
+    N, Cc = nC.shape
+    lab = np.asfortranarray(np.stack([_labels_to_int(nC[:, c]) for c in range(Cc)], 1), dtype=np.int32)
+    minN = 2 if minN_cluster is None else int(minN_cluster)
+    maxN = 40 if maxN_cluster is None else int(maxN_cluster)
+    finalC = np.zeros(N, np.int32)
+    x0 = np.zeros(N * (maxN + 2))
+    ncl = C.c_int()
+    allC = C.c_int()
+    w1 = np.zeros(N) if debug else None
+    cap = N * Cc if N * Cc < 4096 else 4096
+    S = np.zeros(cap * cap) if debug else None
+    tf = np.zeros(cap, np.int32) if debug else None
+    rc = check(lib().sharp_wMetaC(_ip(lab), N, Cc, _hmethod(hmethod), int(enN_cluster or 0), minN, maxN,
+                                  C.c_double(0.0 if sil_thre is None else sil_thre),   # R/wMetaC.R:94-97
+                                  C.c_double(2.0 if height_Ntimes is None else height_Ntimes), _ip(finalC), _dp(x0),
+                                  C.byref(ncl), _dp(w1), _dp(S), C.byref(allC), _ip(tf)), allow=48)
+    out = {"finalC": finalC, "x0": x0[: N * ncl.value].reshape(ncl.value, N).T.copy(), "warn": rc}
+    if debug:
+        A = allC.value
+        out.update(w1=w1, S=S[: A * A].reshape(A, A).copy(), tf=tf[:A].copy(), allC=A)
+    return out
+
+
+def sMetaC(rerowColor, sE1, folds=None, hmethod=None, finalN_cluster=None, minN_cluster=2, maxN_cluster=40,
+           sil_thre=0.35, height_Ntimes=2.0):
+    """R/sMetaC.R:17-210.  Returns dict(finalColor, tf).  `folds` is accepted and unused, as in the reference."""
+    _lib.ensure_init()
+    lab = np.ascontiguousarray(_labels_to_int(rerowColor))
+    E = np.ascontiguousarray(sE1, np.float64)
+    n, p = E.shape
+    fin = np.zeros(n, np.int32)
+    tf = np.zeros(n, np.int32)
+    nC = C.c_int()
+    rc = check(lib().sharp_sMetaC(_ip(lab), _dp(E), C.c_longlong(n), p, _hmethod(hmethod), int(finalN_cluster or 0),
+                                  int(minN_cluster), int(maxN_cluster), C.c_double(sil_thre), C.c_double(height_Ntimes),
+                                  _ip(fin), _ip(tf), C.byref(nC)), allow=16)
+    return {"finalColor": fin, "tf": tf[: nC.value].copy(), "warn": rc}
+
+
+def testlog(scExp, ncells, p, sncells=100, n_cores=None, cells=None):
+    """R/SHARP.R:877-924.  The reference draws the test cells with the unseeded global RNG (:884), so its
+    result is not reproducible; pass `cells` (0-based indices) to fix them."""
+    sncells = min(sncells, ncells)
+    if cells is None:
+        cells = np.random.default_rng().permutation(ncells)[:sncells]
+    sE = np.asarray(scExp, np.float64)[:, np.asarray(cells)]
+    pr = ranM(scExp, p, 5)
+    msil = []
+    for k in (1, 2):
+        E1 = pr.project(sE, logflag=(k == 2))
+        msil.append(getrowColor(E1, "ward.D", None, 2, 40, 0.0, 2.0)["maxsil"])
+    return bool(msil[0] < 0.75 and msil[0] >= 0.95 * msil[1])
+
+
+def _enresults(pred, x0, viE, ncells, ngenes, p, K, t0, paras, forview, key="N.pred_cluster"):
+    import time as _t
+
+    uy = np.unique(pred)
+    out = {"pred_clusters": pred, "unique_pred_clusters": uy, "distr_pred_clusters": {int(u): int((pred == u).sum()) for u in uy},
+           key: int(uy.size)}
+    if forview:
+        out["x0"] = x0
+        out["viE"] = viE
+    out.update({"N.cells": ncells, "N.genes": ngenes, "reduced.dim": p, "ensize.K": K,
+                "time": (_t.time() - t0) / 60.0, "paras": paras})
+    return out
+
+
+def _run_sharp(X, K, p, base_ncells, partition_ncells, hmethod, N_cluster, enpN, indN, minN, maxN, sil_thre,
+               height_Ntimes, flag, rM, rN_seed, forview):
+    X = np.asfortranarray(X, dtype=np.float64)
+    m, n = X.shape
+    pred = np.zeros(n, np.int32)
+    p_eff = p if p else int(np.ceil(np.log2(n) / 0.04))
+    viE = np.zeros((n, p_eff)) if forview else None
+    capc = max(int(maxN or 0), 40, (n + 4999) // 5000) + 2
+    x0 = np.zeros(n * capc) if forview else None
+    npred, x0c, pu, Ku, path = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = check(lib().sharp_SHARP(_dp(X), m, C.c_longlong(n), C.c_longlong(m), int(K or 0), int(p or 0),
+                                 int(base_ncells or 0), int(partition_ncells or 0), _hmethod(hmethod), int(N_cluster or 0),
+                                 int(enpN or 0), int(indN or 0), int(minN or 0), int(maxN or 0),
+                                 C.c_double(-1.0 if sil_thre is None else sil_thre),
+                                 C.c_double(0.0 if height_Ntimes is None else height_Ntimes), int(bool(flag)),
+                                 int(rM.handle if isinstance(rM, Projector) else 0), C.c_double(rN_seed), _ip(pred),
+                                 C.byref(npred), _dp(viE), _dp(x0), capc, C.byref(x0c), C.byref(pu), C.byref(Ku),
+                                 C.byref(path)), allow=48)
+    x0m = x0[: n * x0c.value].reshape(x0c.value, n).T.copy() if forview else None
+    return pred, x0m, viE, pu.value, Ku.value, path.value, rc
+
+
+def SHARP(scExp, exp_type=None, ensize_K=None, reduced_ndim=None, base_ncells=None, partition_ncells=None, hmethod=None,
+          N_cluster=None, enpN_cluster=None, indN_cluster=None, minN_cluster=None, maxN_cluster=None, sil_thre=None,
+          height_Ntimes=None, flashmark=False, logflag=None, sncells=None, n_cores=None, forview=True, prep=None,
+          rM=None, rN_seed=None, gene_names=None, cell_names=None, testlog_cells=None):
+    """R/SHARP.R:44-318.  scExp: (genes, cells).  Returns the `enresults` list as a dict."""
+    import time as _t
+    import warnings
+
+    t0 = _t.time()
+    if scExp is None:
+        raise SharpError("No expression data is provided!")
+    _lib.ensure_init()
+    X = np.array(scExp, dtype=np.float64, copy=True)
+    ngenes, ncells = X.shape
+    if prep is None:
+        prep = ncells < 1e4                                               # :74-80
+    if gene_names is not None:                                            # :83-88
+        _, first = np.unique(np.asarray(gene_names), return_index=True)
+        if first.size < len(gene_names):
+            warnings.warn(f"{len(gene_names) - first.size} duplicated genes are found and then are removed!")
+            X = X[np.sort(first)]
+    if prep:                                                              # :99-106
+        if (X < 0).any():
+            warnings.warn("Your expression matrix contain negative values! SHARP will replace negative values with 0!")
+            X[X < 0] = 0
+        X = X[X.sum(1) != 0]
+    if exp_type is not None and exp_type not in ("CPM", "TPM"):           # :110-114
+        X = X / X.sum(0, keepdims=True) * 1e6
+    if rN_seed is not None:                                               # :169-179
+        if not isinstance(rN_seed, (int, float, np.integer, np.floating)):
+            raise SharpError("The rN.seed should be a numeric!")
+        if rN_seed % 1 != 0 and rN_seed != 0.5:
+            raise SharpError("The rN.seed should be an integer!")
+    else:
+        rN_seed = 0.5
+    p = int(reduced_ndim) if reduced_ndim else int(np.ceil(np.log2(ncells) / 0.04))   # :119-122
+    if logflag is None:
+        logflag = ncells < 1e4                                            # :202-209
+    if logflag:
+        flag = testlog(X, ncells, p, 100 if sncells is None else sncells, n_cores, testlog_cells)   # :211-224
+    else:
+        flag = True                                                       # :225-228
+    pred, x0, viE, pu, Ku, path, rc = _run_sharp(X, ensize_K, p, base_ncells, partition_ncells, hmethod, N_cluster,
+                                                 enpN_cluster, indN_cluster, minN_cluster, maxN_cluster, sil_thre,
+                                                 height_Ntimes, flag, rM, rN_seed, forview)
+    paras = {"ensize.K": Ku, "reduced.ndim": pu, "base.ncells": base_ncells or 5000,
+             "partition.ncells": partition_ncells or 2000, "logmark": flag, "hmethod": hmethod or "ward.D",
+             "N.cluster": N_cluster, "minN.cluster": minN_cluster or 2,
+             "maxN.cluster": maxN_cluster or max(40, -(-ncells // 5000)), "sil.thre": 0.35 if sil_thre is None else sil_thre,
+             "height.Ntimes": height_Ntimes or 2, "n.cores": n_cores}
+    out = _enresults(pred, x0, viE, ncells, ngenes, pu, Ku, t0, paras, forview)
+    out["warn"] = rc
+    out["path"] = "SHARP_large" if path else "SHARP_small"
+    return out
+
+
+def SHARP_small(scExp, ncells=None, ensize_K=15, reduced_ndim=None, hmethod="ward.D", N_cluster=None, indN_cluster=None,
+                minN_cluster=2, maxN_cluster=40, sil_thre=0.35, height_Ntimes=2, flashmark=False, flag=True, n_cores=None,
+                forview=True, rN_seed=0.5):
+    """R/SHARP.R:339-454 (same argument order)."""
+    import time as _t
+
+    t0 = _t.time()
+    _lib.ensure_init()
+    n = np.shape(scExp)[1]
+    pred, x0, viE, pu, Ku, _, rc = _run_sharp(scExp, ensize_K, reduced_ndim, n + 1, None, hmethod, N_cluster, None,
+                                              indN_cluster, minN_cluster, maxN_cluster, sil_thre, height_Ntimes, flag, None,
+                                              rN_seed, forview)
+    return _enresults(pred, x0, viE, n, np.shape(scExp)[0], pu, Ku, t0, {}, forview)
+
+
+def SHARP_large(scExp, ncells=None, ensize_K=5, reduced_dim=None, partition_ncells=2000, hmethod="ward.D", N_cluster=None,
+                enpN_cluster=None, indN_cluster=None, minN_cluster=2, maxN_cluster=40, sil_thre=0.35, height_Ntimes=2,
+                flashmark=False, flag=True, n_cores=None, forview=True, rM=None, rN_seed=0.5):
+    """R/SHARP.R:478-851 (same argument order)."""
+    import time as _t
+
+    t0 = _t.time()
+    _lib.ensure_init()
+    n = np.shape(scExp)[1]
+    pred, x0, viE, pu, Ku, _, rc = _run_sharp(scExp, ensize_K, reduced_dim, 1, partition_ncells, hmethod, N_cluster,
+                                              enpN_cluster, indN_cluster, minN_cluster, maxN_cluster, sil_thre, height_Ntimes,
+                                              flag, rM, rN_seed, forview)
+    return _enresults(pred, x0, viE, n, np.shape(scExp)[0], pu, Ku, t0, {}, forview)
+
+
+def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster=None, minN_cluster=None,
+                    maxN_cluster=None, rN_seed=None):
+    """R/SHARP_unlimited.R:29-242.  scExp: list of (genes, cells) blocks sharing the gene axis."""
+    import time as _t
+    import warnings
+
+    t0 = _t.time()
+    if scExp is None:
+        raise SharpError("No expression data is provided!")
+    if not isinstance(scExp, (list, tuple)):
+        if isinstance(scExp, np.ndarray):                                 # :39-45
+            warnings.warn("SHARP is used instead of SHARP_unlimited because the input is a matrix!")
+            return SHARP(scExp)
+        raise SharpError("The input should be a LIST of partitioned scRNA-seq expression matrices!")
+    if len(scExp) == 1:                                                   # :47-51
+        warnings.warn("SHARP is used instead of SHARP_unlimited because the length of the input is 1!")
+        return SHARP(scExp[0])
+    if rN_seed is not None:
+        if not isinstance(rN_seed, (int, float, np.integer, np.floating)):
+            raise SharpError("The rN.seed should be a numeric!")
+        if rN_seed % 1 != 0:
+            raise SharpError("The rN.seed should be an integer!")
+    else:
+        rN_seed = 0.5
+    _lib.ensure_init()
+    blocks = [np.asfortranarray(b, dtype=np.float64) for b in scExp]
+    m = blocks[0].shape[0]
+    ncb = np.array([b.shape[1] for b in blocks], np.int64)
+    ptrs = (C.POINTER(C.c_double) * len(blocks))(*[_dp(b) for b in blocks])
+    n = int(ncb.sum())
+    pred = np.zeros(n, np.int32)
+    npred, pu = C.c_int(), C.c_int()
+    check(lib().sharp_SHARP_unlimited(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), len(blocks), m, int(ensize_K or 0),
+                                      int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0), C.c_double(rN_seed),
+                                      _ip(pred), C.byref(npred), C.byref(pu)), allow=48)
+    out = _enresults(pred, None, None, n, m, None, ensize_K or 5, t0, {}, False, key="N.pred_clusters")
+    return out
+
+
+def ARI(label, res):
+    """R/ARI.R:20-42: clues::adjustedRand(label, res$pred_clusters) -> Rand, HA, MA, FM, Jaccard."""
+    a = _labels_to_int(np.asarray(label))
+    b = _labels_to_int(np.asarray(res["pred_clusters"] if isinstance(res, dict) else res))
+    n = a.size
+    tab = np.zeros((a.max() + 1, b.max() + 1))
+    np.add.at(tab, (a, b), 1)
+    ra, rb = tab.sum(1), tab.sum(0)
+    sij = (tab * (tab - 1) / 2).sum()
+    si = (ra * (ra - 1) / 2).sum()
+    sj = (rb * (rb - 1) / 2).sum()
+    tot = n * (n - 1) / 2
+    A, B, Cc = sij, si - sij, sj - sij
+    D = tot - A - B - Cc
+    rand = (A + D) / tot
+    e = si * sj / tot
+    ha = (sij - e) / (0.5 * (si + sj) - e)
+    erand = (tot + (ra ** 2).sum() * (rb ** 2).sum() / n ** 2 - 0.5 * ((ra ** 2).sum() + (rb ** 2).sum())) / tot
+    return {"Rand": rand, "HA": ha, "MA": (rand - erand) / (1 - erand), "FM": A / np.sqrt((A + B) * (A + Cc)),
+            "Jaccard": A / (A + B + Cc)}

@@ -1,0 +1,509 @@
+// driver.hip -- the drivers of the hot path, one library call per reference entry point so that no
+// foreach/%dopar% fork ever touches the HIP context (SURVEY.md 8b "Threading"):
+//   SHARP()           R/SHARP.R:44-318    defaults + dispatch                       (row a12)
+//   SHARP_small()     R/SHARP.R:339-454   K projections of all cells + wMetaC       (row a7)
+//   SHARP_large()     R/SHARP.R:478-851   shuffle, 2000-cell folds, K*T tasks as ONE batched launch
+//                                          sequence, per-fold wMetaC, cross-fold sMetaC   (row a8)
+//   SHARP_unlimited() R/SHARP_unlimited.R:29-242  per-block SHARP + centroid-level sMetaC (row a11)
+// X stays resident in HBM as fp32 (genes x cells, column-major); E, viE and every clustering
+// intermediate stay on the device; only labels and a few KB of selection statistics cross PCIe.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <random>
+
+#include "meta.hpp"
+#include "projector.hpp"
+#include "rrng.hpp"
+
+namespace sharp {
+
+struct SharpArgs {
+    int K = 0, reduced_ndim = 0, base_ncells = 0, partition_ncells = 0, hmethod = 0;
+    int N_cluster = 0, enpN = 0, indN = 0, minN = 0, maxN = 0;
+    double sil_thre = -1, height_Ntimes = 0;
+    int flag = 1;            // log-transform
+    int projector = 0;       // handle of a shared rM list, 0 = draw from rN_seed
+    double rN_seed = 0.5;    // 0.5 = the reference's "unseeded" sentinel
+    bool want_viE = false, want_x0 = false;
+};
+struct SharpOut {
+    std::vector<int> pred;           // 1..G, numbered by first appearance (R/SHARP.R:429-443,828-843)
+    int n_pred = 0;
+    DevBuf<double> viE;              // n x p, ORIGINAL cell order, on the device
+    std::vector<double> x0;          // n x x0_cols column-major
+    int x0_cols = 0;
+    int p = 0, K = 0, path = 0, rc = 0;
+};
+
+namespace {
+
+inline bool lex_less_id(int a, int b) {
+    char sa[16], sb[16];
+    snprintf(sa, sizeof sa, "%d", a);
+    snprintf(sb, sizeof sb, "%d", b);
+    return strcmp(sa, sb) < 0;
+}
+
+// clusters with < 10 cells are merged into the one with the smallest id among them
+// (R/SHARP.R:418-427,816-825; R/SHARP_unlimited.R:168-177)
+void merge_small(std::vector<int> &lab) {
+    int mx = 0;
+    for (int v : lab) mx = std::max(mx, v);
+    std::vector<long long> cnt(mx + 1, 0);
+    for (int v : lab) ++cnt[v];
+    int mn = -1;
+    for (int q = 1; q <= mx; ++q) if (cnt[q] > 0 && cnt[q] < 10) { mn = q; break; }
+    if (mn >= 0) for (int &v : lab) if (cnt[v] < 10) v = mn;
+}
+int relabel_first(std::vector<int> &lab) {
+    int mx = 0;
+    for (int v : lab) mx = std::max(mx, v);
+    std::vector<int> map(mx + 1, 0);
+    int k = 0;
+    for (int &v : lab) { if (!map[v]) map[v] = ++k; v = map[v]; }
+    return k;
+}
+
+std::shared_ptr<Projector> projector_for(const SharpArgs &a, int m, int p, int K) {
+    if (a.projector) {
+        auto pr = get_projector(a.projector);
+        SHARP_REQUIRE(pr->m == m && pr->p == p && pr->K >= K, "rM does not match the data (genes, reduced.ndim, ensize.K)");
+        return pr;
+    }
+    std::vector<double> seeds(K);
+    for (int k = 0; k < K; ++k) seeds[k] = (a.rN_seed == 0.5) ? 0.5 : 50 + a.rN_seed + (k + 1);   // R/SHARP.R:360,545
+    return build_projector(m, p, K, seeds.data());
+}
+
+inline int colour_of(int j) { return j > 40 ? ((j - 1) % 40) + 1 : j; }   // R/getrowColor.R:59-68
+
+__global__ void gather_rows_kernel(const double *__restrict__ src, const int *__restrict__ row_of, long long n, int p, double *__restrict__ dst) {
+    const long long tot = n * p;
+    for (long long q = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; q < tot; q += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long i = q / p;
+        dst[q] = src[static_cast<long long>(row_of[i]) * p + (q - i * p)];
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// SHARP_small (R/SHARP.R:339-454)
+// ---------------------------------------------------------------------------------------------
+void sharp_small_dev(const float *dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, HcParams base, SharpOut &out) {
+    auto pr = projector_for(a, m, p, K);
+    const long long ldE = static_cast<long long>(pr->K) * p;
+    DevBuf<double> E(static_cast<size_t>(n) * ldE);
+    project_dev(*pr, dX, m, n, ld, a.flag, E.p, ldE, nullptr);                  // :350-363 for all k at once
+    std::vector<HcTask> tasks(K);
+    HcParams bp = base; bp.N_cluster = a.indN;
+    for (int k = 0; k < K; ++k) { tasks[k].d_mat = E.p + static_cast<long long>(k) * p; tasks[k].ld = ldE; tasks[k].n = n; tasks[k].p = p; tasks[k].prm = bp; }
+    std::vector<HcResult> hr;
+    get_opt_hclust_batch(tasks, false, hr);                                     // :366 getrowColor
+    std::vector<int> enrp(static_cast<size_t>(n) * K);
+    for (int k = 0; k < K; ++k) { out.rc |= hr[k].rc; for (int i = 0; i < n; ++i) enrp[static_cast<size_t>(k) * n + i] = colour_of(hr[k].f[i]); }
+    WmTask wt; wt.nC = enrp.data(); wt.N = n; wt.C = K; wt.prm = base; wt.prm.N_cluster = a.N_cluster;   // :401
+    std::vector<WmTask> wts{wt};
+    std::vector<WmResult> wr;
+    wmetac_batch(wts, a.want_x0, false, wr);
+    out.rc |= wr[0].rc;
+    out.pred = wr[0].finalC;
+    if (a.want_viE || true) { out.viE.alloc(static_cast<size_t>(n) * p); ensemble_mean_dev(E.p, ldE, n, p, K, out.viE.p); }   // :416
+    if (a.N_cluster <= 0 && n > 10000) merge_small(out.pred);                   // :418-427
+    out.n_pred = relabel_first(out.pred);                                       // :429-443
+    if (a.want_x0) { out.x0 = wr[0].x0; out.x0_cols = wr[0].ncl; }
+    stream_sync();
+}
+
+// folds of partition.ncells cells, the last two balanced (R/SHARP.R:513-536)
+static std::vector<int> fold_starts(int n, int ng) {
+    const int T = (n + ng - 1) / ng;
+    std::vector<int> st(T + 1, 0);
+    if (T == 1) { st[1] = n; return st; }
+    for (int t = 0; t < T - 2; ++t) st[t + 1] = (t + 1) * ng;
+    const int nt = n - (T - 2) * ng;
+    st[T - 1] = (T - 2) * ng + std::min(nt / 2, ng);
+    st[T] = n;
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SHARP_large (R/SHARP.R:478-851)
+// ---------------------------------------------------------------------------------------------
+void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, int ng, HcParams base, SharpOut &out) {
+    const bool shuffle = n < 100000;                                            // :504-507
+    std::vector<int> reind;                                                     // shuffled position i holds cell reind[i]-1
+    std::vector<int> pos(n);                                                    // cell -> shuffled position
+    if (shuffle) {
+        RRng rng((a.rN_seed == 0.5) ? static_cast<uint32_t>(std::random_device{}()) : 50u);   // :493-499
+        reind = rng.permutation(n);
+        for (int i = 0; i < n; ++i) pos[reind[i] - 1] = i;
+    } else {
+        std::iota(pos.begin(), pos.end(), 0);
+    }
+    const std::vector<int> fst = fold_starts(n, ng);
+    const int T = static_cast<int>(fst.size()) - 1;
+    auto pr = projector_for(a, m, p, K);                                        // :539-549
+    const long long ldE = static_cast<long long>(pr->K) * p;
+    DevBuf<double> E(static_cast<size_t>(n) * ldE);
+    DevBuf<int> dpos;
+    if (shuffle) { dpos.alloc(n); dpos.upload(pos.data(), n); }
+    // E rows are written straight into shuffled order, so fold t is the contiguous row range [fst[t], fst[t+1])
+    project_dev(*pr, dX, m, n, ld, a.flag, E.p, ldE, shuffle ? dpos.p : nullptr);          // :567-585 for every (k, t)
+    // K*T base-clustering tasks in one batch (:554-618)
+    std::vector<HcTask> tasks(static_cast<size_t>(K) * T);
+    HcParams bp = base; bp.N_cluster = a.indN;
+    for (int k = 0; k < K; ++k)
+        for (int t = 0; t < T; ++t) {
+            HcTask &tk = tasks[static_cast<size_t>(k) * T + t];
+            tk.d_mat = E.p + static_cast<long long>(fst[t]) * ldE + static_cast<long long>(k) * p;
+            tk.ld = ldE; tk.n = fst[t + 1] - fst[t]; tk.p = p; tk.prm = bp;
+        }
+    std::vector<HcResult> hr;
+    get_opt_hclust_batch(tasks, false, hr);
+    // enrp per fold (:627-635); labels "<colour>p<t>" only need to be distinct per (k, t): the colour id does
+    std::vector<std::vector<int>> enrp(T);
+    for (int t = 0; t < T; ++t) {
+        const int nt = fst[t + 1] - fst[t];
+        enrp[t].resize(static_cast<size_t>(nt) * K);
+        for (int k = 0; k < K; ++k) {
+            const HcResult &r = hr[static_cast<size_t>(k) * T + t];
+            out.rc |= r.rc;
+            for (int i = 0; i < nt; ++i) enrp[t][static_cast<size_t>(k) * nt + i] = colour_of(r.f[i]);
+        }
+    }
+    DevBuf<double> viE_sh(static_cast<size_t>(n) * p);                          // enE / K in shuffled order (:750,776)
+    ensemble_mean_dev(E.p, ldE, n, p, K, viE_sh.p);
+    // per-fold wMetaC (:692-709)
+    std::vector<WmTask> wts(T);
+    for (int t = 0; t < T; ++t) {
+        wts[t].nC = enrp[t].data(); wts[t].N = fst[t + 1] - fst[t]; wts[t].C = K;
+        wts[t].prm = base; wts[t].prm.N_cluster = a.enpN;
+    }
+    std::vector<WmResult> wr;
+    wmetac_batch(wts, a.want_x0, false, wr);
+    std::vector<int> Slab(n);                                                   // SrowColor in shuffled order
+    std::vector<int> stf;                                                       // meta id per (fold, cluster) column of sx0
+    std::vector<int> uid(n);
+    int nCu = 0;
+    std::vector<int> col0(T + 1, 0);                                            // first sx0 column of fold t
+    for (int t = 0; t < T; ++t) {
+        out.rc |= wr[t].rc;
+        // fColor "<id>en<t>": unique() order = fold by fold, first appearance inside the fold
+        std::vector<int> u;
+        const int nu = first_appearance_ids(wr[t].finalC.data(), wr[t].finalC.size(), u);
+        for (size_t i = 0; i < u.size(); ++i) uid[fst[t] + i] = nCu + u[i];
+        col0[t] = nCu;
+        nCu += nu;
+    }
+    col0[T] = nCu;
+    if (T == 1) {
+        // :738-746 then :828: as.numeric("<id>en1") is NA for every cell -> a single cluster (reference quirk 2)
+        std::fill(Slab.begin(), Slab.end(), 1);
+        stf.assign(nCu, 1);
+    } else {
+        DevBuf<double> means(static_cast<size_t>(nCu) * p);
+        cluster_means_dev(viE_sh.p, p, n, p, uid, nCu, means.p);                // sMetaC :58-63 on E1 = enE/K
+        HcParams sp = base; sp.N_cluster = a.N_cluster;
+        SmResult sr = smetac_from_means(means.p, nCu, p, n, sp);               // :754
+        out.rc |= sr.rc;
+        stf = sr.tf;
+        for (int i = 0; i < n; ++i) Slab[i] = stf[uid[i]];
+    }
+    out.pred.resize(n);
+    for (int i = 0; i < n; ++i) out.pred[shuffle ? reind[i] - 1 : i] = Slab[i];   // :775-783
+    if (a.want_x0) {
+        // sx0: block-diagonal per-fold soft matrices (:717-731), columns merged by stf (:761-772), un-shuffled
+        const int sn = *std::max_element(stf.begin(), stf.end());
+        out.x0.assign(static_cast<size_t>(n) * sn, 0.0);
+        out.x0_cols = sn;
+        for (int t = 0; t < T; ++t) {
+            const int nt = fst[t + 1] - fst[t], ncl = wr[t].ncl;
+            for (int q = 0; q < ncl; ++q) {
+                const int dstc = stf[col0[t] + q] - 1;
+                for (int i = 0; i < nt; ++i) {
+                    const int cell = shuffle ? reind[fst[t] + i] - 1 : fst[t] + i;
+                    out.x0[static_cast<size_t>(dstc) * n + cell] += wr[t].x0[static_cast<size_t>(q) * nt + i];
+                }
+            }
+        }
+    }
+    // viE back to the original cell order (:776-783)
+    out.viE.alloc(static_cast<size_t>(n) * p);
+    if (shuffle) {
+        Ctx &c = ctx();
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(c.num_cu * 8), dim3(256), 0, c.stream, viE_sh.p, dpos.p, static_cast<long long>(n), p, out.viE.p);
+        launch_check("gather_rows_kernel");
+    } else {
+        SHARP_HIP_CHECK(hipMemcpyAsync(out.viE.p, viE_sh.p, static_cast<size_t>(n) * p * 8, hipMemcpyDeviceToDevice, ctx().stream));
+    }
+    if (a.N_cluster <= 0 && n > 10000) merge_small(out.pred);                   // :816-825
+    out.n_pred = relabel_first(out.pred);                                       // :828-843
+    stream_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// SHARP front door (R/SHARP.R:44-318) for a prepared matrix resident on the device
+// ---------------------------------------------------------------------------------------------
+void sharp_front_dev(const float *dX, int m, long long n_, long long ld, SharpArgs a, SharpOut &out) {
+    SHARP_REQUIRE(dX, "No expression data is provided!");
+    SHARP_REQUIRE(n_ >= 3 && n_ < (1LL << 31) && m >= 2, "SHARP: need at least 3 cells and 2 genes");
+    const int n = static_cast<int>(n_);
+    if (a.rN_seed != 0.5) SHARP_REQUIRE(std::fmod(a.rN_seed, 1.0) == 0.0, "The rN.seed should be an integer!");   // :169-179
+    int p = a.reduced_ndim > 0 ? a.reduced_ndim : static_cast<int>(std::ceil(std::log2(static_cast<double>(n)) / (0.2 * 0.2)));   // :119-122
+    int base_ncells = a.base_ncells > 0 ? a.base_ncells : 5000;                 // :124-128
+    int part = a.partition_ncells > 0 ? a.partition_ncells : 2000;              // :130-132
+    HcParams base;
+    base.hmethod = a.hmethod > 0 ? a.hmethod : 1;                               // :134-136
+    base.minN = a.minN > 0 ? a.minN : 2;                                        // :139-141
+    base.maxN = a.maxN > 0 ? a.maxN : std::max(40, (n + 4999) / 5000);          // :144-146
+    base.sil_thre = a.sil_thre >= 0 ? a.sil_thre : 0.35;                        // :149-151
+    base.height_Ntimes = a.height_Ntimes > 0 ? a.height_Ntimes : 2.0;           // :154-156
+    int K = a.K;
+    if (a.N_cluster > 0 && n < base_ncells) {                                   // :181-191
+        a.indN = a.N_cluster;
+        base_ncells = (n + 1) / 2;
+        part = (n + 1) / 2;
+        if (K <= 0) K = 15;
+    }
+    if (n < base_ncells) {
+        if (K <= 0) K = 15;                                                     // :254-257
+        SHARP_REQUIRE(n <= kHcMaxN, "SHARP_small: more than 7168 cells in one unpartitioned clustering task");
+        out.path = 0;
+        sharp_small_dev(dX, m, n, ld, a, K, p, base, out);
+    } else {
+        if (K <= 0) K = 5;                                                      // :268-271
+        SHARP_REQUIRE(part >= 3 && part <= kHcMaxN, "partition.ncells must be between 3 and 7168");
+        out.path = 1;
+        sharp_large_dev(dX, m, n, ld, a, K, p, part, base, out);
+    }
+    out.p = p; out.K = K;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SHARP_unlimited pieces (R/SHARP_unlimited.R:29-242)
+// ---------------------------------------------------------------------------------------------
+// one block: y[[i]] = SHARP(mat, reduced.ndim = p, prep = FALSE, logflag = FALSE, rM = rM, ensize.K, rN.seed)
+// (:135) and the colMeans of its viE per predicted cluster -- all sMetaC ever uses of E1 (:163, R/sMetaC.R:58-63)
+void unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int K, double rN_seed,
+                         std::vector<int> &pred, std::vector<double> &means, std::vector<long long> &counts) {
+    SharpArgs a;
+    a.K = K; a.reduced_ndim = p; a.flag = 1; a.projector = projector; a.rN_seed = rN_seed; a.want_viE = true;
+    SharpOut o;
+    sharp_front_dev(dX, m, nb, ld, a, o);
+    pred = o.pred;
+    const int G = o.n_pred;
+    std::vector<int> uid(pred.size());
+    counts.assign(G, 0);
+    for (size_t i = 0; i < pred.size(); ++i) { uid[i] = pred[i] - 1; ++counts[pred[i] - 1]; }   // ids are first-appearance ordered
+    DevBuf<double> dm(static_cast<size_t>(G) * p);
+    cluster_means_dev(o.viE.p, p, static_cast<int>(nb), p, uid, G, dm.p);
+    means.resize(static_cast<size_t>(G) * p);
+    dm.download(means.data(), means.size());
+}
+
+// cross-block sMetaC on the gathered centroids, small-cluster merge and size-ordered relabel (:163-183)
+void unlimited_merge(const double *means, const long long *counts, int nC, int p, long long ncells, int N_cluster, int minN, int maxN,
+                     std::vector<int> &final_id, int &n_final) {
+    HcParams prm;                                                               // hmethod/sil.thre/height.Ntimes of y[[1]]$paras = defaults
+    prm.hmethod = 1; prm.N_cluster = N_cluster;
+    prm.minN = minN > 0 ? minN : 2;                                             // :70-72
+    prm.maxN = maxN > 0 ? maxN : static_cast<int>(std::max<long long>(40, (ncells + 4999) / 5000));   // :75-77
+    prm.sil_thre = 0.35; prm.height_Ntimes = 2.0;
+    DevBuf<double> dm(static_cast<size_t>(nC) * p);
+    dm.upload(means, static_cast<size_t>(nC) * p);
+    SmResult sr = smetac_from_means(dm.p, nC, p, ncells, prm);
+    final_id = sr.tf;
+    int mx = *std::max_element(final_id.begin(), final_id.end());
+    std::vector<long long> cnt(mx + 1, 0);
+    for (int q = 0; q < nC; ++q) cnt[final_id[q]] += counts[q];
+    if (N_cluster <= 0 && ncells > 10000) {                                     // :168-177
+        int mn = -1;
+        for (int q = 1; q <= mx; ++q) if (cnt[q] > 0 && cnt[q] < 10) { mn = q; break; }
+        if (mn >= 0) {
+            for (int &v : final_id) if (cnt[v] < 10) v = mn;
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int q = 0; q < nC; ++q) cnt[final_id[q]] += counts[q];
+        }
+    }
+    // x = sort(table(finalrowColor), decreasing = TRUE): size order, ties in string order of the ids (:180-183)
+    std::vector<int> ids;
+    for (int q = 1; q <= mx; ++q) if (cnt[q] > 0) ids.push_back(q);
+    std::stable_sort(ids.begin(), ids.end(), [&](int x, int y) { return lex_less_id(x, y); });
+    std::stable_sort(ids.begin(), ids.end(), [&](int x, int y) { return cnt[x] > cnt[y]; });
+    std::vector<int> map(mx + 1, 0);
+    for (size_t q = 0; q < ids.size(); ++q) map[ids[q]] = static_cast<int>(q) + 1;
+    for (int &v : final_id) v = map[v];
+    n_final = static_cast<int>(ids.size());
+}
+
+}  // namespace sharp
+
+using namespace sharp;
+
+namespace {
+
+void upload_as_float(const double *X, int m, long long n, long long ld, DevBuf<float> &dX, long long &ldd) {
+    ldd = (static_cast<long long>(m) + 3) / 4 * 4;
+    std::vector<float> h(static_cast<size_t>(ldd) * n, 0.0f);
+    for (long long c = 0; c < n; ++c)
+        for (int g = 0; g < m; ++g) h[c * ldd + g] = static_cast<float>(X[c * ld + g]);
+    dX.alloc(h.size());
+    dX.upload(h.data(), h.size());
+    stream_sync();
+}
+
+}  // namespace
+
+extern "C" {
+
+int sharp_SHARP_dev(const float *dX, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells,
+                    int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
+                    double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred, int *n_pred,
+                    double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path) {
+    int warn = 0;
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(pred, "sharp_SHARP_dev: null output");
+    SharpArgs a;
+    a.K = ensize_K; a.reduced_ndim = reduced_ndim; a.base_ncells = base_ncells; a.partition_ncells = partition_ncells;
+    a.hmethod = hmethod; a.N_cluster = N_cluster; a.enpN = enpN_cluster; a.indN = indN_cluster; a.minN = minN; a.maxN = maxN;
+    a.sil_thre = sil_thre; a.height_Ntimes = height_Ntimes; a.flag = log_flag; a.projector = projector; a.rN_seed = rN_seed;
+    a.want_viE = viE != nullptr; a.want_x0 = x0 != nullptr;
+    SharpOut o;
+    sharp_front_dev(dX, m, n, ld, a, o);
+    warn = o.rc;
+    std::copy(o.pred.begin(), o.pred.end(), pred);
+    if (n_pred) *n_pred = o.n_pred;
+    if (viE) o.viE.download(viE, static_cast<size_t>(n) * o.p);
+    if (x0) {
+        SHARP_REQUIRE(o.x0_cols <= x0_cap_cols, "sharp_SHARP_dev: x0 buffer has too few columns");
+        std::copy(o.x0.begin(), o.x0.end(), x0);
+    }
+    if (x0_cols) *x0_cols = o.x0_cols;
+    if (p_used) *p_used = o.p;
+    if (K_used) *K_used = o.K;
+    if (path) *path = o.path;
+    }
+    catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
+    catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
+    return warn;
+}
+
+int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells,
+                int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
+                double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred, int *n_pred,
+                double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path) {
+    DevBuf<float> dX;
+    long long ldd = 0;
+    try {
+        ctx();
+        if (!X || ld < m || n < 1) throw sharp::Error(SHARP_ERR_ARG, "No expression data is provided!");
+        upload_as_float(X, m, n, ld, dX, ldd);
+    }
+    catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
+    catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
+    return sharp_SHARP_dev(dX.p, m, n, ldd, ensize_K, reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
+                           indN_cluster, minN, maxN, sil_thre, height_Ntimes, log_flag, projector, rN_seed, pred, n_pred, viE, x0,
+                           x0_cap_cols, x0_cols, p_used, K_used, path);
+}
+
+int sharp_unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K, double rN_seed,
+                              int *pred, int *n_clusters, double *means, int cap_rows, long long *counts) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(pred && n_clusters && means && counts, "sharp_unlimited_block_dev: null output");
+    std::vector<int> pr;
+    std::vector<double> mn;
+    std::vector<long long> cn;
+    unlimited_block_dev(dX, m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn);
+    SHARP_REQUIRE(static_cast<int>(cn.size()) <= cap_rows, "sharp_unlimited_block_dev: centroid buffer too small");
+    std::copy(pr.begin(), pr.end(), pred);
+    std::copy(mn.begin(), mn.end(), means);
+    std::copy(cn.begin(), cn.end(), counts);
+    *n_clusters = static_cast<int>(cn.size());
+    SHARP_API_END
+}
+
+int sharp_unlimited_merge(const double *means, const long long *counts, int nC, int p, long long ncells, int N_cluster, int minN,
+                          int maxN, int *final_id, int *n_final) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(means && counts && final_id && n_final, "sharp_unlimited_merge: null argument");
+    std::vector<int> fid;
+    int nf = 0;
+    unlimited_merge(means, counts, nC, p, ncells, N_cluster, minN, maxN, fid, nf);
+    std::copy(fid.begin(), fid.end(), final_id);
+    *n_final = nf;
+    SHARP_API_END
+}
+
+int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                              int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(dX_blocks && ncb && ldb && pred, "The input should be a LIST of partitioned scRNA-seq expression matrices!");
+    SHARP_REQUIRE(nblocks >= 2, "SHARP is used instead of SHARP_unlimited because the length of the input is 1!");
+    if (rN_seed != 0.5) SHARP_REQUIRE(std::fmod(rN_seed, 1.0) == 0.0, "The rN.seed should be an integer!");   // :80-90
+    long long ncells = 0;
+    for (int b = 0; b < nblocks; ++b) ncells += ncb[b];
+    const int p = static_cast<int>(std::ceil(std::log2(static_cast<double>(ncells)) / (0.2 * 0.2)));           // :65-66
+    const int K = ensize_K > 0 ? ensize_K : 5;                                                                 // :92-94
+    std::vector<double> seeds(K);
+    for (int k = 0; k < K; ++k) seeds[k] = (rN_seed == 0.5) ? 0.5 : 50 + rN_seed + (k + 1);                    // :97-104
+    const int proj = register_projector(build_projector(m, p, K, seeds.data()));
+    std::vector<double> means;
+    std::vector<long long> counts;
+    std::vector<int> first(nblocks + 1, 0);
+    long long off = 0;
+    try {
+        for (int b = 0; b < nblocks; ++b) {                                                                    // :125-149
+            std::vector<int> pb;
+            std::vector<double> mb;
+            std::vector<long long> cb;
+            unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb);
+            std::copy(pb.begin(), pb.end(), pred + off);
+            means.insert(means.end(), mb.begin(), mb.end());
+            counts.insert(counts.end(), cb.begin(), cb.end());
+            first[b + 1] = first[b] + static_cast<int>(cb.size());
+            off += ncb[b];
+        }
+    } catch (...) { drop_projector(proj); throw; }
+    drop_projector(proj);
+    std::vector<int> fid;
+    int nf = 0;
+    unlimited_merge(means.data(), counts.data(), first[nblocks], p, ncells, N_cluster, minN, maxN, fid, nf);
+    off = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        for (long long i = 0; i < ncb[b]; ++i) pred[off + i] = fid[first[b] + pred[off + i] - 1];
+        off += ncb[b];
+    }
+    if (n_pred) *n_pred = nf;
+    if (p_used) *p_used = p;
+    SHARP_API_END
+}
+
+int sharp_SHARP_unlimited(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,
+                          int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used) {
+    std::vector<DevBuf<float>> bufs(nblocks > 0 ? nblocks : 0);
+    std::vector<const float *> ptrs;
+    std::vector<long long> lds;
+    try {
+        ctx();
+        if (!X_blocks || !ncb || nblocks < 1) throw sharp::Error(SHARP_ERR_ARG, "No expression data is provided!");
+        for (int b = 0; b < nblocks; ++b) {
+            long long ldd = 0;
+            upload_as_float(X_blocks[b], m, ncb[b], m, bufs[b], ldd);
+            ptrs.push_back(bufs[b].p);
+            lds.push_back(ldd);
+        }
+    }
+    catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
+    catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
+    return sharp_SHARP_unlimited_dev(ptrs.data(), ncb, lds.data(), nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred,
+                                     p_used);
+}
+
+}  // extern "C"

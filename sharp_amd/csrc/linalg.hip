@@ -68,10 +68,13 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_kernel(const GemmTask *__rest
                 const int col = n0 + wc + j * 16 + (lane & 15);
                 if (row < t.M && col < t.N) {
                     double v = acc[i][j][r];
-                    if (t.epilogue == 1) {
+                    if (t.epilogue == 1) {          // correlation distance
                         v = v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v);
                         v = 1.0 - v;
                         if (row == col) v = 0.0;
+                    } else if (t.epilogue == 2) {   // correlation similarity, unit diagonal
+                        v = v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v);
+                        if (row == col) v = 1.0;
                     }
                     t.C[static_cast<long long>(row) * t.ldc + col] = v;
                     if (t.symmetric && n0 > m0) t.C[static_cast<long long>(col) * t.ldc + row] = v;

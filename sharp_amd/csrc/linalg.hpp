@@ -7,7 +7,7 @@ namespace sharp {
 
 // One GEMM of a batch:  C[M x N] (row-major, ldc) = sum_k At[k][0..M) * Bt[k][0..N)
 // At is K x M row-major (lda), Bt is K x N row-major (ldb): both operands are "k-major", so tile
-// staging reads contiguous rows.  epilogue: 0 = store v ; 1 = store 1 - clamp(v, -1, 1)
+// staging reads contiguous rows.  epilogue: 0 = store v ; 1 = store 1 - clamp(v, -1, 1), zero diagonal ; 2 = clamp(v), unit diagonal
 // symmetric: At == Bt and M == N -> only tiles on/above the diagonal are computed and mirrored.
 struct GemmTask {
     const double *At;

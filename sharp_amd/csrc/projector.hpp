@@ -43,6 +43,9 @@ struct Projector {
 constexpr int kMaxCompPerGroup = 12288;
 
 std::shared_ptr<Projector> build_projector(int m, int p, int K, const double *seeds);
+// E[row_map ? row_map[cell] : cell][k*p + c]; d_row_map: optional device array of n output rows (rp.hip)
+void project_dev(const Projector &pr, const float *dX, int m, int n, long long ld, int log_flag, double *dE, long long ldE,
+                 const int *d_row_map);
 int register_projector(std::shared_ptr<Projector> pr);
 std::shared_ptr<Projector> get_projector(int handle);
 void drop_projector(int handle);

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
     const float *__restrict__ X, int m, int n, long long ld, int log_flag, double fix_scale, double inv_fix,
     double val, double out_scale, const uint16_t *__restrict__ ent, const uint32_t *__restrict__ ovf_gene,
     const uint2 *__restrict__ ovf_info, int novf, int ncomp, double *__restrict__ E, long long ldE, int comp0,
-    int nsteps, int step_len, int ablate) {
+    int nsteps, int step_len, int ablate, const int *__restrict__ row_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVE = RP_THREADS / 64;
     constexpr int WCAP = RP_CAP / NWAVE;                                               // slots per wave
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
         }
         __syncthreads();   // every wave's atomics for this cell have landed
         // ---- epilogue: E[cell, comp0 + c] = (1/sqrt(p)) * (sqrt(s) * sum), clear accumulators
-        double *erow = E + cell * ldE + comp0;
+        double *erow = E + (row_map ? static_cast<long long>(row_map[cell]) : cell) * ldE + comp0;
         for (int c = tid; c < ncomp; c += RP_THREADS) {
             const long long a = static_cast<long long>(acc[c]);
             acc[c] = 0ull;
@@ -229,7 +229,7 @@ __global__ void absmax_kernel(const float *__restrict__ X, int m, int n, long lo
 
 template <int GW, bool VEC>
 static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float *dX, int m, int n, long long ld,
-                      int log_flag, int fix_bits, double *dE, long long ldE) {
+                      int log_flag, int fix_bits, double *dE, long long ldE, const int *row_map) {
     Ctx &c = ctx();
     const size_t lds = RP_CAP * sizeof(NzSlot) + static_cast<size_t>(g.ncomp) * 8;
     const int nsteps = (m + RP_STEP - 1) / RP_STEP;
@@ -248,11 +248,12 @@ static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float 
     KernelTimer t("rp_scatter");
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(RP_THREADS), lds, c.stream, dX, m, n, ld, log_flag,
                        fix_scale, inv_fix, pr.val, out_scale, g.ent.p, g.ovf_gene.p, g.ovf_info.p, g.novf, g.ncomp, dE, ldE, g.k0 * pr.p,
-                       nsteps, step_len, ablate);
+                       nsteps, step_len, ablate, row_map);
     launch_check("rp_scatter_kernel");
 }
 
-void project_dev(const Projector &pr, const float *dX, int m, int n, long long ld, int log_flag, double *dE, long long ldE) {
+void project_dev(const Projector &pr, const float *dX, int m, int n, long long ld, int log_flag, double *dE, long long ldE,
+                 const int *d_row_map) {
     SHARP_REQUIRE(m == pr.m, "project: gene count differs from the projector's");
     SHARP_REQUIRE(ld >= m, "project: leading dimension smaller than m");
     SHARP_REQUIRE(ldE >= static_cast<long long>(pr.K) * pr.p, "project: ldE smaller than K*p");
@@ -280,8 +281,8 @@ void project_dev(const Projector &pr, const float *dX, int m, int n, long long l
     for (const auto &g : pr.groups) {
         const int gw = g.gw;
 #define SHARP_RP_CASE(GWV)                                                                          \
-    if (vec) launch_rp<GWV, true>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE);                 \
-    else launch_rp<GWV, false>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE)
+    if (vec) launch_rp<GWV, true>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);      \
+    else launch_rp<GWV, false>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map)
         if (gw == 16) { SHARP_RP_CASE(16); }
         else if (gw == 8) { SHARP_RP_CASE(8); }
         else { SHARP_RP_CASE(4); }
@@ -343,7 +344,7 @@ extern "C" {
 int sharp_project_dev(int proj, const float *dX, int m, int n, long long ld, int log_flag, double *dE, long long ldE) {
     SHARP_API_BEGIN
     auto pr = get_projector(proj);
-    project_dev(*pr, dX, m, n, ld, log_flag, dE, ldE);
+    project_dev(*pr, dX, m, n, ld, log_flag, dE, ldE, nullptr);
     SHARP_API_END
 }
 
@@ -360,7 +361,7 @@ int sharp_project(int proj, const double *X, int m, int n, long long ld, int log
     dX.upload(h.data(), h.size());
     const long long ldE = static_cast<long long>(pr->K) * pr->p;
     DevBuf<double> dE(static_cast<size_t>(ldE) * n);
-    project_dev(*pr, dX.p, m, n, ldd, log_flag, dE.p, ldE);
+    project_dev(*pr, dX.p, m, n, ldd, log_flag, dE.p, ldE, nullptr);
     dE.download(E, static_cast<size_t>(ldE) * n);
     SHARP_API_END
 }

@@ -1,0 +1,129 @@
+"""GPU parity tests for rows a7-a12 (wMetaC, sMetaC, SHARP_small/large/unlimited) against the oracle."""
+import numpy as np
+import pytest
+from sklearn.metrics import adjusted_rand_score
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20261003
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import sharp_amd
+
+    sharp_amd.init(0)
+    return sharp_amd
+
+
+def _noisy_ensemble(rng, N, C, G, flip):
+    base = rng.integers(1, G + 1, N)
+    cols = []
+    for c in range(C):
+        col = (base + c) % G + 1          # renamed copy of the same partition
+        f = rng.random(N) < flip
+        col[f] = rng.integers(1, G + 1, f.sum())
+        cols.append(col)
+    return base, np.stack(cols, 1)
+
+
+@pytest.mark.parametrize("N,C,G,flip", [(400, 5, 6, 0.05), (1200, 15, 9, 0.15), (300, 3, 4, 0.0)])
+def test_wmetac_stages_match_oracle(sa, oracle, N, C, G, flip):
+    rng = np.random.default_rng(N + C)
+    base, nC = _noisy_ensemble(rng, N, C, G, flip)
+    ref = oracle.wMetaC(nC, sil_thre=0.35)
+    res = sa.wMetaC(nC, sil_thre=0.35, debug=True)
+    assert res["allC"] == ref["allC"]
+    np.testing.assert_allclose(res["w1"], ref["w1"], rtol=1e-13)
+    np.testing.assert_allclose(res["S"], ref["S"], rtol=1e-12, atol=1e-15)
+    assert np.array_equal(res["S"] == 1.0, ref["S"] == 1.0)      # identical clusters -> exactly 1
+    assert res["S"].max() <= 1.0
+    assert np.array_equal(res["tf"], ref["tf"])
+    assert np.array_equal(res["finalC"], ref["finalC"])
+    np.testing.assert_allclose(res["x0"], ref["x0"], atol=1e-15)
+
+
+def test_wmetac_string_labels_and_vote_tie_break(sa, oracle):
+    # colour-name labels as the reference passes them; a 2-way tie goes to the id whose string sorts first
+    names = np.array(["red", "purple", "blue", "yellow"])
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 4, 200)
+    nC = np.stack([names[base], names[(base + 1) % 4], names[base], names[(base + 2) % 4]], 1)
+    res = sa.wMetaC(nC, sil_thre=0.35)
+    assert adjusted_rand_score(base, res["finalC"]) == 1.0
+
+
+def test_smetac_matches_oracle(sa, oracle):
+    rng = np.random.default_rng(11)
+    n, p, G = 3000, 120, 5
+    truth = rng.integers(0, G, n)
+    centers = rng.normal(size=(G, p)) * 2
+    E = centers[truth] + rng.normal(size=(n, p))
+    # 4 folds, each with its own (over-segmented) cluster ids
+    fold = np.repeat(np.arange(4), n // 4)
+    sub = rng.integers(0, 2, n)
+    labels = fold * 65536 + truth * 2 + sub + 1
+    ref = oracle.sMetaC(labels, E)
+    res = sa.sMetaC(labels, E)
+    assert np.array_equal(res["tf"], ref["tf"])
+    assert np.array_equal(res["finalColor"], ref["finalColor"])
+    assert adjusted_rand_score(truth, res["finalColor"]) > 0.99
+
+
+def test_sharp_small_matches_oracle(sa, oracle):
+    m, n, G, nm = 2000, 300, 6, 200
+    X = oracle.synth_fill(SEED, m, 0, n, G, nm)
+    ref = oracle.SHARP(X, K=5, rN_seed=2103)
+    res = sa.SHARP(X, ensize_K=5, rN_seed=2103, logflag=False, prep=False)
+    assert res["path"] == "SHARP_small" and res["reduced.dim"] == ref["p"]
+    assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])      # identical integer labels
+    np.testing.assert_allclose(res["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
+    s = oracle.SHARP_small(X, K=5, rN_seed=2103)
+    np.testing.assert_allclose(res["x0"], s["x0"], atol=1e-15)
+    # the explicit SHARP_small entry point and the N.cluster-given variant
+    r2 = sa.SHARP_small(X, ensize_K=5, rN_seed=2103)
+    assert np.array_equal(r2["pred_clusters"], ref["pred_clusters"])
+
+
+def test_sharp_large_matches_oracle(sa, oracle):
+    # the SHARP_large path at reduced fold size: shuffle (set.seed(50); sample(n)), 5 folds with the last two
+    # rebalanced, K*T tasks, per-fold wMetaC, cross-fold sMetaC, un-shuffle
+    m, n, G, nm = 3000, 900, 6, 300
+    X = oracle.synth_fill(SEED, m, 0, n, G, nm)
+    truth = oracle.synth_cluster(SEED, range(n), G)
+    ref = oracle.SHARP(X, K=5, base_ncells=300, partition_ncells=200, rN_seed=2103, nthreads=4)
+    res = sa.SHARP(X, ensize_K=5, base_ncells=300, partition_ncells=200, rN_seed=2103, logflag=False, prep=False)
+    assert res["path"] == "SHARP_large"
+    ari = adjusted_rand_score(ref["pred_clusters"], res["pred_clusters"])
+    assert ari >= 0.99, ari
+    assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+    np.testing.assert_allclose(res["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
+    assert res["x0"].shape[0] == n and np.all(res["x0"].max(1) >= 1.0)
+    assert adjusted_rand_score(truth, res["pred_clusters"]) > 0.5
+
+
+def test_sharp_unlimited_matches_oracle(sa, oracle):
+    m, G, nm = 3000, 6, 300
+    blocks = [oracle.synth_fill(SEED, m, i * 6000, 6000, G, nm) for i in range(2)]
+    truth = oracle.synth_cluster(SEED, range(12000), G)
+    ref = oracle.SHARP_unlimited(blocks, rN_seed=2103, nthreads=8)
+    res = sa.SHARP_unlimited(blocks, rN_seed=2103)
+    ari = adjusted_rand_score(ref["pred_clusters"], res["pred_clusters"])
+    assert ari >= 0.99, ari
+    assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+    # ids ordered by decreasing cluster size (R/SHARP_unlimited.R:180-183)
+    sizes = np.bincount(res["pred_clusters"])[1:]
+    assert np.all(np.diff(sizes) <= 0)
+    assert adjusted_rand_score(truth, res["pred_clusters"]) > 0.9
+
+
+def test_reference_error_behaviour(sa, oracle):
+    X = oracle.synth_fill(SEED, 500, 0, 50, 3, 100)
+    with pytest.raises(sa.SharpError, match="rN.seed should be an integer"):
+        sa.SHARP(X, rN_seed=1.5)
+    with pytest.raises(sa.SharpError, match="numeric"):
+        sa.SHARP(X, rN_seed="a")
+    with pytest.raises(sa.SharpError, match="No expression data"):
+        sa.SHARP(None)
+    with pytest.raises(sa.SharpError, match="LIST"):
+        sa.SHARP_unlimited("nope")
