@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cells/sec, end-to-end SHARP (fixed genes, n.RP) on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+`python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU, RCCL).  W untimed warm-up
+steps, then exactly K timed steps bracketed by barrier + device synchronisation on both sides, MAX over
+ranks, rank 0 prints ONE JSON line.
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+  N = 1 : BASELINE.json configs[1]: one SHARP() call on 50 000 cells x 20 000 genes, ensize.K = 15
+          (SHARP_large: projectors, RP matmul, 375 base-clustering tasks, 25 wMetaC, sMetaC).
+  N > 1 : SHARP_unlimited with one such block per GPU (same per-GPU work: weak scaling); the only
+          data-path collective is the all-gather of the per-block centroid table before the final sMetaC.
+The JSON carries `roofline` for the RP scatter kernel (HBM-bound; algorithmic bytes per SURVEY.md 8d) with
+the kernel's duration measured live by HIP events on the library's stream, and `cpu_baseline`: the fp64 CPU
+oracle (a port of the reference's R path, not R itself) timed on the host cores on a bounded sample."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DATA_SEED = 20261003
+RN_SEED = 2103
+M_GENES = 20000
+CELLS_PER_GPU = 50000
+K_RP = 15
+G_TRUE, N_MARK = 12, 1000
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=CELLS_PER_GPU, help="cells per GPU (default: the configs[1] size)")
+    ap.add_argument("--genes", type=int, default=M_GENES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import sharp_amd
+    from sharp_amd import device as dev
+    from sharp_amd import dist as sdist
+
+    sharp_amd.init(local_rank)
+    n, m = args.cells, args.genes
+
+    # ---- synthetic block of this rank, generated on the device (counter-based: identical on CPU and GPU)
+    dX = torch.empty((n, m), dtype=torch.float32, device="cuda")
+    dev.synth_fill(dX, DATA_SEED, rank * n, G_TRUE, N_MARK)
+    truth = dev.synth_labels(DATA_SEED, rank * n, n, G_TRUE)
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        sharp_amd.lib().sharp_synchronize()
+
+    ncb = [n] * world
+    state = {}
+
+    def step():
+        if world == 1:
+            pred, info = dev.SHARP_dev(dX, ensize_K=K_RP, rN_seed=RN_SEED)
+            state["p"], state["pred"], state["n_clusters"] = info["reduced.dim"], pred, info["N.pred_cluster"]
+        else:
+            p = sdist.global_reduced_dim(n * world)
+            proj = sharp_amd.Projector(m, p, [50 + RN_SEED + k for k in range(1, K_RP + 1)])
+
+            def run_block(blk, p_):
+                return dev.unlimited_block_dev(blk, p_, proj.handle, K_RP, RN_SEED)
+
+            out, nfin, p = sdist.unlimited_sharded([dX], [rank], ncb, run_block, dev.unlimited_merge, device="cuda")
+            proj.close()
+            state["p"], state["pred"], state["n_clusters"] = p, out[rank], nfin
+
+    for _ in range(args.warmup):
+        step()
+    dev.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = dev.profile_table()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    cells_per_s = n * world * args.steps / dt
+
+    if rank == 0:
+        p = state["p"]
+        rp_ms, rp_calls = prof.get("rp_scatter", (0.0, 0))
+        rp_avg_s = rp_ms / max(rp_calls, 1) * 1e-3
+        alg_bytes = n * (m * 4 + K_RP * p * 4)          # read m*4 B of X once + write K*p*4 B of E per cell
+        roof = None
+        if rp_calls:
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "rp_traffic.json")
+            if os.path.exists(tf) and n == CELLS_PER_GPU and m == M_GENES:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            ach = alg_bytes / rp_avg_s / 1e9
+            roof = {"kernel": "rp_scatter_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(ach / 8000.0, 4), "traffic": traffic, "launch_ms": round(rp_avg_s * 1e3, 4),
+                    "algorithmic_bytes": alg_bytes, "read_only_frac": round(n * m * 4 / rp_avg_s / 8e12, 4)}
+        stages = {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        from sharp_amd.api import ARI
+
+        result = {
+            "metric": "cells/sec end-to-end SHARP (fixed genes, n.RP); ARI vs reference labels",
+            "value": round(cells_per_s, 1), "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("SHARP() on synthetic %d cells x %d genes, ensize.K=%d, SHARP_large path, rN.seed=%d"
+                                    % (n, m, K_RP, RN_SEED)) if world == 1 else
+                                   ("SHARP_unlimited, %d blocks of %d cells x %d genes (one per GPU), ensize.K=%d, rN.seed=%d"
+                                    % (world, n, m, K_RP, RN_SEED)),
+                       "cells_per_gpu": n, "genes": m, "n_RP": K_RP, "reduced_dim": p, "x_storage": "fp32 in HBM",
+                       "parallelism": "1 block per GPU" if world > 1 else "single GPU"},
+            "roofline": roof,
+            "kernel_ms_per_step": stages,
+            "clusters_found": int(state["n_clusters"]),
+            "ari_vs_planted_truth": round(float(ARI(truth, state["pred"])["HA"]), 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"], result["parity"] = cpu_baseline(np, dX, m)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(np, dX, m):
+    """The oracle (CPU port of the reference path) on a bounded sample of the same workload, on the host
+    cores of this box; plus the GPU-vs-oracle label agreement on that sample."""
+    from oracle import pyoracle as orc
+    from sharp_amd import device as dev
+    from sharp_amd.api import ARI
+
+    orc.build()
+    cores = os.cpu_count() or 1
+    ns = 4000                                          # 2 folds x 15 projections = 30 base-clustering tasks
+    Xs = dX[:ns].cpu().numpy().T.astype(np.float64)    # (genes, cells)
+    t0 = time.perf_counter()
+    ref = orc.SHARP(Xs, K=K_RP, base_ncells=1, rN_seed=RN_SEED, nthreads=cores, want_view=False)
+    t = time.perf_counter() - t0
+    pred, _ = dev.SHARP_dev(dX[:ns], ensize_K=K_RP, base_ncells=1, rN_seed=RN_SEED)
+    ari = float(ARI(ref["pred_clusters"], pred)["HA"])
+    base = {"value": round(ns / t, 2), "unit": "cells/s", "cores": cores, "kind": "port",
+            "sample": "oracle SHARP_large on the first %d cells x %d genes of the same data (2 folds x %d RPs, OpenMP over "
+                      "the K*T task grid), %.1f s" % (ns, m, K_RP, t)}
+    return base, {"ari_gpu_vs_oracle_on_sample": round(ari, 4), "sample_cells": ns}
+
+
+if __name__ == "__main__":
+    main()

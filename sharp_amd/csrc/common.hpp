@@ -79,6 +79,15 @@ struct KernelTimer {
     ~KernelTimer();
 };
 
+// Wall-clock time of a host-side section, reported through the same table with a "host:" prefix.
+struct HostTimer {
+    const char *name;
+    double t0;
+    bool on;
+    explicit HostTimer(const char *n);
+    ~HostTimer();
+};
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;

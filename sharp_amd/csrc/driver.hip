@@ -133,6 +133,7 @@ static std::vector<int> fold_starts(int n, int ng) {
 // SHARP_large (R/SHARP.R:478-851)
 // ---------------------------------------------------------------------------------------------
 void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, int ng, HcParams base, SharpOut &out) {
+    HostTimer ht_all("sharp_large_total");
     const bool shuffle = n < 100000;                                            // :504-507
     std::vector<int> reind;                                                     // shuffled position i holds cell reind[i]-1
     std::vector<int> pos(n);                                                    // cell -> shuffled position
@@ -145,9 +146,11 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
     }
     const std::vector<int> fst = fold_starts(n, ng);
     const int T = static_cast<int>(fst.size()) - 1;
-    auto pr = projector_for(a, m, p, K);                                        // :539-549
+    std::shared_ptr<Projector> pr;
+    { HostTimer ht("projector_build"); pr = projector_for(a, m, p, K); }         // :539-549
     const long long ldE = static_cast<long long>(pr->K) * p;
-    DevBuf<double> E(static_cast<size_t>(n) * ldE);
+    DevBuf<double> E;
+    { HostTimer ht("alloc_E"); E.alloc(static_cast<size_t>(n) * ldE); }
     DevBuf<int> dpos;
     if (shuffle) { dpos.alloc(n); dpos.upload(pos.data(), n); }
     // E rows are written straight into shuffled order, so fold t is the contiguous row range [fst[t], fst[t+1])
@@ -162,7 +165,7 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
             tk.ld = ldE; tk.n = fst[t + 1] - fst[t]; tk.p = p; tk.prm = bp;
         }
     std::vector<HcResult> hr;
-    get_opt_hclust_batch(tasks, false, hr);
+    { HostTimer ht("base_clustering_total"); get_opt_hclust_batch(tasks, false, hr); }
     // enrp per fold (:627-635); labels "<colour>p<t>" only need to be distinct per (k, t): the colour id does
     std::vector<std::vector<int>> enrp(T);
     for (int t = 0; t < T; ++t) {
@@ -183,7 +186,7 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
         wts[t].prm = base; wts[t].prm.N_cluster = a.enpN;
     }
     std::vector<WmResult> wr;
-    wmetac_batch(wts, a.want_x0, false, wr);
+    { HostTimer ht("wmetac_total"); wmetac_batch(wts, a.want_x0, false, wr); }
     std::vector<int> Slab(n);                                                   // SrowColor in shuffled order
     std::vector<int> stf;                                                       // meta id per (fold, cluster) column of sx0
     std::vector<int> uid(n);
@@ -207,7 +210,8 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
         DevBuf<double> means(static_cast<size_t>(nCu) * p);
         cluster_means_dev(viE_sh.p, p, n, p, uid, nCu, means.p);                // sMetaC :58-63 on E1 = enE/K
         HcParams sp = base; sp.N_cluster = a.N_cluster;
-        SmResult sr = smetac_from_means(means.p, nCu, p, n, sp);               // :754
+        SmResult sr;
+        { HostTimer ht("smetac_total"); sr = smetac_from_means(means.p, nCu, p, n, sp); }   // :754
         out.rc |= sr.rc;
         stf = sr.tf;
         for (int i = 0; i < n; ++i) Slab[i] = stf[uid[i]];

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -28,7 +29,7 @@ struct HcMeta {
     long long oOut;           // msil[nk] then CH[nk]
 };
 
-constexpr int HC_THREADS = 1024;
+constexpr int HC_THREADS = 512;
 constexpr double HC_INF = 1.0e300;
 
 struct MinPair { double v; int i; };
@@ -79,7 +80,7 @@ __device__ __forceinline__ double lance_williams(int method, double d1, double d
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HC_THREADS) void hclust_kernel(const HcMeta *__restrict__ metas, double *__restrict__ Dall,
                                                             int *__restrict__ ia_all, int *__restrict__ ib_all,
-                                                            double *__restrict__ h_all) {
+                                                            double *__restrict__ h_all, int ablate) {
     const HcMeta M = metas[blockIdx.x];
     const int n = M.n, nld = M.nld, method = M.method;
     double *D = Dall + M.oD;
@@ -115,56 +116,77 @@ __global__ __launch_bounds__(HC_THREADS) void hclust_kernel(const HcMeta *__rest
     }
     __syncthreads();
 
+    // Four workgroup barriers per merge: the two block reductions use alternating scratch so that no
+    // "scratch is free again" barrier is needed, the merged pair's bookkeeping is done by the thread that
+    // owns index i2 right before it looks at its own entries, and d(i2,j2) is the NN distance just found.
+    double *pvB = reinterpret_cast<double *>(flag + ((n + 7) & ~7));
+    int *piB = reinterpret_cast<int *>(pvB + 32);
     for (int step = 0; step < n - 1; ++step) {
         // (1) least dissimilarity over the NN list (strict <, lowest index)
         MinPair b; b.v = HC_INF; b.i = 0x7fffffff;
         for (int i = tid; i < n - 1; i += HC_THREADS)
             if (flag[i]) { MinPair c; c.v = disnn[i]; c.i = i; if (c.v < b.v) b = c; }
         b = mp_block(b, pv, pi);
-        const int im = b.i < n ? b.i : 0;
-        const int jm = nn[im];
-        const int i2 = im < jm ? im : jm, j2 = im < jm ? jm : im;
-        const double d12 = D[static_cast<long long>(i2) * nld + j2];
+        const int i2 = b.i < n ? b.i : 0;       // NN lists look to the right, so im < nn[im]
+        const int j2 = nn[i2];
+        const double d12 = b.v;                  // DISNN(im) == D(im, NN(im)) is an invariant of the algorithm
         const double mi = membr[i2], mj = membr[j2];
-        __syncthreads();                       // everyone has read nn/membr/pv before they change
         if (tid == 0) {
             ia[step] = i2 + 1; ib[step] = j2 + 1;
             crit[step] = method == 8 ? sqrt(b.v) : b.v;
-            flag[j2] = 0;
             *cnt = 0;
         }
-        __syncthreads();
         // (2) Lance-Williams update of row/column i2; new NN of i2 among k > i2
         MinPair nb; nb.v = HC_INF; nb.i = 0x7fffffff;
         const double *ri = D + static_cast<long long>(i2) * nld, *rj = D + static_cast<long long>(j2) * nld;
-        for (int k = tid; k < n; k += HC_THREADS) {
-            if (flag[k] && k != i2) {
-                const double dn = lance_williams(method, ri[k], rj[k], d12, mi, mj, static_cast<double>(membr[k]));
-                D[static_cast<long long>(i2) * nld + k] = dn;
-                D[static_cast<long long>(k) * nld + i2] = dn;
-                if (i2 < k) { if (dn < nb.v) { nb.v = dn; nb.i = k; } }
-                else if (dn < disnn[k]) { disnn[k] = dn; nn[k] = i2; }
+        // loads are issued unconditionally and in batches: a load under a data-dependent branch would make
+        // every iteration a separate dependent HBM round trip
+        for (int k0 = tid; k0 < n; k0 += 4 * HC_THREADS) {
+            double a1[4], a2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * HC_THREADS;
+                const int kk = k < n ? k : n - 1;
+                a1[u] = ri[kk]; a2[u] = rj[kk];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * HC_THREADS;
+                if (k < n && k != i2 && k != j2 && flag[k]) {
+                    const double dn = lance_williams(method, a1[u], a2[u], d12, mi, mj, static_cast<double>(membr[k]));
+                    D[static_cast<long long>(i2) * nld + k] = dn;
+                    if (!(ablate & 1)) D[static_cast<long long>(k) * nld + i2] = dn;
+                    if (i2 < k) { if (dn < nb.v) { nb.v = dn; nb.i = k; } }
+                    else if (dn < disnn[k]) { disnn[k] = dn; nn[k] = i2; }
+                }
             }
         }
-        nb = mp_block(nb, pv, pi);
-        __syncthreads();
-        if (tid == 0) {
+        nb = mp_block(nb, pvB, piB);
+        if (tid == (i2 % HC_THREADS)) {          // owner of i2: merge bookkeeping before it scans its own entries
             membr[i2] = membr[i2] + membr[j2];
             disnn[i2] = nb.v;
             if (nb.i < n) nn[i2] = nb.i;
         }
-        __syncthreads();
+        if (tid == (j2 % HC_THREADS)) flag[j2] = 0;
         // (3) rows whose nearest neighbour was i2 or j2 look again to their right
         for (int i = tid; i < n - 1; i += HC_THREADS)
-            if (flag[i] && (nn[i] == i2 || nn[i] == j2)) list[atomicAdd(cnt, 1)] = i;
+            if (i != j2 && flag[i] && (nn[i] == i2 || nn[i] == j2)) list[atomicAdd(cnt, 1)] = i;
         __syncthreads();
-        const int nl = *cnt;
+        const int nl = (ablate & 2) ? 0 : *cnt;
         for (int q = wave; q < nl; q += nwave) {
             const int i = list[q];
             const double *row = D + static_cast<long long>(i) * nld;
             MinPair c; c.v = HC_INF; c.i = 0x7fffffff;
-            for (int j = i + 1 + lane; j < n; j += 64)
-                if (flag[j]) { const double d = row[j]; if (d < c.v) { c.v = d; c.i = j; } }
+            for (int j0 = i + 1 + lane; j0 < n; j0 += 64 * 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int j = j0 + 64 * u; v[u] = row[j < n ? j : n - 1]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int j = j0 + 64 * u;
+                    if (j < n && flag[j] && v[u] < c.v) { c.v = v[u]; c.i = j; }
+                }
+            }
             c = mp_wave(c);
             if (lane == 0) { disnn[i] = c.v; if (c.i < n) nn[i] = c.i; }
         }
@@ -469,10 +491,12 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
         max_kpad = std::max(max_kpad, M.kpad);
         any_sym |= tk.symmetric; any_feat |= !tk.symmetric;
     }
+    { HostTimer ht("hc_workspace_alloc");
     W.D.ensure(oD); W.D0.ensure(std::max<long long>(oD0, 1)); W.Cr.ensure(oCr); W.Ct.ensure(oCt); W.nrm.ensure(oN);
     W.height.ensure(oM); W.ia.ensure(oM); W.ib.ensure(oM); W.lab.ensure(oLab);
-    W.H.ensure(oK); W.T.ensure(oK); W.G.ensure(oK); W.CSt.ensure(oCS); W.Q.ensure(oQ); W.out.ensure(oOut);
-    W.meta.ensure(T); W.prep.ensure(T); W.gemm.ensure(5 * static_cast<size_t>(T));
+    W.H.ensure(oK); W.T.ensure(oK); W.G.ensure(oK); W.CSt.ensure(oCS); W.Q.ensure(oQ); W.out.ensure(oOut); }
+    { HostTimer ht("hc_workspace_alloc");
+    W.meta.ensure(T); W.prep.ensure(T); W.gemm.ensure(5 * static_cast<size_t>(T)); }
     W.meta.upload(metas.data(), T);
 
     // a3: rows -> centred/normalised (+ 1 - S for similarity input)
@@ -505,11 +529,13 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
     // a4: agglomeration
     {
         const int nal = (max_n + 1) & ~1;
-        const size_t lds = static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16;
+        const size_t lds = static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16 + 32 * 12 + 16;
         SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             static_cast<int>(lds)));
         KernelTimer tm("hclust");
-        hipLaunchKernelGGL(hclust_kernel, dim3(T), dim3(HC_THREADS), lds, c.stream, W.meta.p, W.D.p, W.ia.p, W.ib.p, W.height.p);
+        const char *abl = getenv("SHARP_HC_ABLATE");
+        hipLaunchKernelGGL(hclust_kernel, dim3(T), dim3(HC_THREADS), lds, c.stream, W.meta.p, W.D.p, W.ia.p, W.ib.p, W.height.p,
+                           abl ? atoi(abl) : 0);
         launch_check("hclust_kernel");
     }
     // a5a: labels for every candidate k
@@ -572,6 +598,7 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
         launch_check("stats_kernel");
     }
     std::vector<double> h_out(oOut), h_height(oM);
+    HostTimer ht_tail("hc_download_select");
     W.out.download(h_out.data(), oOut);
     W.height.download(h_height.data(), oM);
     // model selection on the host (a few dozen numbers per task)

@@ -231,6 +231,7 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
         W.S.download(h_S.data(), oS);
     }
     // per-cell vote and soft matrix on the host
+    HostTimer ht_vote("wmetac_vote");
     for (int t = 0; t < T; ++t) {
         const WmTask &tk = tasks[t];
         WmResult &R = out[t];

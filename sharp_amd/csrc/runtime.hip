@@ -1,5 +1,6 @@
 // runtime.hip -- context, error string, profiling and device-memory helpers of the C ABI.
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <sstream>
 
@@ -58,6 +59,23 @@ KernelTimer::~KernelTimer() {
     if (c.pending.size() > 4096) {
         try { c.resolve_pending(); } catch (...) {}
     }
+}
+
+static double now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+HostTimer::HostTimer(const char *n) : name(n), t0(0), on(false) {
+    Ctx &c = ctx_unchecked();
+    if (c.ready && c.profiling) { on = true; t0 = now_s(); }
+}
+HostTimer::~HostTimer() {
+    if (!on) return;
+    Ctx &c = ctx_unchecked();
+    auto &s = c.stats[std::string("host:") + name];
+    s.ms += (now_s() - t0) * 1e3;
+    s.launches += 1;
 }
 
 }  // namespace sharp

@@ -1,0 +1,93 @@
+"""Device-resident entry points: the expression blocks already live in HBM (fp32, genes x cells,
+column-major = a torch tensor of shape (cells, genes)).  PyTorch is only the allocator here; all
+compute runs in libsharp_hip.so on its own stream (synchronise torch before handing a tensor over)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def synth_fill(dX, seed, cell0, G=12, nmark=1000):
+    """Fill a (cells, genes) float32 cuda tensor with the counter-based synthetic counts."""
+    _lib.ensure_init()
+    ncell, m = dX.shape
+    assert dX.is_contiguous() and str(dX.dtype) == "torch.float32"
+    check(lib().sharp_synth_fill_dev(C.c_uint(seed), m, C.c_longlong(cell0), ncell, G, nmark, C.c_void_p(dX.data_ptr()),
+                                     C.c_longlong(m)))
+    check(lib().sharp_synchronize())
+
+
+def synth_labels(seed, cell0, ncell, G=12):
+    out = np.zeros(ncell, np.int32)
+    check(lib().sharp_synth_labels(C.c_uint(seed), C.c_longlong(cell0), ncell, G, _ip(out)))
+    return out
+
+
+def SHARP_dev(dX, ensize_K=0, reduced_ndim=0, base_ncells=0, partition_ncells=0, hmethod=1, N_cluster=0, enpN_cluster=0,
+              indN_cluster=0, minN_cluster=0, maxN_cluster=0, sil_thre=-1.0, height_Ntimes=0.0, flag=True, projector=0,
+              rN_seed=0.5):
+    """SHARP() (R/SHARP.R:44-318) on a resident block; returns (pred_clusters, info)."""
+    _lib.ensure_init()
+    n, m = dX.shape
+    pred = np.zeros(n, np.int32)
+    npred, pu, Ku, path = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = check(lib().sharp_SHARP_dev(C.c_void_p(dX.data_ptr()), m, C.c_longlong(n), C.c_longlong(dX.stride(0)), ensize_K,
+                                     reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
+                                     indN_cluster, minN_cluster, maxN_cluster, C.c_double(sil_thre), C.c_double(height_Ntimes),
+                                     int(bool(flag)), projector, C.c_double(rN_seed), _ip(pred), C.byref(npred), None, None, 0,
+                                     None, C.byref(pu), C.byref(Ku), C.byref(path)), allow=48)
+    return pred, {"N.pred_cluster": npred.value, "reduced.dim": pu.value, "ensize.K": Ku.value,
+                  "path": "SHARP_large" if path.value else "SHARP_small", "warn": rc}
+
+
+def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096):
+    """One block of SHARP_unlimited: labels, per-cluster means of viE (G x p) and cluster sizes."""
+    _lib.ensure_init()
+    nb, m = dX.shape
+    pred = np.zeros(nb, np.int32)
+    means = np.zeros((cap_rows, p))
+    counts = np.zeros(cap_rows, np.int64)
+    G = C.c_int()
+    check(lib().sharp_unlimited_block_dev(C.c_void_p(dX.data_ptr()), m, C.c_longlong(nb), C.c_longlong(dX.stride(0)), p,
+                                          projector, ensize_K, C.c_double(rN_seed), _ip(pred), C.byref(G), _dp(means), cap_rows,
+                                          counts.ctypes.data_as(C.POINTER(C.c_longlong))))
+    return pred, means[: G.value].copy(), counts[: G.value].copy()
+
+
+def unlimited_merge(means, counts, ncells, N_cluster=0, minN_cluster=0, maxN_cluster=0):
+    """Cross-block sMetaC on gathered centroids -> final 1-based id per (block, cluster) row."""
+    _lib.ensure_init()
+    means = np.ascontiguousarray(means, np.float64)
+    counts = np.ascontiguousarray(counts, np.int64)
+    nC, p = means.shape
+    fid = np.zeros(nC, np.int32)
+    nf = C.c_int()
+    check(lib().sharp_unlimited_merge(_dp(means), counts.ctypes.data_as(C.POINTER(C.c_longlong)), nC, p, C.c_longlong(ncells),
+                                      N_cluster, minN_cluster, maxN_cluster, _ip(fid), C.byref(nf)))
+    return fid, nf.value
+
+
+def profile(enable=True):
+    _lib.ensure_init()
+    check(lib().sharp_profile_enable(1 if enable else 0))
+    check(lib().sharp_profile_reset())
+
+
+def profile_table():
+    buf = C.create_string_buffer(1 << 16)
+    check(lib().sharp_profile_dump(buf, len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, ms, cnt = line.split()
+        out[name] = (float(ms), int(cnt))
+    return out
