@@ -479,7 +479,7 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
         M.oD = oD; oD += static_cast<long long>(M.nld) * M.nld;
         M.oD0 = oD0; if (M.symmetric) oD0 += static_cast<long long>(M.nld) * M.nld;
         M.oCr = oCr; oCr += static_cast<long long>(M.n) * M.p;
-        M.oCt = oCt; oCt += static_cast<long long>(M.p) * M.nld;
+        M.oCt = oCt; oCt += rup(M.p, 16) * M.nld;
         M.oNrm = oN; oN += M.n;
         M.oM = oM; oM += M.n;
         M.oLab = oLab; oLab += static_cast<long long>(M.nk) * M.n;
@@ -504,8 +504,8 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
     for (int t = 0; t < T; ++t) {
         const HcTask &tk = tasks[i0 + t];
         const HcMeta &M = metas[t];
-        prep[t] = RowPrepTask{tk.d_mat, tk.ld, M.n, M.p, M.nld, M.symmetric, W.Cr.p + M.oCr, W.Ct.p + M.oCt, W.nrm.p + M.oNrm,
-                              W.D.p + M.oD};
+        prep[t] = RowPrepTask{tk.d_mat, tk.ld, M.n, M.p, M.nld, static_cast<int>(rup(M.p, 16)), M.symmetric, W.Cr.p + M.oCr,
+                              W.Ct.p + M.oCt, W.nrm.p + M.oNrm, W.D.p + M.oD};
     }
     W.prep.upload(prep.data(), T);
     row_prep_batched(W.prep.p, T, max_n, max_p);
@@ -515,10 +515,10 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
         for (int t = 0; t < T; ++t) {
             const HcMeta &M = metas[t];
             if (M.symmetric) continue;
-            g.push_back(GemmTask{W.Ct.p + M.oCt, W.Ct.p + M.oCt, W.D.p + M.oD, M.n, M.n, M.p, M.nld, M.nld, M.nld, 1, 1});
+            g.push_back(GemmTask{W.Ct.p + M.oCt, W.Ct.p + M.oCt, W.D.p + M.oD, M.n, M.n, M.p, M.nld, M.nld, M.nld, 1, 1, 1});
         }
         W.gemm.upload(g.data(), g.size());
-        gemm_tn_f64_batched(W.gemm.p, static_cast<int>(g.size()), max_n, max_n, "corr_dist_gemm");
+        gemm_tn_f64_batched(W.gemm.p, static_cast<int>(g.size()), max_n, max_n, "corr_dist_gemm", true);
         stream_sync();   // W.gemm is reused below
     }
     if (any_sym) {
@@ -562,19 +562,19 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
     g.clear();
     for (int t = 0; t < T; ++t) {
         const HcMeta &M = metas[t];
-        g.push_back(GemmTask{W.Cr.p + M.oCr, W.H.p + M.oH, W.CSt.p + M.oCSt, M.p, M.kpad, M.n, M.p, M.kpad, M.kpad, 0, 0});
+        g.push_back(GemmTask{W.Cr.p + M.oCr, W.H.p + M.oH, W.CSt.p + M.oCSt, M.p, M.kpad, M.n, M.p, M.kpad, M.kpad, 0, 0, 0});
     }
     run_gemms("cluster_sums_gemm", max_p, max_kpad);
     g.clear();
     for (int t = 0; t < T; ++t) {
         const HcMeta &M = metas[t];
-        g.push_back(GemmTask{W.Ct.p + M.oCt, W.CSt.p + M.oCSt, W.G.p + M.oG, M.n, M.kpad, M.p, M.nld, M.kpad, M.kpad, 0, 0});
+        g.push_back(GemmTask{W.Ct.p + M.oCt, W.CSt.p + M.oCSt, W.G.p + M.oG, M.n, M.kpad, M.p, M.nld, M.kpad, M.kpad, 0, 0, 0});
     }
     run_gemms("row_cluster_dot_gemm", max_n, max_kpad);
     g.clear();
     for (int t = 0; t < T; ++t) {
         const HcMeta &M = metas[t];
-        g.push_back(GemmTask{W.CSt.p + M.oCSt, W.CSt.p + M.oCSt, W.Q.p + M.oQ, M.kpad, M.kpad, M.p, M.kpad, M.kpad, M.kpad, 0, 0});
+        g.push_back(GemmTask{W.CSt.p + M.oCSt, W.CSt.p + M.oCSt, W.Q.p + M.oQ, M.kpad, M.kpad, M.p, M.kpad, M.kpad, M.kpad, 0, 0, 0});
     }
     run_gemms("cluster_gram_gemm", max_kpad, max_kpad);
     if (any_sym) {
@@ -582,7 +582,7 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
         for (int t = 0; t < T; ++t) {
             const HcMeta &M = metas[t];
             if (!M.symmetric) continue;
-            g.push_back(GemmTask{W.D0.p + M.oD0, W.H.p + M.oH, W.T.p + M.oT, M.n, M.kpad, M.n, M.nld, M.kpad, M.kpad, 0, 0});
+            g.push_back(GemmTask{W.D0.p + M.oD0, W.H.p + M.oH, W.T.p + M.oT, M.n, M.kpad, M.n, M.nld, M.kpad, M.kpad, 0, 0, 0});
         }
         run_gemms("dist_cluster_sums_gemm", max_n, max_kpad);
     }

@@ -82,14 +82,91 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_kernel(const GemmTask *__rest
             }
 }
 
-void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_N, const char *timer_name) {
+// Fast path for padded operands (the correlation-distance GEMM): no bounds checks in the K loop, 16-byte
+// loads, and the next K tile is fetched into registers while the MFMAs run on the current LDS tile.
+// (A 128x128 tile with 4x4 MFMA tiles per wave was measured slower: 128 accumulator VGPRs halve occupancy.)
+__global__ __launch_bounds__(256) void gemm_tn_f64_fast_kernel(const GemmTask *__restrict__ tasks) {
+    const GemmTask t = tasks[blockIdx.z];
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    if (m0 >= t.M || n0 >= t.N) return;
+    if (t.symmetric && n0 < m0) return;
+    __shared__ double As[GK][GLD];
+    __shared__ double Bs[GK][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int lrow = tid >> 4, lcol = (tid & 15) * 4;
+    const int Kp = (t.K + GK - 1) / GK * GK;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double *ap = t.At + static_cast<long long>(lrow) * t.lda + m0 + lcol;
+    const double *bp = t.Bt + static_cast<long long>(lrow) * t.ldb + n0 + lcol;
+    d2 ra0 = *reinterpret_cast<const d2 *>(ap), ra1 = *reinterpret_cast<const d2 *>(ap + 2);
+    d2 rb0 = *reinterpret_cast<const d2 *>(bp), rb1 = *reinterpret_cast<const d2 *>(bp + 2);
+    for (int k0 = 0; k0 < Kp; k0 += GK) {
+        As[lrow][lcol] = ra0.x; As[lrow][lcol + 1] = ra0.y; As[lrow][lcol + 2] = ra1.x; As[lrow][lcol + 3] = ra1.y;
+        Bs[lrow][lcol] = rb0.x; Bs[lrow][lcol + 1] = rb0.y; Bs[lrow][lcol + 2] = rb1.x; Bs[lrow][lcol + 3] = rb1.y;
+        __syncthreads();
+        // next tile (the last iteration re-reads the final tile: unconditional loads keep the waits counted)
+        const int kn = k0 + GK < Kp ? k0 + GK : k0;
+        const double *an = ap + static_cast<long long>(kn) * t.lda, *bn = bp + static_cast<long long>(kn) * t.ldb;
+        ra0 = *reinterpret_cast<const d2 *>(an); ra1 = *reinterpret_cast<const d2 *>(an + 2);
+        rb0 = *reinterpret_cast<const d2 *>(bn); rb1 = *reinterpret_cast<const d2 *>(bn + 2);
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 4) {
+            const int kr = kk + (lane >> 4);
+            double a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = As[kr][wr + i * 16 + (lane & 15)];
+                b[i] = Bs[kr][wc + i * 16 + (lane & 15)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr + i * 16 + (lane >> 4) + 4 * r;
+                const int col = n0 + wc + j * 16 + (lane & 15);
+                if (row < t.M && col < t.N) {
+                    double v = acc[i][j][r];
+                    if (t.epilogue == 1) {
+                        v = v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v);
+                        v = 1.0 - v;
+                        if (row == col) v = 0.0;
+                    } else if (t.epilogue == 2) {
+                        v = v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v);
+                        if (row == col) v = 1.0;
+                    }
+                    t.C[static_cast<long long>(row) * t.ldc + col] = v;
+                    if (t.symmetric && n0 > m0) t.C[static_cast<long long>(col) * t.ldc + row] = v;
+                }
+            }
+}
+
+void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_N, const char *timer_name, bool fast) {
     if (count <= 0 || max_M <= 0 || max_N <= 0) return;
     Ctx &c = ctx();
     KernelTimer tm(timer_name);
     for (int z0 = 0; z0 < count; z0 += 65535) {
         const int nz = std::min(65535, count - z0);
-        hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3((max_N + GT - 1) / GT, (max_M + GT - 1) / GT, nz), dim3(256), 0, c.stream,
-                           d_tasks + z0);
+        if (fast)
+            hipLaunchKernelGGL(gemm_tn_f64_fast_kernel, dim3((max_N + GT - 1) / GT, (max_M + GT - 1) / GT, nz), dim3(256), 0, c.stream,
+                               d_tasks + z0);
+        else
+            hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3((max_N + GT - 1) / GT, (max_M + GT - 1) / GT, nz), dim3(256), 0, c.stream,
+                               d_tasks + z0);
         launch_check("gemm_tn_f64_kernel");
     }
 }
@@ -151,7 +228,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const RowPrepTask *__res
     const RowPrepTask t = tasks[blockIdx.z];
     __shared__ double tile[32][33];
     const int r0 = blockIdx.y * 32, q0 = blockIdx.x * 32;
-    if (r0 >= t.nld || q0 >= t.p) return;
+    if (r0 >= t.nld || q0 >= t.p_pad) return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int j = ty; j < 32; j += 8) {
         const int r = r0 + j, q = q0 + tx;
@@ -160,7 +237,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const RowPrepTask *__res
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int q = q0 + j, r = r0 + tx;
-        if (q < t.p && r < t.nld) t.Ct[static_cast<long long>(q) * t.nld + r] = (r < t.n) ? tile[tx][j] : 0.0;
+        if (q < t.p_pad && r < t.nld) t.Ct[static_cast<long long>(q) * t.nld + r] = (r < t.n && q < t.p) ? tile[tx][j] : 0.0;
     }
 }
 
@@ -173,7 +250,7 @@ void row_prep_batched(const RowPrepTask *d_tasks, int count, int max_n, int max_
         hipLaunchKernelGGL(row_prep_kernel, dim3((max_n + 3) / 4, nz), dim3(256), 0, c.stream, d_tasks + z0);
         launch_check("row_prep_kernel");
         const int nld_max = (max_n + 63) / 64 * 64;
-        hipLaunchKernelGGL(transpose_kernel, dim3((max_p + 31) / 32, (nld_max + 31) / 32, nz), dim3(256), 0, c.stream, d_tasks + z0);
+        hipLaunchKernelGGL(transpose_kernel, dim3((max_p + 15 + 31) / 32, (nld_max + 31) / 32, nz), dim3(256), 0, c.stream, d_tasks + z0);
         launch_check("transpose_kernel");
     }
 }

@@ -17,10 +17,12 @@ struct GemmTask {
     long long lda, ldb, ldc;
     int epilogue;
     int symmetric;
+    int fast;   // 1: operands are zero-padded to tile multiples (K % 16, M/N to 64, lda/ldb % 4 == 0): unchecked 16-byte loads,
+                //    register-prefetched K tiles
 };
 
 // Launch over a device-resident array of `count` GemmTask (max_M/max_N size the grid).
-void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_N, const char *timer_name);
+void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_N, const char *timer_name, bool fast = false);
 
 // Row preparation for one matrix of a batch (R/get_opt_hclust.R:66-74 + the centring inside cor()):
 //   mode 0 (feature rows): z = (x - mean)/sd(p-1)  [t(scale(t(mat)))], re-centre as cor() does,
@@ -31,6 +33,7 @@ struct RowPrepTask {
     const double *src;   // n x p row-major, leading dimension lds
     long long lds;
     int n, p, nld;
+    int p_pad;           // rows of Ct (>= p, multiple of 16; the extra rows are zero-filled)
     int mode;
     double *Cr;          // n x p (ld p)
     double *Ct;          // p x nld

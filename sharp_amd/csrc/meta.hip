@@ -321,13 +321,14 @@ SmResult smetac_from_means(const double *d_means, int nC, int p, long long ncell
     MetaWs &W = mws();
     const int nld = (nC + 63) / 64 * 64;
     // S = cor(aG[a,], aG[b,]), diag 1 (R/sMetaC.R:67-85): centre + normalise rows, then one MFMA GEMM
-    W.U.ensure(static_cast<size_t>(nC) * p); W.Ut.ensure(static_cast<size_t>(p) * nld); W.nrm.ensure(nC);
+    const int p_pad = (p + 15) / 16 * 16;
+    W.U.ensure(static_cast<size_t>(nC) * p); W.Ut.ensure(static_cast<size_t>(p_pad) * nld); W.nrm.ensure(nC);
     W.Smat.ensure(static_cast<size_t>(nC) * nC);
     W.prep.ensure(1); W.gemm.ensure(1);
-    RowPrepTask rp{d_means, p, nC, p, nld, 0, W.U.p, W.Ut.p, W.nrm.p, nullptr};
+    RowPrepTask rp{d_means, p, nC, p, nld, p_pad, 0, W.U.p, W.Ut.p, W.nrm.p, nullptr};
     W.prep.upload(&rp, 1);
     row_prep_batched(W.prep.p, 1, nC, p);
-    GemmTask g{W.Ut.p, W.Ut.p, W.Smat.p, nC, nC, p, nld, nld, nC, 2, 1};
+    GemmTask g{W.Ut.p, W.Ut.p, W.Smat.p, nC, nC, p, nld, nld, nC, 2, 1, 0};
     W.gemm.upload(&g, 1);
     gemm_tn_f64_batched(W.gemm.p, 1, nC, nC, "smetac_centroid_corr_gemm");
     stream_sync();

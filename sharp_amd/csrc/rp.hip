@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <string>
 
 namespace sharp {
 
