@@ -14,18 +14,67 @@ namespace sharp {
 
 namespace {
 
+// Bulk Mersenne-Twister: the same stream as RRng::unif() (R's set.seed() scrambling + MT19937 + tempering),
+// produced 624 outputs at a time with loops the host compiler can vectorise.
+struct MtBulk {
+    static constexpr int N = 624, M = 397;
+    uint32_t st[N];
+    explicit MtBulk(uint32_t seed) {
+        for (int j = 0; j < 50; ++j) seed = 69069u * seed + 1u;
+        seed = 69069u * seed + 1u;
+        for (int j = 0; j < N; ++j) { seed = 69069u * seed + 1u; st[j] = seed; }
+    }
+    static inline uint32_t tw(uint32_t hi, uint32_t lo) {
+        const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+        return (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+    }
+    void next(uint32_t *out) {   // regenerate the state, write the 624 tempered outputs
+        for (int k = 0; k < N - M; ++k) st[k] = st[k + M] ^ tw(st[k], st[k + 1]);                  // reads old values only
+        for (int k = N - M; k < 2 * (N - M); ++k) st[k] = st[k + M - N] ^ tw(st[k], st[k + 1]);    // new [0,227) + old
+        for (int k = 2 * (N - M); k < N - 1; ++k) st[k] = st[k + M - N] ^ tw(st[k], st[k + 1]);
+        st[N - 1] = st[M - 1] ^ tw(st[N - 1], st[0]);
+        for (int k = 0; k < N; ++k) {
+            uint32_t y = st[k];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            out[k] = y;
+        }
+    }
+};
+
+// largest 32-bit y with unif(y) <= cut, unif(y) = fixup((double)y * 2^-32-ish) exactly as unif_rand() computes it
+uint32_t unif_threshold(double cut) {
+    const double c = 2.3283064365386963e-10;
+    auto u = [&](uint64_t y) {
+        const double v = static_cast<double>(static_cast<uint32_t>(y)) * c;
+        constexpr double kHalfUlp = 0.5 * 2.328306437080797e-10;
+        if (v <= 0.0) return kHalfUlp;
+        if (1.0 - v <= 0.0) return 1.0 - kHalfUlp;
+        return v;
+    };
+    int64_t y = static_cast<int64_t>(cut / c);
+    if (y > 0xffffffffLL) y = 0xffffffffLL;
+    if (y < 0) y = 0;
+    while (y < 0xffffffffLL && u(static_cast<uint64_t>(y + 1)) <= cut) ++y;
+    while (y > 0 && !(u(static_cast<uint64_t>(y)) <= cut)) --y;
+    return static_cast<uint32_t>(y);
+}
+
 // One projector: m*p draws of sample(c(+v,0,-v), replace=TRUE, prob=c(q,P,q)).
 // ProbSampleReplace sorts the probabilities descending (revsort: P, then the q of
 // element 3, then the q of element 1) and walks the cumulative sums with one
 // unif_rand() per element: u <= P -> 0 ; u <= P+q -> -v ; else +v.
+// The comparisons are done on the raw 32-bit outputs against exact integer thresholds.
 void draw_projector(int m, int p, double seed, std::vector<uint32_t> &rowptr, std::vector<int32_t> &ent) {
     const double s = std::sqrt(static_cast<double>(m));
     double pr[3] = {1.0 / (2.0 * s), 1.0 - 1.0 / s, 1.0 / (2.0 * s)};
     double tot = 0.0;
     for (double v : pr) if (v > 0.0) tot += v;         // FixupProb
     for (double &v : pr) v /= tot;
-    const double cut0 = pr[1];
-    const double cut1 = pr[1] + pr[2];
+    const uint32_t t0 = unif_threshold(pr[1]);
+    const uint32_t t1 = unif_threshold(pr[1] + pr[2]);
     uint32_t useed;
     if (std::fmod(seed, 1.0) == 0.0) {
         useed = static_cast<uint32_t>(static_cast<int32_t>(seed));
@@ -33,17 +82,21 @@ void draw_projector(int m, int p, double seed, std::vector<uint32_t> &rowptr, st
         std::random_device rd;
         useed = rd();
     }
-    RRng rng(useed);
+    MtBulk mt(useed);
     rowptr.assign(static_cast<size_t>(m) + 1, 0);
     ent.clear();
     ent.reserve(static_cast<size_t>(static_cast<double>(m) * p / s * 1.1) + 64);
-    for (int g = 0; g < m; ++g) {
-        for (int c = 0; c < p; ++c) {
-            const double u = rng.unif();
-            if (u <= cut0) continue;
-            ent.push_back(u <= cut1 ? ~c : c);
+    uint32_t buf[MtBulk::N];
+    const unsigned long long total = static_cast<unsigned long long>(m) * p;
+    int g = 0, c = 0;
+    for (unsigned long long base = 0; base < total; base += MtBulk::N) {
+        mt.next(buf);
+        const int cnt = static_cast<int>(std::min<unsigned long long>(MtBulk::N, total - base));
+        for (int i = 0; i < cnt; ++i) {
+            const uint32_t y = buf[i];
+            if (y > t0) ent.push_back(y <= t1 ? ~c : c);
+            if (++c == p) { c = 0; rowptr[++g] = static_cast<uint32_t>(ent.size()); }
         }
-        rowptr[g + 1] = static_cast<uint32_t>(ent.size());
     }
 }
 
