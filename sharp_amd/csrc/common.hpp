@@ -57,6 +57,7 @@ struct Ctx {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // side stream: producer kernels that overlap with consumers on `stream`
     int num_cu = 256;
     size_t lds_per_block = 65536;
     bool profiling = false;

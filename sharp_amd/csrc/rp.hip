@@ -253,6 +253,9 @@ static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float 
     launch_check("rp_scatter_kernel");
 }
 
+void project_dev_split(const Projector &pr, const ProjectorGroup &g, const float *dX, int m, int n, long long ld, int log_flag,
+                       int fix_bits, double *dE, long long ldE, const int *d_row_map);   // rp2.hip
+
 void project_dev(const Projector &pr, const float *dX, int m, int n, long long ld, int log_flag, double *dE, long long ldE,
                  const int *d_row_map) {
     SHARP_REQUIRE(m == pr.m, "project: gene count differs from the projector's");
@@ -284,6 +287,11 @@ void project_dev(const Projector &pr, const float *dX, int m, int n, long long l
 #define SHARP_RP_CASE(GWV)                                                                          \
     if (vec) launch_rp<GWV, true>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);      \
     else launch_rp<GWV, false>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map)
+        const char *kv = getenv("SHARP_RP_KERNEL");   // "fused": the single-kernel form (always used for unaligned X)
+        if (vec && m >= 8 && !(kv && std::string(kv) == "fused")) {
+            project_dev_split(pr, g, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);
+            continue;
+        }
         if (gw == 16) { SHARP_RP_CASE(16); }
         else if (gw == 8) { SHARP_RP_CASE(8); }
         else { SHARP_RP_CASE(4); }

@@ -1,0 +1,272 @@
+// rp2.hip -- the RP matmul (R/RPmat.R:100, R/SHARP.R:343-345,569-585) as a two-kernel
+// producer/consumer pipeline over chunks of cells, on two HIP streams:
+//   rp_compact_kernel (stream2): streams X once (the only HBM-bound part), compacts the non-zeros of every
+//       cell wave-locally (ballot prefix), evaluates fp64 log2(1+x) -> 44-bit fixed point for them and appends
+//       (gene, fix) to the cell's list in a chunk buffer.  No workgroup barriers: every wave is independent
+//       and keeps two 1024-gene units in flight behind the one it is compacting.
+//   rp_apply_kernel (stream): per cell, walks the list in 64-entry batches; each GW-lane group gathers a gene's
+//       packed row list (one 8-byte load per lane, L2 resident) and adds +-fix into the per-cell accumulators
+//       in LDS with ds_add_u64; batches are software-pipelined (entries of batch i+2 and row lists of batch
+//       i+1 are in flight while the atomics of batch i run).  Two barriers per cell around the epilogue that
+//       scales by sqrt(s)/sqrt(p) and writes the K*p row of E.
+// Chunk c+1 is compacted while chunk c is applied, so the HBM stream overlaps the L2 gather and the LDS
+// atomics; integer accumulation keeps E bit-reproducible whatever the interleaving.
+#include "projector.hpp"
+
+#include <cmath>
+
+namespace sharp {
+
+constexpr int CP_THREADS = 256;
+constexpr int CP_UNIT = 1024;           // genes per wave unit = 64 lanes x 4 float4
+constexpr int AP_THREADS = 512;
+
+struct CpVals { float4 v[4]; };
+
+__device__ __forceinline__ CpVals cp_load_unit(const float *col, int u, long long ld, int lane) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    CpVals r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int g = u * CP_UNIT + 4 * (lane + 64 * j);
+        const int gc = g + 3 < ld ? g : 0;      // unconditional, clamped into the column (ld % 4 == 0, ld >= m)
+        const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(col + gc));
+        r.v[j] = make_float4(t.x, t.y, t.z, t.w);
+    }
+    return r;
+}
+
+// One wave per (cell, unit); units of a chunk are dealt round-robin to the waves of a persistent grid.
+__global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__restrict__ X, int m, long long ld, long long cell0,
+                                                                int ncell, int log_flag, double fix_scale, int cap,
+                                                                unsigned int *__restrict__ counts, uint32_t *__restrict__ genes,
+                                                                long long *__restrict__ fixes) {
+    __shared__ uint32_t sg[CP_THREADS / 64][CP_UNIT];
+    __shared__ uint32_t sx[CP_THREADS / 64][CP_UNIT];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int units = (m + CP_UNIT - 1) / CP_UNIT;
+    const long long total = static_cast<long long>(ncell) * units;
+    const long long stride = static_cast<long long>(gridDim.x) * (CP_THREADS / 64);
+    long long it = static_cast<long long>(blockIdx.x) * (CP_THREADS / 64) + w;
+    if (it >= total) return;
+    auto fetch = [&](long long q) -> CpVals {
+        const long long qq = q < total ? q : total - 1;
+        const long long c = qq / units;
+        return cp_load_unit(X + (cell0 + c) * ld, static_cast<int>(qq - c * units), ld, lane);
+    };
+    CpVals b1 = fetch(it), b2 = fetch(it + stride);
+    for (; it < total; it += stride) {
+        const CpVals b0 = b1;
+        b1 = b2;
+        b2 = fetch(it + 2 * stride);
+        const long long c = it / units;
+        const int u = static_cast<int>(it - c * units);
+        const float vals[16] = {b0.v[0].x, b0.v[0].y, b0.v[0].z, b0.v[0].w, b0.v[1].x, b0.v[1].y, b0.v[1].z, b0.v[1].w,
+                                b0.v[2].x, b0.v[2].y, b0.v[2].z, b0.v[2].w, b0.v[3].x, b0.v[3].y, b0.v[3].z, b0.v[3].w};
+        int wn = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int g = u * CP_UNIT + 4 * (lane + 64 * (q >> 2)) + (q & 3);
+            const bool nz = g < m && vals[q] != 0.0f;
+            const unsigned long long mk = __ballot(nz);
+            if (nz) {
+                const int pos = wn + __popcll(mk & ((1ull << lane) - 1ull));
+                sg[w][pos] = static_cast<uint32_t>(g);
+                sx[w][pos] = __float_as_uint(vals[q]);
+            }
+            wn += __popcll(mk);
+        }
+        if (wn == 0) continue;
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(&counts[c], static_cast<unsigned int>(wn));
+        base = __shfl(base, 0);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t *gout = genes + c * cap + base;
+        long long *fout = fixes + c * cap + base;
+        for (int e = lane; e < wn; e += 64) {       // one lane per non-zero: fp64 log2(1+x) -> fixed point
+            const float x = __uint_as_float(sx[w][e]);
+            const double L = log_flag ? log2(1.0 + static_cast<double>(x)) : static_cast<double>(x);
+            gout[e] = sg[w][e];
+            fout[e] = __double2ll_rn(L * fix_scale);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int GW>
+__device__ __forceinline__ void ap_scatter_codes(unsigned long long *acc, uint2 c, long long fix) {
+    const uint32_t w[4] = {c.x & 0xffffu, c.x >> 16, c.y & 0xffffu, c.y >> 16};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (w[q] != 0xffffu) {   // 0xFFFF = padding
+            const long long v = (w[q] & 0x8000u) ? -fix : fix;
+            atomicAdd(&acc[w[q] & 0x7fffu], static_cast<unsigned long long>(v));
+        }
+    }
+}
+
+template <int GW>
+__global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
+    int ncell, long long cell0, int cap, const unsigned int *__restrict__ counts, const uint32_t *__restrict__ genes,
+    const long long *__restrict__ fixes, const uint16_t *__restrict__ ent, unsigned int dummy_seg,
+    const uint32_t *__restrict__ ovf_gene, const uint2 *__restrict__ ovf_info, int novf, int ncomp, double inv_fix, double val,
+    double out_scale, double *__restrict__ E, long long ldE, int comp0, const int *__restrict__ row_map) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NW = AP_THREADS / 64, NG = 64 / GW, SPAN = 4 * GW, U = GW;   // a batch = 64 entries = U per group
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane / GW, lg = lane % GW;
+    // per-wave scratch: two buffers of 64 (gene, fix) entries
+    long long *sfix = reinterpret_cast<long long *>(acc + ncomp) + wave * 128;
+    uint32_t *sgen = reinterpret_cast<uint32_t *>(reinterpret_cast<long long *>(acc + ncomp) + NW * 128) + wave * 128;
+    for (int c = tid; c < ncomp; c += AP_THREADS) acc[c] = 0ull;
+    __syncthreads();
+
+    for (long long ci = blockIdx.x; ci < ncell; ci += gridDim.x) {
+        const int nnz = static_cast<int>(counts[ci]);
+        const int nb = (nnz + 63) >> 6;
+        const uint32_t *gsrc = genes + ci * cap;
+        const long long *fsrc = fixes + ci * cap;
+        auto load_entry = [&](int b, uint32_t &g, long long &f) {   // lane = entry of batch b; unconditional + mask
+            const int e = (b << 6) + lane;
+            const int ec = e < nnz ? e : 0;
+            const uint32_t gg = gsrc[ec];
+            const long long ff = fsrc[ec];
+            g = e < nnz ? gg : dummy_seg;
+            f = e < nnz ? ff : 0ll;
+        };
+        if (wave < nb) {
+            int buf = 0;
+            uint32_t gL; long long fL;
+            uint2 cd[U], cdn[U];
+            // prologue: entries of the first batch -> scratch, its row lists in flight, entries of the second batch in flight
+            load_entry(wave, gL, fL);
+            sgen[lane] = gL; sfix[lane] = fL;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < U; ++u) cd[u] = *reinterpret_cast<const uint2 *>(ent + static_cast<size_t>(sgen[grp + u * NG]) * SPAN + 4 * lg);
+            load_entry(wave + NW, gL, fL);
+            for (int b = wave; b < nb; b += NW) {
+                const int nbuf = buf ^ 1;
+                // entries of batch b+NW (loaded one iteration ago) -> the other scratch buffer
+                sgen[nbuf * 64 + lane] = gL; sfix[nbuf * 64 + lane] = fL;
+                __builtin_amdgcn_wave_barrier();
+                // row lists of batch b+NW and entries of batch b+2NW go in flight ...
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    cdn[u] = *reinterpret_cast<const uint2 *>(ent + static_cast<size_t>(sgen[nbuf * 64 + grp + u * NG]) * SPAN + 4 * lg);
+                load_entry(b + 2 * NW, gL, fL);
+                // ... while the atomics of batch b run
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const long long fix = sfix[buf * 64 + grp + u * NG];
+                    ap_scatter_codes<GW>(acc, cd[u], fix);
+                    if (novf > 0) {   // rare: a full segment may continue in overflow segments
+                        const uint32_t lastcode = __shfl(cd[u].y >> 16, lane | (GW - 1));
+                        if (lastcode != 0xffffu) {
+                            const uint32_t g = sgen[buf * 64 + grp + u * NG];
+                            int lo = 0, hi = novf - 1, hit = -1;
+                            while (lo <= hi) {
+                                const int mid = (lo + hi) >> 1;
+                                const uint32_t gm = ovf_gene[mid];
+                                if (gm == g) { hit = mid; break; }
+                                if (gm < g) lo = mid + 1; else hi = mid - 1;
+                            }
+                            if (hit >= 0) {
+                                const uint2 oi = ovf_info[hit];
+                                for (uint32_t sg = 0; sg < oi.y; ++sg) {
+                                    const uint2 c2 = *reinterpret_cast<const uint2 *>(ent + (static_cast<size_t>(oi.x) + sg) * SPAN + 4 * lg);
+                                    ap_scatter_codes<GW>(acc, c2, fix);
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) cd[u] = cdn[u];
+                buf = nbuf;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();   // every wave's atomics for this cell have landed
+        const long long cell = cell0 + ci;
+        double *erow = E + (row_map ? static_cast<long long>(row_map[cell]) : cell) * ldE + comp0;
+        for (int c = tid; c < ncomp; c += AP_THREADS) {
+            const long long a = static_cast<long long>(acc[c]);
+            acc[c] = 0ull;
+            erow[c] = out_scale * (val * (static_cast<double>(a) * inv_fix));
+        }
+        __syncthreads();
+    }
+}
+
+namespace {
+struct SplitWs {
+    DevBuf<unsigned int> counts[2];
+    DevBuf<uint32_t> genes[2];
+    DevBuf<long long> fixes[2];
+    hipEvent_t ev_compact[2] = {nullptr, nullptr}, ev_apply[2] = {nullptr, nullptr}, ev_start = nullptr;
+};
+SplitWs &sws() { static SplitWs w; return w; }
+}  // namespace
+
+template <int GW>
+static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell, long long cell0, int cap, const unsigned int *counts,
+                         const uint32_t *genes, const long long *fixes, double inv_fix, double *dE, long long ldE, const int *row_map,
+                         hipStream_t st) {
+    Ctx &c = ctx();
+    const size_t lds = static_cast<size_t>(g.ncomp) * 8 + (AP_THREADS / 64) * 128 * 12;
+    auto kern = rp_apply_kernel<GW>;
+    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    int per_cu = 1;
+    SHARP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), AP_THREADS, lds));
+    per_cu = std::max(1, std::min(per_cu, 4));
+    const long long blocks = std::min<long long>(ncell, static_cast<long long>(c.num_cu) * per_cu);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(AP_THREADS), lds, st, ncell, cell0, cap, counts, genes, fixes,
+                       g.ent.p, static_cast<unsigned int>(g.nseg), g.ovf_gene.p, g.ovf_info.p, g.novf, g.ncomp, inv_fix, pr.val,
+                       1.0 / std::sqrt(static_cast<double>(pr.p)), dE, ldE, g.k0 * pr.p, row_map);
+    launch_check("rp_apply_kernel");
+}
+
+// X must be 16-byte aligned with ld % 4 == 0.  One projector group (K*p <= 12288) per call.
+void project_dev_split(const Projector &pr, const ProjectorGroup &g, const float *dX, int m, int n, long long ld, int log_flag,
+                       int fix_bits, double *dE, long long ldE, const int *d_row_map) {
+    Ctx &c = ctx();
+    SplitWs &W = sws();
+    const int cap = (m + 3) / 4 * 4;                         // worst case: every gene non-zero
+    // chunk of cells: two (genes, fix, counts) buffers of <= ~768 MB each
+    long long chunk = std::max<long long>(512, (768LL << 20) / (static_cast<long long>(cap) * 12));
+    chunk = std::min<long long>(chunk, 8192);
+    chunk = std::min<long long>(chunk, n);
+    for (int q = 0; q < 2; ++q) {
+        W.counts[q].ensure(chunk); W.genes[q].ensure(chunk * cap); W.fixes[q].ensure(chunk * cap);
+        if (!W.ev_compact[q]) { SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_compact[q], hipEventDisableTiming)); SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_apply[q], hipEventDisableTiming)); }
+    }
+    if (!W.ev_start) SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_start, hipEventDisableTiming));
+    const double fix_scale = std::ldexp(1.0, fix_bits), inv_fix = std::ldexp(1.0, -fix_bits);
+    KernelTimer t("rp_scatter");                               // the whole stage, measured on the main stream
+    SHARP_HIP_CHECK(hipEventRecord(W.ev_start, c.stream));
+    SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream2, W.ev_start, 0));
+    const int nchunks = static_cast<int>((n + chunk - 1) / chunk);
+    const int units = (m + CP_UNIT - 1) / CP_UNIT;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int q = ch & 1;
+        const long long c0 = ch * chunk;
+        const int nc = static_cast<int>(std::min<long long>(chunk, n - c0));
+        if (ch >= 2) SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream2, W.ev_apply[q], 0));      // buffer q free again
+        SHARP_HIP_CHECK(hipMemsetAsync(W.counts[q].p, 0, static_cast<size_t>(nc) * 4, c.stream2));
+        const long long waves = static_cast<long long>(nc) * units;
+        const int blocks = static_cast<int>(std::min<long long>((waves + 3) / 4, static_cast<long long>(c.num_cu) * 8));
+        hipLaunchKernelGGL(rp_compact_kernel, dim3(blocks), dim3(CP_THREADS), 0, c.stream2, dX, m, ld, c0, nc, log_flag, fix_scale, cap,
+                           W.counts[q].p, W.genes[q].p, W.fixes[q].p);
+        launch_check("rp_compact_kernel");
+        SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[q], c.stream2));
+        SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, W.ev_compact[q], 0));
+        if (g.gw == 16) launch_apply<16>(g, pr, nc, c0, cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
+        else if (g.gw == 8) launch_apply<8>(g, pr, nc, c0, cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
+        else launch_apply<4>(g, pr, nc, c0, cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
+        SHARP_HIP_CHECK(hipEventRecord(W.ev_apply[q], c.stream));
+    }
+}
+
+}  // namespace sharp

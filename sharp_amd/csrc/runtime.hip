@@ -110,7 +110,9 @@ int sharp_init(int device) {
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
         throw Error(SHARP_ERR_NO_DEVICE, std::string("libsharp_hip is built for gfx950 only; device reports ") + prop.gcnArchName);
     if (c.ready && c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
+    if (c.ready && c.stream2) { (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
     SHARP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    SHARP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
     c.device = device;
     c.num_cu = prop.multiProcessorCount;
     c.lds_per_block = prop.sharedMemPerBlock;
@@ -129,6 +131,7 @@ int sharp_shutdown(void) {
         c.event_pool.clear();
         (void)hipStreamDestroy(c.stream);
         c.stream = nullptr;
+        if (c.stream2) { (void)hipStreamSynchronize(c.stream2); (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
         c.ready = false;
     }
     SHARP_API_END
