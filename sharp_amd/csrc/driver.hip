@@ -39,6 +39,10 @@ struct SharpOut {
 
 namespace {
 
+// big per-call device buffers are kept between calls (hipMalloc/hipFree of multi-GB buffers costs up to tens of ms)
+struct DriverWs { DevBuf<double> E, viE_sh; DevBuf<int> pos; };
+DriverWs &dws() { static DriverWs w; return w; }
+
 inline bool lex_less_id(int a, int b) {
     char sa[16], sb[16];
     snprintf(sa, sizeof sa, "%d", a);
@@ -95,7 +99,8 @@ __global__ void gather_rows_kernel(const double *__restrict__ src, const int *__
 void sharp_small_dev(const float *dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, HcParams base, SharpOut &out) {
     auto pr = projector_for(a, m, p, K);
     const long long ldE = static_cast<long long>(pr->K) * p;
-    DevBuf<double> E(static_cast<size_t>(n) * ldE);
+    DevBuf<double> &E = dws().E;
+    E.ensure(static_cast<size_t>(n) * ldE);
     project_dev(*pr, dX, m, n, ld, a.flag, E.p, ldE, nullptr);                  // :350-363 for all k at once
     std::vector<HcTask> tasks(K);
     HcParams bp = base; bp.N_cluster = a.indN;
@@ -149,10 +154,10 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
     std::shared_ptr<Projector> pr;
     { HostTimer ht("projector_build"); pr = projector_for(a, m, p, K); }         // :539-549
     const long long ldE = static_cast<long long>(pr->K) * p;
-    DevBuf<double> E;
-    { HostTimer ht("alloc_E"); E.alloc(static_cast<size_t>(n) * ldE); }
-    DevBuf<int> dpos;
-    if (shuffle) { dpos.alloc(n); dpos.upload(pos.data(), n); }
+    DevBuf<double> &E = dws().E;
+    { HostTimer ht("alloc_E"); E.ensure(static_cast<size_t>(n) * ldE); }
+    DevBuf<int> &dpos = dws().pos;
+    if (shuffle) { dpos.ensure(n); dpos.upload(pos.data(), n); }
     // E rows are written straight into shuffled order, so fold t is the contiguous row range [fst[t], fst[t+1])
     project_dev(*pr, dX, m, n, ld, a.flag, E.p, ldE, shuffle ? dpos.p : nullptr);          // :567-585 for every (k, t)
     // K*T base-clustering tasks in one batch (:554-618)
@@ -177,7 +182,8 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
             for (int i = 0; i < nt; ++i) enrp[t][static_cast<size_t>(k) * nt + i] = colour_of(r.f[i]);
         }
     }
-    DevBuf<double> viE_sh(static_cast<size_t>(n) * p);                          // enE / K in shuffled order (:750,776)
+    DevBuf<double> &viE_sh = dws().viE_sh;                                      // enE / K in shuffled order (:750,776)
+    viE_sh.ensure(static_cast<size_t>(n) * p);
     ensemble_mean_dev(E.p, ldE, n, p, K, viE_sh.p);
     // per-fold wMetaC (:692-709)
     std::vector<WmTask> wts(T);

@@ -246,6 +246,12 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
         const std::vector<uint16_t> &cid = cids[t];
         R.finalC.resize(N);
         std::vector<int> second(N, -1), uv(C), uc(C);
+        // rank of every meta id in R's table() level order (ids compared as character strings)
+        const int maxid = *std::max_element(tf.begin(), tf.end());
+        std::vector<int> order(maxid + 1), lexrank(maxid + 1, 0);
+        for (int q = 0; q <= maxid; ++q) order[q] = q;
+        std::sort(order.begin() + 1, order.end(), [](int a, int b) { return lex_less(a, b); });
+        for (int q = 1; q <= maxid; ++q) lexrank[order[q]] = q;
         auto vote_of = [&](int i, int col) { return tf[cid[static_cast<size_t>(i) * C + col]]; };
         for (int i = 0; i < N; ++i) {
             int nu = 0;
@@ -259,10 +265,10 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
             // names(sort(table(d), decreasing = TRUE)[1]): most votes, ties -> first level in string order
             int best = -1, sec = -1;
             for (int q = 0; q < nu; ++q)
-                if (best < 0 || uc[q] > uc[best] || (uc[q] == uc[best] && lex_less(uv[q], uv[best]))) best = q;
+                if (best < 0 || uc[q] > uc[best] || (uc[q] == uc[best] && lexrank[uv[q]] < lexrank[uv[best]])) best = q;
             for (int q = 0; q < nu; ++q) {
                 if (q == best) continue;
-                if (sec < 0 || uc[q] > uc[sec] || (uc[q] == uc[sec] && lex_less(uv[q], uv[sec]))) sec = q;
+                if (sec < 0 || uc[q] > uc[sec] || (uc[q] == uc[sec] && lexrank[uv[q]] < lexrank[uv[sec]])) sec = q;
             }
             R.finalC[i] = uv[best];
             second[i] = sec >= 0 ? uv[sec] : -1;

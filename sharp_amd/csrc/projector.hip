@@ -86,18 +86,33 @@ void draw_projector(int m, int p, double seed, std::vector<uint32_t> &rowptr, st
     rowptr.assign(static_cast<size_t>(m) + 1, 0);
     ent.clear();
     ent.reserve(static_cast<size_t>(static_cast<double>(m) * p / s * 1.1) + 64);
-    uint32_t buf[MtBulk::N];
+    uint32_t buf[MtBulk::N + 8];
     const unsigned long long total = static_cast<unsigned long long>(m) * p;
-    int g = 0, c = 0;
+    std::vector<uint32_t> hit_gene;
+    hit_gene.reserve(ent.capacity());
+    const uint32_t up = static_cast<uint32_t>(p);
     for (unsigned long long base = 0; base < total; base += MtBulk::N) {
         mt.next(buf);
         const int cnt = static_cast<int>(std::min<unsigned long long>(MtBulk::N, total - base));
-        for (int i = 0; i < cnt; ++i) {
-            const uint32_t y = buf[i];
-            if (y > t0) ent.push_back(y <= t1 ? ~c : c);
-            if (++c == p) { c = 0; rowptr[++g] = static_cast<uint32_t>(ent.size()); }
+        for (int q = cnt; q < cnt + 8 && q < MtBulk::N + 8; ++q) buf[q] = 0;     // neutral tail for the 8-wide test
+        for (int i = 0; i < cnt; i += 8) {
+            // 99.3 % of the draws are zeros of the projector: test eight at a time, locate the few hits by division
+            uint32_t mx = buf[i];
+            for (int j = 1; j < 8; ++j) mx = buf[i + j] > mx ? buf[i + j] : mx;
+            if (mx <= t0) continue;
+            for (int j = 0; j < 8 && i + j < cnt; ++j) {
+                const uint32_t y = buf[i + j];
+                if (y > t0) {
+                    const unsigned long long idx = base + static_cast<unsigned long long>(i + j);   // element i = r*p + c (byrow fill)
+                    const uint32_t g = static_cast<uint32_t>(idx / up), c = static_cast<uint32_t>(idx - static_cast<unsigned long long>(g) * up);
+                    hit_gene.push_back(g);
+                    ent.push_back(y <= t1 ? ~static_cast<int32_t>(c) : static_cast<int32_t>(c));
+                }
+            }
         }
     }
+    for (uint32_t g : hit_gene) ++rowptr[g + 1];
+    for (int g = 0; g < m; ++g) rowptr[g + 1] += rowptr[g];
 }
 
 std::mutex g_mu;
