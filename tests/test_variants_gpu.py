@@ -1,0 +1,112 @@
+"""Edge cases and argument variants of the drivers vs the oracle."""
+import numpy as np
+import pytest
+from sklearn.metrics import adjusted_rand_score
+
+pytestmark = pytest.mark.gpu
+SEED = 20261003
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import sharp_amd
+
+    sharp_amd.init(0)
+    return sharp_amd
+
+
+def _data(oracle, m=2500, n=700, G=5, nm=300, cell0=0):
+    return oracle.synth_fill(SEED, m, cell0, n, G, nm)
+
+
+def test_ragged_folds_and_rebalanced_tail(sa, oracle):
+    # n = 530 with 200-cell folds: T = 3, folds 200 / 165 / 165 (R/SHARP.R:513-536)
+    X = _data(oracle, n=530)
+    ref = oracle.SHARP(X, K=4, base_ncells=100, partition_ncells=200, rN_seed=7)
+    res = sa.SHARP(X, ensize_K=4, base_ncells=100, partition_ncells=200, rN_seed=7, logflag=False, prep=False)
+    assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+
+
+def test_n_cluster_given_reroutes_small_data(sa, oracle):
+    # N.cluster given and n < base.ncells: indN.cluster = N.cluster, two half-folds, K = 15 (R/SHARP.R:181-191)
+    X = _data(oracle, n=240, G=4)
+    ref = oracle.SHARP(X, N_cluster=4, rN_seed=2103)
+    res = sa.SHARP(X, N_cluster=4, rN_seed=2103, logflag=False, prep=False)
+    assert res["path"] == "SHARP_large" and res["ensize.K"] == 15 == ref["K"]
+    assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+
+
+def test_enp_and_ind_n_cluster(sa, oracle):
+    X = _data(oracle, n=600)
+    kw = dict(base_ncells=100, partition_ncells=200, rN_seed=11)
+    ref = oracle.SHARP(X, K=3, enpN=4, indN=6, **kw)
+    res = sa.SHARP(X, ensize_K=3, enpN_cluster=4, indN_cluster=6, logflag=False, prep=False, **kw)
+    assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+
+
+def test_raw_mode_without_log_transform(sa, oracle):
+    # flag = FALSE: projection of the raw values (R/SHARP.R:343-345 skipped); fixed-point scale from a max|x| pre-pass
+    X = _data(oracle, n=300) * 37.5
+    ref = oracle.SHARP(X, K=3, rN_seed=5, flag=False)
+    pred, x0, viE, p, K, path, rc = sa.api._run_sharp(X, 3, None, None, None, None, None, None, None, None, None, None, None, False,
+                                                      None, 5, True)
+    assert np.array_equal(pred, ref["pred_clusters"])
+    np.testing.assert_allclose(viE, ref["viE"], rtol=0, atol=1e-9 * np.abs(ref["viE"]).max())
+
+
+def test_single_fold_large_path_collapses_to_one_cluster(sa, oracle):
+    # reference quirk 2: SHARP_large with T == 1 yields NA labels -> one cluster (R/SHARP.R:738-746,828)
+    X = _data(oracle, n=150)
+    ref = oracle.SHARP(X, K=3, base_ncells=100, partition_ncells=200, rN_seed=3)
+    res = sa.SHARP(X, ensize_K=3, base_ncells=100, partition_ncells=200, rN_seed=3, logflag=False, prep=False)
+    assert set(ref["pred_clusters"]) == {1} and np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+
+
+def test_colour_wrap_beyond_forty_clusters(sa, oracle):
+    # more than 40 base clusters wrap onto the 40 colour names and merge (R/getrowColor.R:59-68, quirk 7)
+    X = _data(oracle, n=200)
+    E = oracle.project(X, oracle.ranM(X.shape[0], 191, 2154), True)
+    ref = oracle.getrowColor(E, indN=45)
+    res = sa.getrowColor(E, indN_cluster=45)
+    assert ref["rowColor"].max() == 40 and np.array_equal(res["rowColor_id"], ref["rowColor"])
+    assert len(set(res["rowColor"])) == 40
+
+
+def test_other_linkage_and_k_range_through_the_driver(sa, oracle):
+    X = _data(oracle, n=420)
+    kw = dict(base_ncells=100, partition_ncells=150, rN_seed=9)
+    ref = oracle.SHARP(X, K=3, hmethod="average", minN=3, maxN=12, sil_thre=0.2, height_Ntimes=1.5, **kw)
+    res = sa.SHARP(X, ensize_K=3, hmethod="average", minN_cluster=3, maxN_cluster=12, sil_thre=0.2, height_Ntimes=1.5,
+                   logflag=False, prep=False, **kw)
+    assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+
+
+def test_front_door_prep_and_normalisation(sa, oracle):
+    # prep (n < 1e4): negatives -> 0 with a warning, all-zero genes dropped; exp.type other than CPM/TPM -> CPM scaling
+    X = _data(oracle, n=260)
+    X[5, :] = 0.0
+    X[7, 3] = -2.0
+    Xp = X.copy()
+    Xp[Xp < 0] = 0
+    Xp = Xp[Xp.sum(1) != 0]
+    Xn = Xp / Xp.sum(0, keepdims=True) * 1e6
+    ref = oracle.SHARP(Xn.astype(np.float32).astype(np.float64), K=3, rN_seed=2103)
+    with pytest.warns(UserWarning, match="negative values"):
+        res = sa.SHARP(X, exp_type="count", ensize_K=3, rN_seed=2103, logflag=False)
+    assert res["N.genes"] == X.shape[0]
+    assert adjusted_rand_score(ref["pred_clusters"], res["pred_clusters"]) >= 0.99
+
+
+def test_testlog_with_fixed_cells(sa, oracle):
+    X = _data(oracle, n=180)
+    cells = np.arange(0, 180, 2)[:60]
+    p = int(np.ceil(np.log2(180) / 0.04))
+    flag_ref, ms = oracle.testlog(X, p, cells)
+    assert sa.testlog(X, 180, p, 60, cells=cells) == flag_ref
+
+
+def test_run_via_host_unlimited_with_ragged_blocks(sa, oracle):
+    blocks = [_data(oracle, n=n, cell0=c0) for n, c0 in [(5200, 0), (300, 6000), (1400, 7000)]]
+    ref = oracle.SHARP_unlimited(blocks, rN_seed=2103, nthreads=8)
+    res = sa.SHARP_unlimited(blocks, rN_seed=2103)
+    assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
