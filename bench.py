@@ -50,12 +50,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # test hook: run several ranks on ONE GPU with gloo (a 1-GPU box cannot host an RCCL world of 2)
+    share_gpu = os.environ.get("SHARP_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("SHARP_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    xdev = "cuda" if backend == "nccl" else "cpu"      # where the centroid tables are exchanged
 
     import sharp_amd
     from sharp_amd import device as dev
@@ -90,7 +99,7 @@ def main():
             def run_block(blk, p_):
                 return dev.unlimited_block_dev(blk, p_, proj.handle, K_RP, RN_SEED)
 
-            out, nfin, p = sdist.unlimited_sharded([dX], [rank], ncb, run_block, dev.unlimited_merge, device="cuda")
+            out, nfin, p = sdist.unlimited_sharded([dX], [rank], ncb, run_block, dev.unlimited_merge, device=xdev)
             proj.close()
             state["p"], state["pred"], state["n_clusters"] = p, out[rank], nfin
 
@@ -105,7 +114,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = dev.profile_table()
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
