@@ -462,7 +462,7 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
         SHARP_REQUIRE(tk.n >= 3, "get_opt_hclust: need at least 3 observations");
         SHARP_REQUIRE(tk.n <= kHcMaxN, "get_opt_hclust: more than 7168 observations in one clustering task is not supported");
         SHARP_REQUIRE(tk.prm.hmethod >= 1 && tk.prm.hmethod <= 8, "get_opt_hclust: unknown agglomeration method");
-        M.n = tk.n; M.p = tk.symmetric ? tk.n : tk.p; M.nld = static_cast<int>(rup(tk.n, 64));
+        M.n = tk.n; M.p = tk.symmetric ? tk.n : tk.p; M.nld = static_cast<int>(rup(tk.n, 128));
         M.method = tk.prm.hmethod; M.symmetric = tk.symmetric ? 1 : 0; M.pad0 = 0;
         if (tk.prm.N_cluster > 0) {
             SHARP_REQUIRE(tk.prm.N_cluster >= 2, "The given N.cluster is less than 2, which is not suitable for clustering!");
@@ -657,7 +657,7 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
         size_t i1 = i0;
         while (i1 < tasks.size()) {
             const HcTask &t = tasks[i1];
-            const double nld = static_cast<double>(rup(t.n, 64));
+            const double nld = static_cast<double>(rup(t.n, 128));
             const double p = t.symmetric ? t.n : t.p;
             const double b = 8.0 * (nld * nld * (t.symmetric ? 2 : 1) + 2 * nld * p + 4.0 * 64 * t.n) + 4.0 * 64 * t.n;
             if (i1 > i0 && bytes + b > budget) break;

@@ -82,24 +82,27 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_kernel(const GemmTask *__rest
             }
 }
 
-// Fast path for padded operands (the correlation-distance GEMM): no bounds checks in the K loop, 16-byte
-// loads, and the next K tile is fetched into registers while the MFMAs run on the current LDS tile.
-// (A 128x128 tile with 4x4 MFMA tiles per wave was measured slower: 128 accumulator VGPRs halve occupancy.)
-__global__ __launch_bounds__(256) void gemm_tn_f64_fast_kernel(const GemmTask *__restrict__ tasks) {
+// Fast path for padded operands (the correlation-distance GEMM).  Measured: with 64x64 tiles the kernel is bound by the
+// L2 -> CU operand traffic (8 flop per byte staged), not by the MFMA pipe, so this path uses a 128x128 tile per
+// 512-thread workgroup (16 flop/byte): 8 waves as 2 (M) x 4 (N), each a 64x32 block = 4x2 MFMA tiles (64 accumulator
+// VGPRs); no bounds checks in the K loop, 16-byte loads, next K tile fetched into registers while the MFMAs run.
+constexpr int FT = 128, FLD = 144;   // 144 doubles per k row: two k rows of a half-wave land 32 banks apart
+
+__global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *__restrict__ tasks) {
     const GemmTask t = tasks[blockIdx.z];
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int m0 = blockIdx.y * FT, n0 = blockIdx.x * FT;
     if (m0 >= t.M || n0 >= t.N) return;
     if (t.symmetric && n0 < m0) return;
-    __shared__ double As[GK][GLD];
-    __shared__ double Bs[GK][GLD];
+    __shared__ double As[GK][FLD];
+    __shared__ double Bs[GK][FLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-    v4f64 acc[2][2];
+    const int wr = (wave >> 2) * 64, wc = (wave & 3) * 32;
+    v4f64 acc[4][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const int lrow = tid >> 4, lcol = (tid & 15) * 4;
+    const int lrow = tid >> 5, lcol = (tid & 31) * 4;
     const int Kp = (t.K + GK - 1) / GK * GK;
     typedef double d2 __attribute__((ext_vector_type(2)));
     const double *ap = t.At + static_cast<long long>(lrow) * t.lda + m0 + lcol;
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_fast_kernel(const GemmTask *_
     for (int k0 = 0; k0 < Kp; k0 += GK) {
         As[lrow][lcol] = ra0.x; As[lrow][lcol + 1] = ra0.y; As[lrow][lcol + 2] = ra1.x; As[lrow][lcol + 3] = ra1.y;
         Bs[lrow][lcol] = rb0.x; Bs[lrow][lcol + 1] = rb0.y; Bs[lrow][lcol + 2] = rb1.x; Bs[lrow][lcol + 3] = rb1.y;
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is in LDS
+        __builtin_amdgcn_s_barrier();
         // next tile (the last iteration re-reads the final tile: unconditional loads keep the waits counted)
         const int kn = k0 + GK < Kp ? k0 + GK : k0;
         const double *an = ap + static_cast<long long>(kn) * t.lda, *bn = bp + static_cast<long long>(kn) * t.ldb;
@@ -118,21 +122,22 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_fast_kernel(const GemmTask *_
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
             const int kr = kk + (lane >> 4);
-            double a[2], b[2];
+            double a[4], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = As[kr][wr + i * 16 + (lane & 15)];
-                b[i] = Bs[kr][wc + i * 16 + (lane & 15)];
-            }
+            for (int i = 0; i < 4; ++i) a[i] = As[kr][wr + i * 16 + (lane & 15)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wc + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        // raw barrier: a __syncthreads() here would also wait (vmcnt(0)) for the prefetch of the next tile
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -162,7 +167,7 @@ void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_
     for (int z0 = 0; z0 < count; z0 += 65535) {
         const int nz = std::min(65535, count - z0);
         if (fast)
-            hipLaunchKernelGGL(gemm_tn_f64_fast_kernel, dim3((max_N + GT - 1) / GT, (max_M + GT - 1) / GT, nz), dim3(256), 0, c.stream,
+            hipLaunchKernelGGL(gemm_tn_f64_fast_kernel, dim3((max_N + FT - 1) / FT, (max_M + FT - 1) / FT, nz), dim3(512), 0, c.stream,
                                d_tasks + z0);
         else
             hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3((max_N + GT - 1) / GT, (max_M + GT - 1) / GT, nz), dim3(256), 0, c.stream,
@@ -249,7 +254,7 @@ void row_prep_batched(const RowPrepTask *d_tasks, int count, int max_n, int max_
         const int nz = std::min(65535, count - z0);
         hipLaunchKernelGGL(row_prep_kernel, dim3((max_n + 3) / 4, nz), dim3(256), 0, c.stream, d_tasks + z0);
         launch_check("row_prep_kernel");
-        const int nld_max = (max_n + 63) / 64 * 64;
+        const int nld_max = (max_n + 127) / 128 * 128;
         hipLaunchKernelGGL(transpose_kernel, dim3((max_p + 15 + 31) / 32, (nld_max + 31) / 32, nz), dim3(256), 0, c.stream, d_tasks + z0);
         launch_check("transpose_kernel");
     }

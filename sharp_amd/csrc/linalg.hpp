@@ -17,7 +17,7 @@ struct GemmTask {
     long long lda, ldb, ldc;
     int epilogue;
     int symmetric;
-    int fast;   // 1: operands are zero-padded to tile multiples (K % 16, M/N to 64, lda/ldb % 4 == 0): unchecked 16-byte loads,
+    int fast;   // 1: operands are zero-padded to tile multiples (K rows to a multiple of 16, M/N to 128, lda/ldb % 4 == 0): unchecked 16-byte loads,
                 //    register-prefetched K tiles
 };
 

@@ -325,7 +325,7 @@ void cluster_means_dev(const double *d_E, long long ld, int n, int p, const std:
 SmResult smetac_from_means(const double *d_means, int nC, int p, long long ncells, HcParams prm) {
     SHARP_REQUIRE(nC >= 3, "sMetaC: fewer than 3 clusters to combine");
     MetaWs &W = mws();
-    const int nld = (nC + 63) / 64 * 64;
+    const int nld = (nC + 127) / 128 * 128;
     // S = cor(aG[a,], aG[b,]), diag 1 (R/sMetaC.R:67-85): centre + normalise rows, then one MFMA GEMM
     const int p_pad = (p + 15) / 16 * 16;
     W.U.ensure(static_cast<size_t>(nC) * p); W.Ut.ensure(static_cast<size_t>(p_pad) * nld); W.nrm.ensure(nC);
