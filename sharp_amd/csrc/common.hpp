@@ -63,7 +63,7 @@ struct Ctx {
     bool profiling = false;
     std::map<std::string, KernelStat> stats;
     // pending (start, stop, name) event triples, resolved lazily at sync points
-    struct Pending { hipEvent_t a, b; std::string name; };
+    struct Pending { hipEvent_t a, b; std::string name; hipStream_t st; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
     hipEvent_t get_event();
@@ -76,7 +76,8 @@ Ctx &ctx_unchecked();
 struct KernelTimer {
     hipEvent_t a = nullptr, b = nullptr;
     const char *name;
-    explicit KernelTimer(const char *n);
+    hipStream_t st = nullptr;
+    explicit KernelTimer(const char *n, hipStream_t stream = nullptr);   // default: the library's main stream
     ~KernelTimer();
 };
 

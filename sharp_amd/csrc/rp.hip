@@ -246,7 +246,7 @@ static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float 
     const double out_scale = 1.0 / std::sqrt(static_cast<double>(pr.p));
     const char *abl = getenv("SHARP_RP_ABLATE");   // debug: 1 no atomics, 2 no scatter pass, 3 no log2 pass either
     const int ablate = abl ? atoi(abl) : 0;
-    KernelTimer t("rp_scatter");
+    KernelTimer t("rp_stage");
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(RP_THREADS), lds, c.stream, dX, m, n, ld, log_flag,
                        fix_scale, inv_fix, pr.val, out_scale, g.ent.p, g.ovf_gene.p, g.ovf_info.p, g.novf, g.ncomp, dE, ldE, g.k0 * pr.p,
                        nsteps, step_len, ablate, row_map);

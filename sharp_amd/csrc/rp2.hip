@@ -14,11 +14,13 @@
 #include "projector.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace sharp {
 
 constexpr int CP_THREADS = 256;
 constexpr int CP_UNIT = 1024;           // genes per wave unit = 64 lanes x 4 float4
+constexpr int CP_WIN = 1024;            // compaction window per wave in LDS = a whole unit (256 was measured slower)
 constexpr int AP_THREADS = 512;
 
 struct CpVals { float4 v[4]; };
@@ -41,8 +43,8 @@ __global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__r
                                                                 int ncell, int log_flag, double fix_scale, int cap,
                                                                 unsigned int *__restrict__ counts, uint32_t *__restrict__ genes,
                                                                 long long *__restrict__ fixes) {
-    __shared__ uint32_t sg[CP_THREADS / 64][CP_UNIT];
-    __shared__ uint32_t sx[CP_THREADS / 64][CP_UNIT];
+    __shared__ uint32_t sg[CP_THREADS / 64][CP_WIN];
+    __shared__ uint32_t sx[CP_THREADS / 64][CP_WIN];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int units = (m + CP_UNIT - 1) / CP_UNIT;
     const long long total = static_cast<long long>(ncell) * units;
@@ -63,33 +65,43 @@ __global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__r
         const int u = static_cast<int>(it - c * units);
         const float vals[16] = {b0.v[0].x, b0.v[0].y, b0.v[0].z, b0.v[0].w, b0.v[1].x, b0.v[1].y, b0.v[1].z, b0.v[1].w,
                                 b0.v[2].x, b0.v[2].y, b0.v[2].z, b0.v[2].w, b0.v[3].x, b0.v[3].y, b0.v[3].z, b0.v[3].w};
-        int wn = 0;
+        unsigned pending = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int g = u * CP_UNIT + 4 * (lane + 64 * (q >> 2)) + (q & 3);
-            const bool nz = g < m && vals[q] != 0.0f;
-            const unsigned long long mk = __ballot(nz);
-            if (nz) {
-                const int pos = wn + __popcll(mk & ((1ull << lane) - 1ull));
-                sg[w][pos] = static_cast<uint32_t>(g);
-                sx[w][pos] = __float_as_uint(vals[q]);
+            pending |= (g < m && vals[q] != 0.0f) ? (1u << q) : 0u;
+        }
+        while (__ballot(pending != 0u) != 0ull) {   // one pass unless the unit holds more than CP_WIN non-zeros
+            int wn = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bool nz = (pending >> q) & 1u;
+                const unsigned long long mk = __ballot(nz);
+                if (nz) {
+                    const int pos = wn + __popcll(mk & ((1ull << lane) - 1ull));
+                    if (pos < CP_WIN) {
+                        sg[w][pos] = static_cast<uint32_t>(u * CP_UNIT + 4 * (lane + 64 * (q >> 2)) + (q & 3));
+                        sx[w][pos] = __float_as_uint(vals[q]);
+                        pending &= ~(1u << q);
+                    }
+                }
+                wn += __popcll(mk);
             }
-            wn += __popcll(mk);
+            const int cntw = wn < CP_WIN ? wn : CP_WIN;
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(&counts[c], static_cast<unsigned int>(cntw));
+            base = __shfl(base, 0);
+            __builtin_amdgcn_wave_barrier();
+            uint32_t *gout = genes + c * cap + base;
+            long long *fout = fixes + c * cap + base;
+            for (int e = lane; e < cntw; e += 64) {       // one lane per non-zero: fp64 log2(1+x) -> fixed point
+                const float x = __uint_as_float(sx[w][e]);
+                const double L = log_flag ? log2(1.0 + static_cast<double>(x)) : static_cast<double>(x);
+                gout[e] = sg[w][e];
+                fout[e] = __double2ll_rn(L * fix_scale);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        if (wn == 0) continue;
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(&counts[c], static_cast<unsigned int>(wn));
-        base = __shfl(base, 0);
-        __builtin_amdgcn_wave_barrier();
-        uint32_t *gout = genes + c * cap + base;
-        long long *fout = fixes + c * cap + base;
-        for (int e = lane; e < wn; e += 64) {       // one lane per non-zero: fp64 log2(1+x) -> fixed point
-            const float x = __uint_as_float(sx[w][e]);
-            const double L = log_flag ? log2(1.0 + static_cast<double>(x)) : static_cast<double>(x);
-            gout[e] = sg[w][e];
-            fout[e] = __double2ll_rn(L * fix_scale);
-        }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -233,6 +245,8 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, const float
                        int fix_bits, double *dE, long long ldE, const int *d_row_map) {
     Ctx &c = ctx();
     SplitWs &W = sws();
+    const char *ser = getenv("SHARP_RP_SERIAL");     // debug: both kernels on the main stream (no overlap)
+    hipStream_t s2 = (ser && ser[0] == '1') ? c.stream : c.stream2;
     const int cap = (m + 3) / 4 * 4;                         // worst case: every gene non-zero
     // chunk of cells: two (genes, fix, counts) buffers of <= ~768 MB each
     long long chunk = std::max<long long>(512, (768LL << 20) / (static_cast<long long>(cap) * 12));
@@ -244,27 +258,33 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, const float
     }
     if (!W.ev_start) SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_start, hipEventDisableTiming));
     const double fix_scale = std::ldexp(1.0, fix_bits), inv_fix = std::ldexp(1.0, -fix_bits);
-    KernelTimer t("rp_scatter");                               // the whole stage, measured on the main stream
+    KernelTimer t("rp_stage");                                 // the whole stage, measured on the main stream
     SHARP_HIP_CHECK(hipEventRecord(W.ev_start, c.stream));
-    SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream2, W.ev_start, 0));
+    SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_start, 0));
     const int nchunks = static_cast<int>((n + chunk - 1) / chunk);
     const int units = (m + CP_UNIT - 1) / CP_UNIT;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int q = ch & 1;
         const long long c0 = ch * chunk;
         const int nc = static_cast<int>(std::min<long long>(chunk, n - c0));
-        if (ch >= 2) SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream2, W.ev_apply[q], 0));      // buffer q free again
-        SHARP_HIP_CHECK(hipMemsetAsync(W.counts[q].p, 0, static_cast<size_t>(nc) * 4, c.stream2));
+        if (ch >= 2) SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_apply[q], 0));      // buffer q free again
+        SHARP_HIP_CHECK(hipMemsetAsync(W.counts[q].p, 0, static_cast<size_t>(nc) * 4, s2));
         const long long waves = static_cast<long long>(nc) * units;
         const int blocks = static_cast<int>(std::min<long long>((waves + 3) / 4, static_cast<long long>(c.num_cu) * 8));
-        hipLaunchKernelGGL(rp_compact_kernel, dim3(blocks), dim3(CP_THREADS), 0, c.stream2, dX, m, ld, c0, nc, log_flag, fix_scale, cap,
-                           W.counts[q].p, W.genes[q].p, W.fixes[q].p);
-        launch_check("rp_compact_kernel");
-        SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[q], c.stream2));
+        {
+            KernelTimer tc("rp_compact", s2);
+            hipLaunchKernelGGL(rp_compact_kernel, dim3(blocks), dim3(CP_THREADS), 0, s2, dX, m, ld, c0, nc, log_flag, fix_scale, cap,
+                               W.counts[q].p, W.genes[q].p, W.fixes[q].p);
+            launch_check("rp_compact_kernel");
+        }
+        SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[q], s2));
         SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, W.ev_compact[q], 0));
-        if (g.gw == 16) launch_apply<16>(g, pr, nc, c0, cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
-        else if (g.gw == 8) launch_apply<8>(g, pr, nc, c0, cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
-        else launch_apply<4>(g, pr, nc, c0, cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
+        {
+            KernelTimer ta("rp_apply");
+            if (g.gw == 16) launch_apply<16>(g, pr, nc, c0, cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
+            else if (g.gw == 8) launch_apply<8>(g, pr, nc, c0, cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
+            else launch_apply<4>(g, pr, nc, c0, cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
+        }
         SHARP_HIP_CHECK(hipEventRecord(W.ev_apply[q], c.stream));
     }
 }

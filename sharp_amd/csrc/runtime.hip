@@ -31,6 +31,7 @@ hipEvent_t Ctx::get_event() {
 void Ctx::resolve_pending() {
     if (pending.empty()) return;
     SHARP_HIP_CHECK(hipStreamSynchronize(stream));
+    if (stream2) SHARP_HIP_CHECK(hipStreamSynchronize(stream2));
     for (auto &p : pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -44,18 +45,19 @@ void Ctx::resolve_pending() {
     pending.clear();
 }
 
-KernelTimer::KernelTimer(const char *n) : name(n) {
+KernelTimer::KernelTimer(const char *n, hipStream_t stream) : name(n) {
     Ctx &c = ctx();
     if (!c.profiling) return;
+    st = stream ? stream : c.stream;
     a = c.get_event();
     b = c.get_event();
-    (void)hipEventRecord(a, c.stream);
+    (void)hipEventRecord(a, st);
 }
 KernelTimer::~KernelTimer() {
     if (!a) return;
     Ctx &c = ctx_unchecked();
-    (void)hipEventRecord(b, c.stream);
-    c.pending.push_back({a, b, name});
+    (void)hipEventRecord(b, st);
+    c.pending.push_back({a, b, name, st});
     if (c.pending.size() > 4096) {
         try { c.resolve_pending(); } catch (...) {}
     }

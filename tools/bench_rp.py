@@ -37,7 +37,7 @@ for (m, n, K, p) in CFGS:
     lib.sharp_synchronize()
     ms = C.c_double()
     cnt = C.c_longlong()
-    lib.sharp_profile_get(b"rp_scatter", C.byref(ms), C.byref(cnt))
+    lib.sharp_profile_get(b"rp_stage", C.byref(ms), C.byref(cnt))
     t = ms.value / cnt.value * 1e-3
     rd = n * m * 4
     wr = n * K * p * 8
