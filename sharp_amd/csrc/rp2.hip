@@ -20,7 +20,6 @@ namespace sharp {
 
 constexpr int CP_THREADS = 256;
 constexpr int CP_UNIT = 1024;           // genes per wave unit = 64 lanes x 4 float4
-constexpr int CP_WIN = 1024;            // compaction window per wave in LDS = a whole unit (256 was measured slower)
 constexpr int AP_THREADS = 512;
 
 struct CpVals { float4 v[4]; };
@@ -38,14 +37,30 @@ __device__ __forceinline__ CpVals cp_load_unit(const float *col, int u, long lon
     return r;
 }
 
+constexpr int CP_TAB = 256;             // log2(1+x) fixed-point table for integer counts x < CP_TAB
+
+// fix(x) = round(log2(1+x) * 2^fix_bits) for x = 0..CP_TAB-1, evaluated by the same device libm as the general path
+__global__ void rp_fixtab_kernel(double fix_scale, long long *__restrict__ tab) {
+    const int x = threadIdx.x;
+    if (x < CP_TAB) tab[x] = __double2ll_rn(log2(1.0 + static_cast<double>(x)) * fix_scale);
+}
+
 // One wave per (cell, unit); units of a chunk are dealt round-robin to the waves of a persistent grid.
+// Compaction is lane-major: a lane counts its own non-zeros (16 candidates), one wave prefix scan places them, the
+// lane appends (gene, x) to the wave's LDS window; then one lane per non-zero turns x into the fixed-point term
+// (table for integer counts, fp64 log2 otherwise -- same bits either way) and the list goes out coalesced.
+// The order of a cell's list is irrelevant: the consumer adds integers.
 __global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__restrict__ X, int m, long long ld, long long cell0,
                                                                 int ncell, int log_flag, double fix_scale, int cap,
+                                                                const long long *__restrict__ fixtab,
                                                                 unsigned int *__restrict__ counts, uint32_t *__restrict__ genes,
                                                                 long long *__restrict__ fixes) {
-    __shared__ uint32_t sg[CP_THREADS / 64][CP_WIN];
-    __shared__ uint32_t sx[CP_THREADS / 64][CP_WIN];
+    __shared__ uint32_t sg[CP_THREADS / 64][CP_UNIT];
+    __shared__ uint32_t sx[CP_THREADS / 64][CP_UNIT];
+    __shared__ long long stab[CP_TAB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < CP_TAB; i += CP_THREADS) stab[i] = fixtab[i];
+    __syncthreads();
     const int units = (m + CP_UNIT - 1) / CP_UNIT;
     const long long total = static_cast<long long>(ncell) * units;
     const long long stride = static_cast<long long>(gridDim.x) * (CP_THREADS / 64);
@@ -65,43 +80,57 @@ __global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__r
         const int u = static_cast<int>(it - c * units);
         const float vals[16] = {b0.v[0].x, b0.v[0].y, b0.v[0].z, b0.v[0].w, b0.v[1].x, b0.v[1].y, b0.v[1].z, b0.v[1].w,
                                 b0.v[2].x, b0.v[2].y, b0.v[2].z, b0.v[2].w, b0.v[3].x, b0.v[3].y, b0.v[3].z, b0.v[3].w};
-        unsigned pending = 0;
+        const int gbase = u * CP_UNIT + 4 * lane;          // gene of candidate q: gbase + 256*(q>>2) + (q&3)
+        unsigned nzm = 0;
+        if (u * CP_UNIT + CP_UNIT <= m) {                  // wave-uniform: only the last unit of a cell is ragged
+#pragma unroll
+            for (int q = 0; q < 16; ++q) nzm |= vals[q] != 0.0f ? (1u << q) : 0u;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) nzm |= (gbase + 256 * (q >> 2) + (q & 3) < m && vals[q] != 0.0f) ? (1u << q) : 0u;
+        }
+        const int mine = __popc(nzm);
+        int incl = mine;                                   // inclusive prefix sum over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            incl += lane >= d ? t : 0;
+        }
+        const int cntw = __shfl(incl, 63);
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(&counts[c], static_cast<unsigned int>(cntw));
+        int pos = incl - mine;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int g = u * CP_UNIT + 4 * (lane + 64 * (q >> 2)) + (q & 3);
-            pending |= (g < m && vals[q] != 0.0f) ? (1u << q) : 0u;
+            if ((nzm >> q) & 1u) {
+                sg[w][pos] = static_cast<uint32_t>(gbase + 256 * (q >> 2) + (q & 3));
+                sx[w][pos] = __float_as_uint(vals[q]);
+                ++pos;
+            }
         }
-        while (__ballot(pending != 0u) != 0ull) {   // one pass unless the unit holds more than CP_WIN non-zeros
-            int wn = 0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const bool nz = (pending >> q) & 1u;
-                const unsigned long long mk = __ballot(nz);
-                if (nz) {
-                    const int pos = wn + __popcll(mk & ((1ull << lane) - 1ull));
-                    if (pos < CP_WIN) {
-                        sg[w][pos] = static_cast<uint32_t>(u * CP_UNIT + 4 * (lane + 64 * (q >> 2)) + (q & 3));
-                        sx[w][pos] = __float_as_uint(vals[q]);
-                        pending &= ~(1u << q);
-                    }
+        base = __shfl(base, 0);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t *gout = genes + c * cap + base;
+        long long *fout = fixes + c * cap + base;
+        for (int e0 = 0; e0 < cntw; e0 += 64) {            // one lane per non-zero
+            const int e = e0 + lane;
+            const bool live = e < cntw;
+            const float x = __uint_as_float(sx[w][live ? e : 0]);
+            const uint32_t gg = sg[w][live ? e : 0];
+            long long fx;
+            if (log_flag) {
+                const unsigned xi = static_cast<unsigned>(x);
+                const bool tab = static_cast<float>(xi) == x && xi < static_cast<unsigned>(CP_TAB);
+                fx = stab[tab ? xi : 0u];
+                if (__ballot(live && !tab) != 0ull) {      // non-integer or large values: the general path
+                    if (!tab) fx = __double2ll_rn(log2(1.0 + static_cast<double>(x)) * fix_scale);
                 }
-                wn += __popcll(mk);
+            } else {
+                fx = __double2ll_rn(static_cast<double>(x) * fix_scale);
             }
-            const int cntw = wn < CP_WIN ? wn : CP_WIN;
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(&counts[c], static_cast<unsigned int>(cntw));
-            base = __shfl(base, 0);
-            __builtin_amdgcn_wave_barrier();
-            uint32_t *gout = genes + c * cap + base;
-            long long *fout = fixes + c * cap + base;
-            for (int e = lane; e < cntw; e += 64) {       // one lane per non-zero: fp64 log2(1+x) -> fixed point
-                const float x = __uint_as_float(sx[w][e]);
-                const double L = log_flag ? log2(1.0 + static_cast<double>(x)) : static_cast<double>(x);
-                gout[e] = sg[w][e];
-                fout[e] = __double2ll_rn(L * fix_scale);
-            }
-            __builtin_amdgcn_wave_barrier();
+            if (live) { gout[e] = gg; fout[e] = fx; }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -217,6 +246,8 @@ struct SplitWs {
     DevBuf<unsigned int> counts[2];
     DevBuf<uint32_t> genes[2];
     DevBuf<long long> fixes[2];
+    DevBuf<long long> fixtab;
+    double fixtab_scale = 0.0;
     hipEvent_t ev_compact[2] = {nullptr, nullptr}, ev_apply[2] = {nullptr, nullptr}, ev_start = nullptr;
 };
 SplitWs &sws() { static SplitWs w; return w; }
@@ -248,16 +279,28 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, const float
     const char *ser = getenv("SHARP_RP_SERIAL");     // debug: both kernels on the main stream (no overlap)
     hipStream_t s2 = (ser && ser[0] == '1') ? c.stream : c.stream2;
     const int cap = (m + 3) / 4 * 4;                         // worst case: every gene non-zero
-    // chunk of cells: two (genes, fix, counts) buffers of <= ~768 MB each
-    long long chunk = std::max<long long>(512, (768LL << 20) / (static_cast<long long>(cap) * 12));
-    chunk = std::min<long long>(chunk, 8192);
+    // chunks of cells: two (genes, fix, counts) buffers of <= 2 GB each (sized for the worst case, every gene non-zero);
+    // few, equal chunks: each launch pays a tail, and a chunk must give every workgroup several cells
+    long long chunk = std::max<long long>(512, (2048LL << 20) / (static_cast<long long>(cap) * 12));
+    chunk = std::min<long long>(chunk, 16384);
+    if (const char *ce = getenv("SHARP_RP_CHUNK")) chunk = std::max(64, atoi(ce));   // tuning knob
     chunk = std::min<long long>(chunk, n);
+    {
+        const long long nch = (n + chunk - 1) / chunk;
+        chunk = (n + nch - 1) / nch;
+    }
     for (int q = 0; q < 2; ++q) {
         W.counts[q].ensure(chunk); W.genes[q].ensure(chunk * cap); W.fixes[q].ensure(chunk * cap);
         if (!W.ev_compact[q]) { SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_compact[q], hipEventDisableTiming)); SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_apply[q], hipEventDisableTiming)); }
     }
     if (!W.ev_start) SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_start, hipEventDisableTiming));
     const double fix_scale = std::ldexp(1.0, fix_bits), inv_fix = std::ldexp(1.0, -fix_bits);
+    if (W.fixtab.n == 0 || W.fixtab_scale != fix_scale) {
+        W.fixtab.ensure(CP_TAB);
+        hipLaunchKernelGGL(rp_fixtab_kernel, dim3(1), dim3(CP_TAB), 0, c.stream, fix_scale, W.fixtab.p);
+        launch_check("rp_fixtab_kernel");
+        W.fixtab_scale = fix_scale;
+    }
     KernelTimer t("rp_stage");                                 // the whole stage, measured on the main stream
     SHARP_HIP_CHECK(hipEventRecord(W.ev_start, c.stream));
     SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_start, 0));
@@ -274,7 +317,7 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, const float
         {
             KernelTimer tc("rp_compact", s2);
             hipLaunchKernelGGL(rp_compact_kernel, dim3(blocks), dim3(CP_THREADS), 0, s2, dX, m, ld, c0, nc, log_flag, fix_scale, cap,
-                               W.counts[q].p, W.genes[q].p, W.fixes[q].p);
+                               W.fixtab.p, W.counts[q].p, W.genes[q].p, W.fixes[q].p);
             launch_check("rp_compact_kernel");
         }
         SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[q], s2));

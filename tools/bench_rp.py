@@ -7,7 +7,11 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
+import os
 import sharp_amd
+from sharp_amd import _lib as _L
+if os.environ.get('SHARP_VARIANT'):
+    _L._SO = os.path.join(os.path.dirname(_L._SO), 'variants', 'libsharp_hip_%s.so' % os.environ['SHARP_VARIANT'])
 
 sharp_amd.init(0)
 lib = sharp_amd.lib()
@@ -42,6 +46,10 @@ for (m, n, K, p) in CFGS:
     rd = n * m * 4
     wr = n * K * p * 8
     nzfrac = float((dX[:2000] != 0).float().mean())
+    per = []
+    for nm in (b"rp_compact", b"rp_apply"):
+        lib.sharp_profile_get(nm, C.byref(ms), C.byref(cnt))
+        per.append("%s %.1f us x%d" % (nm.decode(), ms.value / max(cnt.value, 1) * 1e3, cnt.value // reps))
     print(f"m={m} n={n} K={K} p={p} nnz={pr.nnz()} proj_build={tproj:.2f}s  rp={t*1e3:.3f} ms  read {rd/t/1e12:.2f} TB/s "
-          f"({rd/t/8e12*100:.1f}% of 8TB/s)  read+write {(rd+wr)/t/1e12:.2f} TB/s  nz={nzfrac:.3f}", flush=True)
+          f"({rd/t/8e12*100:.1f}% of 8TB/s)  read+write {(rd+wr)/t/1e12:.2f} TB/s  nz={nzfrac:.3f}  " + "  ".join(per), flush=True)
     del dX, dE
