@@ -2,7 +2,9 @@
 // R/ranM2.R:44-68, R/RPmat.R:82-99) and upload as packed gene-major row lists.
 #include "projector.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <random>
@@ -67,22 +69,25 @@ uint32_t unif_threshold(double cut) {
 // element 3, then the q of element 1) and walks the cumulative sums with one
 // unif_rand() per element: u <= P -> 0 ; u <= P+q -> -v ; else +v.
 // The comparisons are done on the raw 32-bit outputs against exact integer thresholds.
-void draw_projector(int m, int p, double seed, std::vector<uint32_t> &rowptr, std::vector<int32_t> &ent) {
+void draw_thresholds(int m, uint32_t &t0, uint32_t &t1) {
     const double s = std::sqrt(static_cast<double>(m));
     double pr[3] = {1.0 / (2.0 * s), 1.0 - 1.0 / s, 1.0 / (2.0 * s)};
     double tot = 0.0;
     for (double v : pr) if (v > 0.0) tot += v;         // FixupProb
     for (double &v : pr) v /= tot;
-    const uint32_t t0 = unif_threshold(pr[1]);
-    const uint32_t t1 = unif_threshold(pr[1] + pr[2]);
-    uint32_t useed;
-    if (std::fmod(seed, 1.0) == 0.0) {
-        useed = static_cast<uint32_t>(static_cast<int32_t>(seed));
-    } else {  // the reference's 0.5 sentinel = "do not call set.seed()"
-        std::random_device rd;
-        useed = rd();
-    }
-    MtBulk mt(useed);
+    t0 = unif_threshold(pr[1]);
+    t1 = unif_threshold(pr[1] + pr[2]);
+}
+uint32_t seed_word(double seed) {
+    if (std::fmod(seed, 1.0) == 0.0) return static_cast<uint32_t>(static_cast<int32_t>(seed));
+    std::random_device rd;                              // the reference's 0.5 sentinel = "do not call set.seed()"
+    return rd();
+}
+void draw_projector(int m, int p, double seed, std::vector<uint32_t> &rowptr, std::vector<int32_t> &ent) {
+    const double s = std::sqrt(static_cast<double>(m));
+    uint32_t t0, t1;
+    draw_thresholds(m, t0, t1);
+    MtBulk mt(seed_word(seed));
     rowptr.assign(static_cast<size_t>(m) + 1, 0);
     ent.clear();
     ent.reserve(static_cast<size_t>(static_cast<double>(m) * p / s * 1.1) + 64);
@@ -115,13 +120,167 @@ void draw_projector(int m, int p, double seed, std::vector<uint32_t> &rowptr, st
     for (int g = 0; g < m; ++g) rowptr[g + 1] += rowptr[g];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Device construction.  One workgroup per projector regenerates R's Mersenne-Twister state 624 words at a time
+// (three dependent phases of <= 227 independent words, double-buffered in LDS: 3 barriers per regeneration),
+// tempers each word in registers and tests it against the integer thresholds; the 0.7 % hits are staged in LDS and
+// appended to the projector's hit list (element index i = r*p + c of the byrow fill, bit 31 = negative).
+// ---------------------------------------------------------------------------------------------
+constexpr int PD_THREADS = 256;
+constexpr int PD_STAGE = 4096;
+
+__device__ __forceinline__ uint32_t pd_tw(uint32_t hi, uint32_t lo) {
+    const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+}
+__device__ __forceinline__ uint32_t pd_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+__global__ __launch_bounds__(PD_THREADS) void proj_draw_kernel(const uint32_t *__restrict__ seeds, unsigned long long total, uint32_t t0,
+                                                               uint32_t t1, int flush_every, uint32_t *__restrict__ hits,
+                                                               unsigned int cap, unsigned int *__restrict__ nhits,
+                                                               int *__restrict__ err) {
+    constexpr int N = 624, M = 397, D = N - M;   // D = 227
+    __shared__ uint32_t st[2][N];
+    __shared__ uint32_t stage[PD_STAGE];
+    __shared__ unsigned int scount;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    uint32_t *out = hits + static_cast<size_t>(k) * cap;
+    // set.seed(): 50 warm-up steps of x <- 69069 x + 1, one for the position word, then one per state word
+    if (tid == 0) {
+        uint32_t seed = seeds[k];
+        for (int j = 0; j < 51; ++j) seed = 69069u * seed + 1u;
+        for (int j = 0; j < N; ++j) { seed = 69069u * seed + 1u; st[0][j] = seed; }
+        scount = 0u;
+    }
+    __syncthreads();
+    unsigned int gcount = 0;   // hits already flushed (uniform)
+    int cur = 0, since = 0;
+    bool overflow = false;
+    auto emit = [&](uint32_t word, unsigned long long idx) {
+        if (idx < total) {
+            const uint32_t y = pd_temper(word);
+            if (y > t0) {
+                const unsigned int pos = atomicAdd(&scount, 1u);
+                if (pos < PD_STAGE) stage[pos] = static_cast<uint32_t>(idx) | (y <= t1 ? 0x80000000u : 0u);
+            }
+        }
+    };
+    for (unsigned long long base = 0; base < total; base += N) {
+        const uint32_t *c = st[cur];
+        uint32_t *nx = st[cur ^ 1];
+        if (tid < D) {                                   // words [0, 227): old values only
+            const uint32_t v = c[tid + M] ^ pd_tw(c[tid], c[tid + 1]);
+            nx[tid] = v;
+            emit(v, base + tid);
+        }
+        __syncthreads();
+        if (tid < D) {                                   // words [227, 454): new [0, 227) + old
+            const int q = D + tid;
+            const uint32_t v = nx[q - D] ^ pd_tw(c[q], c[q + 1]);
+            nx[q] = v;
+            emit(v, base + q);
+        }
+        __syncthreads();
+        if (tid < N - 2 * D) {                           // words [454, 624): new [227, 397) + old; the last one wraps to new word 0
+            const int q = 2 * D + tid;
+            const uint32_t v = nx[q - D] ^ pd_tw(c[q], q == N - 1 ? nx[0] : c[q + 1]);
+            nx[q] = v;
+            emit(v, base + q);
+        }
+        __syncthreads();
+        cur ^= 1;
+        if (++since == flush_every || base + N >= total) {
+            const unsigned int cnt = scount;
+            if (cnt > PD_STAGE || gcount + cnt > cap) overflow = true;
+            const unsigned int cc = cnt > PD_STAGE ? PD_STAGE : cnt;
+            for (unsigned int i = tid; i < cc && gcount + i < cap; i += PD_THREADS) out[gcount + i] = stage[i];
+            gcount += cc;
+            since = 0;
+            __syncthreads();
+            if (tid == 0) scount = 0u;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        nhits[k] = gcount < cap ? gcount : cap;
+        if (overflow) *err = 1;
+    }
+}
+
+// entries per gene over the projectors [k0, k0+kcount) of one group
+__global__ void proj_count_kernel(const uint32_t *__restrict__ hits, unsigned int cap, const unsigned int *__restrict__ nhits, int k0,
+                                  uint32_t p, unsigned int *__restrict__ len) {
+    const int k = k0 + blockIdx.y;
+    const unsigned int n = nhits[k];
+    const uint32_t *h = hits + static_cast<size_t>(k) * cap;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        atomicAdd(&len[(h[i] & 0x7fffffffu) / p], 1u);
+}
+// codes (kk*p + c, bit 15 = negative) into the gene's CSR slot range, in arrival order
+__global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int cap, const unsigned int *__restrict__ nhits, int k0,
+                                 uint32_t p, const uint32_t *__restrict__ rowptr, unsigned int *__restrict__ fill,
+                                 uint16_t *__restrict__ flat) {
+    const int kk = blockIdx.y, k = k0 + kk;
+    const unsigned int n = nhits[k];
+    const uint32_t *h = hits + static_cast<size_t>(k) * cap;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t w = h[i], idx = w & 0x7fffffffu;
+        const uint32_t g = idx / p, c = idx - g * p;
+        const unsigned int slot = atomicAdd(&fill[g], 1u);
+        flat[rowptr[g] + slot] = static_cast<uint16_t>(kk * p + c) | ((w >> 31) ? 0x8000u : 0u);
+    }
+}
+// one thread per gene: order the gene's codes by component (the order of the host build: projector, then column) and
+// write them into the fixed-stride lane-major segments (+ overflow segments)
+__global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, uint16_t *__restrict__ flat, int gw,
+                                   const uint32_t *__restrict__ ovf_gene, const uint2 *__restrict__ ovf_info, int novf,
+                                   uint16_t *__restrict__ ent) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= m) return;
+    const uint32_t b = rowptr[g], len = rowptr[g + 1] - b;
+    uint16_t *src = flat + b;
+    for (uint32_t i = 1; i < len; ++i) {                 // insertion sort: lists are a few dozen entries, nearly sorted
+        const uint16_t v = src[i];
+        uint32_t j = i;
+        while (j > 0 && (src[j - 1] & 0x7fffu) > (v & 0x7fffu)) { src[j] = src[j - 1]; --j; }
+        src[j] = v;
+    }
+    const uint32_t span = 4u * gw;
+    size_t extra_base = 0;
+    if (len > span) {
+        int lo = 0, hi = novf - 1;
+        while (lo <= hi) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t gm = ovf_gene[mid];
+            if (gm == static_cast<uint32_t>(g)) { extra_base = ovf_info[mid].x; break; }
+            if (gm < static_cast<uint32_t>(g)) lo = mid + 1; else hi = mid - 1;
+        }
+    }
+    for (uint32_t i = 0; i < len; ++i) {
+        const uint32_t sgm = i / span, r = i % span;
+        const uint32_t q = r / gw, lane = r % gw;
+        const size_t seg = sgm == 0 ? static_cast<size_t>(g) : extra_base + (sgm - 1);
+        ent[seg * span + 4 * lane + q] = src[i];
+    }
+}
+__global__ void proj_fill_u16_kernel(uint16_t *p, size_t n, uint16_t v) {
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) p[i] = v;
+}
+
 std::mutex g_mu;
 std::map<int, std::shared_ptr<Projector>> g_table;
 int g_next = 1;
 
 }  // namespace
 
-std::shared_ptr<Projector> build_projector(int m, int p, int K, const double *seeds) {
+static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, const double *seeds) {
     SHARP_REQUIRE(m >= 2 && p >= 1 && K >= 1, "projector: need m >= 2, p >= 1, K >= 1");
     SHARP_REQUIRE(p <= kMaxCompPerGroup, "projector: reduced dimension p too large for one launch group");
     auto pr = std::make_shared<Projector>();
@@ -216,6 +375,138 @@ std::shared_ptr<Projector> build_projector(int m, int p, int K, const double *se
     return pr;
 }
 
+
+// Device build: draws on the GPU (proj_draw_kernel), per-gene counts, then -- after one 80 KB download to size the
+// segments on the host -- fill + layout kernels.  Same packed result as the host build (tests compare both).
+static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, const double *seeds) {
+    SHARP_REQUIRE(m >= 2 && p >= 1 && K >= 1, "projector: need m >= 2, p >= 1, K >= 1");
+    SHARP_REQUIRE(p <= kMaxCompPerGroup, "projector: reduced dimension p too large for one launch group");
+    Ctx &c = ctx();
+    auto pr = std::make_shared<Projector>();
+    pr->m = m; pr->p = p; pr->K = K;
+    pr->val = std::sqrt(std::sqrt(static_cast<double>(m)));
+    pr->h_rowptr.resize(K);
+    pr->h_ent.resize(K);
+    uint32_t t0, t1;
+    draw_thresholds(m, t0, t1);
+    std::vector<uint32_t> useed(K);
+    for (int k = 0; k < K; ++k) useed[k] = seed_word(seeds[k]);
+    const unsigned long long total = static_cast<unsigned long long>(m) * p;
+    const double expect = static_cast<double>(total) / std::sqrt(static_cast<double>(m));
+    pr->hit_cap = static_cast<unsigned int>(expect * 1.25 + 8.0 * std::sqrt(expect) + 4096.0);
+    pr->d_hits.alloc(static_cast<size_t>(K) * pr->hit_cap);
+    pr->d_nhits.alloc(K);
+    // regenerations between flushes of the LDS stage: about a quarter of its capacity in expected hits
+    const int flush_every = std::max(1, static_cast<int>(PD_STAGE / 4 / (624.0 / std::sqrt(static_cast<double>(m)))));
+    DevBuf<uint32_t> d_seed(K);
+    DevBuf<int> d_err(1);
+    d_seed.upload(useed.data(), K);
+    d_err.zero();
+    {
+        KernelTimer t("projector_draw");
+        hipLaunchKernelGGL(proj_draw_kernel, dim3(K), dim3(PD_THREADS), 0, c.stream, d_seed.p, total, t0, t1, flush_every, pr->d_hits.p, pr->hit_cap,
+                           pr->d_nhits.p, d_err.p);
+        launch_check("proj_draw_kernel");
+    }
+    pr->h_nhits.resize(K);
+    const int per_group = std::max(1, kMaxCompPerGroup / p);
+    bool first = true;
+    for (int k0 = 0; k0 < K; k0 += per_group) {
+        ProjectorGroup grp;
+        grp.k0 = k0;
+        grp.kcount = std::min(per_group, K - k0);
+        grp.ncomp = grp.kcount * p;
+        DevBuf<unsigned int> d_len(static_cast<size_t>(m) + 1), d_fill(static_cast<size_t>(m) + 1);
+        d_len.zero(); d_fill.zero();
+        hipLaunchKernelGGL(proj_count_kernel, dim3(64, grp.kcount), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
+                           static_cast<uint32_t>(p), d_len.p);
+        launch_check("proj_count_kernel");
+        std::vector<unsigned int> len(static_cast<size_t>(m) + 1);
+        d_len.download(len.data(), len.size());          // synchronises the stream
+        if (first) {
+            int err = 0;
+            d_err.download(&err, 1);
+            SHARP_REQUIRE(err == 0, "projector: hit list overflow in the device build");
+            pr->d_nhits.download(pr->h_nhits.data(), K);
+            first = false;
+        }
+        std::vector<uint32_t> rowptr(static_cast<size_t>(m) + 1, 0);
+        int max_len = 0;
+        for (int g = 0; g < m; ++g) { rowptr[g + 1] = rowptr[g] + len[g]; max_len = std::max<int>(max_len, static_cast<int>(len[g])); }
+        grp.nnz = rowptr[m];
+        grp.mean_len = static_cast<double>(grp.nnz) / m;
+        grp.max_len = max_len;
+        const double cover = grp.mean_len + 3.0 * std::sqrt(grp.mean_len) + 1.0;
+        grp.gw = cover <= 16 ? 4 : (cover <= 32 ? 8 : 16);
+        const int span = 4 * grp.gw;
+        std::vector<uint32_t> ovf_gene;
+        std::vector<uint2> ovf_info;
+        long long nseg = m;
+        for (int g = 0; g < m; ++g) {
+            if (len[g] > static_cast<unsigned int>(span)) {
+                const uint32_t extra = (len[g] - span + span - 1) / span;
+                ovf_gene.push_back(static_cast<uint32_t>(g));
+                ovf_info.push_back(make_uint2(static_cast<uint32_t>(nseg), extra));
+                nseg += extra;
+            }
+        }
+        grp.nseg = nseg;
+        grp.novf = static_cast<int>(ovf_gene.size());
+        ovf_gene.push_back(0xFFFFFFFFu);               // keep the tables non-empty
+        ovf_info.push_back(make_uint2(0u, 0u));
+        grp.ovf_gene.alloc(ovf_gene.size());
+        grp.ovf_info.alloc(ovf_info.size());
+        grp.ovf_gene.upload(ovf_gene.data(), ovf_gene.size());
+        grp.ovf_info.upload(ovf_info.data(), ovf_info.size());
+        DevBuf<uint32_t> d_rowptr(rowptr.size());
+        d_rowptr.upload(rowptr.data(), rowptr.size());
+        DevBuf<uint16_t> d_flat(static_cast<size_t>(std::max<long long>(grp.nnz, 1)));
+        const size_t nent = static_cast<size_t>(nseg + 1) * span;
+        grp.ent.alloc(nent);
+        hipLaunchKernelGGL(proj_fill_u16_kernel, dim3(256), dim3(256), 0, c.stream, grp.ent.p, nent, static_cast<uint16_t>(0xFFFFu));
+        hipLaunchKernelGGL(proj_fill_kernel, dim3(64, grp.kcount), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
+                           static_cast<uint32_t>(p), d_rowptr.p, d_fill.p, d_flat.p);
+        hipLaunchKernelGGL(proj_layout_kernel, dim3((m + 255) / 256), dim3(256), 0, c.stream, m, d_rowptr.p, d_flat.p, grp.gw,
+                           grp.ovf_gene.p, grp.ovf_info.p, grp.novf, grp.ent.p);
+        launch_check("proj_layout_kernel");
+        stream_sync();                                   // the temporaries above are released on scope exit
+        pr->groups.push_back(std::move(grp));
+    }
+    pr->device_built = true;
+    return pr;
+}
+
+// Host lists (one CSR per projector, column order) for sharp_projector_triplets(): made on demand from the hit list.
+void ensure_host_lists(Projector &pr, int k) {
+    if (!pr.device_built || !pr.h_rowptr[k].empty()) return;
+    const unsigned int n = pr.h_nhits[k];
+    std::vector<uint32_t> h(n);
+    if (n) {
+        SHARP_HIP_CHECK(hipMemcpyAsync(h.data(), pr.d_hits.p + static_cast<size_t>(k) * pr.hit_cap, static_cast<size_t>(n) * 4,
+                                       hipMemcpyDeviceToHost, ctx().stream));
+        stream_sync();
+    }
+    std::sort(h.begin(), h.end(), [](uint32_t a, uint32_t b) { return (a & 0x7fffffffu) < (b & 0x7fffffffu); });
+    auto &rp = pr.h_rowptr[k];
+    auto &en = pr.h_ent[k];
+    rp.assign(static_cast<size_t>(pr.m) + 1, 0);
+    en.resize(n);
+    const uint32_t up = static_cast<uint32_t>(pr.p);
+    for (unsigned int i = 0; i < n; ++i) {
+        const uint32_t idx = h[i] & 0x7fffffffu, g = idx / up, c = idx - g * up;
+        ++rp[g + 1];
+        en[i] = (h[i] >> 31) ? ~static_cast<int32_t>(c) : static_cast<int32_t>(c);
+    }
+    for (int g = 0; g < pr.m; ++g) rp[g + 1] += rp[g];
+}
+
+std::shared_ptr<Projector> build_projector(int m, int p, int K, const double *seeds) {
+    const char *host = getenv("SHARP_PROJ_HOST");       // debug / cross-check: the host build of the same projector
+    if ((host && host[0] == '1') || static_cast<unsigned long long>(m) * static_cast<unsigned long long>(p) >= (1ull << 31))
+        return build_projector_host(m, p, K, seeds);
+    return build_projector_device(m, p, K, seeds);
+}
+
 int register_projector(std::shared_ptr<Projector> pr) {
     std::lock_guard<std::mutex> lk(g_mu);
     const int h = g_next++;
@@ -265,6 +556,7 @@ int sharp_projector_triplets(int handle, int k, int *gene, int *col, signed char
     SHARP_API_BEGIN
     auto pr = get_projector(handle);
     SHARP_REQUIRE(k >= 0 && k < pr->K, "sharp_projector_triplets: k out of range");
+    ensure_host_lists(*pr, k);
     const auto &rp = pr->h_rowptr[k];
     const auto &en = pr->h_ent[k];
     if (nnz) *nnz = static_cast<long long>(en.size());

@@ -1,5 +1,5 @@
 // projector.hpp -- the K sparse ternary random-projection matrices of ranM()
-// (R/ranM.R:11-33), drawn on the host with R's RNG stream and kept on the device as
+// (R/ranM.R:11-33), drawn with R's RNG stream (on the GPU; a host build exists for cross-checks) and kept on the device as
 // gene-major packed row lists: for gene g the entries (k*p + c, sign) of every
 // projector in the group, 16 bits each (bit 15 = negative).
 #pragma once
@@ -36,6 +36,12 @@ struct Projector {
     std::vector<std::vector<uint32_t>> h_rowptr;
     std::vector<std::vector<int32_t>> h_ent;
     std::vector<ProjectorGroup> groups;
+    // device build: per projector the list of non-zero elements (index r*p + c of the byrow fill, bit 31 = negative)
+    bool device_built = false;
+    unsigned int hit_cap = 0;
+    DevBuf<uint32_t> d_hits;
+    DevBuf<unsigned int> d_nhits;
+    std::vector<unsigned int> h_nhits;
     long long nnz_total() const { long long s = 0; for (auto &g : groups) s += g.nnz; return s; }
 };
 

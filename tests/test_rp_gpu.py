@@ -28,6 +28,22 @@ def test_projector_matches_r_stream(sa, oracle, m, p, seed):
     assert pr.nnz() == gi.size
 
 
+def test_projector_device_build_equals_host_build(sa, oracle, monkeypatch):
+    """The GPU Mersenne-Twister build and the host build of the same projectors give the same lists and the same E."""
+    m, p, n = 5000, 300, 40
+    seeds = [50 + 2103 + k for k in range(1, 8)]
+    X = oracle.synth_fill(SEED, m, 0, n, 4, 600)
+    dev = sa.Projector(m, p, seeds)
+    monkeypatch.setenv("SHARP_PROJ_HOST", "1")
+    host = sa.Projector(m, p, seeds)
+    monkeypatch.delenv("SHARP_PROJ_HOST")
+    assert dev.nnz() == host.nnz()
+    for k in range(len(seeds)):
+        for a, b in zip(dev.triplets(k), host.triplets(k)):
+            assert np.array_equal(a, b)
+    assert np.array_equal(dev.project(X, True), host.project(X, True))
+
+
 @pytest.mark.parametrize("m,n,K,logflag", [(1500, 96, 3, True), (1500, 96, 3, False), (2003, 130, 1, True),
                                             (6000, 70, 15, True), (4097, 33, 5, True)])
 def test_rp_matmul_matches_oracle(sa, oracle, m, n, K, logflag):
