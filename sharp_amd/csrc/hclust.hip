@@ -31,20 +31,36 @@ struct HcMeta {
 
 constexpr int HC_THREADS = 512;
 constexpr double HC_INF = 1.0e300;
+constexpr int HC_RS = 16;   // loads in flight per lane in a rescan pass
 
 struct MinPair { double v; int i; };
 __device__ __forceinline__ MinPair mp_better(MinPair a, MinPair b) {
     return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
+// Wave-wide lexicographic min of (value, index) with DPP moves (no LDS traffic: a ds_bpermute butterfly costs six dependent
+// LDS round trips, which was 40 % of the unloaded merge latency).  The result is valid in lane 63 and broadcast from there.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ MinPair mp_dpp_step(MinPair x) {
+    const int lo = __double2loint(x.v), hi = __double2hiint(x.v);
+    // lanes outside ROW_MASK (and lanes whose source is invalid) keep their own value: op(x, x) = x
+    const int ylo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int yhi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    MinPair y;
+    y.i = __builtin_amdgcn_update_dpp(x.i, x.i, CTRL, ROW_MASK, 0xf, false);
+    y.v = __hiloint2double(yhi, ylo);
+    return mp_better(x, y);
+}
 __device__ __forceinline__ MinPair mp_wave(MinPair x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        MinPair y;
-        y.v = __shfl_xor(x.v, o);
-        y.i = __shfl_xor(x.i, o);
-        x = mp_better(x, y);
-    }
-    return x;
+    x = mp_dpp_step<0xB1, 0xf>(x);     // quad_perm [1,0,3,2]
+    x = mp_dpp_step<0x4E, 0xf>(x);     // quad_perm [2,3,0,1]
+    x = mp_dpp_step<0x141, 0xf>(x);    // row_half_mirror
+    x = mp_dpp_step<0x140, 0xf>(x);    // row_mirror: every lane of a 16-lane row holds the row's result
+    x = mp_dpp_step<0x142, 0xa>(x);    // row_bcast15 into rows 1 and 3
+    x = mp_dpp_step<0x143, 0xc>(x);    // row_bcast31 into rows 2 and 3: lane 63 holds the wave's result
+    MinPair r;
+    r.i = __builtin_amdgcn_readlane(x.i, 63);
+    r.v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x.v), 63), __builtin_amdgcn_readlane(__double2loint(x.v), 63));
+    return r;
 }
 // block-wide min; pv/pi: LDS scratch [32]; every thread returns the result.  The caller must have a
 // barrier between two uses of the same scratch (there always is one in the merge loop).
@@ -80,7 +96,7 @@ __device__ __forceinline__ double lance_williams(int method, double d1, double d
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HC_THREADS) void hclust_kernel(const HcMeta *__restrict__ metas, double *__restrict__ Dall,
                                                             int *__restrict__ ia_all, int *__restrict__ ib_all,
-                                                            double *__restrict__ h_all, int ablate) {
+                                                            double *__restrict__ h_all, int ablate, long long *__restrict__ dbg) {
     const HcMeta M = metas[blockIdx.x];
     const int n = M.n, nld = M.nld, method = M.method;
     double *D = Dall + M.oD;
@@ -121,12 +137,15 @@ __global__ __launch_bounds__(HC_THREADS) void hclust_kernel(const HcMeta *__rest
     // owns index i2 right before it looks at its own entries, and d(i2,j2) is the NN distance just found.
     double *pvB = reinterpret_cast<double *>(flag + ((n + 7) & ~7));
     int *piB = reinterpret_cast<int *>(pvB + 32);
+    long long tacc[6] = {0, 0, 0, 0, 0, 0};
     for (int step = 0; step < n - 1; ++step) {
+        const long long tt0 = dbg ? __builtin_readcyclecounter() : 0;
         // (1) least dissimilarity over the NN list (strict <, lowest index)
         MinPair b; b.v = HC_INF; b.i = 0x7fffffff;
         for (int i = tid; i < n - 1; i += HC_THREADS)
             if (flag[i]) { MinPair c; c.v = disnn[i]; c.i = i; if (c.v < b.v) b = c; }
         b = mp_block(b, pv, pi);
+        const long long tt1 = dbg ? __builtin_readcyclecounter() : 0;
         const int i2 = b.i < n ? b.i : 0;       // NN lists look to the right, so im < nn[im]
         const int j2 = nn[i2];
         const double d12 = b.v;                  // DISNN(im) == D(im, NN(im)) is an invariant of the algorithm
@@ -161,7 +180,9 @@ __global__ __launch_bounds__(HC_THREADS) void hclust_kernel(const HcMeta *__rest
                 }
             }
         }
+        const long long tt2 = dbg ? __builtin_readcyclecounter() : 0;
         nb = mp_block(nb, pvB, piB);
+        const long long tt3 = dbg ? __builtin_readcyclecounter() : 0;
         if (tid == (i2 % HC_THREADS)) {          // owner of i2: merge bookkeeping before it scans its own entries
             membr[i2] = membr[i2] + membr[j2];
             disnn[i2] = nb.v;
@@ -172,17 +193,18 @@ __global__ __launch_bounds__(HC_THREADS) void hclust_kernel(const HcMeta *__rest
         for (int i = tid; i < n - 1; i += HC_THREADS)
             if (i != j2 && flag[i] && (nn[i] == i2 || nn[i] == j2)) list[atomicAdd(cnt, 1)] = i;
         __syncthreads();
+        const long long tt4 = dbg ? __builtin_readcyclecounter() : 0;
         const int nl = (ablate & 2) ? 0 : *cnt;
         for (int q = wave; q < nl; q += nwave) {
             const int i = list[q];
             const double *row = D + static_cast<long long>(i) * nld;
             MinPair c; c.v = HC_INF; c.i = 0x7fffffff;
-            for (int j0 = i + 1 + lane; j0 < n; j0 += 64 * 16) {
-                double v[16];
+            for (int j0 = i + 1 + lane; j0 < n; j0 += 64 * HC_RS) {   // one pass (one HBM round trip) covers 2048 entries
+                double v[HC_RS];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { const int j = j0 + 64 * u; v[u] = row[j < n ? j : n - 1]; }
+                for (int u = 0; u < HC_RS; ++u) { const int j = j0 + 64 * u; v[u] = row[j < n ? j : n - 1]; }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
+                for (int u = 0; u < HC_RS; ++u) {
                     const int j = j0 + 64 * u;
                     if (j < n && flag[j] && v[u] < c.v) { c.v = v[u]; c.i = j; }
                 }
@@ -190,8 +212,11 @@ __global__ __launch_bounds__(HC_THREADS) void hclust_kernel(const HcMeta *__rest
             c = mp_wave(c);
             if (lane == 0) { disnn[i] = c.v; if (c.i < n) nn[i] = c.i; }
         }
+        const long long tt5 = dbg ? __builtin_readcyclecounter() : 0;
         __syncthreads();
+        if (dbg) { const long long tt6 = __builtin_readcyclecounter(); tacc[0] += tt1 - tt0; tacc[1] += tt2 - tt1; tacc[2] += tt3 - tt2; tacc[3] += tt4 - tt3; tacc[4] += tt5 - tt4; tacc[5] += tt6 - tt5; }
     }
+    if (dbg && tid == 0) for (int q = 0; q < 6; ++q) dbg[blockIdx.x * 6 + q] = tacc[q];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -529,13 +554,25 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
     // a4: agglomeration
     {
         const int nal = (max_n + 1) & ~1;
+        KernelTimer tm("hclust");
         const size_t lds = static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16 + 32 * 12 + 16;
         SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             static_cast<int>(lds)));
-        KernelTimer tm("hclust");
         const char *abl = getenv("SHARP_HC_ABLATE");
+        const char *tim = getenv("SHARP_HC_TIMING");       // debug: per-phase cycle counts of the merge loop
+        DevBuf<long long> dbg;
+        if (tim) { dbg.alloc(static_cast<size_t>(T) * 6); dbg.zero(); }
         hipLaunchKernelGGL(hclust_kernel, dim3(T), dim3(HC_THREADS), lds, c.stream, W.meta.p, W.D.p, W.ia.p, W.ib.p, W.height.p,
-                           abl ? atoi(abl) : 0);
+                           abl ? atoi(abl) : 0, dbg.p);
+        if (tim) {
+            std::vector<long long> h(static_cast<size_t>(T) * 6);
+            dbg.download(h.data(), h.size());
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            for (int t = 0; t < T; ++t) for (int q = 0; q < 6; ++q) acc[q] += static_cast<double>(h[static_cast<size_t>(t) * 6 + q]);
+            fprintf(stderr, "hclust phases T=%d n=%d, mean shader cycles per task: argmin %.0f | loads+LW+stores %.0f | nb reduce %.0f | "
+                            "list+barrier %.0f | rescans %.0f | end barrier %.0f\n", T, max_n, acc[0] / T, acc[1] / T, acc[2] / T, acc[3] / T,
+                    acc[4] / T, acc[5] / T);
+        }
         launch_check("hclust_kernel");
     }
     // a5a: labels for every candidate k

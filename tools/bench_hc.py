@@ -4,7 +4,11 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
+import os
 import sharp_amd
+from sharp_amd import _lib as _L
+if os.environ.get('SHARP_VARIANT'):
+    _L._SO = os.path.join(os.path.dirname(_L._SO), 'variants', 'libsharp_hip_%s.so' % os.environ['SHARP_VARIANT'])
 from sharp_amd import device as dev
 
 sharp_amd.init(0)
