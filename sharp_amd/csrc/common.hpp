@@ -58,6 +58,8 @@ struct Ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // side stream: producer kernels that overlap with consumers on `stream`
+    std::vector<hipStream_t> aux;    // extra streams for pipelined task ranges (created on demand, see aux_stream())
+    hipStream_t aux_stream(int i);
     int num_cu = 256;
     size_t lds_per_block = 65536;
     bool profiling = false;
@@ -119,6 +121,16 @@ struct DevBuf {
         SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream));
     }
     void zero() { if (n) SHARP_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), ctx().stream)); }
+};
+
+// Makes `s` the library's current stream for the lifetime of the object: every launch helper, DevBuf transfer and
+// KernelTimer below it then works on `s` (used to pipeline independent task ranges on several streams).
+struct StreamScope {
+    hipStream_t saved;
+    explicit StreamScope(hipStream_t s) : saved(ctx().stream) { ctx().stream = s; }
+    ~StreamScope() { ctx_unchecked().stream = saved; }
+    StreamScope(const StreamScope &) = delete;
+    StreamScope &operator=(const StreamScope &) = delete;
 };
 
 inline void stream_sync() { SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream)); }

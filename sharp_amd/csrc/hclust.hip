@@ -1,6 +1,6 @@
 // hclust.hip -- batched get_opt_hclust on the GPU (R/get_opt_hclust.R:33-244):
 //   a3  distance build      row_prep + fp64-MFMA correlation GEMM (linalg.hip)       :66-74
-//   a4  stats::hclust       one 1024-thread workgroup per task, NN-list algorithm      :76-83
+//   a4  stats::hclust       one 512-thread workgroup per task, NN-list algorithm      :76-83
 //   a5  cutree k=min..max, median silhouette, get_CH("1-corr"), model selection        :90-231
 // Third-party algorithms restated (not vendored by the reference): stats::hclust's Fortran NN-list
 // agglomeration with Lance-Williams updates (fp64, same operation order, lowest-index tie-breaks),
@@ -524,7 +524,12 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
     W.meta.ensure(T); W.prep.ensure(T); W.gemm.ensure(5 * static_cast<size_t>(T)); }
     W.meta.upload(metas.data(), T);
 
-    // a3: rows -> centred/normalised (+ 1 - S for similarity input)
+    // Every descriptor of the chunk goes up once; the device work is then enqueued per RANGE of tasks, each range on its
+    // own stream: the agglomeration is a memory-latency/scatter-bound kernel and the correlation GEMM an MFMA-bound one,
+    // so a range's GEMM, cutree and silhouette statistics run underneath the agglomeration of the other ranges.
+    int NS = T >= 96 ? 2 : 1;   // measured: 2 ranges -4 ms, 3 or more slower than one (the GEMM slows the agglomeration it overlaps)
+    if (const char *e = getenv("SHARP_HC_RANGES")) NS = std::max(1, std::min(8, atoi(e)));
+    NS = std::min(NS, T);
     std::vector<RowPrepTask> prep(T);
     for (int t = 0; t < T; ++t) {
         const HcTask &tk = tasks[i0 + t];
@@ -533,106 +538,123 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
                               W.Ct.p + M.oCt, W.nrm.p + M.oNrm, W.D.p + M.oD};
     }
     W.prep.upload(prep.data(), T);
-    row_prep_batched(W.prep.p, T, max_n, max_p);
+    struct Range { int t0, t1; int off[5], cnt[5]; bool any_sym, any_feat; };
+    std::vector<Range> ranges(NS);
     std::vector<GemmTask> g;
-    if (any_feat) {   // D = 1 - U U^T
-        g.clear();
-        for (int t = 0; t < T; ++t) {
-            const HcMeta &M = metas[t];
-            if (M.symmetric) continue;
-            g.push_back(GemmTask{W.Ct.p + M.oCt, W.Ct.p + M.oCt, W.D.p + M.oD, M.n, M.n, M.p, M.nld, M.nld, M.nld, 1, 1, 1});
+    g.reserve(5 * static_cast<size_t>(T));
+    for (int s = 0; s < NS; ++s) {
+        Range &R = ranges[s];
+        R.t0 = static_cast<int>(static_cast<long long>(T) * s / NS);
+        R.t1 = static_cast<int>(static_cast<long long>(T) * (s + 1) / NS);
+        R.any_sym = R.any_feat = false;
+        for (int kind = 0; kind < 5; ++kind) {
+            R.off[kind] = static_cast<int>(g.size());
+            for (int t = R.t0; t < R.t1; ++t) {
+                const HcMeta &M = metas[t];
+                R.any_sym |= M.symmetric != 0; R.any_feat |= M.symmetric == 0;
+                switch (kind) {
+                    case 0:   // D = 1 - U U^T (feature tasks)
+                        if (!M.symmetric) g.push_back(GemmTask{W.Ct.p + M.oCt, W.Ct.p + M.oCt, W.D.p + M.oD, M.n, M.n, M.p, M.nld, M.nld, M.nld, 1, 1, 1});
+                        break;
+                    case 1:   // finest-level sums on the MFMA:  CSt = Cr^T H
+                        g.push_back(GemmTask{W.Cr.p + M.oCr, W.H.p + M.oH, W.CSt.p + M.oCSt, M.p, M.kpad, M.n, M.p, M.kpad, M.kpad, 0, 0, 0});
+                        break;
+                    case 2:   // G = C CS^T
+                        g.push_back(GemmTask{W.Ct.p + M.oCt, W.CSt.p + M.oCSt, W.G.p + M.oG, M.n, M.kpad, M.p, M.nld, M.kpad, M.kpad, 0, 0, 0});
+                        break;
+                    case 3:   // Q = CS CS^T
+                        g.push_back(GemmTask{W.CSt.p + M.oCSt, W.CSt.p + M.oCSt, W.Q.p + M.oQ, M.kpad, M.kpad, M.p, M.kpad, M.kpad, M.kpad, 0, 0, 0});
+                        break;
+                    default:  // (symmetric) T = D0 H
+                        if (M.symmetric) g.push_back(GemmTask{W.D0.p + M.oD0, W.H.p + M.oH, W.T.p + M.oT, M.n, M.kpad, M.n, M.nld, M.kpad, M.kpad, 0, 0, 0});
+                        break;
+                }
+            }
+            R.cnt[kind] = static_cast<int>(g.size()) - R.off[kind];
         }
-        W.gemm.upload(g.data(), g.size());
-        gemm_tn_f64_batched(W.gemm.p, static_cast<int>(g.size()), max_n, max_n, "corr_dist_gemm", true);
-        stream_sync();   // W.gemm is reused below
     }
-    if (any_sym) {
-        KernelTimer tm("copy_d");
-        hipLaunchKernelGGL(copy_d_kernel, dim3(64, T), dim3(256), 0, c.stream, W.meta.p, W.D.p, W.D0.p);
-        launch_check("copy_d_kernel");
+    W.gemm.upload(g.data(), g.size());
+    (void)any_sym; (void)any_feat;
+    static hipEvent_t ev_in = nullptr, ev_out[8] = {nullptr};
+    if (!ev_in) {
+        SHARP_HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+        for (auto &e : ev_out) SHARP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    // a4: agglomeration
-    {
-        const int nal = (max_n + 1) & ~1;
-        KernelTimer tm("hclust");
-        const size_t lds = static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16 + 32 * 12 + 16;
-        SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            static_cast<int>(lds)));
-        const char *abl = getenv("SHARP_HC_ABLATE");
-        const char *tim = getenv("SHARP_HC_TIMING");       // debug: per-phase cycle counts of the merge loop
-        DevBuf<long long> dbg;
-        if (tim) { dbg.alloc(static_cast<size_t>(T) * 6); dbg.zero(); }
-        hipLaunchKernelGGL(hclust_kernel, dim3(T), dim3(HC_THREADS), lds, c.stream, W.meta.p, W.D.p, W.ia.p, W.ib.p, W.height.p,
-                           abl ? atoi(abl) : 0, dbg.p);
-        if (tim) {
-            std::vector<long long> h(static_cast<size_t>(T) * 6);
-            dbg.download(h.data(), h.size());
-            double acc[6] = {0, 0, 0, 0, 0, 0};
-            for (int t = 0; t < T; ++t) for (int q = 0; q < 6; ++q) acc[q] += static_cast<double>(h[static_cast<size_t>(t) * 6 + q]);
-            fprintf(stderr, "hclust phases T=%d n=%d, mean shader cycles per task: argmin %.0f | loads+LW+stores %.0f | nb reduce %.0f | "
-                            "list+barrier %.0f | rescans %.0f | end barrier %.0f\n", T, max_n, acc[0] / T, acc[1] / T, acc[2] / T, acc[3] / T,
-                    acc[4] / T, acc[5] / T);
+    hipStream_t main_stream = c.stream;
+    if (NS > 1) SHARP_HIP_CHECK(hipEventRecord(ev_in, main_stream));     // inputs and descriptors are ready
+
+    for (int s = 0; s < NS; ++s) {
+        const Range &R = ranges[s];
+        const int Ts = R.t1 - R.t0;
+        hipStream_t st = NS > 1 ? c.aux_stream(s) : main_stream;
+        if (NS > 1) SHARP_HIP_CHECK(hipStreamWaitEvent(st, ev_in, 0));
+        StreamScope scope(st);
+        const HcMeta *dmeta = W.meta.p + R.t0;
+        // a3: rows -> centred/normalised (+ 1 - S for similarity input), then D = 1 - U U^T
+        row_prep_batched(W.prep.p + R.t0, Ts, max_n, max_p);
+        if (R.cnt[0]) gemm_tn_f64_batched(W.gemm.p + R.off[0], R.cnt[0], max_n, max_n, "corr_dist_gemm", true, true);
+        if (R.any_sym) {
+            KernelTimer tm("copy_d");
+            hipLaunchKernelGGL(copy_d_kernel, dim3(64, Ts), dim3(256), 0, st, dmeta, W.D.p, W.D0.p);
+            launch_check("copy_d_kernel");
         }
-        launch_check("hclust_kernel");
-    }
-    // a5a: labels for every candidate k
-    {
-        const size_t lds = static_cast<size_t>(max_n) * 4 * 3 + (HC_THREADS / 64 + 1) * 4;
-        SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cutree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            static_cast<int>(lds)));
-        KernelTimer tm("cutree");
-        hipLaunchKernelGGL(cutree_kernel, dim3(T), dim3(HC_THREADS), lds, c.stream, W.meta.p, W.ia.p, W.ib.p, W.lab.p);
-        launch_check("cutree_kernel");
-    }
-    {
-        KernelTimer tm("onehot");
-        hipLaunchKernelGGL(onehot_kernel, dim3(64, T), dim3(256), 0, c.stream, W.meta.p, W.lab.p, W.H.p);
-        launch_check("onehot_kernel");
-    }
-    // finest-level sums on the MFMA:  CSt = Cr^T H ; G = C CS^T ; Q = CS CS^T ; (symmetric) T = D0 H
-    auto run_gemms = [&](const char *name, int mM, int mN) {
-        if (g.empty()) return;
-        W.gemm.upload(g.data(), g.size());
-        gemm_tn_f64_batched(W.gemm.p, static_cast<int>(g.size()), mM, mN, name);
-        stream_sync();
-    };
-    g.clear();
-    for (int t = 0; t < T; ++t) {
-        const HcMeta &M = metas[t];
-        g.push_back(GemmTask{W.Cr.p + M.oCr, W.H.p + M.oH, W.CSt.p + M.oCSt, M.p, M.kpad, M.n, M.p, M.kpad, M.kpad, 0, 0, 0});
-    }
-    run_gemms("cluster_sums_gemm", max_p, max_kpad);
-    g.clear();
-    for (int t = 0; t < T; ++t) {
-        const HcMeta &M = metas[t];
-        g.push_back(GemmTask{W.Ct.p + M.oCt, W.CSt.p + M.oCSt, W.G.p + M.oG, M.n, M.kpad, M.p, M.nld, M.kpad, M.kpad, 0, 0, 0});
-    }
-    run_gemms("row_cluster_dot_gemm", max_n, max_kpad);
-    g.clear();
-    for (int t = 0; t < T; ++t) {
-        const HcMeta &M = metas[t];
-        g.push_back(GemmTask{W.CSt.p + M.oCSt, W.CSt.p + M.oCSt, W.Q.p + M.oQ, M.kpad, M.kpad, M.p, M.kpad, M.kpad, M.kpad, 0, 0, 0});
-    }
-    run_gemms("cluster_gram_gemm", max_kpad, max_kpad);
-    if (any_sym) {
-        g.clear();
-        for (int t = 0; t < T; ++t) {
-            const HcMeta &M = metas[t];
-            if (!M.symmetric) continue;
-            g.push_back(GemmTask{W.D0.p + M.oD0, W.H.p + M.oH, W.T.p + M.oT, M.n, M.kpad, M.n, M.nld, M.kpad, M.kpad, 0, 0, 0});
+        // a4: agglomeration
+        {
+            const int nal = (max_n + 1) & ~1;
+            KernelTimer tm("hclust");
+            const size_t lds = static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16 + 32 * 12 + 16;
+            SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                static_cast<int>(lds)));
+            const char *abl = getenv("SHARP_HC_ABLATE");
+            const char *tim = getenv("SHARP_HC_TIMING");       // debug: per-phase cycle counts of the merge loop
+            DevBuf<long long> dbg;
+            if (tim) { dbg.alloc(static_cast<size_t>(Ts) * 6); dbg.zero(); }
+            hipLaunchKernelGGL(hclust_kernel, dim3(Ts), dim3(HC_THREADS), lds, st, dmeta, W.D.p, W.ia.p, W.ib.p, W.height.p,
+                               abl ? atoi(abl) : 0, dbg.p);
+            launch_check("hclust_kernel");
+            if (tim) {
+                std::vector<long long> h(static_cast<size_t>(Ts) * 6);
+                dbg.download(h.data(), h.size());
+                double acc[6] = {0, 0, 0, 0, 0, 0};
+                for (int t = 0; t < Ts; ++t) for (int q = 0; q < 6; ++q) acc[q] += static_cast<double>(h[static_cast<size_t>(t) * 6 + q]);
+                fprintf(stderr, "hclust phases T=%d n=%d, mean shader cycles per task: argmin %.0f | loads+LW+stores %.0f | nb reduce %.0f | "
+                                "list+barrier %.0f | rescans %.0f | end barrier %.0f\n", Ts, max_n, acc[0] / Ts, acc[1] / Ts, acc[2] / Ts,
+                        acc[3] / Ts, acc[4] / Ts, acc[5] / Ts);
+            }
         }
-        run_gemms("dist_cluster_sums_gemm", max_n, max_kpad);
-    }
-    // a5b: silhouette medians + CH per level
-    {
-        int npow2 = 1; while (npow2 < max_n) npow2 <<= 1;
-        const size_t lds = static_cast<size_t>(npow2) * 8 + ST_THREADS * 8 + 2 * ST_MAXK * 8 + (5 * ST_MAXK + 8) * 4;
-        SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            static_cast<int>(lds)));
-        KernelTimer tm("sil_ch_stats");
-        hipLaunchKernelGGL(stats_kernel, dim3(max_nk, T), dim3(ST_THREADS), lds, c.stream, W.meta.p, W.lab.p, W.T.p, W.G.p, W.Q.p,
-                           W.nrm.p, W.out.p);
-        launch_check("stats_kernel");
+        // a5a: labels for every candidate k
+        {
+            const size_t lds = static_cast<size_t>(max_n) * 4 * 3 + (HC_THREADS / 64 + 1) * 4;
+            SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cutree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                static_cast<int>(lds)));
+            KernelTimer tm("cutree");
+            hipLaunchKernelGGL(cutree_kernel, dim3(Ts), dim3(HC_THREADS), lds, st, dmeta, W.ia.p, W.ib.p, W.lab.p);
+            launch_check("cutree_kernel");
+        }
+        {
+            KernelTimer tm("onehot");
+            hipLaunchKernelGGL(onehot_kernel, dim3(64, Ts), dim3(256), 0, st, dmeta, W.lab.p, W.H.p);
+            launch_check("onehot_kernel");
+        }
+        if (R.cnt[1]) gemm_tn_f64_batched(W.gemm.p + R.off[1], R.cnt[1], max_p, max_kpad, "cluster_sums_gemm");
+        if (R.cnt[2]) gemm_tn_f64_batched(W.gemm.p + R.off[2], R.cnt[2], max_n, max_kpad, "row_cluster_dot_gemm");
+        if (R.cnt[3]) gemm_tn_f64_batched(W.gemm.p + R.off[3], R.cnt[3], max_kpad, max_kpad, "cluster_gram_gemm");
+        if (R.cnt[4]) gemm_tn_f64_batched(W.gemm.p + R.off[4], R.cnt[4], max_n, max_kpad, "dist_cluster_sums_gemm");
+        // a5b: silhouette medians + CH per level
+        {
+            int npow2 = 1; while (npow2 < max_n) npow2 <<= 1;
+            const size_t lds = static_cast<size_t>(npow2) * 8 + ST_THREADS * 8 + 2 * ST_MAXK * 8 + (5 * ST_MAXK + 8) * 4;
+            SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                static_cast<int>(lds)));
+            KernelTimer tm("sil_ch_stats");
+            hipLaunchKernelGGL(stats_kernel, dim3(max_nk, Ts), dim3(ST_THREADS), lds, st, dmeta, W.lab.p, W.T.p, W.G.p, W.Q.p,
+                               W.nrm.p, W.out.p);
+            launch_check("stats_kernel");
+        }
+        if (NS > 1) {
+            SHARP_HIP_CHECK(hipEventRecord(ev_out[s], st));
+            SHARP_HIP_CHECK(hipStreamWaitEvent(main_stream, ev_out[s], 0));
+        }
     }
     std::vector<double> h_out(oOut), h_height(oM);
     HostTimer ht_tail("hc_download_select");

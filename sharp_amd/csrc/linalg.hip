@@ -6,6 +6,12 @@
 
 namespace sharp {
 
+// Pointers read out of a descriptor in memory are generic (flat) to the compiler: flat loads count on lgkmcnt as well as
+// vmcnt, so every LDS wait would also wait for the global prefetch.  Casting to the global address space gives global_load.
+typedef __attribute__((address_space(1))) const double *gcdp;   // global const double *
+typedef __attribute__((address_space(1))) double *gdp;          // global double *
+
+
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
@@ -38,8 +44,8 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_kernel(const GemmTask *__rest
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int mm = m0 + lcol + q, nn = n0 + lcol + q;
-            As[lrow][lcol + q] = (k < t.K && mm < t.M) ? t.At[static_cast<long long>(k) * t.lda + mm] : 0.0;
-            Bs[lrow][lcol + q] = (k < t.K && nn < t.N) ? t.Bt[static_cast<long long>(k) * t.ldb + nn] : 0.0;
+            As[lrow][lcol + q] = (k < t.K && mm < t.M) ? ((gcdp)t.At)[static_cast<long long>(k) * t.lda + mm] : 0.0;
+            Bs[lrow][lcol + q] = (k < t.K && nn < t.N) ? ((gcdp)t.Bt)[static_cast<long long>(k) * t.ldb + nn] : 0.0;
         }
         __syncthreads();
 #pragma unroll
@@ -76,8 +82,8 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_kernel(const GemmTask *__rest
                         v = v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v);
                         if (row == col) v = 1.0;
                     }
-                    t.C[static_cast<long long>(row) * t.ldc + col] = v;
-                    if (t.symmetric && n0 > m0) t.C[static_cast<long long>(col) * t.ldc + row] = v;
+                    ((gdp)t.C)[static_cast<long long>(row) * t.ldc + col] = v;
+                    if (t.symmetric && n0 > m0) ((gdp)t.C)[static_cast<long long>(col) * t.ldc + row] = v;
                 }
             }
 }
@@ -88,11 +94,29 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_kernel(const GemmTask *__rest
 // VGPRs); no bounds checks in the K loop, 16-byte loads, next K tile fetched into registers while the MFMAs run.
 constexpr int FT = 128, FLD = 144;   // 144 doubles per k row: two k rows of a half-wave land 32 banks apart
 
-__global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *__restrict__ tasks) {
-    const GemmTask t = tasks[blockIdx.z];
-    const int m0 = blockIdx.y * FT, n0 = blockIdx.x * FT;
-    if (m0 >= t.M || n0 >= t.N) return;
-    if (t.symmetric && n0 < m0) return;
+// Block -> (task, tile).  Only live tiles are launched (a workgroup that exits at once still costs a full dispatch: with
+// the lower-triangle tiles of a symmetric product in the grid the kernel ran at 43 TF/s instead of 76, see
+// tools/micro/mfma_f64_loop.hip), and the linear id is dealt so that the eight tasks of a group sit on the eight XCDs
+// (workgroups go round-robin to XCDs): all tiles of a task then share one L2.
+__global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *__restrict__ tasks, int count, int tiles_max) {
+    const long long B = blockIdx.x;
+    const long long per_group = 8LL * tiles_max;
+    const int zt = static_cast<int>(B / per_group) * 8 + static_cast<int>(B % 8);
+    if (zt >= count) return;
+    int L = static_cast<int>((B % per_group) / 8);
+    const GemmTask t = tasks[zt];
+    const int ntm = (t.M + FT - 1) / FT, ntn = (t.N + FT - 1) / FT;
+    int ti, tj;
+    if (t.symmetric) {            // upper triangle incl. diagonal, row by row
+        ti = 0;
+        while (ti < ntn && L >= ntn - ti) { L -= ntn - ti; ++ti; }
+        if (ti >= ntn) return;
+        tj = ti + L;
+    } else {
+        if (L >= ntm * ntn) return;
+        ti = L / ntn; tj = L % ntn;
+    }
+    const int m0 = ti * FT, n0 = tj * FT;
     __shared__ double As[GK][FLD];
     __shared__ double Bs[GK][FLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -105,28 +129,45 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
     const int lrow = tid >> 5, lcol = (tid & 31) * 4;
     const int Kp = (t.K + GK - 1) / GK * GK;
     typedef double d2 __attribute__((ext_vector_type(2)));
-    const double *ap = t.At + static_cast<long long>(lrow) * t.lda + m0 + lcol;
-    const double *bp = t.Bt + static_cast<long long>(lrow) * t.ldb + n0 + lcol;
-    d2 ra0 = *reinterpret_cast<const d2 *>(ap), ra1 = *reinterpret_cast<const d2 *>(ap + 2);
-    d2 rb0 = *reinterpret_cast<const d2 *>(bp), rb1 = *reinterpret_cast<const d2 *>(bp + 2);
+    gcdp ap = (gcdp)t.At + static_cast<long long>(lrow) * t.lda + m0 + lcol;
+    gcdp bp = (gcdp)t.Bt + static_cast<long long>(lrow) * t.ldb + n0 + lcol;
+    typedef __attribute__((address_space(1))) const d2 *gd2p;
+    d2 ra0 = *(gd2p)(ap), ra1 = *(gd2p)(ap + 2);
+    d2 rb0 = *(gd2p)(bp), rb1 = *(gd2p)(bp + 2);
     for (int k0 = 0; k0 < Kp; k0 += GK) {
+#ifdef GEMM_ABL_NOFILL
+        if (k0 == 0) {
+#endif
         As[lrow][lcol] = ra0.x; As[lrow][lcol + 1] = ra0.y; As[lrow][lcol + 2] = ra1.x; As[lrow][lcol + 3] = ra1.y;
         Bs[lrow][lcol] = rb0.x; Bs[lrow][lcol + 1] = rb0.y; Bs[lrow][lcol + 2] = rb1.x; Bs[lrow][lcol + 3] = rb1.y;
+#ifdef GEMM_ABL_NOFILL
+        }
+#endif
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is in LDS
         __builtin_amdgcn_s_barrier();
         // next tile (the last iteration re-reads the final tile: unconditional loads keep the waits counted)
         const int kn = k0 + GK < Kp ? k0 + GK : k0;
-        const double *an = ap + static_cast<long long>(kn) * t.lda, *bn = bp + static_cast<long long>(kn) * t.ldb;
-        ra0 = *reinterpret_cast<const d2 *>(an); ra1 = *reinterpret_cast<const d2 *>(an + 2);
-        rb0 = *reinterpret_cast<const d2 *>(bn); rb1 = *reinterpret_cast<const d2 *>(bn + 2);
+        gcdp an = ap + static_cast<long long>(kn) * t.lda;
+        gcdp bn = bp + static_cast<long long>(kn) * t.ldb;
+#ifndef GEMM_ABL_NOFILL
+        ra0 = *(gd2p)(an); ra1 = *(gd2p)(an + 2);
+        rb0 = *(gd2p)(bn); rb1 = *(gd2p)(bn + 2);
+#endif
+#ifdef GEMM_ABL_NOLDSREAD
+        double a[4], b[2];
+        for (int i = 0; i < 4; ++i) a[i] = As[lane >> 4][wr + i * 16 + (lane & 15)];
+        for (int j = 0; j < 2; ++j) b[j] = Bs[lane >> 4][wc + j * 16 + (lane & 15)];
+#endif
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
+#ifndef GEMM_ABL_NOLDSREAD
             const int kr = kk + (lane >> 4);
             double a[4], b[2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] = As[kr][wr + i * 16 + (lane & 15)];
 #pragma unroll
             for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wc + j * 16 + (lane & 15)];
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -154,21 +195,31 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
                         v = v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v);
                         if (row == col) v = 1.0;
                     }
-                    t.C[static_cast<long long>(row) * t.ldc + col] = v;
-                    if (t.symmetric && n0 > m0) t.C[static_cast<long long>(col) * t.ldc + row] = v;
+#ifndef GEMM_NO_STORE
+                    ((gdp)t.C)[static_cast<long long>(row) * t.ldc + col] = v;
+#else
+                    if (v == 123.456) t.C[0] = v;
+#endif
+#ifndef GEMM_NO_MIRROR
+                    if (t.symmetric && n0 > m0) ((gdp)t.C)[static_cast<long long>(col) * t.ldc + row] = v;
+#endif
                 }
             }
 }
 
-void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_N, const char *timer_name, bool fast) {
+void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_N, const char *timer_name, bool fast, bool symmetric) {
     if (count <= 0 || max_M <= 0 || max_N <= 0) return;
     Ctx &c = ctx();
     KernelTimer tm(timer_name);
     for (int z0 = 0; z0 < count; z0 += 65535) {
         const int nz = std::min(65535, count - z0);
-        if (fast)
-            hipLaunchKernelGGL(gemm_tn_f64_fast_kernel, dim3((max_N + FT - 1) / FT, (max_M + FT - 1) / FT, nz), dim3(512), 0, c.stream,
-                               d_tasks + z0);
+        if (fast) {
+            const int ntm = (max_M + FT - 1) / FT, ntn = (max_N + FT - 1) / FT;
+            const int tiles_max = symmetric ? ntn * (ntn + 1) / 2 : ntm * ntn;
+            const long long blocks = static_cast<long long>((nz + 7) / 8) * 8 * tiles_max;
+            hipLaunchKernelGGL(gemm_tn_f64_fast_kernel, dim3(static_cast<unsigned>(blocks)), dim3(512), 0, c.stream, d_tasks + z0, nz,
+                               tiles_max);
+        }
         else
             hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3((max_N + GT - 1) / GT, (max_M + GT - 1) / GT, nz), dim3(256), 0, c.stream,
                                d_tasks + z0);
@@ -185,14 +236,44 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// sum over the row held as RP_MAXV values per lane (entries beyond p are zero and masked by the caller)
+constexpr int RP_MAXV = 8;
+
 __global__ __launch_bounds__(256) void row_prep_kernel(const RowPrepTask *__restrict__ tasks) {
     const RowPrepTask t = tasks[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= t.n) return;
-    const double *x = t.src + static_cast<long long>(row) * t.lds;
-    double *cr = t.Cr + static_cast<long long>(row) * t.p;
+    gcdp x = (gcdp)t.src + static_cast<long long>(row) * t.lds;
+    gdp cr = (gdp)t.Cr + static_cast<long long>(row) * t.p;
     const int p = t.p;
+    if (t.mode == 0 && p <= 64 * RP_MAXV) {
+        // feature rows of a base-clustering task (p = reduced dimension): the row is read once and kept in registers;
+        // the arithmetic and its order are those of the general path below
+        double xv[RP_MAXV];
+#pragma unroll
+        for (int u = 0; u < RP_MAXV; ++u) { const int q = lane + 64 * u; xv[u] = x[q < p ? q : 0]; }
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < RP_MAXV; ++u) if (lane + 64 * u < p) s += xv[u];
+        const double mean = wave_sum(s) / p;
+        double ss = 0.0;
+#pragma unroll
+        for (int u = 0; u < RP_MAXV; ++u) if (lane + 64 * u < p) { const double c = xv[u] - mean; ss += c * c; }
+        const double sd = sqrt(wave_sum(ss) / static_cast<double>(p - 1 > 1 ? p - 1 : 1));
+        double s2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < RP_MAXV; ++u) if (lane + 64 * u < p) { xv[u] = (xv[u] - mean) / sd; s2 += xv[u]; }
+        const double mean2 = wave_sum(s2) / p;
+        double n2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < RP_MAXV; ++u) if (lane + 64 * u < p) { xv[u] -= mean2; n2 += xv[u] * xv[u]; }
+        const double nr = sqrt(wave_sum(n2));
+#pragma unroll
+        for (int u = 0; u < RP_MAXV; ++u) if (lane + 64 * u < p) cr[lane + 64 * u] = xv[u] / nr;
+        if (lane == 0) ((gdp)t.nrm)[row] = 1.0;
+        return;
+    }
     double s = 0.0;
     for (int q = lane; q < p; q += 64) s += x[q];
     const double mean = wave_sum(s) / p;
@@ -209,20 +290,20 @@ __global__ __launch_bounds__(256) void row_prep_kernel(const RowPrepTask *__rest
         for (int q = lane; q < p; q += 64) { const double c = (x[q] - mean) / sd - mean2; n2 += c * c; }
         const double nr = sqrt(wave_sum(n2));
         for (int q = lane; q < p; q += 64) cr[q] = ((x[q] - mean) / sd - mean2) / nr;
-        if (lane == 0) t.nrm[row] = 1.0;
+        if (lane == 0) ((gdp)t.nrm)[row] = 1.0;
     } else {
         // symmetric similarity: rows of S are the feature vectors of get_CH (centred, not scaled),
         // and d = as.dist(1 - S) takes the lower triangle (R/get_opt_hclust.R:66-69)
         double n2 = 0.0;
         for (int q = lane; q < p; q += 64) { const double c = x[q] - mean; n2 += c * c; cr[q] = c; }
         const double nr = sqrt(wave_sum(n2));
-        if (lane == 0) t.nrm[row] = nr;
-        double *drow = t.D + static_cast<long long>(row) * t.nld;
+        if (lane == 0) ((gdp)t.nrm)[row] = nr;
+        gdp drow = (gdp)t.D + static_cast<long long>(row) * t.nld;
         for (int q = lane; q < p; q += 64) {
             double d;
             if (q == row) d = 0.0;
             else if (q < row) d = 1.0 - x[q];                                         // S[row][q], row > q
-            else d = 1.0 - t.src[static_cast<long long>(q) * t.lds + row];           // S[q][row], q > row
+            else d = 1.0 - ((gcdp)t.src)[static_cast<long long>(q) * t.lds + row];   // S[q][row], q > row
             drow[q] = d;
         }
     }
@@ -237,12 +318,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const RowPrepTask *__res
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int j = ty; j < 32; j += 8) {
         const int r = r0 + j, q = q0 + tx;
-        tile[j][tx] = (r < t.n && q < t.p) ? t.Cr[static_cast<long long>(r) * t.p + q] : 0.0;
+        tile[j][tx] = (r < t.n && q < t.p) ? ((gcdp)t.Cr)[static_cast<long long>(r) * t.p + q] : 0.0;
     }
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int q = q0 + j, r = r0 + tx;
-        if (q < t.p_pad && r < t.nld) t.Ct[static_cast<long long>(q) * t.nld + r] = (r < t.n && q < t.p) ? tile[tx][j] : 0.0;
+        if (q < t.p_pad && r < t.nld) ((gdp)t.Ct)[static_cast<long long>(q) * t.nld + r] = (r < t.n && q < t.p) ? tile[tx][j] : 0.0;
     }
 }
 

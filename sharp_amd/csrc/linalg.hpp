@@ -22,7 +22,10 @@ struct GemmTask {
 };
 
 // Launch over a device-resident array of `count` GemmTask (max_M/max_N size the grid).
-void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_N, const char *timer_name, bool fast = false);
+// fast: 128x128 MFMA tiles (needs 16-byte aligned panels padded to 4 columns); symmetric: every task of the batch has
+// symmetric = 1, so only upper-triangle tiles are launched
+void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_N, const char *timer_name, bool fast = false,
+                         bool symmetric = false);
 
 // Row preparation for one matrix of a batch (R/get_opt_hclust.R:66-74 + the centring inside cor()):
 //   mode 0 (feature rows): z = (x - mean)/sd(p-1)  [t(scale(t(mat)))], re-centre as cor() does,

@@ -28,10 +28,19 @@ hipEvent_t Ctx::get_event() {
     SHARP_HIP_CHECK(hipEventCreate(&e));
     return e;
 }
+hipStream_t Ctx::aux_stream(int i) {
+    while (static_cast<int>(aux.size()) <= i) {
+        hipStream_t s;
+        SHARP_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        aux.push_back(s);
+    }
+    return aux[i];
+}
 void Ctx::resolve_pending() {
     if (pending.empty()) return;
     SHARP_HIP_CHECK(hipStreamSynchronize(stream));
     if (stream2) SHARP_HIP_CHECK(hipStreamSynchronize(stream2));
+    for (hipStream_t s : aux) SHARP_HIP_CHECK(hipStreamSynchronize(s));
     for (auto &p : pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -113,6 +122,8 @@ int sharp_init(int device) {
         throw Error(SHARP_ERR_NO_DEVICE, std::string("libsharp_hip is built for gfx950 only; device reports ") + prop.gcnArchName);
     if (c.ready && c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
     if (c.ready && c.stream2) { (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
+    for (hipStream_t s : c.aux) (void)hipStreamDestroy(s);
+    c.aux.clear();
     SHARP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     SHARP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
     c.device = device;
@@ -134,6 +145,8 @@ int sharp_shutdown(void) {
         (void)hipStreamDestroy(c.stream);
         c.stream = nullptr;
         if (c.stream2) { (void)hipStreamSynchronize(c.stream2); (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
+        for (hipStream_t s : c.aux) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        c.aux.clear();
         c.ready = false;
     }
     SHARP_API_END
