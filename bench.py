@@ -136,13 +136,16 @@ def main():
             alg_launch = cells_per_launch * m * 4                   # X is read once for all K projectors
             t_stage = sms / scalls * 1e-3
             alg_stage = n * (m * 4 + K_RP * p * 4)                  # + K*p*4 B of E per cell, written by rp_apply_kernel
-            traffic = None
+            traffic = traffic_compact = None                      # PMC-measured HBM bytes (profiles/rp_traffic.json, tools/profile_round.sh)
             tf = os.path.join(ROOT, "profiles", "rp_traffic.json")
             if os.path.exists(tf) and n == CELLS_PER_GPU and m == M_GENES:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tf))
+                traffic = tj.get("hbm_bytes_per_launch")             # both kernels, one SHARP() call
+                traffic_compact = tj.get("hbm_bytes_per_kernel_per_SHARP_call", {}).get("sharp::rp_compact_kernel")
             ach = alg_launch / t_launch / 1e9
             roof = {"kernel": "rp_compact_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(ach / 8000.0, 4), "traffic": None if traffic is None else int(traffic / launches_per_stage),
+                    "frac": round(ach / 8000.0, 4),
+                    "traffic": None if traffic_compact is None else int(traffic_compact / launches_per_stage),
                     "launch_ms": round(t_launch * 1e3, 4), "cells_per_launch": round(cells_per_launch, 1),
                     "algorithmic_bytes": int(alg_launch),
                     "stage": {"what": "whole RP matmul (rp_compact + rp_apply overlapped on two streams), per SHARP() call",
