@@ -153,6 +153,25 @@ def main():
                               "achieved": round(alg_stage / t_stage / 1e9, 1), "frac": round(alg_stage / t_stage / 8e12, 4),
                               "read_only_frac": round(n * m * 4 / t_stage / 8e12, 4),
                               "rp_apply_launch_ms": round(ams / max(acalls, 1), 4), "hbm_bytes_measured": traffic}}
+        # the two other heavy kernels, for context (launches of the two pipelined task ranges overlap each other and the
+        # GEMM, so their event times are upper bounds of their share of the step)
+        others = []
+        T_tasks = K_RP * len(range(0, n, 2000)) if n >= 5000 else K_RP
+        gms, gcalls = prof.get("corr_dist_gemm", (0.0, 0))
+        if gcalls:
+            fl = T_tasks * 2000.0 * 2000.0 * p                   # upper triangle of n_t^2 * p * 2 flop per task
+            tg = gms / args.steps * 1e-3
+            others.append({"kernel": "gemm_tn_f64_fast_kernel", "bound": "mfma", "achieved": round(fl / tg / 1e12, 1), "peak": 78.6,
+                           "unit": "TFLOP/s", "frac": round(fl / tg / 78.6e12, 3), "ms_per_step": round(tg * 1e3, 2),
+                           "work": "%d tasks x n_t^2 x p flop (upper triangle), f64 MFMA" % T_tasks})
+        hms, hcalls = prof.get("hclust", (0.0, 0))
+        if hcalls:
+            by = T_tasks * 2000.0 * 2000.0 * 8 * 3               # per merge: two rows read, one row+column written (mean n/2 active)
+            th = hms / args.steps * 1e-3
+            others.append({"kernel": "hclust_kernel", "bound": "hbm", "achieved": round(by / th / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(by / th / 8e12, 3), "ms_per_step_sum_of_overlapping_launches": round(th * 1e3, 2),
+                           "work": "%d tasks x 3 n_t^2 x 8 B (2 row reads + row/column write per merge); PMC traffic 102 GB per step "
+                                   "(scattered 8-byte column writes), see DESIGN.md 5" % T_tasks})
         stages = {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         from sharp_amd.api import ARI
 
@@ -168,6 +187,7 @@ def main():
                        "cells_per_gpu": n, "genes": m, "n_RP": K_RP, "reduced_dim": p, "x_storage": "fp32 in HBM",
                        "parallelism": "1 block per GPU" if world > 1 else "single GPU"},
             "roofline": roof,
+            "other_kernels": others,
             "kernel_ms_per_step": stages,
             "clusters_found": int(state["n_clusters"]),
             "ari_vs_planted_truth": round(float(ARI(truth, state["pred"])["HA"]), 4),
