@@ -157,6 +157,15 @@ int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *nc
                               int *p_used);
 int sharp_SHARP_unlimited(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K,
                           int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used);
+/* The same with the viewflag output (R/SHARP_unlimited.R:153,216-228): viE = the blocks' ensemble-mean projections E1,
+ * ncells x p row-major in block order (NULL: not wanted).  The 50-dimension reduction the reference applies above 1e5
+ * cells is one more sharp_project() call on this matrix (host side: sharp_amd/api.py). */
+int sharp_SHARP_unlimited_view(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K,
+                               int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used,
+                               double *viE);
+int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                                   int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred,
+                                   int *p_used, double *viE);
 /* The same split for one-block-per-GPU sharding: every rank runs its blocks through
  * sharp_unlimited_block_dev (block labels 1..*n_clusters by first appearance, the cluster means of viE,
  * n_clusters x p row-major into `means` with room for cap_rows rows, and the cluster sizes), the

@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import SharpError, check, lib
 
 __all__ = ["ranM", "ranM2", "RPmat", "Projector", "SharpError", "get_opt_hclust", "getrowColor", "colorL", "HMETHODS",
-           "wMetaC", "sMetaC", "SHARP", "SHARP_small", "SHARP_large", "SHARP_unlimited", "testlog", "ARI"]
+           "wMetaC", "sMetaC", "SHARP", "SHARP_small", "SHARP_large", "SHARP_unlimited", "run_Mtimes_SHARP", "testlog", "ARI"]
 
 
 def _dp(a):
@@ -399,11 +399,59 @@ def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster
     n = int(ncb.sum())
     pred = np.zeros(n, np.int32)
     npred, pu = C.c_int(), C.c_int()
-    check(lib().sharp_SHARP_unlimited(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), len(blocks), m, int(ensize_K or 0),
-                                      int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0), C.c_double(rN_seed),
-                                      _ip(pred), C.byref(npred), C.byref(pu)), allow=48)
-    out = _enresults(pred, None, None, n, m, None, ensize_K or 5, t0, {}, False, key="N.pred_clusters")
+    p = int(np.ceil(np.log2(n) / 0.04))                                   # :65-66, from the TOTAL number of cells
+    viE = np.zeros((n, p)) if viewflag else None
+    check(lib().sharp_SHARP_unlimited_view(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), len(blocks), m, int(ensize_K or 0),
+                                           int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0),
+                                           C.c_double(rN_seed), _ip(pred), C.byref(npred), C.byref(pu), _dp(viE)), allow=48)
+    K = int(ensize_K or 5)
+    out = _enresults(pred, None, None, n, m, pu.value, K, t0, {}, False, key="N.pred_clusters")
+    if viewflag:                                                          # :215-232
+        out["viE"] = _view_reduce(viE, rN_seed, K) if n > 1e5 else viE
+        out["x0"] = _one_hot(pred, npred.value)
     return out
+
+
+def _view_reduce(E1, rN_seed, ensize_K, kdim=50):
+    """R/SHARP_unlimited.R:217-225: above 1e5 cells viE = 1/sqrt(kdim) * E1 %*% ranM2(p, kdim, seed).
+
+    The reference's seed expression `50 + rN.seed + k` reads a variable `k` that only exists inside the foreach at :96
+    (an error in R whenever a seed is given); fixed here as the next seed of that sequence,
+    k = ensize.K + 1."""
+    p = E1.shape[1]
+    seed = 0.5 if rN_seed == 0.5 else 50 + rN_seed + ensize_K + 1
+    pr = Projector(p, kdim, [seed])
+    try:
+        return pr.project(np.ascontiguousarray(E1.T), logflag=False)     # (1/sqrt(kdim)) z0^T E1^T, cells x kdim
+    finally:
+        pr.close()
+
+
+def _one_hot(pred, ncl):
+    """x0 = sparseMatrix(i = 1:ncells, j = finalrowColor, x = 1) (R/SHARP_unlimited.R:230): CSR if scipy is there."""
+    n = pred.size
+    try:
+        from scipy.sparse import csr_matrix
+
+        return csr_matrix((np.ones(n), (np.arange(n), pred - 1)), shape=(n, ncl))
+    except Exception:  # pragma: no cover
+        x0 = np.zeros((n, ncl))
+        x0[np.arange(n), pred - 1] = 1.0
+        return x0
+
+
+def run_Mtimes_SHARP(scExp, Mtimes=10, Kset=15, **kwargs):
+    """R/run_Mtimes_SHARP.R:20-60: SHARP(scExp, ensize.K = k, forview = FALSE, ...) Mtimes for every k of Kset.
+
+    Returns {"enSize_<k>": {"Run_<j>": enresults}} like the reference's nested lists."""
+    ks = [Kset] if np.isscalar(Kset) else list(Kset)
+    allresults = {}
+    for k in ks:
+        info = {}
+        for j in range(1, int(Mtimes) + 1):
+            info["Run_%d" % j] = SHARP(scExp, ensize_K=int(k), forview=False, **kwargs)
+        allresults["enSize_%d" % int(k)] = info
+    return allresults
 
 
 def ARI(label, res):

@@ -298,7 +298,7 @@ void sharp_front_dev(const float *dX, int m, long long n_, long long ld, SharpAr
 // one block: y[[i]] = SHARP(mat, reduced.ndim = p, prep = FALSE, logflag = FALSE, rM = rM, ensize.K, rN.seed)
 // (:135) and the colMeans of its viE per predicted cluster -- all sMetaC ever uses of E1 (:163, R/sMetaC.R:58-63)
 void unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int K, double rN_seed,
-                         std::vector<int> &pred, std::vector<double> &means, std::vector<long long> &counts) {
+                         std::vector<int> &pred, std::vector<double> &means, std::vector<long long> &counts, double *viE_host) {
     SharpArgs a;
     a.K = K; a.reduced_ndim = p; a.flag = 1; a.projector = projector; a.rN_seed = rN_seed; a.want_viE = true;
     SharpOut o;
@@ -312,6 +312,7 @@ void unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int
     cluster_means_dev(o.viE.p, p, static_cast<int>(nb), p, uid, G, dm.p);
     means.resize(static_cast<size_t>(G) * p);
     dm.download(means.data(), means.size());
+    if (viE_host) o.viE.download(viE_host, static_cast<size_t>(nb) * p);        // E1 rows of this block (:153), viewflag only
 }
 
 // cross-block sMetaC on the gathered centroids, small-cluster merge and size-ordered relabel (:163-183)
@@ -428,7 +429,7 @@ int sharp_unlimited_block_dev(const float *dX, int m, long long nb, long long ld
     std::vector<int> pr;
     std::vector<double> mn;
     std::vector<long long> cn;
-    unlimited_block_dev(dX, m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn);
+    unlimited_block_dev(dX, m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, nullptr);
     SHARP_REQUIRE(static_cast<int>(cn.size()) <= cap_rows, "sharp_unlimited_block_dev: centroid buffer too small");
     std::copy(pr.begin(), pr.end(), pred);
     std::copy(mn.begin(), mn.end(), means);
@@ -450,8 +451,9 @@ int sharp_unlimited_merge(const double *means, const long long *counts, int nC, 
     SHARP_API_END
 }
 
-int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
-                              int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used) {
+int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                                   int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used,
+                                   double *viE) {
     SHARP_API_BEGIN
     ctx();
     SHARP_REQUIRE(dX_blocks && ncb && ldb && pred, "The input should be a LIST of partitioned scRNA-seq expression matrices!");
@@ -473,7 +475,8 @@ int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *nc
             std::vector<int> pb;
             std::vector<double> mb;
             std::vector<long long> cb;
-            unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb);
+            unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb,
+                                viE ? viE + static_cast<size_t>(off) * p : nullptr);
             std::copy(pb.begin(), pb.end(), pred + off);
             means.insert(means.end(), mb.begin(), mb.end());
             counts.insert(counts.end(), cb.begin(), cb.end());
@@ -495,8 +498,14 @@ int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *nc
     SHARP_API_END
 }
 
-int sharp_SHARP_unlimited(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,
-                          int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used) {
+int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                              int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used) {
+    return sharp_SHARP_unlimited_view_dev(dX_blocks, ncb, ldb, nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred,
+                                          p_used, nullptr);
+}
+
+int sharp_SHARP_unlimited_view(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,
+                               int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used, double *viE) {
     std::vector<DevBuf<float>> bufs(nblocks > 0 ? nblocks : 0);
     std::vector<const float *> ptrs;
     std::vector<long long> lds;
@@ -512,8 +521,13 @@ int sharp_SHARP_unlimited(const double *const *X_blocks, const long long *ncb, i
     }
     catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
     catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
-    return sharp_SHARP_unlimited_dev(ptrs.data(), ncb, lds.data(), nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred,
-                                     p_used);
+    return sharp_SHARP_unlimited_view_dev(ptrs.data(), ncb, lds.data(), nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred,
+                                          n_pred, p_used, viE);
+}
+
+int sharp_SHARP_unlimited(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,
+                          int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used) {
+    return sharp_SHARP_unlimited_view(X_blocks, ncb, nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred, p_used, nullptr);
 }
 
 }  // extern "C"

@@ -106,15 +106,44 @@ def test_sharp_unlimited_matches_oracle(sa, oracle):
     m, G, nm = 3000, 6, 300
     blocks = [oracle.synth_fill(SEED, m, i * 6000, 6000, G, nm) for i in range(2)]
     truth = oracle.synth_cluster(SEED, range(12000), G)
-    ref = oracle.SHARP_unlimited(blocks, rN_seed=2103, nthreads=8)
+    ref = oracle.SHARP_unlimited(blocks, rN_seed=2103, nthreads=8, want_view=True)
     res = sa.SHARP_unlimited(blocks, rN_seed=2103)
     ari = adjusted_rand_score(ref["pred_clusters"], res["pred_clusters"])
     assert ari >= 0.99, ari
     assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+    # viewflag outputs (R/SHARP_unlimited.R:215-232): viE = E1 of every block, x0 = one-hot of the final labels
+    assert res["reduced.dim"] == ref["p"] and res["viE"].shape == (12000, ref["p"])
+    np.testing.assert_allclose(res["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
+    x0 = res["x0"].toarray() if hasattr(res["x0"], "toarray") else res["x0"]
+    assert x0.shape == (12000, res["N.pred_clusters"]) and np.array_equal(x0.argmax(1) + 1, res["pred_clusters"])
+    assert "viE" not in sa.SHARP_unlimited(blocks, rN_seed=2103, viewflag=False)
     # ids ordered by decreasing cluster size (R/SHARP_unlimited.R:180-183)
     sizes = np.bincount(res["pred_clusters"])[1:]
     assert np.all(np.diff(sizes) <= 0)
     assert adjusted_rand_score(truth, res["pred_clusters"]) > 0.9
+
+
+def test_view_reduction_above_1e5_cells(sa, oracle):
+    """R/SHARP_unlimited.R:217-225: viE = 1/sqrt(50) * E1 %*% ranM2(p, 50, seed) (the branch itself needs > 1e5 cells;
+    the reduction is checked on a small E1).  Inputs go through the fp32 block format, hence the 1e-6 tolerance."""
+    from sharp_amd.api import _view_reduce
+
+    rng = np.random.default_rng(7)
+    E1 = rng.standard_normal((300, 420))
+    K, seed = 5, 2103
+    got = _view_reduce(E1, seed, K)
+    ref = oracle.project(E1.T, oracle.ranM(420, 50, 50 + seed + K + 1), False)     # (1/sqrt(50)) * t(z0) %*% t(E1), cells x 50
+    assert got.shape == (300, 50)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6 * np.abs(ref).max())
+
+
+def test_run_Mtimes_SHARP(sa, oracle):
+    X = oracle.synth_fill(SEED, 1500, 0, 300, 4, 200)
+    out = sa.run_Mtimes_SHARP(X, Mtimes=2, Kset=[3, 5], rN_seed=2103)
+    assert sorted(out) == ["enSize_3", "enSize_5"] and sorted(out["enSize_3"]) == ["Run_1", "Run_2"]
+    a, b = out["enSize_5"]["Run_1"], out["enSize_5"]["Run_2"]
+    assert a["ensize.K"] == 5 and "viE" not in a
+    assert np.array_equal(a["pred_clusters"], b["pred_clusters"])          # seeded runs repeat exactly
 
 
 def test_reference_error_behaviour(sa, oracle):
