@@ -173,6 +173,11 @@ int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long lon
  * which returns the final 1-based id of each gathered (block, cluster) row. */
 int sharp_unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
                               double rN_seed, int *pred, int *n_clusters, double *means, int cap_rows, long long *counts);
+/* The block step with the log flag of the per-block SHARP() call (SHARP_unlimited3 leaves it to testlog,
+ * R/SHARP_unlimited3.R:122) and, optionally, the block's viE rows (nb x p row-major, host; NULL: not wanted). */
+int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
+                                   double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
+                                   long long *counts, double *viE);
 int sharp_unlimited_merge(const double *means, const long long *counts, int nC, int p, long long ncells, int N_cluster,
                           int minN, int maxN, int *final_id, int *n_final);
 

@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import SharpError, check, lib
 
 __all__ = ["ranM", "ranM2", "RPmat", "Projector", "SharpError", "get_opt_hclust", "getrowColor", "colorL", "HMETHODS",
-           "wMetaC", "sMetaC", "SHARP", "SHARP_small", "SHARP_large", "SHARP_unlimited", "run_Mtimes_SHARP", "testlog", "ARI"]
+           "wMetaC", "sMetaC", "SHARP", "SHARP_small", "SHARP_large", "SHARP_unlimited", "SHARP_unlimited3", "run_Mtimes_SHARP", "testlog", "ARI"]
 
 
 def _dp(a):
@@ -409,6 +409,73 @@ def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster
     if viewflag:                                                          # :215-232
         out["viE"] = _view_reduce(viE, rN_seed, K) if n > 1e5 else viE
         out["x0"] = _one_hot(pred, npred.value)
+    return out
+
+
+def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed=None, N_cluster=None, minN_cluster=None,
+                     maxN_cluster=None, logflag=False, testlog_cells=None):
+    """R/SHARP_unlimited3.R:29-235: SHARP_unlimited over a DIRECTORY of partitions.
+
+    ndinfo: dict(dir=..., ncells=..., ngenes=...) like the reference's list; the partitions are block files written by
+    sharp_amd.blocks.write_block (the reference's .rds needs R to be read), taken in the order of the first number in
+    their path (:59-61) and streamed disk -> pinned memory -> HBM one block ahead of the clustering.
+    logflag: False = log2 always on, as SHARP_unlimited passes it; True = leave it to testlog() per block, which is
+    what unlimited3's SHARP() call does (:122; unseeded sample -> not reproducible unless testlog_cells is given)."""
+    import time as _t
+
+    import torch
+
+    from . import blocks as _blocks
+    from . import device as _device
+
+    t0 = _t.time()
+    if ndinfo is None:
+        raise SharpError("No expression data is provided!")
+    try:
+        files = _blocks.list_block_files(ndinfo["dir"])
+    except FileNotFoundError as e:
+        raise SharpError(str(e))
+    ncells, ngenes = int(ndinfo["ncells"]), int(ndinfo["ngenes"])
+    if rN_seed is not None:
+        if not isinstance(rN_seed, (int, float, np.integer, np.floating)):
+            raise SharpError("The rN.seed should be a numeric!")
+        if rN_seed % 1 != 0:
+            raise SharpError("The rN.seed should be an integer!")
+    else:
+        rN_seed = 0.5
+    K = int(ensize_K or 5)
+    p = int(np.ceil(np.log2(ncells) / 0.04))                                       # :66, from ndinfo$ncells
+    _lib.ensure_init()
+    proj = Projector(ngenes, p, [0.5 if rN_seed == 0.5 else 50 + rN_seed + k for k in range(1, K + 1)])   # :84-90
+    preds, means, counts, views, nnc = [], [], [], [], []
+    try:
+        stream = _blocks.BlockStreamer(files)
+        for i, hdr, dX in stream:
+            if hdr["genes"] != ngenes:
+                raise SharpError("%s has %d genes, ndinfo$ngenes is %d" % (files[i], hdr["genes"], ngenes))
+            nb = hdr["cells"]
+            flag = True
+            if logflag:                                                            # the block's SHARP() runs testlog (R/SHARP.R:205-222)
+                cells = testlog_cells if testlog_cells is not None else np.random.default_rng().permutation(nb)[:100]
+                cells = np.asarray(cells)[np.asarray(cells) < nb]
+                sample = dX[torch.as_tensor(cells, device=dX.device)].cpu().numpy().T.astype(np.float64)
+                flag = testlog(sample, sample.shape[1], p, cells=np.arange(sample.shape[1]))
+            vi = np.zeros((nb, p)) if viewflag else None
+            pr, mn, cn = _device.unlimited_block_dev(dX, p, proj.handle, K, rN_seed, flag=flag, viE=vi)
+            preds.append(pr); means.append(mn); counts.append(cn); views.append(vi); nnc.append(nb)
+    finally:
+        proj.close()
+    n = int(sum(nnc))
+    first = np.concatenate([[0], np.cumsum([m_.shape[0] for m_ in means])])
+    fid, nf = _device.unlimited_merge(np.concatenate(means, 0), np.concatenate(counts, 0), n, int(N_cluster or 0),
+                                      int(minN_cluster or 0), int(maxN_cluster or 0))
+    pred = np.concatenate([np.asarray(fid)[first[b] + preds[b] - 1] for b in range(len(preds))]).astype(np.int32)
+    out = _enresults(pred, None, None, n, ngenes, p, K, t0, {}, False, key="N.pred_clusters")
+    if viewflag:
+        E1 = np.concatenate(views, 0)
+        out["viE"] = _view_reduce(E1, rN_seed, K) if n > 1e5 else E1
+        out["x0"] = _one_hot(pred, nf)
+    out["bytes_streamed"] = stream.bytes_streamed
     return out
 
 

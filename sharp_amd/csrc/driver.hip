@@ -298,9 +298,10 @@ void sharp_front_dev(const float *dX, int m, long long n_, long long ld, SharpAr
 // one block: y[[i]] = SHARP(mat, reduced.ndim = p, prep = FALSE, logflag = FALSE, rM = rM, ensize.K, rN.seed)
 // (:135) and the colMeans of its viE per predicted cluster -- all sMetaC ever uses of E1 (:163, R/sMetaC.R:58-63)
 void unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int K, double rN_seed,
-                         std::vector<int> &pred, std::vector<double> &means, std::vector<long long> &counts, double *viE_host) {
+                         std::vector<int> &pred, std::vector<double> &means, std::vector<long long> &counts, double *viE_host,
+                         int flag = 1) {
     SharpArgs a;
-    a.K = K; a.reduced_ndim = p; a.flag = 1; a.projector = projector; a.rN_seed = rN_seed; a.want_viE = true;
+    a.K = K; a.reduced_ndim = p; a.flag = flag; a.projector = projector; a.rN_seed = rN_seed; a.want_viE = true;
     SharpOut o;
     sharp_front_dev(dX, m, nb, ld, a, o);
     pred = o.pred;
@@ -419,6 +420,24 @@ int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K,
     return sharp_SHARP_dev(dX.p, m, n, ldd, ensize_K, reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
                            indN_cluster, minN, maxN, sil_thre, height_Ntimes, log_flag, projector, rN_seed, pred, n_pred, viE, x0,
                            x0_cap_cols, x0_cols, p_used, K_used, path);
+}
+
+int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
+                                   double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
+                                   long long *counts, double *viE) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(pred && n_clusters && means && counts, "sharp_unlimited_block_view_dev: null output");
+    std::vector<int> pr;
+    std::vector<double> mn;
+    std::vector<long long> cn;
+    unlimited_block_dev(dX, m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, viE, flag != 0);
+    SHARP_REQUIRE(static_cast<int>(cn.size()) <= cap_rows, "sharp_unlimited_block_view_dev: centroid buffer too small");
+    std::copy(pr.begin(), pr.end(), pred);
+    std::copy(mn.begin(), mn.end(), means);
+    std::copy(cn.begin(), cn.end(), counts);
+    *n_clusters = static_cast<int>(cn.size());
+    SHARP_API_END
 }
 
 int sharp_unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K, double rN_seed,

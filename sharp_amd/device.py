@@ -50,17 +50,20 @@ def SHARP_dev(dX, ensize_K=0, reduced_ndim=0, base_ncells=0, partition_ncells=0,
                   "path": "SHARP_large" if path.value else "SHARP_small", "warn": rc}
 
 
-def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096):
-    """One block of SHARP_unlimited: labels, per-cluster means of viE (G x p) and cluster sizes."""
+def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag=True, viE=None):
+    """One block of SHARP_unlimited: labels, per-cluster means of viE (G x p) and cluster sizes.
+
+    flag: the log flag of the block's SHARP() call; viE: optional (nb, p) float64 host array that receives the block's
+    ensemble-mean projection (viewflag)."""
     _lib.ensure_init()
     nb, m = dX.shape
     pred = np.zeros(nb, np.int32)
     means = np.zeros((cap_rows, p))
     counts = np.zeros(cap_rows, np.int64)
     G = C.c_int()
-    check(lib().sharp_unlimited_block_dev(C.c_void_p(dX.data_ptr()), m, C.c_longlong(nb), C.c_longlong(dX.stride(0)), p,
-                                          projector, ensize_K, C.c_double(rN_seed), _ip(pred), C.byref(G), _dp(means), cap_rows,
-                                          counts.ctypes.data_as(C.POINTER(C.c_longlong))))
+    check(lib().sharp_unlimited_block_view_dev(C.c_void_p(dX.data_ptr()), m, C.c_longlong(nb), C.c_longlong(dX.stride(0)), p,
+                                               projector, ensize_K, C.c_double(rN_seed), int(bool(flag)), _ip(pred), C.byref(G),
+                                               _dp(means), cap_rows, counts.ctypes.data_as(C.POINTER(C.c_longlong)), _dp(viE)))
     return pred, means[: G.value].copy(), counts[: G.value].copy()
 
 
