@@ -306,9 +306,16 @@ constexpr int ST_MAXK = 512;
 __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const HcMeta *__restrict__ metas, const int *__restrict__ lab_all,
                                                            const double *__restrict__ T_all, const double *__restrict__ G_all,
                                                            const double *__restrict__ Q_all, const double *__restrict__ nrm_all,
-                                                           double *__restrict__ out_all) {
-    const HcMeta M = metas[blockIdx.y];
-    const int L = blockIdx.x;
+                                                           double *__restrict__ out_all, int count, int max_nk) {
+    // One workgroup per (task, level).  The levels of a task all read the task's G (n x kpad): the linear workgroup id is
+    // dealt so that the eight tasks of a group sit on the eight XCDs (workgroups go round-robin to XCDs) and G is
+    // fetched into one L2 once instead of once per level (34 GB -> 0.3 GB of HBM reads per step).
+    const long long B = blockIdx.x;
+    const long long per_group = 8LL * max_nk;
+    const int zt = static_cast<int>(B / per_group) * 8 + static_cast<int>(B % 8);
+    if (zt >= count) return;
+    const HcMeta M = metas[zt];
+    const int L = static_cast<int>((B % per_group) / 8);
     if (L >= M.nk) return;
     const int n = M.n, k = M.kmin + L, kf = M.kmax, kpad = M.kpad;
     const int *lab = lab_all + M.oLab + static_cast<long long>(L) * n;
@@ -356,22 +363,43 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const HcMeta *__restr
     __syncthreads();
     for (int c = 0; c < k; ++c) tot2 += ctot[c];             // |total|^2 (every thread, same order)
     const bool tfromG = !M.symmetric;
+    const int nld = M.nld;
     double wpart = 0.0;
     for (int i = tid; i < n; i += ST_THREADS) {
         const int own = lab[i] - 1;
-        const double *Ti = T + static_cast<long long>(i) * kpad, *Gi = G + static_cast<long long>(i) * kpad;
+        // T and G are stored transposed (kpad x nld): for a fixed finest cluster f the lanes read consecutive cells.
+        // The kf finest clusters are walked in the order that groups them by level cluster, eight loads at a time.
+        const double *Ti = T + i, *Gi = G + i;
         double a = 0.0, bmin = 0.0, gown = 0.0;
         bool have_b = false;
-        for (int c = 0; c < k; ++c) {
-            double sc = 0.0, gc = 0.0;
-            for (int q = start[c]; q < start[c + 1]; ++q) {
-                const int f = order[q];
-                const double g = Gi[f];
-                sc += tfromG ? (static_cast<double>(cntF[f]) - g) : Ti[f];
-                gc += g;
+        int c = 0;
+        while (c < k && start[c + 1] == start[c]) ++c;           // (levels never have empty clusters; defensive)
+        double sc = 0.0, gc = 0.0;
+        for (int q0 = 0; q0 < kf; q0 += 8) {
+            double gv[8], tv[8];
+            int fv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u < kf ? q0 + u : kf - 1;
+                fv[u] = order[q];
+                gv[u] = Gi[static_cast<long long>(fv[u]) * nld];
+                tv[u] = tfromG ? 0.0 : Ti[static_cast<long long>(fv[u]) * nld];
             }
-            if (c == own) { a = sc / static_cast<double>(cnt[c] - 1); gown = gc; }
-            else { const double bb = sc / static_cast<double>(cnt[c]); if (!have_b || bmin > bb) { bmin = bb; have_b = true; } }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u;
+                if (q < kf) {
+                    sc += tfromG ? (static_cast<double>(cntF[fv[u]]) - gv[u]) : tv[u];
+                    gc += gv[u];
+                    if (q + 1 == start[c + 1]) {                   // cluster c complete
+                        if (c == own) { a = sc / static_cast<double>(cnt[c] - 1); gown = gc; }
+                        else { const double bb = sc / static_cast<double>(cnt[c]); if (!have_b || bmin > bb) { bmin = bb; have_b = true; } }
+                        sc = 0.0; gc = 0.0;
+                        ++c;
+                        while (c < k && start[c + 1] == start[c]) ++c;
+                    }
+                }
+            }
         }
         double s = 0.0;
         if (cnt[own] > 1 && bmin != a) s = (bmin - a) / fmax(a, bmin);
@@ -508,7 +536,7 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
         M.oNrm = oN; oN += M.n;
         M.oM = oM; oM += M.n;
         M.oLab = oLab; oLab += static_cast<long long>(M.nk) * M.n;
-        M.oH = M.oT = M.oG = oK; oK += static_cast<long long>(M.n) * M.kpad;
+        M.oH = M.oT = M.oG = oK; oK += static_cast<long long>(M.nld) * M.kpad;   // H: n x kpad; T, G: kpad x nld (transposed)
         M.oCSt = oCS; oCS += static_cast<long long>(M.p) * M.kpad;
         M.oQ = oQ; oQ += static_cast<long long>(M.kpad) * M.kpad;
         M.oOut = oOut; oOut += 2LL * M.nk;
@@ -559,14 +587,14 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
                     case 1:   // finest-level sums on the MFMA:  CSt = Cr^T H
                         g.push_back(GemmTask{W.Cr.p + M.oCr, W.H.p + M.oH, W.CSt.p + M.oCSt, M.p, M.kpad, M.n, M.p, M.kpad, M.kpad, 0, 0, 0});
                         break;
-                    case 2:   // G = C CS^T
-                        g.push_back(GemmTask{W.Ct.p + M.oCt, W.CSt.p + M.oCSt, W.G.p + M.oG, M.n, M.kpad, M.p, M.nld, M.kpad, M.kpad, 0, 0, 0});
+                    case 2:   // G^T = CS C^T  (kpad x nld: the statistics kernel reads it with lanes along the cells)
+                        g.push_back(GemmTask{W.CSt.p + M.oCSt, W.Ct.p + M.oCt, W.G.p + M.oG, M.kpad, M.n, M.p, M.kpad, M.nld, M.nld, 0, 0, 0});
                         break;
                     case 3:   // Q = CS CS^T
                         g.push_back(GemmTask{W.CSt.p + M.oCSt, W.CSt.p + M.oCSt, W.Q.p + M.oQ, M.kpad, M.kpad, M.p, M.kpad, M.kpad, M.kpad, 0, 0, 0});
                         break;
-                    default:  // (symmetric) T = D0 H
-                        if (M.symmetric) g.push_back(GemmTask{W.D0.p + M.oD0, W.H.p + M.oH, W.T.p + M.oT, M.n, M.kpad, M.n, M.nld, M.kpad, M.kpad, 0, 0, 0});
+                    default:  // (symmetric) T^T = H^T D0  (kpad x nld)
+                        if (M.symmetric) g.push_back(GemmTask{W.H.p + M.oH, W.D0.p + M.oD0, W.T.p + M.oT, M.kpad, M.n, M.n, M.kpad, M.nld, M.nld, 0, 0, 0});
                         break;
                 }
             }
@@ -637,9 +665,9 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
             launch_check("onehot_kernel");
         }
         if (R.cnt[1]) gemm_tn_f64_batched(W.gemm.p + R.off[1], R.cnt[1], max_p, max_kpad, "cluster_sums_gemm");
-        if (R.cnt[2]) gemm_tn_f64_batched(W.gemm.p + R.off[2], R.cnt[2], max_n, max_kpad, "row_cluster_dot_gemm");
+        if (R.cnt[2]) gemm_tn_f64_batched(W.gemm.p + R.off[2], R.cnt[2], max_kpad, max_n, "row_cluster_dot_gemm");
         if (R.cnt[3]) gemm_tn_f64_batched(W.gemm.p + R.off[3], R.cnt[3], max_kpad, max_kpad, "cluster_gram_gemm");
-        if (R.cnt[4]) gemm_tn_f64_batched(W.gemm.p + R.off[4], R.cnt[4], max_n, max_kpad, "dist_cluster_sums_gemm");
+        if (R.cnt[4]) gemm_tn_f64_batched(W.gemm.p + R.off[4], R.cnt[4], max_kpad, max_n, "dist_cluster_sums_gemm");
         // a5b: silhouette medians + CH per level
         {
             int npow2 = 1; while (npow2 < max_n) npow2 <<= 1;
@@ -647,8 +675,9 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
             SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 static_cast<int>(lds)));
             KernelTimer tm("sil_ch_stats");
-            hipLaunchKernelGGL(stats_kernel, dim3(max_nk, Ts), dim3(ST_THREADS), lds, st, dmeta, W.lab.p, W.T.p, W.G.p, W.Q.p,
-                               W.nrm.p, W.out.p);
+            const long long blocks = static_cast<long long>((Ts + 7) / 8) * 8 * max_nk;
+            hipLaunchKernelGGL(stats_kernel, dim3(static_cast<unsigned>(blocks)), dim3(ST_THREADS), lds, st, dmeta, W.lab.p, W.T.p,
+                               W.G.p, W.Q.p, W.nrm.p, W.out.p, Ts, max_nk);
             launch_check("stats_kernel");
         }
         if (NS > 1) {
