@@ -166,12 +166,12 @@ def main():
                            "work": "%d tasks x n_t^2 x p flop (upper triangle), f64 MFMA" % T_tasks})
         hms, hcalls = prof.get("hclust", (0.0, 0))
         if hcalls:
-            by = T_tasks * 2000.0 * 2000.0 * 8 * 3               # per merge: two rows read, one row+column written (mean n/2 active)
+            by = T_tasks * 2000.0 * 2000.0 * 8 * 9.3             # rounds of (read n_a^2 + write n_a'^2): ~9.3 n_t^2 entries per task
             th = hms / args.steps * 1e-3
-            others.append({"kernel": "hclust_kernel", "bound": "hbm", "achieved": round(by / th / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+            others.append({"kernel": "hclust_rnn_kernel", "bound": "hbm", "achieved": round(by / th / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                            "frac": round(by / th / 8e12, 3), "ms_per_step_sum_of_overlapping_launches": round(th * 1e3, 2),
-                           "work": "%d tasks x 3 n_t^2 x 8 B (2 row reads + row/column write per merge); PMC traffic 102 GB per step "
-                                   "(scattered 8-byte column writes), see DESIGN.md 5" % T_tasks})
+                           "work": "%d tasks x ~9.3 n_t^2 x 8 B (every round streams the distance matrix into a compacted copy, "
+                                   "~44 rounds); see DESIGN.md 5" % T_tasks})
         stages = {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         from sharp_amd.api import ARI
 

@@ -96,7 +96,9 @@ __device__ __forceinline__ double lance_williams(int method, double d1, double d
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HC_THREADS) void hclust_kernel(const HcMeta *__restrict__ metas, double *__restrict__ Dall,
                                                             int *__restrict__ ia_all, int *__restrict__ ib_all,
-                                                            double *__restrict__ h_all, int ablate, long long *__restrict__ dbg) {
+                                                            double *__restrict__ h_all, int ablate, long long *__restrict__ dbg,
+                                                            const int *__restrict__ only_if) {
+    if (only_if && only_if[blockIdx.x] == 0) return;      // the bulk-synchronous kernel already did this task
     const HcMeta M = metas[blockIdx.x];
     const int n = M.n, nld = M.nld, method = M.method;
     double *D = Dall + M.oD;
@@ -217,6 +219,369 @@ __global__ __launch_bounds__(HC_THREADS) void hclust_kernel(const HcMeta *__rest
         if (dbg) { const long long tt6 = __builtin_readcyclecounter(); tacc[0] += tt1 - tt0; tacc[1] += tt2 - tt1; tacc[2] += tt3 - tt2; tacc[3] += tt4 - tt3; tacc[4] += tt5 - tt4; tacc[5] += tt6 - tt5; }
     }
     if (dbg && tid == 0) for (int q = 0; q < 6; ++q) dbg[blockIdx.x * 6 + q] = tacc[q];
+}
+
+// ---------------------------------------------------------------------------------------------
+// a4, bulk-synchronous form for the reducible methods (ward.D, ward.D2, single, complete, average, mcquitty).
+// For a reducible Lance-Williams update, merging a reciprocal-nearest-neighbour (RNN) pair never brings anything closer to
+// any other cluster than that cluster's current nearest neighbour, so every RNN pair of the current matrix is a merge of
+// the sequential algorithm, at the same height.  A round therefore (1) pairs up all RNN pairs, (2) ranks them by
+// (height, lowest index) -- the order in which the sequential algorithm would perform them -- and (3) writes the next
+// distance matrix compacted to the survivors, one wave per new row, reading whole old rows and writing whole new rows:
+// pure streaming instead of one scattered 8-byte column write per (merge, cluster).  The nearest neighbour of every new
+// row falls out of the same pass.  Entries between two clusters merged in the same round apply the two updates in rank
+// order, exactly the arithmetic of the sequential algorithm; across rounds the association order can differ from the
+// sequential one, so heights agree to rounding (1e-15), not bit for bit.  The merges are sorted by (height, index) at the
+// end.  Any exact tie for a row minimum (or a round without a pair) abandons the task: status = 1, and the host runs
+// hclust_kernel on it (R breaks ties by index order inside its nearest-neighbour lists; that is only restated there).
+// D is left untouched; the rounds ping-pong between two scratch matrices.
+// ---------------------------------------------------------------------------------------------
+constexpr int HR_MAXN = 4096;
+constexpr uint16_t HR_NONE = 0xffffu;
+
+struct HrBest { double v; int i; int tie; };
+__device__ __forceinline__ HrBest hr_combine(HrBest x, HrBest y) {
+    HrBest r;
+    if (y.v < x.v) r = y; else if (x.v < y.v) r = x;
+    else { r.v = x.v; r.i = x.i < y.i ? x.i : y.i; r.tie = (x.i != y.i && x.i < 0x7fffffff && y.i < 0x7fffffff) ? 1 : (x.tie | y.tie); }
+    return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ HrBest hr_dpp_step(HrBest x) {
+    const int lo = __double2loint(x.v), hi = __double2hiint(x.v);
+    HrBest y;
+    y.v = __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false),
+                           __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false));
+    y.i = __builtin_amdgcn_update_dpp(x.i, x.i, CTRL, ROW_MASK, 0xf, false);
+    y.tie = __builtin_amdgcn_update_dpp(x.tie, x.tie, CTRL, ROW_MASK, 0xf, false);
+    return hr_combine(x, y);
+}
+__device__ __forceinline__ HrBest hr_wave(HrBest x) {
+    x = hr_dpp_step<0xB1, 0xf>(x);
+    x = hr_dpp_step<0x4E, 0xf>(x);
+    x = hr_dpp_step<0x141, 0xf>(x);
+    x = hr_dpp_step<0x140, 0xf>(x);
+    x = hr_dpp_step<0x142, 0xa>(x);
+    x = hr_dpp_step<0x143, 0xc>(x);
+    HrBest r;
+    r.i = __builtin_amdgcn_readlane(x.i, 63);
+    r.tie = __builtin_amdgcn_readlane(x.tie, 63);
+    r.v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x.v), 63), __builtin_amdgcn_readlane(__double2loint(x.v), 63));
+    return r;
+}
+
+constexpr int HR_THREADS = 512;    // two tasks per CU (LDS state 37 B per observation, <= 128 VGPRs)
+
+__global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__restrict__ metas, const double *__restrict__ Dall,
+                                                                double *__restrict__ S0all, double *__restrict__ S1all,
+                                                                int *__restrict__ ia_all, int *__restrict__ ib_all,
+                                                                double *__restrict__ h_all, int *__restrict__ status) {
+    const HcMeta M = metas[blockIdx.x];
+    const int n = M.n, nld = M.nld, method = M.method;
+    const double *D = Dall + M.oD;
+    double *Sb[2] = {S0all + M.oD, S1all + M.oD};
+    int *ia = ia_all + M.oM, *ib = ib_all + M.oM;
+    double *crit = h_all + M.oM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = HR_THREADS / 64;
+    if (method == 6 || method == 7 || n > HR_MAXN) {            // centroid / median are not reducible; large n: LDS
+        if (tid == 0) status[blockIdx.x] = 1;
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int nal = (n + 3) & ~3;
+    double *dnnA = reinterpret_cast<double *>(sm);             // [2][nal]  NN distance (also the pair's height)
+    uint16_t *cidA = reinterpret_cast<uint16_t *>(dnnA + 2 * nal);   // [2][nal]  smallest original member
+    uint16_t *cszA = cidA + 2 * nal;                           // [2][nal]  cluster size
+    uint16_t *nn = cszA + 2 * nal;                             // [nal]
+    uint16_t *partner = nn + nal;                              // [nal]     old index of the RNN partner or NONE
+    uint16_t *pseq = partner + nal;                            // [nal]     rank of the pair in the round
+    uint16_t *oldidx = pseq + nal;                             // [nal]     new index -> old index
+    uint16_t *newidx = oldidx + nal;                           // [nal]     old index -> new index (survivors)
+    uint16_t *plist = newidx + nal;                            // [nal]     first members of the pairs
+    int *ctl = reinterpret_cast<int *>(plist + nal);           // [8]: npairs, abort, nsurv
+    int *wsum = ctl + 8;                                        // [nwave + 1]
+    unsigned char *tie = reinterpret_cast<unsigned char *>(wsum + nwave + 1);   // [nal]
+
+    int cur = 0, na = n, done = 0;
+    for (int i = tid; i < n; i += HR_THREADS) { cidA[i] = static_cast<uint16_t>(i); cszA[i] = 1; }
+    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
+    __syncthreads();
+    // round 0 nearest neighbours from the pristine matrix (squared for ward.D2)
+    for (int a = wave; a < n; a += nwave) {
+        const double *row = D + static_cast<long long>(a) * nld;
+        HrBest b; b.v = HC_INF; b.i = 0x7fffffff; b.tie = 0;
+        for (int j0 = lane; j0 < n; j0 += 64 * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = j0 + 64 * u; v[u] = row[j < n ? j : n - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 64 * u;
+                if (j < n && j != a) {
+                    const double x = method == 8 ? v[u] * v[u] : v[u];
+                    if (x < b.v) { b.v = x; b.i = j; b.tie = 0; } else if (x == b.v) b.tie = 1;
+                }
+            }
+        }
+        b = hr_wave(b);
+        if (lane == 0) { nn[a] = static_cast<uint16_t>(b.i < n ? b.i : 0); dnnA[a] = b.v; tie[a] = static_cast<unsigned char>(b.tie); }
+    }
+    __syncthreads();
+
+    int src = -1;                                               // -1: D (pristine), else scratch index
+    while (na > 1) {
+        double *dnn = dnnA + cur * nal;
+        uint16_t *cid = cidA + cur * nal, *csz = cszA + cur * nal;
+        double *dnnN = dnnA + (cur ^ 1) * nal;
+        uint16_t *cidN = cidA + (cur ^ 1) * nal, *cszN = cszA + (cur ^ 1) * nal;
+        // (1) reciprocal pairs
+        for (int a = tid; a < na; a += HR_THREADS) {
+            partner[a] = HR_NONE;
+            if (tie[a]) ctl[1] = 1;
+        }
+        __syncthreads();
+        for (int a = tid; a < na; a += HR_THREADS) {
+            const int b = nn[a];
+            if (b > a && nn[b] == a) {
+                partner[a] = static_cast<uint16_t>(b); partner[b] = static_cast<uint16_t>(a);
+                plist[atomicAdd(&ctl[0], 1)] = static_cast<uint16_t>(a);
+            }
+        }
+        __syncthreads();
+        const int np = ctl[0];
+        if (ctl[1] || np == 0) {                                // tie or no pair: the sequential kernel takes this task
+            if (tid == 0) status[blockIdx.x] = 1;
+            return;
+        }
+        // (2) rank of each pair by (height, lower original index) = the sequential algorithm's order
+        for (int q = tid; q < np; q += HR_THREADS) {
+            const int a = plist[q];
+            const double h = dnn[a];
+            const int ida = cid[a] < cid[partner[a]] ? cid[a] : cid[partner[a]];
+            int rank = 0;
+            for (int q2 = 0; q2 < np; ++q2) {
+                const int a2 = plist[q2];
+                const double h2 = dnn[a2];
+                const int id2 = cid[a2] < cid[partner[a2]] ? cid[a2] : cid[partner[a2]];
+                rank += (h2 < h || (h2 == h && id2 < ida)) ? 1 : 0;
+            }
+            pseq[a] = static_cast<uint16_t>(rank); pseq[partner[a]] = static_cast<uint16_t>(rank);
+            const int ib_ = cid[a] < cid[partner[a]] ? cid[partner[a]] : cid[a];
+            ia[done + rank] = ida + 1; ib[done + rank] = ib_ + 1;
+            crit[done + rank] = h;                               // squared for ward.D2 until the final pass
+        }
+        // (3) survivors: everything but the second member of a pair; new index = rank among survivors
+        {
+            const int chunk = (na + HR_THREADS - 1) / HR_THREADS;
+            const int lo = tid * chunk, hi = lo + chunk < na ? lo + chunk : na;
+            int c = 0;
+            for (int a = lo; a < hi; ++a) c += (partner[a] == HR_NONE || partner[a] > a) ? 1 : 0;
+            int incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); incl += lane >= d ? t : 0; }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            if (tid == 0) { int run = 0; for (int w = 0; w < nwave; ++w) { const int t = wsum[w]; wsum[w] = run; run += t; } wsum[nwave] = run; }
+            __syncthreads();
+            int pos = wsum[wave] + incl - c;
+            for (int a = lo; a < hi; ++a)
+                if (partner[a] == HR_NONE || partner[a] > a) { newidx[a] = static_cast<uint16_t>(pos); oldidx[pos++] = static_cast<uint16_t>(a); }
+        }
+        __syncthreads();
+        const int nb = wsum[nwave];                             // = na - np
+        // (4) next matrix, one wave per new row; nearest neighbour of the new row on the fly.
+        // Rows of unmerged clusters (~90 %) are a gathered copy of the old row (eight loads in flight per lane) plus one
+        // Lance-Williams value per merged column; rows of merged clusters take the general path.
+        const double *Dsrc = src < 0 ? D : Sb[src];
+        double *Ddst = Sb[src < 0 ? 0 : (src ^ 1)];
+        const bool sq = (src < 0 && method == 8);
+        auto do_row = [&](int A) {
+            const int a = oldidx[A];
+            const int pa = partner[a];                          // NONE or j > a
+            const bool am = pa != HR_NONE;
+            const double *ra = Dsrc + static_cast<long long>(a) * nld;
+            double *wr = Ddst + static_cast<long long>(A) * nld;
+            const double na_ = csz[a];
+            HrBest best; best.v = HC_INF; best.i = 0x7fffffff; best.tie = 0;
+            auto consider = [&](double v, int B) {
+                if (v < best.v || (v == best.v && B < best.i)) { best.tie = (v == best.v) ? 1 : 0; best.v = v; best.i = B; }
+                else if (v == best.v && B != best.i) best.tie = 1;
+            };
+            if (!am) {
+                for (int B0 = lane; B0 < nb; B0 += 64 * 8) {
+                    int bb[8];
+                    double x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int B = B0 + 64 * u;
+                        bb[u] = oldidx[B < nb ? B : nb - 1];
+                        x[u] = ra[bb[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int B = B0 + 64 * u;
+                        if (B < nb && partner[bb[u]] == HR_NONE) {
+                            const double v = B == A ? 0.0 : (sq ? x[u] * x[u] : x[u]);
+                            wr[B] = v;
+                            if (B != A) consider(v, B);
+                        }
+                    }
+                }
+                for (int q = lane; q < np; q += 64) {           // merged columns: d(a, k u l) from d(a,k), d(a,l)
+                    const int k1 = plist[q], l1 = partner[k1], B = newidx[k1];
+                    double d1 = ra[k1], d2 = ra[l1];
+                    if (sq) { d1 *= d1; d2 *= d2; }
+                    const double v = lance_williams(method, d1, d2, dnn[k1], static_cast<double>(csz[k1]), static_cast<double>(csz[l1]), na_);
+                    wr[B] = v;
+                    consider(v, B);
+                }
+            } else {
+                const double *rj = Dsrc + static_cast<long long>(pa) * nld;
+                const double hP = dnn[a];
+                const double nj_ = csz[pa];
+                const int seqP = pseq[a];
+                for (int B0 = lane; B0 < nb; B0 += 64 * 4) {
+                    int bb[4], pbv[4];
+                    double x00[4], x01[4], x10[4], x11[4];      // D[a][b], D[a][pb], D[j][b], D[j][pb]
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int B = B0 + 64 * u;
+                        bb[u] = oldidx[B < nb ? B : nb - 1];
+                        const int pb = partner[bb[u]];
+                        pbv[u] = pb;
+                        const int pbc = pb == HR_NONE ? bb[u] : pb;
+                        x00[u] = ra[bb[u]]; x01[u] = ra[pbc]; x10[u] = rj[bb[u]]; x11[u] = rj[pbc];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int B = B0 + 64 * u;
+                        if (B < nb) {
+                            const int b = bb[u];
+                            const bool bm = pbv[u] != HR_NONE;
+                            double d00 = x00[u], d01 = x01[u], d10 = x10[u], d11 = x11[u];
+                            if (sq) { d00 *= d00; d01 *= d01; d10 *= d10; d11 *= d11; }
+                            double v;
+                            if (B == A) v = 0.0;
+                            else if (!bm) v = lance_williams(method, d00, d10, hP, na_, nj_, static_cast<double>(csz[b]));
+                            else {
+                                const double nk_ = csz[b], nl_ = csz[pbv[u]], hQ = dnn[b];
+                                if (seqP < static_cast<int>(pseq[b])) {   // (a, j) merges first, then (b, l) against the merged cluster
+                                    const double t1 = lance_williams(method, d00, d10, hP, na_, nj_, nk_);
+                                    const double t2 = lance_williams(method, d01, d11, hP, na_, nj_, nl_);
+                                    v = lance_williams(method, t1, t2, hQ, nk_, nl_, na_ + nj_);
+                                } else {
+                                    const double t1 = lance_williams(method, d00, d01, hQ, nk_, nl_, na_);
+                                    const double t2 = lance_williams(method, d10, d11, hQ, nk_, nl_, nj_);
+                                    v = lance_williams(method, t1, t2, hP, na_, nj_, nk_ + nl_);
+                                }
+                            }
+                            wr[B] = v;
+                            if (B != A) consider(v, B);
+                        }
+                    }
+                }
+            }
+            best = hr_wave(best);
+            if (lane == 0) {
+                // the merged cluster keeps the smaller original index as its name (R: i2 < j2)
+                cidN[A] = am ? (cid[a] < cid[pa] ? cid[a] : cid[pa]) : cid[a];
+                cszN[A] = static_cast<uint16_t>(csz[a] + (am ? csz[pa] : 0));
+                dnnN[A] = best.v;
+            }
+            // nn / tie of the new round live in the single-buffered arrays: nothing reads the old ones in this phase
+            if (lane == 1) { nn[A] = static_cast<uint16_t>(best.i < nb ? best.i : 0); }
+            if (lane == 2) { tie[A] = static_cast<unsigned char>(nb > 2 ? best.tie : 0); }
+        };
+        // two unmerged rows at a time share the column map (one set of LDS reads) and keep 16 loads in flight per lane
+        auto finish_row = [&](int A, int a, HrBest best) {
+            best = hr_wave(best);
+            if (lane == 0) { cidN[A] = cid[a]; cszN[A] = csz[a]; dnnN[A] = best.v; }
+            if (lane == 1) { nn[A] = static_cast<uint16_t>(best.i < nb ? best.i : 0); }
+            if (lane == 2) { tie[A] = static_cast<unsigned char>(nb > 2 ? best.tie : 0); }
+        };
+        for (int A = wave; A < nb; A += 2 * nwave) {
+            const int A2 = A + nwave;
+            const int a1 = oldidx[A], a2 = A2 < nb ? oldidx[A2] : 0;
+            if (A2 >= nb || partner[a1] != HR_NONE || partner[a2] != HR_NONE) {
+                do_row(A);
+                if (A2 < nb) do_row(A2);
+                continue;
+            }
+            const double *r1 = Dsrc + static_cast<long long>(a1) * nld, *r2 = Dsrc + static_cast<long long>(a2) * nld;
+            double *w1 = Ddst + static_cast<long long>(A) * nld, *w2 = Ddst + static_cast<long long>(A2) * nld;
+            HrBest b1, b2;
+            b1.v = b2.v = HC_INF; b1.i = b2.i = 0x7fffffff; b1.tie = b2.tie = 0;
+            for (int B0 = lane; B0 < nb; B0 += 64 * 8) {
+                int bb[8];
+                double x1[8], x2[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int B = B0 + 64 * u;
+                    bb[u] = oldidx[B < nb ? B : nb - 1];
+                    x1[u] = r1[bb[u]]; x2[u] = r2[bb[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int B = B0 + 64 * u;
+                    if (B < nb && partner[bb[u]] == HR_NONE) {
+                        const double v1 = B == A ? 0.0 : (sq ? x1[u] * x1[u] : x1[u]);
+                        const double v2 = B == A2 ? 0.0 : (sq ? x2[u] * x2[u] : x2[u]);
+                        w1[B] = v1; w2[B] = v2;
+                        if (B != A) { if (v1 < b1.v) { b1.v = v1; b1.i = B; b1.tie = 0; } else if (v1 == b1.v) b1.tie = 1; }
+                        if (B != A2) { if (v2 < b2.v) { b2.v = v2; b2.i = B; b2.tie = 0; } else if (v2 == b2.v) b2.tie = 1; }
+                    }
+                }
+            }
+            const double n1 = csz[a1], n2 = csz[a2];
+            for (int q = lane; q < np; q += 64) {               // merged columns: d(a, k u l) from d(a,k), d(a,l)
+                const int k1 = plist[q], l1 = partner[k1], B = newidx[k1];
+                double d1 = r1[k1], d2 = r1[l1], e1 = r2[k1], e2 = r2[l1];
+                if (sq) { d1 *= d1; d2 *= d2; e1 *= e1; e2 *= e2; }
+                const double nk_ = csz[k1], nl_ = csz[l1], hQ = dnn[k1];
+                const double v1 = lance_williams(method, d1, d2, hQ, nk_, nl_, n1);
+                const double v2 = lance_williams(method, e1, e2, hQ, nk_, nl_, n2);
+                w1[B] = v1; w2[B] = v2;
+                if (v1 < b1.v || (v1 == b1.v && B < b1.i)) { b1.tie = (v1 == b1.v) ? 1 : 0; b1.v = v1; b1.i = B; } else if (v1 == b1.v && B != b1.i) b1.tie = 1;
+                if (v2 < b2.v || (v2 == b2.v && B < b2.i)) { b2.tie = (v2 == b2.v) ? 1 : 0; b2.v = v2; b2.i = B; } else if (v2 == b2.v && B != b2.i) b2.tie = 1;
+            }
+            finish_row(A, a1, b1);
+            finish_row(A2, a2, b2);
+        }
+        __syncthreads();
+        if (tid == 0) { ctl[0] = 0; }
+        done += np; na = nb; cur ^= 1; src = src < 0 ? 0 : (src ^ 1);
+        __syncthreads();
+    }
+    // (5) the sequential algorithm's order: ascending height, lowest index first; ward.D2 reports sqrt
+    __syncthreads();
+    {
+        int npow2 = 1; while (npow2 < n - 1) npow2 <<= 1;
+        double *kh = reinterpret_cast<double *>(sm);            // the state is dead: reuse LDS (16 B per entry <= state size)
+        int *ki = reinterpret_cast<int *>(kh + npow2);
+        int *kj = ki + npow2;
+        for (int q = tid; q < npow2; q += HR_THREADS) {
+            if (q < n - 1) { kh[q] = crit[q]; ki[q] = ia[q]; kj[q] = ib[q]; } else { kh[q] = HC_INF; ki[q] = 0x7fffffff; kj[q] = 0; }
+        }
+        __syncthreads();
+        for (int size = 2; size <= npow2; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < (npow2 >> 1); t += HR_THREADS) {
+                    const int lo = ((t / stride) * stride * 2) + (t % stride), hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const double x = kh[lo], y = kh[hi];
+                    const bool gt = x > y || (x == y && ki[lo] > ki[hi]);
+                    if (gt == up) {
+                        kh[lo] = y; kh[hi] = x;
+                        const int t1 = ki[lo]; ki[lo] = ki[hi]; ki[hi] = t1;
+                        const int t2 = kj[lo]; kj[lo] = kj[hi]; kj[hi] = t2;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int q = tid; q < n - 1; q += HR_THREADS) { crit[q] = method == 8 ? sqrt(kh[q]) : kh[q]; ia[q] = ki[q]; ib[q] = kj[q]; }
+    }
+    if (tid == 0) status[blockIdx.x] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -456,8 +821,8 @@ __global__ void pack_labels_kernel(const HcMeta *__restrict__ metas, const int *
 namespace {
 
 struct Workspace {
-    DevBuf<double> D, D0, Cr, Ct, nrm, height, H, T, G, CSt, Q, out;
-    DevBuf<int> ia, ib, lab, chosen, packed;
+    DevBuf<double> D, D0, S0, S1, Cr, Ct, nrm, height, H, T, G, CSt, Q, out;
+    DevBuf<int> ia, ib, lab, chosen, packed, status;
     DevBuf<long long> packoff;
     DevBuf<HcMeta> meta;
     DevBuf<RowPrepTask> prep;
@@ -545,11 +910,11 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
         any_sym |= tk.symmetric; any_feat |= !tk.symmetric;
     }
     { HostTimer ht("hc_workspace_alloc");
-    W.D.ensure(oD); W.D0.ensure(std::max<long long>(oD0, 1)); W.Cr.ensure(oCr); W.Ct.ensure(oCt); W.nrm.ensure(oN);
+    W.D.ensure(oD); W.S0.ensure(oD); W.S1.ensure(oD); W.D0.ensure(std::max<long long>(oD0, 1)); W.Cr.ensure(oCr); W.Ct.ensure(oCt); W.nrm.ensure(oN);
     W.height.ensure(oM); W.ia.ensure(oM); W.ib.ensure(oM); W.lab.ensure(oLab);
     W.H.ensure(oK); W.T.ensure(oK); W.G.ensure(oK); W.CSt.ensure(oCS); W.Q.ensure(oQ); W.out.ensure(oOut); }
     { HostTimer ht("hc_workspace_alloc");
-    W.meta.ensure(T); W.prep.ensure(T); W.gemm.ensure(5 * static_cast<size_t>(T)); }
+    W.meta.ensure(T); W.prep.ensure(T); W.gemm.ensure(5 * static_cast<size_t>(T)); W.status.ensure(T); }
     W.meta.upload(metas.data(), T);
 
     // Every descriptor of the chunk goes up once; the device work is then enqueued per RANGE of tasks, each range on its
@@ -626,10 +991,25 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
             hipLaunchKernelGGL(copy_d_kernel, dim3(64, Ts), dim3(256), 0, st, dmeta, W.D.p, W.D0.p);
             launch_check("copy_d_kernel");
         }
-        // a4: agglomeration
+        // a4: agglomeration.  Reducible methods go through the bulk-synchronous kernel (streams whole rows between two scratch
+        // matrices, D stays pristine); whatever it abandons (exact ties, centroid/median, n > 4096) is done by the
+        // sequential NN-list kernel, which skips the tasks whose status is 0 -- no host round trip in between.
         {
-            const int nal = (max_n + 1) & ~1;
+            const char *seq = getenv("SHARP_HC_SEQ");           // debug / cross-check: the sequential kernel only
+            const bool use_rnn = !(seq && seq[0] == '1') && max_n <= HR_MAXN;
             KernelTimer tm("hclust");
+            if (use_rnn) {
+                const int nal = (max_n + 3) & ~3;
+                int npow2 = 1; while (npow2 < max_n - 1) npow2 <<= 1;
+                const size_t state = static_cast<size_t>(nal) * (16 + 4 + 4 + 2 * 6 + 1) + 8 * 4 + (HR_THREADS / 64 + 1) * 4 + 64;
+                const size_t lds = std::max(state, static_cast<size_t>(npow2) * 16);
+                SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_rnn_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+                hipLaunchKernelGGL(hclust_rnn_kernel, dim3(Ts), dim3(HR_THREADS), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
+                                   W.height.p, W.status.p + R.t0);
+                launch_check("hclust_rnn_kernel");
+            }
+            const int nal = (max_n + 1) & ~1;
             const size_t lds = static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16 + 32 * 12 + 16;
             SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 static_cast<int>(lds)));
@@ -638,7 +1018,7 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
             DevBuf<long long> dbg;
             if (tim) { dbg.alloc(static_cast<size_t>(Ts) * 6); dbg.zero(); }
             hipLaunchKernelGGL(hclust_kernel, dim3(Ts), dim3(HC_THREADS), lds, st, dmeta, W.D.p, W.ia.p, W.ib.p, W.height.p,
-                               abl ? atoi(abl) : 0, dbg.p);
+                               abl ? atoi(abl) : 0, dbg.p, use_rnn ? W.status.p + R.t0 : nullptr);
             launch_check("hclust_kernel");
             if (tim) {
                 std::vector<long long> h(static_cast<size_t>(Ts) * 6);
@@ -686,6 +1066,18 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
         }
     }
     std::vector<double> h_out(oOut), h_height(oM);
+    if (c.profiling) {      // which agglomeration kernel did the work (tests assert on it)
+        const char *seq = getenv("SHARP_HC_SEQ");
+        int fallback = T;
+        if (!(seq && seq[0] == '1') && max_n <= HR_MAXN) {
+            std::vector<int> st(T);
+            W.status.download(st.data(), T);
+            fallback = 0;
+            for (int v : st) fallback += v != 0;
+        }
+        c.stats["host:hclust_tasks_bulk_synchronous"].launches += T - fallback;
+        c.stats["host:hclust_tasks_sequential"].launches += fallback;
+    }
     HostTimer ht_tail("hc_download_select");
     W.out.download(h_out.data(), oOut);
     W.height.download(h_height.data(), oM);
@@ -747,7 +1139,7 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
             const HcTask &t = tasks[i1];
             const double nld = static_cast<double>(rup(t.n, 128));
             const double p = t.symmetric ? t.n : t.p;
-            const double b = 8.0 * (nld * nld * (t.symmetric ? 2 : 1) + 2 * nld * p + 4.0 * 64 * t.n) + 4.0 * 64 * t.n;
+            const double b = 8.0 * (nld * nld * (t.symmetric ? 4 : 3) + 2 * nld * p + 4.0 * 64 * t.n) + 4.0 * 64 * t.n;   // D, two scratch matrices (+ D0)
             if (i1 > i0 && bytes + b > budget) break;
             bytes += b;
             ++i1;

@@ -124,3 +124,44 @@ def test_getrowcolor_names_and_edge_sizes(sa, oracle):
     assert np.array_equal(r3["f"], oracle.get_opt_hclust(E3)["f"])
     with pytest.raises(sa.SharpError):
         sa.get_opt_hclust(E[:2])
+
+
+def _hc_counts(dev):
+    tab = dev.profile_table()
+    return tab.get("host:hclust_tasks_bulk_synchronous", (0, 0))[1], tab.get("host:hclust_tasks_sequential", (0, 0))[1]
+
+
+def test_bulk_synchronous_and_sequential_agglomeration_agree(sa, oracle, monkeypatch):
+    """Continuous data goes through hclust_rnn_kernel (all reciprocal-nearest-neighbour pairs per round); SHARP_HC_SEQ=1
+    forces the sequential NN-list kernel.  Same merges (every cutree level) and heights to rounding; data with exact ties
+    (integer vectors, duplicated observations) is abandoned by the bulk kernel and done by the sequential one."""
+    from sharp_amd import device as dev
+
+    rng = np.random.default_rng(11)
+    E = rng.standard_normal((700, 60)) + np.repeat(rng.standard_normal((7, 60)) * 2.0, 100, axis=0)
+    for hm in ["ward.D", "ward.D2", "average", "complete", "single", "mcquitty"]:
+        dev.profile(True)
+        a = sa.get_opt_hclust(E, hmethod=hm)
+        bulk, seq = _hc_counts(dev)
+        assert (bulk, seq) == (1, 0), (hm, bulk, seq)
+        monkeypatch.setenv("SHARP_HC_SEQ", "1")
+        dev.profile(True)
+        b = sa.get_opt_hclust(E, hmethod=hm)
+        assert _hc_counts(dev) == (0, 1)
+        monkeypatch.delenv("SHARP_HC_SEQ")
+        assert np.array_equal(a["v"], b["v"]) and np.array_equal(a["f"], b["f"]), hm
+        np.testing.assert_allclose(a["height"], b["height"], rtol=1e-12, atol=1e-14)
+        ref = oracle.get_opt_hclust(E, hmethod=hm)
+        assert np.array_equal(a["f"], ref["f"])
+    for hm in ["centroid", "median"]:                          # not reducible: sequential kernel
+        dev.profile(True)
+        a = sa.get_opt_hclust(E, hmethod=hm)
+        assert _hc_counts(dev) == (0, 1)
+        assert np.array_equal(a["f"], oracle.get_opt_hclust(E, hmethod=hm)["f"])
+    T = np.vstack([E[:300], E[:50]]).copy()                     # 50 exact duplicates -> exact ties
+    dev.profile(True)
+    a = sa.get_opt_hclust(T)
+    assert _hc_counts(dev) == (0, 1)
+    ref = oracle.get_opt_hclust(T)
+    assert np.array_equal(a["v"], ref["v"])
+    dev.profile(False)
