@@ -112,7 +112,19 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    prof_timed = dev.profile_table()
+    # Attribution pass, outside the timed region: the timed steps run the base-clustering tasks as two ranges on two streams,
+    # so their per-kernel event times overlap; one more step with a single range gives each kernel's own time.
+    os.environ["SHARP_HC_RANGES"] = "1"
+    dev.profile(True)
+    step()
+    barrier()
     prof = dev.profile_table()
+    del os.environ["SHARP_HC_RANGES"]
+    for kname in ("rp_compact", "rp_apply", "rp_stage"):           # the RP stage is not affected: keep the timed-region statistics
+        if kname in prof_timed:
+            prof[kname] = prof_timed[kname]
+    attr_steps = {k: (args.steps if k in ("rp_compact", "rp_apply", "rp_stage") else 1) for k in prof}
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -153,26 +165,25 @@ def main():
                               "achieved": round(alg_stage / t_stage / 1e9, 1), "frac": round(alg_stage / t_stage / 8e12, 4),
                               "read_only_frac": round(n * m * 4 / t_stage / 8e12, 4),
                               "rp_apply_launch_ms": round(ams / max(acalls, 1), 4), "hbm_bytes_measured": traffic}}
-        # the two other heavy kernels, for context (launches of the two pipelined task ranges overlap each other and the
-        # GEMM, so their event times are upper bounds of their share of the step)
+        # the two other heavy kernels, for context (from the single-range attribution step)
         others = []
         T_tasks = K_RP * len(range(0, n, 2000)) if n >= 5000 else K_RP
         gms, gcalls = prof.get("corr_dist_gemm", (0.0, 0))
         if gcalls:
             fl = T_tasks * 2000.0 * 2000.0 * p                   # upper triangle of n_t^2 * p * 2 flop per task
-            tg = gms / args.steps * 1e-3
+            tg = gms / attr_steps.get("corr_dist_gemm", 1) * 1e-3
             others.append({"kernel": "gemm_tn_f64_fast_kernel", "bound": "mfma", "achieved": round(fl / tg / 1e12, 1), "peak": 78.6,
                            "unit": "TFLOP/s", "frac": round(fl / tg / 78.6e12, 3), "ms_per_step": round(tg * 1e3, 2),
                            "work": "%d tasks x n_t^2 x p flop (upper triangle), f64 MFMA" % T_tasks})
         hms, hcalls = prof.get("hclust", (0.0, 0))
         if hcalls:
             by = T_tasks * 2000.0 * 2000.0 * 8 * 9.3             # rounds of (read n_a^2 + write n_a'^2): ~9.3 n_t^2 entries per task
-            th = hms / args.steps * 1e-3
+            th = hms / attr_steps.get("hclust", 1) * 1e-3
             others.append({"kernel": "hclust_rnn_kernel", "bound": "hbm", "achieved": round(by / th / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(by / th / 8e12, 3), "ms_per_step_sum_of_overlapping_launches": round(th * 1e3, 2),
+                           "frac": round(by / th / 8e12, 3), "ms_per_step": round(th * 1e3, 2),
                            "work": "%d tasks x ~9.3 n_t^2 x 8 B (every round streams the distance matrix into a compacted copy, "
                                    "~44 rounds); see DESIGN.md 5" % T_tasks})
-        stages = {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        stages = {k: round(v[0] / attr_steps.get(k, 1), 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0] / attr_steps.get(kv[0], 1))}
         from sharp_amd.api import ARI
 
         result = {
@@ -189,6 +200,7 @@ def main():
             "roofline": roof,
             "other_kernels": others,
             "kernel_ms_per_step": stages,
+            "kernel_ms_note": "per-kernel times from one extra un-pipelined step outside the timed region (SHARP_HC_RANGES=1); the timed steps overlap two task ranges, so these add up to more than ms_per_step",
             "clusters_found": int(state["n_clusters"]),
             "ari_vs_planted_truth": round(float(ARI(truth, state["pred"])["HA"]), 4),
         }
