@@ -127,7 +127,10 @@ void draw_projector(int m, int p, double seed, std::vector<uint32_t> &rowptr, st
 // tempers each word in registers and tests it against the integer thresholds; the 0.7 % hits are staged in LDS and
 // appended to the projector's hit list (element index i = r*p + c of the byrow fill, bit 31 = negative).
 // ---------------------------------------------------------------------------------------------
+#include "mt_jump_table.inc"
+
 constexpr int PD_THREADS = 256;
+constexpr int PD_XS = 19937 + 624 + 227;   // raw words needed to jump: x_0 .. x_(19936+623), rounded up to whole 227-word steps
 constexpr int PD_STAGE = 4096;
 
 __device__ __forceinline__ uint32_t pd_tw(uint32_t hi, uint32_t lo) {
@@ -146,12 +149,22 @@ __global__ __launch_bounds__(PD_THREADS) void proj_draw_kernel(const uint32_t *_
                                                                uint32_t t1, int flush_every, uint32_t *__restrict__ hits,
                                                                unsigned int cap, unsigned int *__restrict__ nhits,
                                                                int *__restrict__ err) {
+    // One workgroup per (projector, segment of 2^20 draws).  Segment t > 0 first jumps the seed state t * 2^20 draws ahead:
+    // with g_t(x) = x^(t 2^20) mod phi (mt_jump_table.inc), the state window at that offset is w_j = XOR_{i : g_t has x^i}
+    // x_(i+j), j = 0..623, over the raw word sequence x -- 20 560 words regenerated into LDS, then 624 independent XOR
+    // chains.  All segments of a projector therefore start at once instead of one after the other.
     constexpr int N = 624, M = 397, D = N - M;   // D = 227
-    __shared__ uint32_t st[2][N];
-    __shared__ uint32_t stage[PD_STAGE];
-    __shared__ unsigned int scount;
-    const int k = blockIdx.x, tid = threadIdx.x;
-    uint32_t *out = hits + static_cast<size_t>(k) * cap;
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    uint32_t *xs = reinterpret_cast<uint32_t *>(psm);                 // [PD_XS]   (jump only)
+    uint32_t(*st)[N] = reinterpret_cast<uint32_t(*)[N]>(xs + PD_XS);  // [2][N]
+    uint32_t *stage = reinterpret_cast<uint32_t *>(st + 2);           // [PD_STAGE]
+    unsigned int *scount_p = reinterpret_cast<unsigned int *>(stage + PD_STAGE);
+#define scount (*scount_p)
+    const int k = blockIdx.x, seg = blockIdx.y, nseg = gridDim.y, tid = threadIdx.x;
+    const unsigned long long d0 = static_cast<unsigned long long>(seg) << MT_JUMP_LOG2;
+    const unsigned long long dlim = d0 + (1ull << MT_JUMP_LOG2);
+    const unsigned long long d1 = dlim < total ? dlim : total;
+    uint32_t *out = hits + (static_cast<size_t>(k) * nseg + seg) * cap;
     // set.seed(): 50 warm-up steps of x <- 69069 x + 1, one for the position word, then one per state word
     if (tid == 0) {
         uint32_t seed = seeds[k];
@@ -160,11 +173,35 @@ __global__ __launch_bounds__(PD_THREADS) void proj_draw_kernel(const uint32_t *_
         scount = 0u;
     }
     __syncthreads();
+    if (seg > 0) {
+        for (int j = tid; j < N; j += PD_THREADS) xs[j] = st[0][j];
+        __syncthreads();
+        for (int n0 = 0; n0 + N < PD_XS; n0 += D) {                   // x_(n+624) = x_(n+397) ^ tw(x_n, x_(n+1)), 227 at a time
+            if (tid < D && n0 + N + tid < PD_XS) xs[n0 + N + tid] = xs[n0 + M + tid] ^ pd_tw(xs[n0 + tid], xs[n0 + tid + 1]);
+            __syncthreads();
+        }
+        const unsigned int *g = mt_jump_poly[seg - 1];
+        uint32_t acc[3] = {0u, 0u, 0u};
+        for (int w = 0; w < N; ++w) {
+            uint32_t word = g[w];                                      // same word in every lane: scalar control flow
+            while (word) {
+                const int bit = __builtin_ctz(word);
+                word &= word - 1u;
+                const int i = 32 * w + bit;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { const int j = tid + q * PD_THREADS; if (j < N) acc[q] ^= xs[i + j]; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const int j = tid + q * PD_THREADS; if (j < N) st[0][j] = acc[q]; }
+        __syncthreads();
+    }
     unsigned int gcount = 0;   // hits already flushed (uniform)
     int cur = 0, since = 0;
     bool overflow = false;
     auto emit = [&](uint32_t word, unsigned long long idx) {
-        if (idx < total) {
+        if (idx < d1) {
             const uint32_t y = pd_temper(word);
             if (y > t0) {
                 const unsigned int pos = atomicAdd(&scount, 1u);
@@ -172,7 +209,7 @@ __global__ __launch_bounds__(PD_THREADS) void proj_draw_kernel(const uint32_t *_
             }
         }
     };
-    for (unsigned long long base = 0; base < total; base += N) {
+    for (unsigned long long base = d0; base < d1; base += N) {
         const uint32_t *c = st[cur];
         uint32_t *nx = st[cur ^ 1];
         if (tid < D) {                                   // words [0, 227): old values only
@@ -196,7 +233,7 @@ __global__ __launch_bounds__(PD_THREADS) void proj_draw_kernel(const uint32_t *_
         }
         __syncthreads();
         cur ^= 1;
-        if (++since == flush_every || base + N >= total) {
+        if (++since == flush_every || base + N >= d1) {
             const unsigned int cnt = scount;
             if (cnt > PD_STAGE || gcount + cnt > cap) overflow = true;
             const unsigned int cc = cnt > PD_STAGE ? PD_STAGE : cnt;
@@ -209,17 +246,19 @@ __global__ __launch_bounds__(PD_THREADS) void proj_draw_kernel(const uint32_t *_
         }
     }
     if (tid == 0) {
-        nhits[k] = gcount < cap ? gcount : cap;
+        nhits[k * nseg + seg] = gcount < cap ? gcount : cap;
         if (overflow) *err = 1;
     }
+#undef scount
 }
 
 // entries per gene over the projectors [k0, k0+kcount) of one group
 __global__ void proj_count_kernel(const uint32_t *__restrict__ hits, unsigned int cap, const unsigned int *__restrict__ nhits, int k0,
                                   uint32_t p, unsigned int *__restrict__ len) {
     const int k = k0 + blockIdx.y;
-    const unsigned int n = nhits[k];
-    const uint32_t *h = hits + static_cast<size_t>(k) * cap;
+    const size_t list = static_cast<size_t>(k) * gridDim.z + blockIdx.z;      // (projector, draw segment)
+    const unsigned int n = nhits[list];
+    const uint32_t *h = hits + list * cap;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         atomicAdd(&len[(h[i] & 0x7fffffffu) / p], 1u);
 }
@@ -228,8 +267,9 @@ __global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int
                                  uint32_t p, const uint32_t *__restrict__ rowptr, unsigned int *__restrict__ fill,
                                  uint16_t *__restrict__ flat) {
     const int kk = blockIdx.y, k = k0 + kk;
-    const unsigned int n = nhits[k];
-    const uint32_t *h = hits + static_cast<size_t>(k) * cap;
+    const size_t list = static_cast<size_t>(k) * gridDim.z + blockIdx.z;
+    const unsigned int n = nhits[list];
+    const uint32_t *h = hits + list * cap;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t w = h[i], idx = w & 0x7fffffffu;
         const uint32_t g = idx / p, c = idx - g * p;
@@ -392,10 +432,12 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
     std::vector<uint32_t> useed(K);
     for (int k = 0; k < K; ++k) useed[k] = seed_word(seeds[k]);
     const unsigned long long total = static_cast<unsigned long long>(m) * p;
-    const double expect = static_cast<double>(total) / std::sqrt(static_cast<double>(m));
-    pr->hit_cap = static_cast<unsigned int>(expect * 1.25 + 8.0 * std::sqrt(expect) + 4096.0);
-    pr->d_hits.alloc(static_cast<size_t>(K) * pr->hit_cap);
-    pr->d_nhits.alloc(K);
+    const int S = static_cast<int>((total + (1ull << MT_JUMP_LOG2) - 1) >> MT_JUMP_LOG2);    // draw segments per projector
+    const double expect = static_cast<double>(std::min<unsigned long long>(total, 1ull << MT_JUMP_LOG2)) / std::sqrt(static_cast<double>(m));
+    pr->hit_cap = static_cast<unsigned int>(expect * 1.25 + 8.0 * std::sqrt(expect) + 4096.0);   // per (projector, segment) list
+    pr->draw_segments = S;
+    pr->d_hits.alloc(static_cast<size_t>(K) * S * pr->hit_cap);
+    pr->d_nhits.alloc(static_cast<size_t>(K) * S);
     // regenerations between flushes of the LDS stage: about a quarter of its capacity in expected hits
     const int flush_every = std::max(1, static_cast<int>(PD_STAGE / 4 / (624.0 / std::sqrt(static_cast<double>(m)))));
     DevBuf<uint32_t> d_seed(K);
@@ -404,11 +446,14 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
     d_err.zero();
     {
         KernelTimer t("projector_draw");
-        hipLaunchKernelGGL(proj_draw_kernel, dim3(K), dim3(PD_THREADS), 0, c.stream, d_seed.p, total, t0, t1, flush_every, pr->d_hits.p, pr->hit_cap,
-                           pr->d_nhits.p, d_err.p);
+        const size_t lds = (static_cast<size_t>(PD_XS) + 2 * 624 + PD_STAGE + 4) * 4;
+        SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(proj_draw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            static_cast<int>(lds)));
+        hipLaunchKernelGGL(proj_draw_kernel, dim3(K, S), dim3(PD_THREADS), lds, c.stream, d_seed.p, total, t0, t1, flush_every,
+                           pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, d_err.p);
         launch_check("proj_draw_kernel");
     }
-    pr->h_nhits.resize(K);
+    pr->h_nhits.resize(static_cast<size_t>(K) * S);
     const int per_group = std::max(1, kMaxCompPerGroup / p);
     bool first = true;
     for (int k0 = 0; k0 < K; k0 += per_group) {
@@ -418,7 +463,7 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         grp.ncomp = grp.kcount * p;
         DevBuf<unsigned int> d_len(static_cast<size_t>(m) + 1), d_fill(static_cast<size_t>(m) + 1);
         d_len.zero(); d_fill.zero();
-        hipLaunchKernelGGL(proj_count_kernel, dim3(64, grp.kcount), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
+        hipLaunchKernelGGL(proj_count_kernel, dim3(16, grp.kcount, S), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
                            static_cast<uint32_t>(p), d_len.p);
         launch_check("proj_count_kernel");
         std::vector<unsigned int> len(static_cast<size_t>(m) + 1);
@@ -427,7 +472,7 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
             int err = 0;
             d_err.download(&err, 1);
             SHARP_REQUIRE(err == 0, "projector: hit list overflow in the device build");
-            pr->d_nhits.download(pr->h_nhits.data(), K);
+            pr->d_nhits.download(pr->h_nhits.data(), pr->h_nhits.size());
             first = false;
         }
         std::vector<uint32_t> rowptr(static_cast<size_t>(m) + 1, 0);
@@ -464,7 +509,7 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         const size_t nent = static_cast<size_t>(nseg + 1) * span;
         grp.ent.alloc(nent);
         hipLaunchKernelGGL(proj_fill_u16_kernel, dim3(256), dim3(256), 0, c.stream, grp.ent.p, nent, static_cast<uint16_t>(0xFFFFu));
-        hipLaunchKernelGGL(proj_fill_kernel, dim3(64, grp.kcount), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
+        hipLaunchKernelGGL(proj_fill_kernel, dim3(16, grp.kcount, S), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
                            static_cast<uint32_t>(p), d_rowptr.p, d_fill.p, d_flat.p);
         hipLaunchKernelGGL(proj_layout_kernel, dim3((m + 255) / 256), dim3(256), 0, c.stream, m, d_rowptr.p, d_flat.p, grp.gw,
                            grp.ovf_gene.p, grp.ovf_info.p, grp.novf, grp.ent.p);
@@ -479,13 +524,18 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
 // Host lists (one CSR per projector, column order) for sharp_projector_triplets(): made on demand from the hit list.
 void ensure_host_lists(Projector &pr, int k) {
     if (!pr.device_built || !pr.h_rowptr[k].empty()) return;
-    const unsigned int n = pr.h_nhits[k];
+    const int S = pr.draw_segments;
+    unsigned int n = 0;
+    for (int t = 0; t < S; ++t) n += pr.h_nhits[static_cast<size_t>(k) * S + t];
     std::vector<uint32_t> h(n);
-    if (n) {
-        SHARP_HIP_CHECK(hipMemcpyAsync(h.data(), pr.d_hits.p + static_cast<size_t>(k) * pr.hit_cap, static_cast<size_t>(n) * 4,
-                                       hipMemcpyDeviceToHost, ctx().stream));
-        stream_sync();
+    unsigned int off = 0;
+    for (int t = 0; t < S; ++t) {
+        const unsigned int nt = pr.h_nhits[static_cast<size_t>(k) * S + t];
+        if (nt) SHARP_HIP_CHECK(hipMemcpyAsync(h.data() + off, pr.d_hits.p + (static_cast<size_t>(k) * S + t) * pr.hit_cap,
+                                               static_cast<size_t>(nt) * 4, hipMemcpyDeviceToHost, ctx().stream));
+        off += nt;
     }
+    stream_sync();
     std::sort(h.begin(), h.end(), [](uint32_t a, uint32_t b) { return (a & 0x7fffffffu) < (b & 0x7fffffffu); });
     auto &rp = pr.h_rowptr[k];
     auto &en = pr.h_ent[k];
@@ -502,7 +552,8 @@ void ensure_host_lists(Projector &pr, int k) {
 
 std::shared_ptr<Projector> build_projector(int m, int p, int K, const double *seeds) {
     const char *host = getenv("SHARP_PROJ_HOST");       // debug / cross-check: the host build of the same projector
-    if ((host && host[0] == '1') || static_cast<unsigned long long>(m) * static_cast<unsigned long long>(p) >= (1ull << 31))
+    const unsigned long long draws = static_cast<unsigned long long>(m) * static_cast<unsigned long long>(p);
+    if ((host && host[0] == '1') || draws >= (1ull << 31) || draws > (static_cast<unsigned long long>(MT_JUMP_COUNT + 1) << MT_JUMP_LOG2))
         return build_projector_host(m, p, K, seeds);
     return build_projector_device(m, p, K, seeds);
 }
