@@ -47,13 +47,13 @@ for counter, sub in (("FETCH_SIZE", "_pmc_fetch"), ("WRITE_SIZE", "_pmc_write"))
             agg[k][counter] += float(row["Counter_Value"])
             if counter == "FETCH_SIZE":
                 agg[k]["launches"] += 1
-steps = 4  # bench.py --steps 3 --warmup 1
+steps = 5  # bench.py --steps 3 --warmup 1: 1 warm-up + 3 timed + 1 attribution step = 5 SHARP() calls
 rows = []
 for k, v in sorted(agg.items(), key=lambda kv: -(2 * kv[1]["FETCH_SIZE"] + kv[1]["WRITE_SIZE"])):
     hbm = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
     rows.append((k, v["launches"], round(v["FETCH_SIZE"], 1), round(v["WRITE_SIZE"], 1), int(hbm), int(hbm / steps)))
 with open(os.path.join(prof, tag + "_pmc_hbm_traffic.csv"), "w") as fh:
-    fh.write("kernel,launches(%d SHARP calls: 1 warm-up + 3),FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum,"
+    fh.write("kernel,launches(%d SHARP calls: 1 warm-up + 3 timed + 1 attribution),FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum,"
              "hbm_bytes_total(2xFETCH gfx950 correction + WRITE),hbm_bytes_per_SHARP_call\n" % steps)
     for r in rows:
         fh.write(",".join(str(x) for x in r) + "\n")
