@@ -173,6 +173,18 @@ int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long lon
  * which returns the final 1-based id of each gathered (block, cluster) row. */
 int sharp_unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
                               double rN_seed, int *pred, int *n_clusters, double *means, int cap_rows, long long *counts);
+/* SHARP_unlimited2 (R/SHARP_unlimited2.R:29-292, with SHARP_fpart :297-544): log10 instead of log2, E1 rounded to one
+ * decimal before the base clustering (maxN.cluster = 40 there), and a single sMetaC over the per-fold ensemble clusters of
+ * all blocks.  flag: log-transform (the reference's testlog decision); viE: ncells x p row-major E1 or NULL.  0 / negative
+ * parameters take the reference defaults (:39-69). */
+int sharp_SHARP_unlimited2(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K,
+                           int reduced_ndim, int partition_ncells, int hmethod, int N_cluster, int enpN, int indN, int minN,
+                           int maxN, double sil_thre, double height_Ntimes, int flag, double rN_seed, int *pred, int *n_pred,
+                           int *p_used, double *viE);
+int sharp_SHARP_unlimited2_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                               int ensize_K, int reduced_ndim, int partition_ncells, int hmethod, int N_cluster, int enpN,
+                               int indN, int minN, int maxN, double sil_thre, double height_Ntimes, int flag, double rN_seed,
+                               int *pred, int *n_pred, int *p_used, double *viE);
 /* The block step with the log flag of the per-block SHARP() call (SHARP_unlimited3 leaves it to testlog,
  * R/SHARP_unlimited3.R:122) and, optionally, the block's viE rows (nb x p row-major, host; NULL: not wanted). */
 int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,

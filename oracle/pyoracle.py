@@ -242,6 +242,28 @@ def SHARP_unlimited(blocks, K=0, N_cluster=0, minN=0, maxN=0, rN_seed=2103, nthr
     return dict(rc=rc, pred_clusters=pred, viE=viE, p=po.value)
 
 
+def SHARP_unlimited2(blocks, K=0, reduced_ndim=0, partition_ncells=0, hmethod="ward.D", N_cluster=0, enpN=0, indN=0, minN=0,
+                     maxN=0, sil_thre=-1.0, height_Ntimes=0.0, flag=True, rN_seed=2103, nthreads=1, want_view=False):
+    m = blocks[0].shape[0]
+    ncb = np.array([b.shape[1] for b in blocks], np.int32)
+    Xcat = np.concatenate([np.asfortranarray(b, dtype=np.float64).ravel(order="F") for b in blocks])
+    n = int(ncb.sum())
+    p = int(reduced_ndim) if reduced_ndim else int(np.ceil(np.log2(n) / 0.04))
+    pred = np.zeros(n, np.int32)
+    viE = np.zeros((n, p)) if want_view else None
+    po = C.c_int()
+    rc = lib().oracle_SHARP_unlimited2(_dp(Xcat), m, len(blocks), _ip(ncb), K, int(reduced_ndim), int(partition_ncells),
+                                       HMETHODS[hmethod], int(N_cluster or 0), int(enpN or 0), int(indN or 0), minN, maxN,
+                                       C.c_double(sil_thre), C.c_double(height_Ntimes), int(bool(flag)), C.c_double(rN_seed),
+                                       nthreads, _ip(pred), _dp(viE), C.byref(po))
+    return dict(rc=rc, pred_clusters=pred, viE=viE, p=po.value)
+
+
+def round1(x):
+    lib().oracle_round1.restype = C.c_double
+    return np.array([lib().oracle_round1(C.c_double(float(v))) for v in np.ravel(x)]).reshape(np.shape(x))
+
+
 def testlog(X, p, cells):
     m, n = X.shape
     Xf = np.asfortranarray(X, dtype=np.float64)

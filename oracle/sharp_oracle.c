@@ -4,7 +4,7 @@
  * A plain-C, fp64 (long double where R itself uses LDOUBLE) restatement of the
  * SHARP hot path of the reference R package (shibiaowan/SHARP, /root/reference):
  *   ranM / RPmat -> get_opt_hclust / getrowColor -> wMetaC -> sMetaC ->
- *   SHARP_small / SHARP_large / SHARP_unlimited.
+ *   SHARP_small / SHARP_large / SHARP_unlimited / SHARP_unlimited2 (SHARP_fpart).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call
  * into this file.  The product (sharp_amd/, libsharp_hip.so) never does.
@@ -19,7 +19,7 @@
  *   - ARI against sklearn.metrics.adjusted_rand_score.
  * Third-party arithmetic restated here (none of it is vendored in the reference):
  *   R core (unpinned, >= 3.6 assumed): set.seed, sample, scale, cor, hclust.f,
- *   cutree, median, table/sort/unique;  cluster::silhouette (sildist.c);
+ *   cutree, median, table/sort/unique, round(x, 1) (nmath/fround.c of R >= 4.0);  cluster::silhouette (sildist.c);
  *   clues 0.6.2.2 get_CH / adjustedRand (formula per SURVEY.md App. A.6, unverified);
  *   clusterCrit::intCriteria("Calinski_Harabasz");  Matrix sparse %*% dense
  *   (ascending-row accumulation).
@@ -201,7 +201,7 @@ void oracle_project(const double *X, int m, int n, const int8_t *tern, int p,
         double *e = E + (size_t)cell * (size_t)p;
         for (int c = 0; c < p; c++) e[c] = 0.0;
         for (int g = 0; g < m; g++) {          /* ascending gene order per output */
-            double lv = logflag ? log2(x[g] + 1.0) : x[g];
+            double lv = logflag == 2 ? log10(x[g] + 1.0) : (logflag ? log2(x[g] + 1.0) : x[g]);   /* 2: R/SHARP_unlimited2.R:391 */
             if (lv == 0.0) continue;           /* adding fl(v*0) = +-0 changes nothing */
             double tp = val * lv, tm = -val * lv;
             for (size_t q = rp[g]; q < rp[g + 1]; q++) {
@@ -916,10 +916,25 @@ int oracle_make_folds(int ncells, int ng, int *folds) {
 /* Outputs: pred[n]; viE (n x p, original cell order) or NULL.                 */
 /* nthreads: OpenMP threads over the K*T task grid (the %dopar% at :554).      */
 /* ------------------------------------------------------------------------- */
-int oracle_SHARP_large(const double *X, int m, int n, int K, int p, int ng, int hmethod,
-                       int N_cluster, int enpN, int indN, int minN, int maxN, double sil_thre,
-                       double height_Ntimes, int flag, const int8_t *tern_in, double rN_seed,
-                       int nthreads, int *pred, double *viE_out) {
+/* R's round(x, 1): nmath/fround.c of R >= 4.0.0 restated (R core: unpinned third-party dependency of the reference):  */
+/* the closer of floor(10x)/10 and ceil(10x)/10, the even multiple on a tie.  Used by R/SHARP_unlimited2.R:410.        */
+double oracle_round1(double x) {
+    if (x != x || x == 0.0 || x - x != 0.0) return x;
+    double sgn = x < 0.0 ? -1.0 : 1.0;
+    x = fabs(x);
+    if (x >= 1e14) return sgn * x;
+    double x10 = 10.0 * x, i10 = floor(x10), xd = i10 / 10.0, xu = ceil(x10) / 10.0;
+    double du = xu - x, dd = x - xd;
+    return sgn * ((dd < du || (dd == du && fmod(i10, 2.0) == 0.0)) ? xd : xu);
+}
+
+/* fpart != 0: SHARP_fpart (R/SHARP_unlimited2.R:297-544) = the same path with flag 2 = log10 (:391), newE1 rounded to  */
+/* one decimal (:410), maxN.cluster = 40 for the base tasks only (:421), and no sMetaC: pred receives the per-fold        */
+/* ensemble labels "<id>en<t>" packed as t*65536+id in the ORIGINAL cell order (:522-526), viE_out = E1 = enE/K.          */
+static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng, int hmethod,
+                            int N_cluster, int enpN, int indN, int minN, int maxN, double sil_thre,
+                            double height_Ntimes, int flag, const int8_t *tern_in, double rN_seed,
+                            int nthreads, int *pred, double *viE_out, int fpart) {
     int rc = OR_OK;
     (void)nthreads;
     int *reind = (int *)xmalloc(sizeof(int) * (size_t)n);
@@ -953,8 +968,9 @@ int oracle_SHARP_large(const double *X, int m, int n, int K, int p, int ng, int 
         }
         double *Et = Eall + ((size_t)k * n + c0) * p;
         oracle_project(Xt, m, nt, tn + (size_t)k * m * p, p, flag, Et);
+        if (fpart) for (size_t q = 0; q < (size_t)nt * (size_t)p; q++) Et[q] = oracle_round1(Et[q]);
         double maxsil;
-        int r = oracle_getrowColor(Et, nt, p, hmethod, indN, minN, maxN, sil_thre, height_Ntimes,
+        int r = oracle_getrowColor(Et, nt, p, hmethod, indN, minN, fpart ? 40 : maxN, sil_thre, height_Ntimes,
                                    enrp + (size_t)k * n + c0, &maxsil);
         if (r) {
             #pragma omp atomic
@@ -984,6 +1000,15 @@ int oracle_SHARP_large(const double *X, int m, int n, int K, int p, int ng, int 
     int *S = (int *)xmalloc(sizeof(int) * (size_t)n);
     double *E1 = (double *)xmalloc(sizeof(double) * (size_t)n * (size_t)p);
     for (size_t q = 0; q < (size_t)n * (size_t)p; q++) E1[q] = enE[q] / K;   /* :750 */
+    if (fpart) {
+        for (int i = 0; i < n; i++) {
+            int dst = shuffle ? reind[i] - 1 : i;
+            pred[dst] = fColor[i];
+            if (viE_out) memcpy(viE_out + (size_t)dst * p, E1 + (size_t)i * p, sizeof(double) * (size_t)p);
+        }
+        free(reind); free(folds); free(tern); free(fstart); free(enrp); free(enE); free(fColor); free(S); free(E1);
+        return rc;
+    }
     if (T == 1) {
         /* :738-746 then :828: as.numeric("<id>en1") is NA for every cell -> one cluster */
         for (int i = 0; i < n; i++) S[i] = 1;
@@ -1001,6 +1026,14 @@ int oracle_SHARP_large(const double *X, int m, int n, int K, int p, int ng, int 
     relabel_first_appearance(pred, n);                                       /* :828-843 */
     free(reind); free(folds); free(tern); free(fstart); free(enrp); free(enE); free(fColor); free(S); free(E1);
     return rc;
+}
+
+int oracle_SHARP_large(const double *X, int m, int n, int K, int p, int ng, int hmethod,
+                       int N_cluster, int enpN, int indN, int minN, int maxN, double sil_thre,
+                       double height_Ntimes, int flag, const int8_t *tern_in, double rN_seed,
+                       int nthreads, int *pred, double *viE_out) {
+    return sharp_large_core(X, m, n, K, p, ng, hmethod, N_cluster, enpN, indN, minN, maxN, sil_thre, height_Ntimes, flag, tern_in,
+                            rN_seed, nthreads, pred, viE_out, 0);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1098,6 +1131,74 @@ int oracle_SHARP_unlimited(const double *Xcat, int m, int nb, const int *ncb, in
     if (viE_out) memcpy(viE_out, E1, sizeof(double) * (size_t)ncells * (size_t)p);
     if (p_out) *p_out = p;
     free(tern); free(fColor); free(E1);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SHARP_unlimited2 (R/SHARP_unlimited2.R:29-292): SHARP_fpart per block, one  */
+/* sMetaC over the per-fold ensemble clusters of all blocks, small-cluster      */
+/* merge, size-ordered ids.  flag: the testlog decision (1 = log10 transform).  */
+/* 0 / negative parameters take the defaults of :39-69.                         */
+/* ------------------------------------------------------------------------- */
+static int cmp_int3(const void *a, const void *b) {
+    const int *x = (const int *)a, *y = (const int *)b;   /* {block, packed label, first cell} */
+    if (x[0] != y[0]) return (x[0] > y[0]) - (x[0] < y[0]);
+    return (x[1] > y[1]) - (x[1] < y[1]);
+}
+int oracle_SHARP_unlimited2(const double *Xcat, int m, int nb, const int *ncb, int K, int reduced_ndim, int ng,
+                            int hmethod, int N_cluster, int enpN, int indN, int minN, int maxN, double sil_thre,
+                            double height_Ntimes, int flag, double rN_seed, int nthreads, int *pred, double *viE_out,
+                            int *p_out) {
+    int rc = OR_OK;
+    int ncells = 0; for (int b = 0; b < nb; b++) ncells += ncb[b];
+    if (K <= 0) K = 5;                                                       /* :39-41 */
+    int p = reduced_ndim > 0 ? reduced_ndim : (int)ceil(log2((double)ncells) / (0.2 * 0.2));   /* :42-44 */
+    if (ng <= 0) ng = 2000;                                                  /* :45-47 */
+    if (hmethod <= 0) hmethod = 1;                                           /* :48-50 */
+    if (minN <= 0) minN = 2;                                                 /* :51-53 */
+    if (maxN <= 0) { int c = (ncells + 4999) / 5000; maxN = c > 40 ? c : 40; }   /* :54-56 */
+    if (sil_thre < 0) sil_thre = 0.35;                                       /* :57-59 */
+    if (height_Ntimes <= 0) height_Ntimes = 2.0;                             /* :60-62 */
+    int8_t *tern = (int8_t *)xmalloc((size_t)K * (size_t)m * (size_t)p);     /* :130-137 */
+    for (int k = 1; k <= K; k++) oracle_ranM(m, p, (rN_seed == 0.5) ? 0.5 : 50 + rN_seed + k, tern + (size_t)(k - 1) * m * p);
+    int *lab = (int *)xmalloc(sizeof(int) * (size_t)ncells);
+    int (*keys)[3] = (int (*)[3])xmalloc(sizeof(int) * 3 * (size_t)ncells);
+    double *E1 = (double *)xmalloc(sizeof(double) * (size_t)ncells * (size_t)p);
+    size_t off = 0;
+    for (int b = 0; b < nb; b++) {                                           /* :146-163 */
+        int nbk = ncb[b];
+        rc |= sharp_large_core(Xcat + off * (size_t)m, m, nbk, K, p, ng, hmethod, 0, enpN, indN, minN, maxN, sil_thre,
+                               height_Ntimes, flag ? 2 : 0, tern, rN_seed, nthreads, lab + off, E1 + off * (size_t)p, 1);
+        for (int j = 0; j < nbk; j++) { keys[off + j][0] = b; keys[off + j][1] = lab[off + j]; keys[off + j][2] = (int)(off + j); }
+        off += (size_t)nbk;
+    }
+    /* "<fColor>s<i>" (:159): one integer id per distinct (block, label); any injective map does (sMetaC takes unique()) */
+    qsort(keys, (size_t)ncells, sizeof(int) * 3, cmp_int3);
+    {   int id = 0;
+        for (int q = 0; q < ncells; q++) {
+            if (q == 0 || keys[q][0] != keys[q - 1][0] || keys[q][1] != keys[q - 1][1]) id++;
+            lab[keys[q][2]] = id;
+        }
+    }
+    int *tf = (int *)xmalloc(sizeof(int) * (size_t)ncells); int nCu;
+    rc |= oracle_sMetaC(lab, E1, ncells, p, hmethod, N_cluster, minN, maxN, sil_thre, height_Ntimes, pred, tf, &nCu);   /* :184-186 */
+    free(tf);
+    if (N_cluster <= 0 && ncells > 10000) merge_small_clusters(pred, ncells);       /* :189-198 */
+    {   /* size-ordered ids (:200-203) */
+        int mx = 0; for (int i = 0; i < ncells; i++) if (pred[i] > mx) mx = pred[i];
+        int *cnt = (int *)xcalloc((size_t)mx + 1, sizeof(int));
+        for (int i = 0; i < ncells; i++) cnt[pred[i]]++;
+        int (*pairs)[2] = (int (*)[2])xmalloc(sizeof(int) * 2 * (size_t)(mx + 1)); int np = 0;
+        for (int q = 1; q <= mx; q++) if (cnt[q]) { pairs[np][0] = cnt[q]; pairs[np][1] = q; np++; }
+        qsort(pairs, (size_t)np, sizeof(int) * 2, cmp_size_then_lex);
+        int *map = (int *)xcalloc((size_t)mx + 1, sizeof(int));
+        for (int q = 0; q < np; q++) map[pairs[q][1]] = q + 1;
+        for (int i = 0; i < ncells; i++) pred[i] = map[pred[i]];
+        free(cnt); free(pairs); free(map);
+    }
+    if (viE_out) memcpy(viE_out, E1, sizeof(double) * (size_t)ncells * (size_t)p);
+    if (p_out) *p_out = p;
+    free(tern); free(lab); free(keys); free(E1);
     return rc;
 }
 

@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import SharpError, check, lib
 
 __all__ = ["ranM", "ranM2", "RPmat", "Projector", "SharpError", "get_opt_hclust", "getrowColor", "colorL", "HMETHODS",
-           "wMetaC", "sMetaC", "SHARP", "SHARP_small", "SHARP_large", "SHARP_unlimited", "SHARP_unlimited3", "run_Mtimes_SHARP", "testlog", "ARI"]
+           "wMetaC", "sMetaC", "SHARP", "SHARP_small", "SHARP_large", "SHARP_unlimited", "SHARP_unlimited2", "SHARP_unlimited3", "run_Mtimes_SHARP", "testlog", "ARI"]
 
 
 def _dp(a):
@@ -409,6 +409,63 @@ def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster
     if viewflag:                                                          # :215-232
         out["viE"] = _view_reduce(viE, rN_seed, K) if n > 1e5 else viE
         out["x0"] = _one_hot(pred, npred.value)
+    return out
+
+
+def SHARP_unlimited2(scExp, ensize_K=None, reduced_ndim=None, partition_ncells=None, hmethod=None, N_cluster=None,
+                     enpN_cluster=None, indN_cluster=None, minN_cluster=None, maxN_cluster=None, sil_thre=None,
+                     height_Ntimes=None, logflag=None, n_cores=None, forview=True, rN_seed=None, testlog_cells=None):
+    """R/SHARP_unlimited2.R:29-292 (with SHARP_fpart, :297-544): the list-of-blocks variant that takes log10, rounds the
+    projections to one decimal before the base clustering and runs ONE sMetaC over the per-fold ensemble clusters of all
+    blocks.  scExp: list of (genes, cells) blocks."""
+    import time as _t
+
+    t0 = _t.time()
+    if scExp is None:
+        raise SharpError("No expression data is provided!")
+    if not isinstance(scExp, (list, tuple)):
+        raise SharpError("The input should be a LIST of partitioned scRNA-seq expression matrices!")
+    if rN_seed is not None:
+        if not isinstance(rN_seed, (int, float, np.integer, np.floating)):
+            raise SharpError("The rN.seed should be a numeric!")
+        if rN_seed % 1 != 0:
+            raise SharpError("The rN.seed should be an integer!")
+    else:
+        rN_seed = 0.5
+    _lib.ensure_init()
+    blocks = [np.asfortranarray(b, dtype=np.float64) for b in scExp]
+    m = blocks[0].shape[0]
+    ncb = np.array([b.shape[1] for b in blocks], np.int64)
+    n = int(ncb.sum())
+    p = int(reduced_ndim) if reduced_ndim else int(np.ceil(np.log2(n) / 0.04))          # :42-44
+    if logflag is None:
+        logflag = n < 1e4                                                               # :64-70
+    flag = True
+    if logflag:                                                                         # :71-82: testlog on the FIRST block
+        nc1 = blocks[0].shape[1]
+        flag = testlog(blocks[0], nc1, p, sncells=100, cells=testlog_cells)
+    ptrs = (C.POINTER(C.c_double) * len(blocks))(*[_dp(b) for b in blocks])
+    pred = np.zeros(n, np.int32)
+    npred, pu = C.c_int(), C.c_int()
+    viE = np.zeros((n, p)) if forview else None
+    rc = check(lib().sharp_SHARP_unlimited2(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), len(blocks), m, int(ensize_K or 0),
+                                            int(reduced_ndim or 0), int(partition_ncells or 0), _hmethod(hmethod),
+                                            int(N_cluster or 0), int(enpN_cluster or 0), int(indN_cluster or 0),
+                                            int(minN_cluster or 0), int(maxN_cluster or 0),
+                                            C.c_double(-1.0 if sil_thre is None else sil_thre),
+                                            C.c_double(0.0 if height_Ntimes is None else height_Ntimes), int(bool(flag)),
+                                            C.c_double(rN_seed), _ip(pred), C.byref(npred), C.byref(pu), _dp(viE)), allow=48)
+    K = int(ensize_K or 5)
+    paras = {"ensize.K": K, "reduced.ndim": pu.value, "partition.ncells": int(partition_ncells or 2000), "logmark": bool(flag),
+             "hmethod": hmethod or "ward.D", "N.cluster": N_cluster, "minN.cluster": int(minN_cluster or 2),
+             "maxN.cluster": int(maxN_cluster or max(40, -(-n // 5000))), "sil.thre": 0.35 if sil_thre is None else sil_thre,
+             "height.Ntimes": 2 if height_Ntimes is None else height_Ntimes, "n.cores": n_cores}
+    out = _enresults(pred, None, None, n, m, pu.value, K, t0, paras, False, key="N.pred_clusters")
+    out["reduced.ndim"] = pu.value                                                      # :226 (this variant names it so)
+    if forview:
+        out["viE"] = viE
+        out["x0"] = _one_hot(pred, npred.value)
+    out["warn"] = rc
     return out
 
 

@@ -27,6 +27,9 @@ struct SharpArgs {
     int projector = 0;       // handle of a shared rM list, 0 = draw from rN_seed
     double rN_seed = 0.5;    // 0.5 = the reference's "unseeded" sentinel
     bool want_viE = false, want_x0 = false;
+    // SHARP_fpart (R/SHARP_unlimited2.R:297-544): the large path with log10 (flag = 2), E1 rounded to one decimal before
+    // clustering, maxN.cluster = 40 for the base tasks, and NO sMetaC: the per-fold ensemble labels go up to the caller
+    bool fpart = false;
 };
 struct SharpOut {
     std::vector<int> pred;           // 1..G, numbered by first appearance (R/SHARP.R:429-443,828-843)
@@ -79,6 +82,22 @@ std::shared_ptr<Projector> projector_for(const SharpArgs &a, int m, int p, int K
     std::vector<double> seeds(K);
     for (int k = 0; k < K; ++k) seeds[k] = (a.rN_seed == 0.5) ? 0.5 : 50 + a.rN_seed + (k + 1);   // R/SHARP.R:360,545
     return build_projector(m, p, K, seeds.data());
+}
+
+// R's round(x, 1) (nmath/fround.c, R >= 4.0.0, restated; R core is an unpinned third-party dependency of the reference):
+// the closer of floor(10 x)/10 and ceil(10 x)/10 as doubles, the even multiple on a tie; used by R/SHARP_unlimited2.R:410
+__host__ __device__ inline double r_round1(double x) {
+    if (!(x == x) || x == 0.0 || x - x != 0.0) return x;            // NaN, 0, +-Inf
+    const double sgn = x < 0.0 ? -1.0 : 1.0;
+    x = x < 0.0 ? -x : x;
+    if (x >= 1e14) return sgn * x;                                    // nothing to round beyond DBL_DIG
+    const double x10 = 10.0 * x, i10 = floor(x10), xd = i10 / 10.0, xu = ceil(x10) / 10.0;
+    const double du = xu - x, dd = x - xd;
+    return sgn * ((dd < du || (dd == du && fmod(i10, 2.0) == 0.0)) ? xd : xu);
+}
+__global__ void round1_kernel(double *__restrict__ E, long long count) {
+    for (long long q = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; q < count; q += static_cast<long long>(gridDim.x) * blockDim.x)
+        E[q] = r_round1(E[q]);
 }
 
 inline int colour_of(int j) { return j > 40 ? ((j - 1) % 40) + 1 : j; }   // R/getrowColor.R:59-68
@@ -160,9 +179,15 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
     if (shuffle) { dpos.ensure(n); dpos.upload(pos.data(), n); }
     // E rows are written straight into shuffled order, so fold t is the contiguous row range [fst[t], fst[t+1])
     project_dev(*pr, dX, m, n, ld, a.flag, E.p, ldE, shuffle ? dpos.p : nullptr);          // :567-585 for every (k, t)
+    if (a.fpart) {                                                              // newE1 = round(newE1, digits = 1)  (unlimited2 :410)
+        Ctx &c = ctx();
+        hipLaunchKernelGGL(round1_kernel, dim3(c.num_cu * 8), dim3(256), 0, c.stream, E.p, static_cast<long long>(n) * ldE);
+        launch_check("round1_kernel");
+    }
     // K*T base-clustering tasks in one batch (:554-618)
     std::vector<HcTask> tasks(static_cast<size_t>(K) * T);
     HcParams bp = base; bp.N_cluster = a.indN;
+    if (a.fpart) bp.maxN = 40;                                                  // "for partition clustering" (unlimited2 :421)
     for (int k = 0; k < K; ++k)
         for (int t = 0; t < T; ++t) {
             HcTask &tk = tasks[static_cast<size_t>(k) * T + t];
@@ -208,6 +233,24 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
         nCu += nu;
     }
     col0[T] = nCu;
+    if (a.fpart) {
+        // fColor[reind] = fColor (unlimited2 :522-526): labels back in the original cell order; the caller's sMetaC takes
+        // unique() of the concatenated blocks, i.e. first appearance in THAT order
+        std::vector<int> lab(n);
+        for (int i = 0; i < n; ++i) lab[shuffle ? reind[i] - 1 : i] = uid[i] + 1;
+        out.pred = lab;
+        out.n_pred = relabel_first(out.pred);
+        out.viE.alloc(static_cast<size_t>(n) * p);
+        if (shuffle) {
+            Ctx &c = ctx();
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(c.num_cu * 8), dim3(256), 0, c.stream, viE_sh.p, dpos.p, static_cast<long long>(n), p, out.viE.p);
+            launch_check("gather_rows_kernel");
+        } else {
+            SHARP_HIP_CHECK(hipMemcpyAsync(out.viE.p, viE_sh.p, static_cast<size_t>(n) * p * 8, hipMemcpyDeviceToDevice, ctx().stream));
+        }
+        stream_sync();
+        return;
+    }
     if (T == 1) {
         // :738-746 then :828: as.numeric("<id>en1") is NA for every cell -> a single cluster (reference quirk 2)
         std::fill(Slab.begin(), Slab.end(), 1);
@@ -278,7 +321,12 @@ void sharp_front_dev(const float *dX, int m, long long n_, long long ld, SharpAr
         part = (n + 1) / 2;
         if (K <= 0) K = 15;
     }
-    if (n < base_ncells) {
+    if (a.fpart) {                                                              // SHARP_fpart has no small path
+        if (K <= 0) K = 5;
+        SHARP_REQUIRE(part >= 3 && part <= kHcMaxN, "partition.ncells must be between 3 and 7168");
+        out.path = 1;
+        sharp_large_dev(dX, m, n, ld, a, K, p, part, base, out);
+    } else if (n < base_ncells) {
         if (K <= 0) K = 15;                                                     // :254-257
         SHARP_REQUIRE(n <= kHcMaxN, "SHARP_small: more than 7168 cells in one unpartitioned clustering task");
         out.path = 0;
@@ -299,9 +347,11 @@ void sharp_front_dev(const float *dX, int m, long long n_, long long ld, SharpAr
 // (:135) and the colMeans of its viE per predicted cluster -- all sMetaC ever uses of E1 (:163, R/sMetaC.R:58-63)
 void unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int K, double rN_seed,
                          std::vector<int> &pred, std::vector<double> &means, std::vector<long long> &counts, double *viE_host,
-                         int flag = 1) {
+                         int flag = 1, const SharpArgs *fpart_args = nullptr) {
     SharpArgs a;
+    if (fpart_args) a = *fpart_args;                                            // SHARP_unlimited2: every SHARP_fpart parameter
     a.K = K; a.reduced_ndim = p; a.flag = flag; a.projector = projector; a.rN_seed = rN_seed; a.want_viE = true;
+    a.fpart = fpart_args != nullptr;
     SharpOut o;
     sharp_front_dev(dX, m, nb, ld, a, o);
     pred = o.pred;
@@ -318,12 +368,12 @@ void unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int
 
 // cross-block sMetaC on the gathered centroids, small-cluster merge and size-ordered relabel (:163-183)
 void unlimited_merge(const double *means, const long long *counts, int nC, int p, long long ncells, int N_cluster, int minN, int maxN,
-                     std::vector<int> &final_id, int &n_final) {
+                     std::vector<int> &final_id, int &n_final, int hmethod = 1, double sil_thre = 0.35, double height_Ntimes = 2.0) {
     HcParams prm;                                                               // hmethod/sil.thre/height.Ntimes of y[[1]]$paras = defaults
-    prm.hmethod = 1; prm.N_cluster = N_cluster;
+    prm.hmethod = hmethod; prm.N_cluster = N_cluster;
     prm.minN = minN > 0 ? minN : 2;                                             // :70-72
     prm.maxN = maxN > 0 ? maxN : static_cast<int>(std::max<long long>(40, (ncells + 4999) / 5000));   // :75-77
-    prm.sil_thre = 0.35; prm.height_Ntimes = 2.0;
+    prm.sil_thre = sil_thre; prm.height_Ntimes = height_Ntimes;
     DevBuf<double> dm(static_cast<size_t>(nC) * p);
     dm.upload(means, static_cast<size_t>(nC) * p);
     SmResult sr = smetac_from_means(dm.p, nC, p, ncells, prm);
@@ -515,6 +565,84 @@ int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long lon
     if (n_pred) *n_pred = nf;
     if (p_used) *p_used = p;
     SHARP_API_END
+}
+
+// SHARP_unlimited2 (R/SHARP_unlimited2.R:29-292): SHARP_fpart per block, then ONE sMetaC over the fold-level ensemble
+// clusters of all blocks -- which, like every sMetaC, only needs their centroids in E1 = enE/K.
+int sharp_SHARP_unlimited2_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                               int ensize_K, int reduced_ndim, int partition_ncells, int hmethod, int N_cluster, int enpN, int indN,
+                               int minN, int maxN, double sil_thre, double height_Ntimes, int flag, double rN_seed, int *pred,
+                               int *n_pred, int *p_used, double *viE) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(dX_blocks && ncb && ldb && pred && nblocks >= 1, "No expression data is provided!");
+    if (rN_seed != 0.5) SHARP_REQUIRE(std::fmod(rN_seed, 1.0) == 0.0, "The rN.seed should be an integer!");   // :117-127
+    long long ncells = 0;
+    for (int b = 0; b < nblocks; ++b) ncells += ncb[b];
+    const int p = reduced_ndim > 0 ? reduced_ndim : static_cast<int>(std::ceil(std::log2(static_cast<double>(ncells)) / (0.2 * 0.2)));   // :42-44
+    const int K = ensize_K > 0 ? ensize_K : 5;                                                                 // :39-41
+    SharpArgs fa;
+    fa.partition_ncells = partition_ncells; fa.hmethod = hmethod; fa.enpN = enpN; fa.indN = indN;
+    fa.minN = minN > 0 ? minN : 2;                                                                             // :51-53
+    fa.maxN = maxN > 0 ? maxN : static_cast<int>(std::max<long long>(40, (ncells + 4999) / 5000));             // :54-56 (total cells)
+    fa.sil_thre = sil_thre; fa.height_Ntimes = height_Ntimes;
+    fa.N_cluster = 0;                                                                                          // fpart does not cut; the final sMetaC does
+    std::vector<double> seeds(K);
+    for (int k = 0; k < K; ++k) seeds[k] = (rN_seed == 0.5) ? 0.5 : 50 + rN_seed + (k + 1);                    // :130-137
+    const int proj = register_projector(build_projector(m, p, K, seeds.data()));
+    std::vector<double> means;
+    std::vector<long long> counts;
+    std::vector<int> first(nblocks + 1, 0);
+    long long off = 0;
+    try {
+        for (int b = 0; b < nblocks; ++b) {                                                                    // :146-163
+            std::vector<int> pb;
+            std::vector<double> mb;
+            std::vector<long long> cb;
+            unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb,
+                                viE ? viE + static_cast<size_t>(off) * p : nullptr, flag ? 2 : 0, &fa);
+            std::copy(pb.begin(), pb.end(), pred + off);
+            means.insert(means.end(), mb.begin(), mb.end());
+            counts.insert(counts.end(), cb.begin(), cb.end());
+            first[b + 1] = first[b] + static_cast<int>(cb.size());
+            off += ncb[b];
+        }
+    } catch (...) { drop_projector(proj); throw; }
+    drop_projector(proj);
+    std::vector<int> fid;
+    int nf = 0;
+    unlimited_merge(means.data(), counts.data(), first[nblocks], p, ncells, N_cluster, minN, maxN, fid, nf, hmethod > 0 ? hmethod : 1,
+                    sil_thre >= 0 ? sil_thre : 0.35, height_Ntimes > 0 ? height_Ntimes : 2.0);               // :184-205
+    off = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        for (long long i = 0; i < ncb[b]; ++i) pred[off + i] = fid[first[b] + pred[off + i] - 1];
+        off += ncb[b];
+    }
+    if (n_pred) *n_pred = nf;
+    if (p_used) *p_used = p;
+    SHARP_API_END
+}
+
+int sharp_SHARP_unlimited2(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int reduced_ndim,
+                           int partition_ncells, int hmethod, int N_cluster, int enpN, int indN, int minN, int maxN, double sil_thre,
+                           double height_Ntimes, int flag, double rN_seed, int *pred, int *n_pred, int *p_used, double *viE) {
+    std::vector<DevBuf<float>> bufs(nblocks > 0 ? nblocks : 0);
+    std::vector<const float *> ptrs;
+    std::vector<long long> lds;
+    try {
+        ctx();
+        if (!X_blocks || !ncb || nblocks < 1) throw sharp::Error(SHARP_ERR_ARG, "No expression data is provided!");
+        for (int b = 0; b < nblocks; ++b) {
+            long long ldd = 0;
+            upload_as_float(X_blocks[b], m, ncb[b], m, bufs[b], ldd);
+            ptrs.push_back(bufs[b].p);
+            lds.push_back(ldd);
+        }
+    }
+    catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
+    catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
+    return sharp_SHARP_unlimited2_dev(ptrs.data(), ncb, lds.data(), nblocks, m, ensize_K, reduced_ndim, partition_ncells, hmethod,
+                                      N_cluster, enpN, indN, minN, maxN, sil_thre, height_Ntimes, flag, rN_seed, pred, n_pred, p_used, viE);
 }
 
 int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,

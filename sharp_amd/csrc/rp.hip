@@ -161,7 +161,7 @@ __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
                     // ---- pass 2 (under the loads): one lane per non-zero, fixed-point log2(1+x) in fp64
                     if (ablate < 3) for (int e = e0 + lane; e < nnz && e < e0 + U * NG; e += 64) {
                         const float x = __uint_as_float(list[e].xbits);
-                        const double L = log_flag ? log2(1.0 + static_cast<double>(x)) : static_cast<double>(x);
+                        const double L = log_flag == 2 ? log10(1.0 + static_cast<double>(x)) : (log_flag ? log2(1.0 + static_cast<double>(x)) : static_cast<double>(x));   // 2: SHARP_unlimited2's log10
                         list[e].fix = __double2ll_rn(L * fix_scale);
                     }
                     __builtin_amdgcn_wave_barrier();

@@ -40,9 +40,9 @@ __device__ __forceinline__ CpVals cp_load_unit(const float *col, int u, long lon
 constexpr int CP_TAB = 256;             // log2(1+x) fixed-point table for integer counts x < CP_TAB
 
 // fix(x) = round(log2(1+x) * 2^fix_bits) for x = 0..CP_TAB-1, evaluated by the same device libm as the general path
-__global__ void rp_fixtab_kernel(double fix_scale, long long *__restrict__ tab) {
+__global__ void rp_fixtab_kernel(double fix_scale, int log10_mode, long long *__restrict__ tab) {
     const int x = threadIdx.x;
-    if (x < CP_TAB) tab[x] = __double2ll_rn(log2(1.0 + static_cast<double>(x)) * fix_scale);
+    if (x < CP_TAB) tab[x] = __double2ll_rn((log10_mode ? log10(1.0 + static_cast<double>(x)) : log2(1.0 + static_cast<double>(x))) * fix_scale);
 }
 
 // One wave per (cell, unit); units of a chunk are dealt round-robin to the waves of a persistent grid.
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__r
                 const bool tab = static_cast<float>(xi) == x && xi < static_cast<unsigned>(CP_TAB);
                 fx = stab[tab ? xi : 0u];
                 if (__ballot(live && !tab) != 0ull) {      // non-integer or large values: the general path
-                    if (!tab) fx = __double2ll_rn(log2(1.0 + static_cast<double>(x)) * fix_scale);
+                    if (!tab) fx = __double2ll_rn((log_flag == 2 ? log10(1.0 + static_cast<double>(x)) : log2(1.0 + static_cast<double>(x))) * fix_scale);
                 }
             } else {
                 fx = __double2ll_rn(static_cast<double>(x) * fix_scale);
@@ -295,11 +295,12 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, const float
     }
     if (!W.ev_start) SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_start, hipEventDisableTiming));
     const double fix_scale = std::ldexp(1.0, fix_bits), inv_fix = std::ldexp(1.0, -fix_bits);
-    if (W.fixtab.n == 0 || W.fixtab_scale != fix_scale) {
+    const double tab_key = log_flag == 2 ? -fix_scale : fix_scale;       // the table depends on the scale and on the log base
+    if (W.fixtab.n == 0 || W.fixtab_scale != tab_key) {
         W.fixtab.ensure(CP_TAB);
-        hipLaunchKernelGGL(rp_fixtab_kernel, dim3(1), dim3(CP_TAB), 0, c.stream, fix_scale, W.fixtab.p);
+        hipLaunchKernelGGL(rp_fixtab_kernel, dim3(1), dim3(CP_TAB), 0, c.stream, fix_scale, log_flag == 2 ? 1 : 0, W.fixtab.p);
         launch_check("rp_fixtab_kernel");
-        W.fixtab_scale = fix_scale;
+        W.fixtab_scale = tab_key;
     }
     KernelTimer t("rp_stage");                                 // the whole stage, measured on the main stream
     SHARP_HIP_CHECK(hipEventRecord(W.ev_start, c.stream));

@@ -125,6 +125,32 @@ def test_sharp_unlimited_matches_oracle(sa, oracle):
     assert adjusted_rand_score(truth, res["pred_clusters"]) > 0.9
 
 
+def test_sharp_unlimited2_matches_oracle(sa, oracle):
+    """R/SHARP_unlimited2.R: log10, projections rounded to one decimal, one sMetaC over the fold-level clusters of all blocks."""
+    m, G, nm = 3000, 6, 300
+    blocks = [oracle.synth_fill(SEED, m, i * 6000, 6000, G, nm) for i in range(2)]
+    truth = oracle.synth_cluster(SEED, range(12000), G)
+    ref = oracle.SHARP_unlimited2(blocks, rN_seed=2103, nthreads=8, want_view=True)
+    res = sa.SHARP_unlimited2(blocks, rN_seed=2103, logflag=False)
+    assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+    assert res["reduced.ndim"] == ref["p"] and res["paras"]["logmark"] is True
+    # E1 = mean over K of projections ROUNDED to one decimal: multiples of 0.1/K up to rounding; same values as the oracle
+    # unless a projection sits within 1e-12 of a rounding boundary (then one entry moves by 0.1/K)
+    d = np.abs(res["viE"] - ref["viE"])
+    assert (d > 1e-9).mean() < 1e-6
+    assert np.allclose(np.round(res["viE"] * 5 * 10), res["viE"] * 5 * 10, atol=1e-6)
+    sizes = np.bincount(res["pred_clusters"])[1:]
+    assert np.all(np.diff(sizes) <= 0)
+    assert adjusted_rand_score(truth, res["pred_clusters"]) > 0.9
+    # a different ensemble size / partition size / seed, and the one-decimal rounding rule itself
+    small = [b[:, :3000] for b in blocks]
+    ref2 = oracle.SHARP_unlimited2(small, K=3, partition_ncells=1500, rN_seed=7, nthreads=8)
+    res2 = sa.SHARP_unlimited2(small, ensize_K=3, partition_ncells=1500, rN_seed=7, logflag=False, forview=False)
+    assert res2["N.cells"] == 6000 and "viE" not in res2
+    assert np.array_equal(res2["pred_clusters"], ref2["pred_clusters"])
+    assert oracle.round1([0.25, 0.35, 0.15, 2.5, -0.25]).tolist() == [0.2, 0.3, 0.1, 2.5, -0.2]
+
+
 @pytest.fixture
 def digit_free_dir():
     """The reference orders partitions by the first number in the FULL path (R/SHARP_unlimited3.R:60), so a digit in a
