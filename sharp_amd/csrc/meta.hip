@@ -26,30 +26,40 @@ struct WmMeta {
 };
 
 // ---- point weights: w0_i = 4/N * sum_j AA_ij (1 - AA_ij), AA_ij = #{c: lab_ic == lab_jc} / C; ascending j
-__global__ __launch_bounds__(256) void wm_weights_kernel(const WmMeta *__restrict__ metas, const uint16_t *__restrict__ cid_all,
-                                                         double *__restrict__ w_all) {
+constexpr int WW_THREADS = 1024;   // 16 waves, one cell i per wave; the fold's label table is shared through LDS
+
+// w0_i = (4/N) sum_j AA_ij (1 - AA_ij), AA_ij = (number of the C clusterings that put i and j together) / C
+// (R/wMetaC.R:24-44).  One wave per cell i, lanes over the other cells j: the labels are held column-wise
+// (clustering-major) in LDS so that lanes read consecutive cells; each lane adds x(1-x) for its cells in ascending j and
+// the 64 partial sums are combined in a fixed order.
+__global__ __launch_bounds__(WW_THREADS) void wm_weights_kernel(const WmMeta *__restrict__ metas, const uint16_t *__restrict__ cid_all,
+                                                                double *__restrict__ w_all) {
     const WmMeta M = metas[blockIdx.y];
     const int N = M.N, C = M.C;
-    if (blockIdx.x * 256 >= N) return;
+    constexpr int NW = WW_THREADS / 64;
+    if (blockIdx.x * NW >= N) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    uint16_t *lab = reinterpret_cast<uint16_t *>(sm);                 // N*C
+    uint16_t *labt = reinterpret_cast<uint16_t *>(sm);                // [C][N]  (cid is [N][C])
     double *tab = reinterpret_cast<double *>(sm + ((static_cast<size_t>(N) * C * 2 + 15) & ~static_cast<size_t>(15)));   // C+1
     const uint16_t *cid = cid_all + M.oCid;
-    for (int q = threadIdx.x; q < N * C; q += 256) lab[q] = cid[q];
-    for (int q = threadIdx.x; q <= C; q += 256) { const double x = static_cast<double>(q) / static_cast<double>(C); tab[q] = x * (1 - x); }
+    for (int q = threadIdx.x; q < N * C; q += WW_THREADS) { const int j = q / C, c = q - j * C; labt[c * N + j] = cid[q]; }
+    for (int q = threadIdx.x; q <= C; q += WW_THREADS) { const double x = static_cast<double>(q) / static_cast<double>(C); tab[q] = x * (1 - x); }
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * NW + wave;
     if (i >= N) return;
-    const uint16_t *mine = lab + static_cast<size_t>(i) * C;
     double rs = 0.0;
-    for (int j = 0; j < N; ++j) {
-        const uint16_t *oth = lab + static_cast<size_t>(j) * C;
+    for (int j = lane; j < N; j += 64) {
         int cnt = 0;
-        for (int c = 0; c < C; ++c) cnt += (oth[c] == mine[c]);
+        for (int c = 0; c < C; ++c) cnt += (labt[c * N + j] == labt[c * N + i]);
         rs += tab[cnt];
     }
-    const double w0 = 4.0 / N * rs;
-    w_all[M.oW + i] = (w0 + 0.01) / (1 + 0.01);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rs += __shfl_xor(rs, o);
+    if (lane == 0) {
+        const double w0 = 4.0 / N * rs;
+        w_all[M.oW + i] = (w0 + 0.01) / (1 + 0.01);
+    }
 }
 
 // ---- S[a][b] = sum(w1[a n b]) / sum(w1[a u b]) for a < b, in R's set orders:
@@ -206,7 +216,8 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
         SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wm_weights_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             static_cast<int>(max_lds)));
         KernelTimer tm("wmetac_weights");
-        hipLaunchKernelGGL(wm_weights_kernel, dim3((maxN + 255) / 256, T), dim3(256), max_lds, c.stream, W.meta.p, W.cid.p, W.w.p);
+        hipLaunchKernelGGL(wm_weights_kernel, dim3((maxN + WW_THREADS / 64 - 1) / (WW_THREADS / 64), T), dim3(WW_THREADS), max_lds, c.stream, W.meta.p,
+                           W.cid.p, W.w.p);
         launch_check("wm_weights_kernel");
     }
     {
