@@ -8,6 +8,7 @@
 #include "meta.hpp"
 
 #include <algorithm>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -243,7 +244,8 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
     }
     // per-cell vote and soft matrix on the host
     HostTimer ht_vote("wmetac_vote");
-    for (int t = 0; t < T; ++t) {
+    // the folds are independent: vote them on a few host threads (each writes only its own result)
+    auto vote_fold = [&](int t) {
         const WmTask &tk = tasks[t];
         WmResult &R = out[t];
         const int N = tk.N, C = tk.C;
@@ -309,6 +311,18 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
                     if (y) R.x0[static_cast<size_t>(q) * N + i] = 0.5 * static_cast<double>(y) / static_cast<double>(own);
                 }
             }
+        }
+    };
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        const int nthr = T >= 4 ? static_cast<int>(std::min<unsigned>(std::min<unsigned>(hw ? hw : 4, 16), static_cast<unsigned>(T))) : 1;
+        if (nthr <= 1) {
+            for (int t = 0; t < T; ++t) vote_fold(t);
+        } else {
+            std::vector<std::thread> pool;
+            for (int w = 0; w < nthr; ++w)
+                pool.emplace_back([&, w] { for (int t = w; t < T; t += nthr) vote_fold(t); });
+            for (auto &th : pool) th.join();
         }
     }
 }
