@@ -270,8 +270,9 @@ __device__ __forceinline__ HrBest hr_wave(HrBest x) {
     return r;
 }
 
-constexpr int HR_THREADS = 512;    // two tasks per CU (LDS state 37 B per observation, <= 128 VGPRs)
-
+// HR_THREADS = 512: two tasks per CU (LDS state 37 B per observation, <= 128 VGPRs) when there are more tasks than CUs;
+// 1024: one task per CU with twice the loads in flight when there are not (a task streams ~300 MB through ONE workgroup).
+template <int HR_THREADS>
 __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__restrict__ metas, const double *__restrict__ Dall,
                                                                 double *__restrict__ S0all, double *__restrict__ S1all,
                                                                 int *__restrict__ ia_all, int *__restrict__ ib_all,
@@ -298,7 +299,8 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     uint16_t *oldidx = pseq + nal;                             // [nal]     new index -> old index
     uint16_t *newidx = oldidx + nal;                           // [nal]     old index -> new index (survivors)
     uint16_t *plist = newidx + nal;                            // [nal]     first members of the pairs
-    int *ctl = reinterpret_cast<int *>(plist + nal);           // [8]: npairs, abort, nsurv
+    uint16_t *srow = plist + nal;                              // [nal]     new indices of the rows of unmerged clusters
+    int *ctl = reinterpret_cast<int *>(srow + nal);            // [8]: npairs, abort, work counters (single rows, merged rows), nsingle
     int *wsum = ctl + 8;                                        // [nwave + 1]
     unsigned char *tie = reinterpret_cast<unsigned char *>(wsum + nwave + 1);   // [nal]
 
@@ -334,6 +336,9 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         uint16_t *cid = cidA + cur * nal, *csz = cszA + cur * nal;
         double *dnnN = dnnA + (cur ^ 1) * nal;
         uint16_t *cidN = cidA + (cur ^ 1) * nal, *cszN = cszA + (cur ^ 1) * nal;
+#ifdef HR_TIMING
+        const long long hr_t0 = __builtin_readcyclecounter();
+#endif
         // (1) reciprocal pairs
         for (int a = tid; a < na; a += HR_THREADS) {
             partner[a] = HR_NONE;
@@ -389,6 +394,16 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         }
         __syncthreads();
         const int nb = wsum[nwave];                             // = na - np
+        if (tid == 0) { ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; }
+        __syncthreads();
+        for (int A = tid; A < nb; A += HR_THREADS)
+            if (partner[oldidx[A]] == HR_NONE) srow[atomicAdd(&ctl[4], 1)] = static_cast<uint16_t>(A);
+        __syncthreads();
+        const int ns = ctl[4];                                  // rows of unmerged clusters (= nb - np)
+#ifdef HR_TIMING
+        const long long hr_t1 = __builtin_readcyclecounter();
+        long long hr_dual = 0, hr_slow = 0;
+#endif
         // (4) next matrix, one wave per new row; nearest neighbour of the new row on the fly.
         // Rows of unmerged clusters (~90 %) are a gathered copy of the old row (eight loads in flight per lane) plus one
         // Lance-Williams value per merged column; rows of merged clusters take the general path.
@@ -499,14 +514,33 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
             if (lane == 1) { nn[A] = static_cast<uint16_t>(best.i < nb ? best.i : 0); }
             if (lane == 2) { tie[A] = static_cast<unsigned char>(nb > 2 ? best.tie : 0); }
         };
-        for (int A = wave; A < nb; A += 2 * nwave) {
-            const int A2 = A + nwave;
-            const int a1 = oldidx[A], a2 = A2 < nb ? oldidx[A2] : 0;
-            if (A2 >= nb || partner[a1] != HR_NONE || partner[a2] != HR_NONE) {
-                do_row(A);
-                if (A2 < nb) do_row(A2);
-                continue;
-            }
+        // work is handed out dynamically (the rows of merged clusters cost about twice a pair of plain rows, and a static
+        // split left a quarter of the phase waiting at the barrier): merged rows first, then plain rows two at a time
+        for (;;) {
+            int q = 0;
+            if (lane == 0) q = atomicAdd(&ctl[3], 1);
+            q = __builtin_amdgcn_readfirstlane(q);
+            if (q >= np) break;
+#ifdef HR_TIMING
+            const long long q0 = __builtin_readcyclecounter();
+#endif
+            do_row(newidx[plist[q]]);
+#ifdef HR_TIMING
+            hr_slow += __builtin_readcyclecounter() - q0;
+#endif
+        }
+        for (;;) {
+            int q = 0;
+            if (lane == 0) q = atomicAdd(&ctl[2], 2);
+            q = __builtin_amdgcn_readfirstlane(q);
+            if (q >= ns) break;
+            const int A = srow[q];
+            if (q + 1 >= ns) { do_row(A); break; }
+            const int A2 = srow[q + 1];
+            const int a1 = oldidx[A], a2 = oldidx[A2];
+#ifdef HR_TIMING
+            const long long q1 = __builtin_readcyclecounter();
+#endif
             const double *r1 = Dsrc + static_cast<long long>(a1) * nld, *r2 = Dsrc + static_cast<long long>(a2) * nld;
             double *w1 = Ddst + static_cast<long long>(A) * nld, *w2 = Ddst + static_cast<long long>(A2) * nld;
             HrBest b1, b2;
@@ -546,9 +580,20 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
             }
             finish_row(A, a1, b1);
             finish_row(A2, a2, b2);
+#ifdef HR_TIMING
+            hr_dual += __builtin_readcyclecounter() - q1;
+#endif
         }
+#ifdef HR_TIMING
+        const long long hr_t2 = __builtin_readcyclecounter();
+#endif
         __syncthreads();
         if (tid == 0) { ctl[0] = 0; }
+#ifdef HR_TIMING
+        if (blockIdx.x == 0 && tid == 0 && (done == 0 || na < 1200 && na > 1100 || na < 300 && na > 280))
+            printf("round na=%d np=%d nb=%d: setup %lld  rebuild %lld (wave0: dual %lld slow %lld)  tail-barrier %lld cycles\n", na, np, nb,
+                   hr_t1 - hr_t0, hr_t2 - hr_t1, hr_dual, hr_slow, (long long)__builtin_readcyclecounter() - hr_t2);
+#endif
         done += np; na = nb; cur ^= 1; src = src < 0 ? 0 : (src ^ 1);
         __syncthreads();
     }
@@ -1001,12 +1046,19 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
             if (use_rnn) {
                 const int nal = (max_n + 3) & ~3;
                 int npow2 = 1; while (npow2 < max_n - 1) npow2 <<= 1;
-                const size_t state = static_cast<size_t>(nal) * (16 + 4 + 4 + 2 * 6 + 1) + 8 * 4 + (HR_THREADS / 64 + 1) * 4 + 64;
+                const size_t state = static_cast<size_t>(nal) * (16 + 4 + 4 + 2 * 7 + 1) + 8 * 4 + (1024 / 64 + 1) * 4 + 64;
                 const size_t lds = std::max(state, static_cast<size_t>(npow2) * 16);
-                SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_rnn_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-                hipLaunchKernelGGL(hclust_rnn_kernel, dim3(Ts), dim3(HR_THREADS), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
-                                   W.height.p, W.status.p + R.t0);
+                if (Ts <= c.num_cu) {
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_rnn_kernel<1024>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+                    hipLaunchKernelGGL(hclust_rnn_kernel<1024>, dim3(Ts), dim3(1024), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
+                                       W.height.p, W.status.p + R.t0);
+                } else {
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_rnn_kernel<512>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+                    hipLaunchKernelGGL(hclust_rnn_kernel<512>, dim3(Ts), dim3(512), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
+                                       W.height.p, W.status.p + R.t0);
+                }
                 launch_check("hclust_rnn_kernel");
             }
             const int nal = (max_n + 1) & ~1;
