@@ -65,7 +65,7 @@ class BlockStreamer:
     Two pinned host buffers and two device buffers; the worker thread reads file i+1 and enqueues its host->device copy on
     a side stream while the caller works on block i; the consumer's stream waits on the copy's event only."""
 
-    def __init__(self, files, device="cuda"):
+    def __init__(self, files, device="cuda", read_threads=8):
         import torch
 
         self.torch = torch
@@ -78,17 +78,41 @@ class BlockStreamer:
         self.events = [None, None]
         self.threads = [None, None]
         self.bytes_streamed = 0
+        self.read_threads = int(read_threads)
 
     def _load(self, i):
         slot = i & 1
         h = self.hdrs[i]
         cnt = h["cells"] * h["ld"]
-        dst = self.pinned[slot].numpy()[:cnt]
-        with open(self.files[i], "rb") as fh:
-            fh.seek(HEADER_BYTES)
-            got = fh.readinto(memoryview(dst).cast("B"))
-        if got != cnt * 4:
-            raise IOError("%s: short read" % self.files[i])
+        dst = memoryview(self.pinned[slot].numpy()[:cnt]).cast("B")
+        nbytes = cnt * 4
+        fd = os.open(self.files[i], os.O_RDONLY)
+        try:
+            # several positional reads in parallel (they release the GIL): one thread copies from the page cache at a few GB/s
+            nthr = max(1, min(self.read_threads, nbytes >> 26))
+            step = (nbytes + nthr - 1) // nthr
+            step = (step + 4095) // 4096 * 4096
+            errs = []
+
+            def part(lo):
+                hi = min(lo + step, nbytes)
+                pos = lo
+                while pos < hi:
+                    got = os.preadv(fd, [dst[pos:hi]], HEADER_BYTES + pos)
+                    if got <= 0:
+                        errs.append("%s: short read" % self.files[i])
+                        return
+                    pos += got
+
+            ths = [threading.Thread(target=part, args=(lo,), daemon=True) for lo in range(0, nbytes, step)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            if errs:
+                raise IOError(errs[0])
+        finally:
+            os.close(fd)
         torch = self.torch
         with torch.cuda.stream(self.copy_stream):
             self.dev[slot][:cnt].copy_(self.pinned[slot][:cnt], non_blocking=True)
