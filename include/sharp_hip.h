@@ -193,6 +193,17 @@ int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long lo
 int sharp_unlimited_merge(const double *means, const long long *counts, int nC, int p, long long ncells, int N_cluster,
                           int minN, int maxN, int *final_id, int *n_final);
 
+/* ---- get_marker_genes (R/get_marker_genes.R:25-264), the per-gene pass :120-152 ---------------- */
+/* X genes x cells column-major (host, leading dimension ld) or dX fp32 on the device; label[n] in 1..n_cluster
+ * (y$pred_clusters after the match() of :96-99).  out: m x 5 row-major = auc, icluster, pvalue (before p.adjust),
+ * sparsity, FC for every gene; genes with sparsity <= theta get (0, 0, 1, sparsity, 0) like :146-149.  ng: how many
+ * of the clusters with the highest mean rank are tried (:118).  Filtering, Holm adjustment and ordering (:153-187)
+ * are host work (sharp_amd/api.py). */
+int sharp_marker_genes(const double *X, int m, long long n, long long ld, const int *label, int n_cluster, double theta, int ng,
+                       double *out);
+int sharp_marker_genes_dev(const float *dX, int m, long long n, long long ld, const int *label, int n_cluster, double theta, int ng,
+                           double *out);
+
 /* ---- synthetic inputs (bench / tests; not part of the reference) ------------ */
 /* Counter-based generator, value = f(seed, gene, cell): bit-identical to
  * oracle_synth_value().  Fills dX (fp32, m x ncell column-major, leading dim ld). */

@@ -259,6 +259,16 @@ def SHARP_unlimited2(blocks, K=0, reduced_ndim=0, partition_ncells=0, hmethod="w
     return dict(rc=rc, pred_clusters=pred, viE=viE, p=po.value)
 
 
+def marker_genes(X, label, G, theta=1e-4, ng=1):
+    """Per-gene (auc, icluster, pvalue, sparsity, FC) of R/get_marker_genes.R:120-152; X genes x cells."""
+    X = np.asfortranarray(X, dtype=np.float64)
+    m, n = X.shape
+    lab = np.ascontiguousarray(label, np.int32)
+    out = np.zeros((m, 5))
+    lib().oracle_marker_genes(_dp(X), m, n, _ip(lab), int(G), C.c_double(theta), int(ng), _dp(out))
+    return out
+
+
 def round1(x):
     lib().oracle_round1.restype = C.c_double
     return np.array([lib().oracle_round1(C.c_double(float(v))) for v in np.ravel(x)]).reshape(np.shape(x))

@@ -1203,6 +1203,78 @@ int oracle_SHARP_unlimited2(const double *Xcat, int m, int nb, const int *ncb, i
 }
 
 /* ------------------------------------------------------------------------- */
+/* get_marker_genes, the per-gene statistics (R/get_marker_genes.R:120-152).   */
+/* X: genes x cells column-major (a cell is contiguous, stride m); label 1..G.  */
+/* out: m x 5 row-major: auc, icluster, pvalue (unadjusted), sparsity, FC.      */
+/* Third-party pieces restated: base::rank (average ties), ROCR's "auc"         */
+/* (trapezoidal area under the ROC of the rank score, ties as one threshold),   */
+/* stats::wilcox.test (normal approximation, correct = TRUE, tie correction;    */
+/* the exact small-sample branch n1 < 50 && n2 < 50 without ties is not built). */
+/* ------------------------------------------------------------------------- */
+typedef struct { double v; int i; } mg_pair;
+static int mg_cmp(const void *a, const void *b) {
+    const mg_pair *x = (const mg_pair *)a, *y = (const mg_pair *)b;
+    return (x->v > y->v) - (x->v < y->v);
+}
+int oracle_marker_genes(const double *X, int m, int n, const int *label, int G, double theta, int ng, double *out) {
+    mg_pair *pr = (mg_pair *)xmalloc(sizeof(mg_pair) * (size_t)n);
+    double *rank = (double *)xmalloc(sizeof(double) * (size_t)n);
+    long double *sr = (long double *)xmalloc(sizeof(long double) * (size_t)G), *sx = (long double *)xmalloc(sizeof(long double) * (size_t)G);
+    int *cs = (int *)xcalloc((size_t)G, sizeof(int));
+    char *taken = (char *)xmalloc((size_t)G);
+    for (int i = 0; i < n; i++) cs[label[i] - 1]++;
+    int rr = ng < G ? ng : G; if (rr < 1) rr = 1;
+    for (int g = 0; g < m; g++) {
+        double *o = out + (size_t)g * 5;
+        int nz = 0;
+        for (int i = 0; i < n; i++) { pr[i].v = X[(size_t)i * m + g]; pr[i].i = i; nz += pr[i].v != 0.0; }
+        double dp = (double)nz / (double)n;                                     /* :122 */
+        if (!(dp > theta)) { o[0] = 0; o[1] = 0; o[2] = 1; o[3] = dp; o[4] = 0; continue; }
+        qsort(pr, (size_t)n, sizeof(mg_pair), mg_cmp);
+        long double ties = 0;
+        for (int a = 0; a < n;) {                                               /* rank(): average ranks */
+            int b = a; while (b < n && pr[b].v == pr[a].v) b++;
+            double r = 0.5 * ((double)(a + 1) + (double)b);
+            for (int q = a; q < b; q++) rank[pr[q].i] = r;
+            long double t = (long double)(b - a); ties += t * t * t - t;
+            a = b;
+        }
+        for (int c = 0; c < G; c++) { sr[c] = 0; sx[c] = 0; taken[c] = 0; }
+        for (int i = 0; i < n; i++) { sr[label[i] - 1] += rank[i]; sx[label[i] - 1] += X[(size_t)i * m + g]; }   /* aggregate(..., mean) */
+        double best_auc = -1; int best_c = -1;
+        for (int pick = 0; pick < rr; pick++) {                                 /* order(-s$r)[1:rr] */
+            int arg = -1; double top = -1;
+            for (int c = 0; c < G; c++) { double mr = (double)(sr[c] / cs[c]); if (!taken[c] && mr > top) { top = mr; arg = c; } }
+            if (arg < 0) break;
+            taken[arg] = 1;
+            /* ROCR prediction/performance("auc"): thresholds = distinct scores, descending; trapezoids */
+            long double area = 0; long tp = 0, fp = 0;
+            for (int b = n; b > 0;) {
+                int a = b - 1; while (a > 0 && pr[a - 1].v == pr[b - 1].v) a--;
+                long dtp = 0, dfp = 0;
+                for (int q = a; q < b; q++) { if (label[pr[q].i] - 1 == arg) dtp++; else dfp++; }
+                area += (long double)dfp * ((long double)tp + 0.5L * (long double)dtp);
+                tp += dtp; fp += dfp;
+                b = a;
+            }
+            double auc = (double)(area / ((long double)tp * (long double)fp));
+            if (auc > best_auc) { best_auc = auc; best_c = arg; }               /* which.max */
+        }
+        double n1 = cs[best_c], n2 = n - cs[best_c], nn = n;
+        double W = (double)sr[best_c] - n1 * (n1 + 1) / 2;                      /* wilcox.test STATISTIC */
+        double z = W - n1 * n2 / 2;
+        double sigma = sqrt((n1 * n2 / 12) * ((nn + 1) - (double)ties / (nn * (nn - 1))));
+        double corr = z > 0 ? 0.5 : (z < 0 ? -0.5 : 0.0);
+        z = (z - corr) / sigma;
+        double y1 = (double)(sx[best_c] / cs[best_c]), y2 = -1e300;
+        for (int c = 0; c < G; c++) if (c != best_c) { double v = (double)(sx[c] / cs[c]); if (v > y2) y2 = v; }
+        o[0] = best_auc; o[1] = best_c + 1; o[2] = erfc(fabs(z) * 0.70710678118654752440); o[3] = dp; o[4] = y1 / y2;
+    }
+    free(pr); free(rank); free(sr); free(sx); free(cs); free(taken);
+    return OR_OK;
+}
+
+/* ------------------------------------------------------------------------- */
 /* testlog (R/SHARP.R:877-924).  The reference samples cells with the UNSEEDED */
 /* global RNG (:884); here the caller passes the sampled (0-based) cell ids.   */
 /* Returns flag (1 = log-transform).                                           */

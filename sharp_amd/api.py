@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import SharpError, check, lib
 
 __all__ = ["ranM", "ranM2", "RPmat", "Projector", "SharpError", "get_opt_hclust", "getrowColor", "colorL", "HMETHODS",
-           "wMetaC", "sMetaC", "SHARP", "SHARP_small", "SHARP_large", "SHARP_unlimited", "SHARP_unlimited2", "SHARP_unlimited3", "run_Mtimes_SHARP", "testlog", "ARI"]
+           "wMetaC", "sMetaC", "SHARP", "SHARP_small", "SHARP_large", "SHARP_unlimited", "SHARP_unlimited2", "SHARP_unlimited3", "run_Mtimes_SHARP", "get_marker_genes", "testlog", "ARI"]
 
 
 def _dp(a):
@@ -576,6 +576,63 @@ def run_Mtimes_SHARP(scExp, Mtimes=10, Kset=15, **kwargs):
             info["Run_%d" % j] = SHARP(scExp, ensize_K=int(k), forview=False, **kwargs)
         allresults["enSize_%d" % int(k)] = info
     return allresults
+
+
+def get_marker_genes(scExp, y, theta=1e-4, auc=0.7, pvalue=0.01, FC=2, ng=1, n_cores=None, gene_names=None):
+    """R/get_marker_genes.R:25-264.  scExp: (genes, cells); y: a SHARP() result (or anything with "pred_clusters").
+
+    Returns dict(mginfo, gallinfo, mat, label, logmark): `gallinfo` has one row per gene that passed the sparsity / NaN
+    filters (columns gene, auc, icluster, pvalue (Holm-adjusted), sparsity, FC); `mginfo` the selected marker genes ordered
+    by (icluster, -FC, -auc, pvalue, -sparsity) like :177; `mat` their expression rows.  Tables are dicts of numpy columns."""
+    _lib.ensure_init()
+    X = np.asfortranarray(scExp, dtype=np.float64)
+    m, n = X.shape
+    names = np.arange(m) if gene_names is None else np.asarray(gene_names)
+    keep = np.ones(m, bool)
+    if gene_names is not None:                                            # :49-54 duplicated gene names are dropped
+        _, first = np.unique(names, return_index=True)
+        keep[:] = False
+        keep[first] = True
+        X, names = np.asfortranarray(X[keep]), names[keep]
+        m = X.shape[0]
+    pred = np.asarray(y["pred_clusters"] if isinstance(y, dict) else y)
+    uy = np.unique(pred)                                                  # :95-99: use the index among the unique ids
+    label = (np.searchsorted(uy, pred) + 1).astype(np.int32)
+    G = int(uy.size)
+    out = np.zeros((m, 5))
+    check(lib().sharp_marker_genes(_dp(X), m, C.c_longlong(n), C.c_longlong(m), _ip(label), G, C.c_double(theta), int(ng), _dp(out)))
+    cols = {"gene": names, "auc": out[:, 0], "icluster": out[:, 1].astype(np.int64), "pvalue": out[:, 2].copy(),
+            "sparsity": out[:, 3], "FC": out[:, 4]}
+    sel = (cols["sparsity"] > theta) & ~np.isnan(cols["pvalue"])          # :158-159
+    g = {k: v[sel] for k, v in cols.items()}
+    g["pvalue"] = _p_adjust_holm(g["pvalue"])                             # :160
+    gall = {k: v.copy() for k, v in g.items()}
+    if g["auc"].size:                                                     # :166-169: adauc = min(auc, min over clusters of max auc)
+        maxauc = [g["auc"][g["icluster"] == c].max() for c in np.unique(g["icluster"])]
+        adauc = min(auc, min(maxauc))
+    else:
+        adauc = auc
+    pick = (g["pvalue"] < pvalue) & (g["auc"] > adauc) & (g["FC"] >= FC)  # :171-176
+    s = {k: v[pick] for k, v in g.items()}
+    order = np.lexsort((-s["sparsity"], s["pvalue"], -s["auc"], -s["FC"], s["icluster"]))   # :177
+    s = {k: v[order] for k, v in s.items()}
+    idx = {nm: i for i, nm in enumerate(names.tolist())}
+    rows = np.array([idx[nm] for nm in s["gene"].tolist()], dtype=np.int64)
+    return {"mginfo": s, "gallinfo": gall, "mat": X[rows] if rows.size else X[:0], "label": label,
+            "logmark": (y.get("paras", {}) or {}).get("logmark") if isinstance(y, dict) else None}
+
+
+def _p_adjust_holm(p):
+    """stats::p.adjust(p, "holm"): pmin(1, cummax((n - i + 1) * p[o]))[ro]."""
+    p = np.asarray(p, np.float64)
+    n = p.size
+    if n == 0:
+        return p
+    o = np.argsort(p, kind="stable")
+    adj = np.minimum(1.0, np.maximum.accumulate((n - np.arange(n)) * p[o]))
+    out = np.empty(n)
+    out[o] = adj
+    return out
 
 
 def ARI(label, res):

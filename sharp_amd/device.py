@@ -80,6 +80,17 @@ def unlimited_merge(means, counts, ncells, N_cluster=0, minN_cluster=0, maxN_clu
     return fid, nf.value
 
 
+def marker_genes_dev(dX, labels, n_cluster, theta=1e-4, ng=1):
+    """Per-gene (auc, icluster, pvalue, sparsity, FC) of get_marker_genes on a resident (cells, genes) float32 block."""
+    _lib.ensure_init()
+    n, m = dX.shape
+    lab = np.ascontiguousarray(labels, np.int32)
+    out = np.zeros((m, 5))
+    check(lib().sharp_marker_genes_dev(C.c_void_p(dX.data_ptr()), m, C.c_longlong(n), C.c_longlong(dX.stride(0)), _ip(lab), int(n_cluster),
+                                       C.c_double(theta), int(ng), _dp(out)))
+    return out
+
+
 def profile(enable=True):
     _lib.ensure_init()
     check(lib().sharp_profile_enable(1 if enable else 0))
