@@ -1183,11 +1183,21 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
     size_t free_b = 0, total_b = 0;
     SHARP_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     const double budget = std::max(0.5 * static_cast<double>(free_b), 2.0e9);
+    // More tasks than CUs: equal chunks of at most one task per CU.  The agglomeration kernel then runs its 1024-thread form
+    // (one task per CU, twice the loads in flight) chunk after chunk -- as fast as all tasks at once with two per CU -- and the
+    // workspaces (three distance-matrix-sized buffers per task) are sized for a chunk: 18 GB instead of 36 GB at cfg2, which
+    // is what the first call pays in hipMalloc time.
+    size_t max_tasks = tasks.size();
+    {
+        const size_t ncu = static_cast<size_t>(ctx().num_cu);
+        if (const char *e = getenv("SHARP_HC_CHUNK")) max_tasks = std::max<size_t>(1, static_cast<size_t>(atoll(e)));
+        else if (tasks.size() > ncu) { const size_t nch = (tasks.size() + ncu - 1) / ncu; max_tasks = (tasks.size() + nch - 1) / nch; }
+    }
     size_t i0 = 0;
     while (i0 < tasks.size()) {
         double bytes = 0;
         size_t i1 = i0;
-        while (i1 < tasks.size()) {
+        while (i1 < tasks.size() && i1 - i0 < max_tasks) {
             const HcTask &t = tasks[i1];
             const double nld = static_cast<double>(rup(t.n, 128));
             const double p = t.symmetric ? t.n : t.p;
