@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 
 #include "linalg.hpp"
 
@@ -390,14 +391,17 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
             __syncthreads();
             int pos = wsum[wave] + incl - c;
             for (int a = lo; a < hi; ++a)
-                if (partner[a] == HR_NONE || partner[a] > a) { newidx[a] = static_cast<uint16_t>(pos); oldidx[pos++] = static_cast<uint16_t>(a); }
+                if (partner[a] == HR_NONE || partner[a] > a) {   // bit 15 of oldidx: the survivor is a merged cluster
+                    newidx[a] = static_cast<uint16_t>(pos);
+                    oldidx[pos++] = static_cast<uint16_t>(a | (partner[a] == HR_NONE ? 0 : 0x8000));
+                }
         }
         __syncthreads();
         const int nb = wsum[nwave];                             // = na - np
         if (tid == 0) { ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; }
         __syncthreads();
         for (int A = tid; A < nb; A += HR_THREADS)
-            if (partner[oldidx[A]] == HR_NONE) srow[atomicAdd(&ctl[4], 1)] = static_cast<uint16_t>(A);
+            if (!(oldidx[A] & 0x8000)) srow[atomicAdd(&ctl[4], 1)] = static_cast<uint16_t>(A);
         __syncthreads();
         const int ns = ctl[4];                                  // rows of unmerged clusters (= nb - np)
 #ifdef HR_TIMING
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         double *Ddst = Sb[src < 0 ? 0 : (src ^ 1)];
         const bool sq = (src < 0 && method == 8);
         auto do_row = [&](int A) {
-            const int a = oldidx[A];
+            const int a = oldidx[A] & 0x7fff;
             const int pa = partner[a];                          // NONE or j > a
             const bool am = pa != HR_NONE;
             const double *ra = Dsrc + static_cast<long long>(a) * nld;
@@ -429,14 +433,14 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int B = B0 + 64 * u;
-                        bb[u] = oldidx[B < nb ? B : nb - 1];
+                        bb[u] = oldidx[B < nb ? B : nb - 1] & 0x7fff;
                         x[u] = ra[bb[u]];
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int B = B0 + 64 * u;
                         if (B < nb && partner[bb[u]] == HR_NONE) {
-                            const double v = B == A ? 0.0 : (sq ? x[u] * x[u] : x[u]);
+                            const double v = B == A ? HC_INF : (sq ? x[u] * x[u] : x[u]);   // scratch diagonals hold +inf: no test in later rounds
                             wr[B] = v;
                             if (B != A) consider(v, B);
                         }
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int B = B0 + 64 * u;
-                        bb[u] = oldidx[B < nb ? B : nb - 1];
+                        bb[u] = oldidx[B < nb ? B : nb - 1] & 0x7fff;
                         const int pb = partner[bb[u]];
                         pbv[u] = pb;
                         const int pbc = pb == HR_NONE ? bb[u] : pb;
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                             double d00 = x00[u], d01 = x01[u], d10 = x10[u], d11 = x11[u];
                             if (sq) { d00 *= d00; d01 *= d01; d10 *= d10; d11 *= d11; }
                             double v;
-                            if (B == A) v = 0.0;
+                            if (B == A) v = HC_INF;
                             else if (!bm) v = lance_williams(method, d00, d10, hP, na_, nj_, static_cast<double>(csz[b]));
                             else {
                                 const double nk_ = csz[b], nl_ = csz[pbv[u]], hQ = dnn[b];
@@ -534,15 +538,78 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
             if (lane == 0) q = atomicAdd(&ctl[2], 2);
             q = __builtin_amdgcn_readfirstlane(q);
             if (q >= ns) break;
-            const int A = srow[q];
+            const int A = __builtin_amdgcn_readfirstlane(srow[q]);
             if (q + 1 >= ns) { do_row(A); break; }
-            const int A2 = srow[q + 1];
-            const int a1 = oldidx[A], a2 = oldidx[A2];
+            const int A2 = __builtin_amdgcn_readfirstlane(srow[q + 1]);
+            const int a1 = __builtin_amdgcn_readfirstlane(oldidx[A] & 0x7fff), a2 = __builtin_amdgcn_readfirstlane(oldidx[A2] & 0x7fff);
 #ifdef HR_TIMING
             const long long q1 = __builtin_readcyclecounter();
 #endif
             const double *r1 = Dsrc + static_cast<long long>(a1) * nld, *r2 = Dsrc + static_cast<long long>(a2) * nld;
             double *w1 = Ddst + static_cast<long long>(A) * nld, *w2 = Ddst + static_cast<long long>(A2) * nld;
+            if (src >= 0) {
+                // Later rounds (the bulk of the work): the source is a scratch matrix whose diagonal holds +inf, so a plain
+                // gathered copy needs no diagonal test; per element: one LDS read (old column | merged flag), two loads, two
+                // stores and a six-instruction running (min, second min, arg min) per row -- the kernel is bound by the vector
+                // ALU (53 instructions per element before this path: SQ_INSTS_VALU, tools/pmc_hclust.sh), not by memory.
+                double m1 = HC_INF, s1 = HC_INF, m2 = HC_INF, s2 = HC_INF;
+                int i1 = 0x7fffffff, i2 = 0x7fffffff;
+                auto upd = [](double &mn, double &sc, int &ix, double v, int B) {
+                    sc = fmin(sc, fmax(mn, v));
+                    if (v < mn) { mn = v; ix = B; }
+                };
+                int B0 = lane;
+                // passes of 16, 8, 4, 2, 1 columns per lane, none with bounds tests: the waves spend most of their time parked
+                // on these loads (SQ_WAIT_ANY 64 % of the wave cycles), so as many as the registers allow go out together
+                auto pass = [&](auto U_) {
+                    constexpr int U = decltype(U_)::value;
+                    for (; B0 + 64 * (U - 1) < nb; B0 += 64 * U) {
+                        unsigned mm[U];
+                        double x1[U], x2[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) mm[u] = oldidx[B0 + 64 * u];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) { const unsigned bcol = mm[u] & 0x7fffu; x1[u] = r1[bcol]; x2[u] = r2[bcol]; }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (!(mm[u] & 0x8000u)) {
+                                const int B = B0 + 64 * u;
+                                w1[B] = x1[u]; w2[B] = x2[u];
+                                upd(m1, s1, i1, x1[u], B); upd(m2, s2, i2, x2[u], B);
+                            }
+                        }
+                        if (U == 1) break;
+                    }
+                };
+                pass(std::integral_constant<int, 16>());
+                pass(std::integral_constant<int, 8>());
+                pass(std::integral_constant<int, 4>());
+                pass(std::integral_constant<int, 2>());
+                pass(std::integral_constant<int, 1>());
+                const double n1 = csz[a1], n2 = csz[a2];
+                for (int q = lane; q < np; q += 64) {           // merged columns: d(a, k u l) from d(a,k), d(a,l)
+                    const int k1 = plist[q], l1 = partner[k1], B = newidx[k1];
+                    const double nk_ = csz[k1], nl_ = csz[l1], hQ = dnn[k1];
+                    const double v1 = lance_williams(method, r1[k1], r1[l1], hQ, nk_, nl_, n1);
+                    const double v2 = lance_williams(method, r2[k1], r2[l1], hQ, nk_, nl_, n2);
+                    w1[B] = v1; w2[B] = v2;
+                    // equal values: the lower column wins, like the ascending sweep above
+                    s1 = fmin(s1, fmax(m1, v1)); if (v1 < m1 || (v1 == m1 && B < i1)) { m1 = v1; i1 = B; }
+                    s2 = fmin(s2, fmax(m2, v2)); if (v2 < m2 || (v2 == m2 && B < i2)) { m2 = v2; i2 = B; }
+                }
+                HrBest g1, g2;
+                g1.v = m1; g1.i = i1; g1.tie = 0; g2.v = m2; g2.i = i2; g2.tie = 0;
+                g1 = hr_wave(g1); g2 = hr_wave(g2);
+                g1.tie |= __ballot(s1 == g1.v) != 0ull ? 1 : 0;     // a lane saw the minimum twice
+                g2.tie |= __ballot(s2 == g2.v) != 0ull ? 1 : 0;
+                if (lane == 0) { cidN[A] = cid[a1]; cszN[A] = csz[a1]; dnnN[A] = g1.v; cidN[A2] = cid[a2]; cszN[A2] = csz[a2]; dnnN[A2] = g2.v; }
+                if (lane == 1) { nn[A] = static_cast<uint16_t>(g1.i < nb ? g1.i : 0); nn[A2] = static_cast<uint16_t>(g2.i < nb ? g2.i : 0); }
+                if (lane == 2) { tie[A] = static_cast<unsigned char>(nb > 2 ? g1.tie : 0); tie[A2] = static_cast<unsigned char>(nb > 2 ? g2.tie : 0); }
+#ifdef HR_TIMING
+                hr_dual += __builtin_readcyclecounter() - q1;
+#endif
+                continue;
+            }
             HrBest b1, b2;
             b1.v = b2.v = HC_INF; b1.i = b2.i = 0x7fffffff; b1.tie = b2.tie = 0;
             for (int B0 = lane; B0 < nb; B0 += 64 * 8) {
@@ -551,15 +618,15 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int B = B0 + 64 * u;
-                    bb[u] = oldidx[B < nb ? B : nb - 1];
+                    bb[u] = oldidx[B < nb ? B : nb - 1] & 0x7fff;
                     x1[u] = r1[bb[u]]; x2[u] = r2[bb[u]];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int B = B0 + 64 * u;
                     if (B < nb && partner[bb[u]] == HR_NONE) {
-                        const double v1 = B == A ? 0.0 : (sq ? x1[u] * x1[u] : x1[u]);
-                        const double v2 = B == A2 ? 0.0 : (sq ? x2[u] * x2[u] : x2[u]);
+                        const double v1 = B == A ? HC_INF : (sq ? x1[u] * x1[u] : x1[u]);
+                        const double v2 = B == A2 ? HC_INF : (sq ? x2[u] * x2[u] : x2[u]);
                         w1[B] = v1; w2[B] = v2;
                         if (B != A) { if (v1 < b1.v) { b1.v = v1; b1.i = B; b1.tie = 0; } else if (v1 == b1.v) b1.tie = 1; }
                         if (B != A2) { if (v2 < b2.v) { b2.v = v2; b2.i = B; b2.tie = 0; } else if (v2 == b2.v) b2.tie = 1; }

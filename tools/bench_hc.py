@@ -3,7 +3,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import os
 import sharp_amd
 from sharp_amd import _lib as _L

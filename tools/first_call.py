@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import sharp_amd
 from sharp_amd import device as dev
 sharp_amd.init(0)
