@@ -273,11 +273,19 @@ __device__ __forceinline__ HrBest hr_wave(HrBest x) {
 
 // HR_THREADS = 512: two tasks per CU (LDS state 37 B per observation, <= 128 VGPRs) when there are more tasks than CUs;
 // 1024: one task per CU with twice the loads in flight when there are not (a task streams ~300 MB through ONE workgroup).
-template <int HR_THREADS>
+// MODE 0: the whole agglomeration in one launch, one workgroup per task.
+// MODE 1 / 2: one ROUND per pair of launches, so that a task is no longer confined to the ~34 GB/s one CU can move: the
+// LDS state lives as an image in global memory between launches; MODE 1 (one workgroup per task) loads it, applies the
+// previous round's transition, finds and ranks the reciprocal pairs, builds the column maps and stores it back; MODE 2
+// (gridDim.y workgroups per task) loads it read-only and rebuilds its share of the rows (work is handed out by counters in
+// the image), writing the new rows' nearest neighbours straight into the image.
+template <int HR_THREADS, int MODE>
 __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__restrict__ metas, const double *__restrict__ Dall,
                                                                 double *__restrict__ S0all, double *__restrict__ S1all,
                                                                 int *__restrict__ ia_all, int *__restrict__ ib_all,
-                                                                double *__restrict__ h_all, int *__restrict__ status) {
+                                                                double *__restrict__ h_all, int *__restrict__ status,
+                                                                unsigned char *__restrict__ images, long long image_stride,
+                                                                int lds_bytes, int round, int *__restrict__ remaining) {
     const HcMeta M = metas[blockIdx.x];
     const int n = M.n, nld = M.nld, method = M.method;
     const double *D = Dall + M.oD;
@@ -285,8 +293,9 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     int *ia = ia_all + M.oM, *ib = ib_all + M.oM;
     double *crit = h_all + M.oM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = HR_THREADS / 64;
+    unsigned char *img = MODE ? images + static_cast<long long>(blockIdx.x) * image_stride : nullptr;
     if (method == 6 || method == 7 || n > HR_MAXN) {            // centroid / median are not reducible; large n: LDS
-        if (tid == 0) status[blockIdx.x] = 1;
+        if (MODE != 2 && (MODE == 0 || round == 0) && tid == 0) { status[blockIdx.x] = 1; if (MODE == 1) atomicSub(remaining, 1); }
         return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -301,13 +310,31 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     uint16_t *newidx = oldidx + nal;                           // [nal]     old index -> new index (survivors)
     uint16_t *plist = newidx + nal;                            // [nal]     first members of the pairs
     uint16_t *srow = plist + nal;                              // [nal]     new indices of the rows of unmerged clusters
-    int *ctl = reinterpret_cast<int *>(srow + nal);            // [8]: npairs, abort, work counters (single rows, merged rows), nsingle
-    int *wsum = ctl + 8;                                        // [nwave + 1]
+    int *ctl = reinterpret_cast<int *>(srow + nal);            // [16]: 0 npairs, 1 abort, 2/3 work counters (plain / merged rows), 4 nsingle,
+                                                                //       5 cur, 6 na, 7 done, 8 src + 1, 9 nb, 10 state, 11 pending  (5..11: MODE 1/2)
+    int *wsum = ctl + 16;                                       // [nwave + 1]
     unsigned char *tie = reinterpret_cast<unsigned char *>(wsum + nwave + 1);   // [nal]
 
     int cur = 0, na = n, done = 0;
+    int src = -1;                                               // -1: D (pristine), else scratch index
+    const bool fresh = MODE == 0 || (MODE == 1 && round == 0);
+    if (!fresh) {                                               // the state image of the previous launches
+        const uint4 *gi = reinterpret_cast<const uint4 *>(img);
+        uint4 *li = reinterpret_cast<uint4 *>(sm);
+        for (int q = tid; q < lds_bytes / 16; q += HR_THREADS) li[q] = gi[q];
+        __syncthreads();
+        if (ctl[10] != 0 || (MODE == 2 && !ctl[11])) return;   // finished / abandoned, or nothing pending
+        cur = ctl[5]; na = ctl[6]; done = ctl[7]; src = ctl[8] - 1;
+        if (MODE == 1 && ctl[11]) {                             // apply the transition of the round that MODE 2 just rebuilt
+            done += ctl[0]; na = ctl[9]; cur ^= 1; src = src < 0 ? 0 : (src ^ 1);
+            __syncthreads();
+            if (tid == 0) { ctl[0] = 0; ctl[11] = 0; }
+            __syncthreads();
+        }
+    }
+    if (fresh) {
     for (int i = tid; i < n; i += HR_THREADS) { cidA[i] = static_cast<uint16_t>(i); cszA[i] = 1; }
-    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
+    if (tid == 0) { for (int q = 0; q < 16; ++q) ctl[q] = 0; }
     __syncthreads();
     // round 0 nearest neighbours from the pristine matrix (squared for ward.D2)
     for (int a = wave; a < n; a += nwave) {
@@ -330,13 +357,26 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         if (lane == 0) { nn[a] = static_cast<uint16_t>(b.i < n ? b.i : 0); dnnA[a] = b.v; tie[a] = static_cast<unsigned char>(b.tie); }
     }
     __syncthreads();
+    }   // fresh
 
-    int src = -1;                                               // -1: D (pristine), else scratch index
+    // where the results of a rebuilt row go: the LDS arrays (MODE 0) or the global image (MODE 2)
+    auto outp = [&](auto *lds_ptr) { return MODE == 2 ? reinterpret_cast<decltype(lds_ptr)>(img + (reinterpret_cast<unsigned char *>(lds_ptr) - sm)) : lds_ptr; };
+    int *wctl = outp(ctl);
+    auto store_image = [&]() {
+        __syncthreads();
+        uint4 *gi = reinterpret_cast<uint4 *>(img);
+        const uint4 *li = reinterpret_cast<const uint4 *>(sm);
+        for (int q = tid; q < lds_bytes / 16; q += HR_THREADS) gi[q] = li[q];
+    };
     while (na > 1) {
         double *dnn = dnnA + cur * nal;
         uint16_t *cid = cidA + cur * nal, *csz = cszA + cur * nal;
-        double *dnnN = dnnA + (cur ^ 1) * nal;
-        uint16_t *cidN = cidA + (cur ^ 1) * nal, *cszN = cszA + (cur ^ 1) * nal;
+        double *dnnN = outp(dnnA + (cur ^ 1) * nal);
+        uint16_t *cidN = outp(cidA + (cur ^ 1) * nal), *cszN = outp(cszA + (cur ^ 1) * nal);
+        uint16_t *nnW = outp(nn);
+        unsigned char *tieW = outp(tie);
+        int np = 0, nb = 0, ns = 0;
+        if (MODE != 2) {
 #ifdef HR_TIMING
         const long long hr_t0 = __builtin_readcyclecounter();
 #endif
@@ -354,9 +394,12 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
             }
         }
         __syncthreads();
-        const int np = ctl[0];
+        np = ctl[0];
         if (ctl[1] || np == 0) {                                // tie or no pair: the sequential kernel takes this task
-            if (tid == 0) status[blockIdx.x] = 1;
+            if (tid == 0) {
+                status[blockIdx.x] = 1;
+                if (MODE == 1) { reinterpret_cast<int *>(img + (reinterpret_cast<unsigned char *>(ctl) - sm))[10] = 1; atomicSub(remaining, 1); }
+            }
             return;
         }
         // (2) rank of each pair by (height, lower original index) = the sequential algorithm's order
@@ -397,13 +440,21 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                 }
         }
         __syncthreads();
-        const int nb = wsum[nwave];                             // = na - np
+        nb = wsum[nwave];                                       // = na - np
         if (tid == 0) { ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; }
         __syncthreads();
         for (int A = tid; A < nb; A += HR_THREADS)
             if (!(oldidx[A] & 0x8000)) srow[atomicAdd(&ctl[4], 1)] = static_cast<uint16_t>(A);
         __syncthreads();
-        const int ns = ctl[4];                                  // rows of unmerged clusters (= nb - np)
+        ns = ctl[4];                                            // rows of unmerged clusters (= nb - np)
+        }   // MODE != 2
+        if (MODE == 1) {                                        // hand the round over to the rebuild launch
+            __syncthreads();
+            if (tid == 0) { ctl[5] = cur; ctl[6] = na; ctl[7] = done; ctl[8] = src + 1; ctl[9] = nb; ctl[10] = 0; ctl[11] = 1; }
+            store_image();
+            return;
+        }
+        if (MODE == 2) { np = ctl[0]; nb = ctl[9]; ns = ctl[4]; }
 #ifdef HR_TIMING
         const long long hr_t1 = __builtin_readcyclecounter();
         long long hr_dual = 0, hr_slow = 0;
@@ -508,21 +559,21 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                 dnnN[A] = best.v;
             }
             // nn / tie of the new round live in the single-buffered arrays: nothing reads the old ones in this phase
-            if (lane == 1) { nn[A] = static_cast<uint16_t>(best.i < nb ? best.i : 0); }
-            if (lane == 2) { tie[A] = static_cast<unsigned char>(nb > 2 ? best.tie : 0); }
+            if (lane == 1) { nnW[A] = static_cast<uint16_t>(best.i < nb ? best.i : 0); }
+            if (lane == 2) { tieW[A] = static_cast<unsigned char>(nb > 2 ? best.tie : 0); }
         };
         // two unmerged rows at a time share the column map (one set of LDS reads) and keep 16 loads in flight per lane
         auto finish_row = [&](int A, int a, HrBest best) {
             best = hr_wave(best);
             if (lane == 0) { cidN[A] = cid[a]; cszN[A] = csz[a]; dnnN[A] = best.v; }
-            if (lane == 1) { nn[A] = static_cast<uint16_t>(best.i < nb ? best.i : 0); }
-            if (lane == 2) { tie[A] = static_cast<unsigned char>(nb > 2 ? best.tie : 0); }
+            if (lane == 1) { nnW[A] = static_cast<uint16_t>(best.i < nb ? best.i : 0); }
+            if (lane == 2) { tieW[A] = static_cast<unsigned char>(nb > 2 ? best.tie : 0); }
         };
         // work is handed out dynamically (the rows of merged clusters cost about twice a pair of plain rows, and a static
         // split left a quarter of the phase waiting at the barrier): merged rows first, then plain rows two at a time
         for (;;) {
             int q = 0;
-            if (lane == 0) q = atomicAdd(&ctl[3], 1);
+            if (lane == 0) q = atomicAdd(wctl + 3, 1);
             q = __builtin_amdgcn_readfirstlane(q);
             if (q >= np) break;
 #ifdef HR_TIMING
@@ -535,7 +586,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         }
         for (;;) {
             int q = 0;
-            if (lane == 0) q = atomicAdd(&ctl[2], 2);
+            if (lane == 0) q = atomicAdd(wctl + 2, 2);
             q = __builtin_amdgcn_readfirstlane(q);
             if (q >= ns) break;
             const int A = __builtin_amdgcn_readfirstlane(srow[q]);
@@ -603,8 +654,8 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                 g1.tie |= __ballot(s1 == g1.v) != 0ull ? 1 : 0;     // a lane saw the minimum twice
                 g2.tie |= __ballot(s2 == g2.v) != 0ull ? 1 : 0;
                 if (lane == 0) { cidN[A] = cid[a1]; cszN[A] = csz[a1]; dnnN[A] = g1.v; cidN[A2] = cid[a2]; cszN[A2] = csz[a2]; dnnN[A2] = g2.v; }
-                if (lane == 1) { nn[A] = static_cast<uint16_t>(g1.i < nb ? g1.i : 0); nn[A2] = static_cast<uint16_t>(g2.i < nb ? g2.i : 0); }
-                if (lane == 2) { tie[A] = static_cast<unsigned char>(nb > 2 ? g1.tie : 0); tie[A2] = static_cast<unsigned char>(nb > 2 ? g2.tie : 0); }
+                if (lane == 1) { nnW[A] = static_cast<uint16_t>(g1.i < nb ? g1.i : 0); nnW[A2] = static_cast<uint16_t>(g2.i < nb ? g2.i : 0); }
+                if (lane == 2) { tieW[A] = static_cast<unsigned char>(nb > 2 ? g1.tie : 0); tieW[A2] = static_cast<unsigned char>(nb > 2 ? g2.tie : 0); }
 #ifdef HR_TIMING
                 hr_dual += __builtin_readcyclecounter() - q1;
 #endif
@@ -654,6 +705,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
 #ifdef HR_TIMING
         const long long hr_t2 = __builtin_readcyclecounter();
 #endif
+        if (MODE == 2) return;                                  // the next MODE 1 launch applies the transition
         __syncthreads();
         if (tid == 0) { ctl[0] = 0; }
 #ifdef HR_TIMING
@@ -693,7 +745,10 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         }
         for (int q = tid; q < n - 1; q += HR_THREADS) { crit[q] = method == 8 ? sqrt(kh[q]) : kh[q]; ia[q] = ki[q]; ib[q] = kj[q]; }
     }
-    if (tid == 0) status[blockIdx.x] = 0;
+    if (tid == 0) {
+        status[blockIdx.x] = 0;
+        if (MODE == 1) { reinterpret_cast<int *>(img + (reinterpret_cast<unsigned char *>(ctl) - sm))[10] = 2; atomicSub(remaining, 1); }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -934,7 +989,8 @@ namespace {
 
 struct Workspace {
     DevBuf<double> D, D0, S0, S1, Cr, Ct, nrm, height, H, T, G, CSt, Q, out;
-    DevBuf<int> ia, ib, lab, chosen, packed, status;
+    DevBuf<int> ia, ib, lab, chosen, packed, status, remaining;
+    DevBuf<unsigned char> img;          // LDS state images of the round-per-launch agglomeration
     DevBuf<long long> packoff;
     DevBuf<HcMeta> meta;
     DevBuf<RowPrepTask> prep;
@@ -1033,6 +1089,13 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
     // own stream: the agglomeration is a memory-latency/scatter-bound kernel and the correlation GEMM an MFMA-bound one,
     // so a range's GEMM, cutree and silhouette statistics run underneath the agglomeration of the other ranges.
     int NS = T >= 96 ? 2 : 1;   // measured: 2 ranges -4 ms, 3 or more slower than one (the GEMM slows the agglomeration it overlaps)
+    {
+        // the round-per-launch agglomeration synchronises with the host every few rounds: one range at a time
+        const char *mono = getenv("SHARP_HC_MONO"), *seq = getenv("SHARP_HC_SEQ");
+        const char *splt = getenv("SHARP_HC_SPLIT");
+        const bool split = splt ? splt[0] == '1' : T <= 64;
+        if (!(mono && mono[0] == '1') && !(seq && seq[0] == '1') && max_n <= HR_MAXN && split) NS = 1;
+    }
     if (const char *e = getenv("SHARP_HC_RANGES")) NS = std::max(1, std::min(8, atoi(e)));
     NS = std::min(NS, T);
     std::vector<RowPrepTask> prep(T);
@@ -1113,18 +1176,49 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
             if (use_rnn) {
                 const int nal = (max_n + 3) & ~3;
                 int npow2 = 1; while (npow2 < max_n - 1) npow2 <<= 1;
-                const size_t state = static_cast<size_t>(nal) * (16 + 4 + 4 + 2 * 7 + 1) + 8 * 4 + (1024 / 64 + 1) * 4 + 64;
+                const size_t state = (static_cast<size_t>(nal) * (16 + 4 + 4 + 2 * 7 + 1) + 16 * 4 + (1024 / 64 + 1) * 4 + 64 + 15) / 16 * 16;
                 const size_t lds = std::max(state, static_cast<size_t>(npow2) * 16);
-                if (Ts <= c.num_cu) {
-                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_rnn_kernel<1024>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-                    hipLaunchKernelGGL(hclust_rnn_kernel<1024>, dim3(Ts), dim3(1024), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
-                                       W.height.p, W.status.p + R.t0);
+                const char *mono = getenv("SHARP_HC_MONO");       // debug / cross-check: the whole agglomeration in one launch
+                // Few tasks (one projection, the wMetaC / sMetaC similarity tasks, a cross-block sMetaC of thousands of meta-clusters):
+                // one round per pair of launches, every task spread over several workgroups -- 25 tasks of 2000: 5.5 ms against
+                // 13.5 ms in one launch.  Many tasks: one launch is as fast or faster (125 tasks equal, 188 tasks 21 vs 25 ms: the
+                // chip then moves the same 2.3-2.7 TB/s either way and the per-round launches only add their gaps).
+                const char *splt = getenv("SHARP_HC_SPLIT");     // 1 / 0 force the choice
+                const bool split = splt ? splt[0] == '1' : Ts <= 64;
+                if (!(mono && mono[0] == '1') && split) {
+                    const int wpt = std::max(1, std::min(8, (5 * c.num_cu / 2 + Ts - 1) / Ts));
+                    W.img.ensure(static_cast<size_t>(Ts) * lds);
+                    W.remaining.ensure(1);
+                    const int rem0 = Ts;
+                    W.remaining.upload(&rem0, 1);
+                    auto ka = hclust_rnn_kernel<1024, 1>;
+                    auto kb = hclust_rnn_kernel<1024, 2>;
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+                    const int max_rounds = max_n + 8;               // every round merges at least one pair
+                    for (int r = 0; r < max_rounds; ++r) {
+                        hipLaunchKernelGGL(ka, dim3(Ts), dim3(1024), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p, W.height.p,
+                                           W.status.p + R.t0, W.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W.remaining.p);
+                        hipLaunchKernelGGL(kb, dim3(Ts, wpt), dim3(1024), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p, W.height.p,
+                                           W.status.p + R.t0, W.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W.remaining.p);
+                        if ((r & 7) == 7) {                         // a finished task costs two empty workgroups per round: look now and then
+                            int rem = 0;
+                            W.remaining.download(&rem, 1);
+                            if (rem <= 0) break;
+                        }
+                    }
+                } else if (Ts <= c.num_cu) {
+                    auto k0 = hclust_rnn_kernel<1024, 0>;
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        static_cast<int>(lds)));
+                    hipLaunchKernelGGL(k0, dim3(Ts), dim3(1024), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
+                                       W.height.p, W.status.p + R.t0, nullptr, 0LL, static_cast<int>(lds), 0, nullptr);
                 } else {
-                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_rnn_kernel<512>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-                    hipLaunchKernelGGL(hclust_rnn_kernel<512>, dim3(Ts), dim3(512), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
-                                       W.height.p, W.status.p + R.t0);
+                    auto k0 = hclust_rnn_kernel<512, 0>;
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        static_cast<int>(lds)));
+                    hipLaunchKernelGGL(k0, dim3(Ts), dim3(512), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
+                                       W.height.p, W.status.p + R.t0, nullptr, 0LL, static_cast<int>(lds), 0, nullptr);
                 }
                 launch_check("hclust_rnn_kernel");
             }
