@@ -103,15 +103,37 @@ __global__ __launch_bounds__(256) void wm_similarity_kernel(const WmMeta *__rest
 }
 
 // ---- per-label column sums: one wave-column-chunk per cluster, members in ascending cell order
-__global__ __launch_bounds__(64) void cluster_means_kernel(const double *__restrict__ E, long long ld, int p, const int *__restrict__ start,
-                                                           const int *__restrict__ members, double *__restrict__ means) {
+// colMeans(sE1[cluster, ]) (R/sMetaC.R:58-63).  One workgroup per (cluster, 64-column slab): eight waves take the members
+// round-robin with four loads in flight each (a big final cluster has thousands of members: one sequential chain of
+// dependent loads took 4 ms per call), and the 32 partial sums are added in a fixed order.
+constexpr int CM_WAVES = 8;
+__global__ __launch_bounds__(64 * CM_WAVES) void cluster_means_kernel(const double *__restrict__ E, long long ld, int p,
+                                                                      const int *__restrict__ start, const int *__restrict__ members,
+                                                                      double *__restrict__ means) {
+    __shared__ double part[CM_WAVES][64];
     const int t = blockIdx.x;
-    const int col = blockIdx.y * 64 + threadIdx.x;
-    if (col >= p) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.y * 64 + lane;
     const int s0 = start[t], s1 = start[t + 1];
-    double acc = 0.0;
-    for (int q = s0; q < s1; ++q) acc += E[static_cast<long long>(members[q]) * ld + col];
-    means[static_cast<long long>(t) * p + col] = acc / static_cast<double>(s1 - s0);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (col < p) {
+        int q = s0 + w;
+        for (; q + 3 * CM_WAVES < s1; q += 4 * CM_WAVES) {
+            const double x0 = E[static_cast<long long>(members[q]) * ld + col];
+            const double x1 = E[static_cast<long long>(members[q + CM_WAVES]) * ld + col];
+            const double x2 = E[static_cast<long long>(members[q + 2 * CM_WAVES]) * ld + col];
+            const double x3 = E[static_cast<long long>(members[q + 3 * CM_WAVES]) * ld + col];
+            a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+        }
+        for (; q < s1; q += CM_WAVES) a0 += E[static_cast<long long>(members[q]) * ld + col];
+    }
+    part[w][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (w == 0 && col < p) {
+        double acc = 0.0;
+        for (int q = 0; q < CM_WAVES; ++q) acc += part[q][lane];
+        means[static_cast<long long>(t) * p + col] = acc / static_cast<double>(s1 - s0);
+    }
 }
 
 __global__ void ensemble_mean_kernel(const double *__restrict__ E, long long ldE, int n, int p, int K, double *__restrict__ viE) {
@@ -342,7 +364,8 @@ void cluster_means_dev(const double *d_E, long long ld, int n, int p, const std:
     W.start.upload(start.data(), nC + 1);
     W.members.upload(members.data(), n);
     KernelTimer tm("smetac_centroids");
-    hipLaunchKernelGGL(cluster_means_kernel, dim3(nC, (p + 63) / 64), dim3(64), 0, c.stream, d_E, ld, p, W.start.p, W.members.p, d_means);
+    hipLaunchKernelGGL(cluster_means_kernel, dim3(nC, (p + 63) / 64), dim3(64 * CM_WAVES), 0, c.stream, d_E, ld, p, W.start.p, W.members.p,
+                       d_means);
     launch_check("cluster_means_kernel");
     stream_sync();
 }
