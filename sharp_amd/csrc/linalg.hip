@@ -135,39 +135,24 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
     d2 ra0 = *(gd2p)(ap), ra1 = *(gd2p)(ap + 2);
     d2 rb0 = *(gd2p)(bp), rb1 = *(gd2p)(bp + 2);
     for (int k0 = 0; k0 < Kp; k0 += GK) {
-#ifdef GEMM_ABL_NOFILL
-        if (k0 == 0) {
-#endif
         As[lrow][lcol] = ra0.x; As[lrow][lcol + 1] = ra0.y; As[lrow][lcol + 2] = ra1.x; As[lrow][lcol + 3] = ra1.y;
         Bs[lrow][lcol] = rb0.x; Bs[lrow][lcol + 1] = rb0.y; Bs[lrow][lcol + 2] = rb1.x; Bs[lrow][lcol + 3] = rb1.y;
-#ifdef GEMM_ABL_NOFILL
-        }
-#endif
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is in LDS
         __builtin_amdgcn_s_barrier();
         // next tile (the last iteration re-reads the final tile: unconditional loads keep the waits counted)
         const int kn = k0 + GK < Kp ? k0 + GK : k0;
         gcdp an = ap + static_cast<long long>(kn) * t.lda;
         gcdp bn = bp + static_cast<long long>(kn) * t.ldb;
-#ifndef GEMM_ABL_NOFILL
         ra0 = *(gd2p)(an); ra1 = *(gd2p)(an + 2);
         rb0 = *(gd2p)(bn); rb1 = *(gd2p)(bn + 2);
-#endif
-#ifdef GEMM_ABL_NOLDSREAD
-        double a[4], b[2];
-        for (int i = 0; i < 4; ++i) a[i] = As[lane >> 4][wr + i * 16 + (lane & 15)];
-        for (int j = 0; j < 2; ++j) b[j] = Bs[lane >> 4][wc + j * 16 + (lane & 15)];
-#endif
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
-#ifndef GEMM_ABL_NOLDSREAD
             const int kr = kk + (lane >> 4);
             double a[4], b[2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] = As[kr][wr + i * 16 + (lane & 15)];
 #pragma unroll
             for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wc + j * 16 + (lane & 15)];
-#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -195,14 +180,8 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
                         v = v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v);
                         if (row == col) v = 1.0;
                     }
-#ifndef GEMM_NO_STORE
                     ((gdp)t.C)[static_cast<long long>(row) * t.ldc + col] = v;
-#else
-                    if (v == 123.456) t.C[0] = v;
-#endif
-#ifndef GEMM_NO_MIRROR
                     if (t.symmetric && n0 > m0) ((gdp)t.C)[static_cast<long long>(col) * t.ldc + row] = v;
-#endif
                 }
             }
 }
