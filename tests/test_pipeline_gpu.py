@@ -225,3 +225,21 @@ def test_reference_error_behaviour(sa, oracle):
         sa.SHARP(None)
     with pytest.raises(sa.SharpError, match="LIST"):
         sa.SHARP_unlimited("nope")
+
+
+@pytest.mark.parametrize("trial", range(6))
+def test_randomised_sharp_parity(sa, oracle, trial):
+    """Randomised end-to-end sweep (tools/parity_sweep.py in miniature): random data seed, size class (SHARP_small,
+    SHARP_large, SHARP_large + small-cluster merge), ensemble size, linkage and projector seed; labels bit-identical."""
+    rng = np.random.default_rng(9000 + trial)
+    seed = int(rng.integers(1, 2**31 - 1))
+    lo, hi = [(300, 2000), (5200, 8000), (10001, 16000)][trial % 3]
+    n, m, G = int(rng.integers(lo, hi)), int(rng.integers(1200, 2400)), int(rng.integers(3, 9))
+    K = int(rng.choice([3, 5, 7]))
+    hm = str(rng.choice(["ward.D", "average", "complete", "ward.D2"]))
+    rs = int(rng.integers(1, 5000))
+    X = oracle.synth_fill(seed, m, 0, n, G, max(50, m // (2 * G)))
+    ref = oracle.SHARP(X, K=K, rN_seed=rs, hmethod=hm, nthreads=8)
+    # logflag=False: no testlog (the reference samples its cells with an unseeded RNG), log2 on -- what the oracle runs
+    res = sa.SHARP(X, ensize_K=K, rN_seed=rs, hmethod=hm, forview=False, logflag=False)
+    assert np.array_equal(res["pred_clusters"], ref["pred_clusters"]), (seed, n, m, G, K, hm, rs)

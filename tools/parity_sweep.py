@@ -1,0 +1,35 @@
+"""Randomised label-parity sweep GPU vs oracle (different data seeds, sizes, ensemble sizes, methods)."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import sharp_amd
+from oracle import pyoracle as orc
+
+sharp_amd.init(0)
+orc.build()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+bad = 0
+mixed = len(sys.argv) > 3 and sys.argv[3] == "mixed"      # also SHARP_small sizes and n > 1e4 (small-cluster merge)
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
+    seed = int(rng.integers(1, 2**31 - 1))
+    lo, hi = [(300, 3000), (5200, 9000), (10001, 24000)][int(rng.integers(0, 3))] if mixed else (5200, 9000)
+    n = int(rng.integers(lo, hi))
+    m = int(rng.integers(1500, 3000))
+    G = int(rng.integers(3, 9))
+    K = int(rng.choice([3, 5, 7]))
+    hm = str(rng.choice(["ward.D", "ward.D", "average", "complete", "ward.D2"]))
+    rs = int(rng.integers(1, 5000))
+    X = orc.synth_fill(seed, m, 0, n, G, max(50, m // (2 * G)))
+    t0 = time.time()
+    ref = orc.SHARP(X, K=K, rN_seed=rs, hmethod=hm, nthreads=8)
+    t1 = time.time()
+    res = sharp_amd.SHARP(X, ensize_K=K, rN_seed=rs, hmethod=hm, forview=False, logflag=False)   # logflag=False: skip testlog (unseeded sample in the reference), log2 on, as the oracle does
+    same = np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+    ari = orc.adjusted_rand(res["pred_clusters"], ref["pred_clusters"])["HA"]
+    bad += not same
+    print("trial %d seed=%d n=%d m=%d G=%d K=%d %s rN=%d: identical=%s ARI=%.6f clusters=%d  (oracle %.1fs)"
+          % (trial, seed, n, m, G, K, hm, rs, same, ari, len(set(ref["pred_clusters"].tolist())), t1 - t0), flush=True)
+print("mismatching runs:", bad)
