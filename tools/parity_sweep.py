@@ -12,7 +12,8 @@ sharp_amd.init(0)
 orc.build()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 bad = 0
-mixed = len(sys.argv) > 3 and sys.argv[3] == "mixed"      # also SHARP_small sizes and n > 1e4 (small-cluster merge)
+mixed = len(sys.argv) > 3 and sys.argv[3] in ("mixed", "weak")      # also SHARP_small sizes and n > 1e4 (small-cluster merge)
+weak = len(sys.argv) > 3 and sys.argv[3] == "weak"   # few marker genes: median silhouettes <= 0.35, the CH / height-gap branches decide
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
     seed = int(rng.integers(1, 2**31 - 1))
     lo, hi = [(300, 3000), (5200, 9000), (10001, 24000)][int(rng.integers(0, 3))] if mixed else (5200, 9000)
@@ -22,7 +23,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
     K = int(rng.choice([3, 5, 7]))
     hm = str(rng.choice(["ward.D", "ward.D", "average", "complete", "ward.D2"]))
     rs = int(rng.integers(1, 5000))
-    X = orc.synth_fill(seed, m, 0, n, G, max(50, m // (2 * G)))
+    nmark = int(rng.integers(15, 60)) if weak else max(50, m // (2 * G))
+    X = orc.synth_fill(seed, m, 0, n, G, nmark)
     t0 = time.time()
     ref = orc.SHARP(X, K=K, rN_seed=rs, hmethod=hm, nthreads=8)
     t1 = time.time()
