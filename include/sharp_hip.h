@@ -148,6 +148,22 @@ int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K,
                 double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred,
                 int *n_pred, double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path);
 
+/* Releases the resident fp32 copy of the last host matrix and the pinned staging buffers that sharp_SHARP / sharp_SHARP_csc keep
+ * between calls (the analogue of R's gc() after a SHARP() run; no reference counterpart). */
+int sharp_trim(void);
+
+/* Sparse input: the reference takes whatever `log2(scExp + 1)` and `%*%` accept (R/SHARP.R:343-345,579), which includes the
+ * Matrix package's dgCMatrix -- the usual container of scRNA-seq counts.  colptr = @p (n + 1 ints), rowidx = @i (0-based),
+ * val = @x; canonical CSC (no duplicated entries).  Only the non-zeros cross PCIe; the block is expanded to the same dense fp32
+ * layout on the device, so results are bit-identical to the dense entry points.  sharp_csc_to_dense_dev fills a caller-owned
+ * device block (m x n fp32, column stride ld >= m) for the *_dev entry points. */
+int sharp_csc_to_dense_dev(const int *colptr, const int *rowidx, const double *val, int m, long long n, float *dX, long long ld);
+int sharp_SHARP_csc(const int *colptr, const int *rowidx, const double *val, int m, long long n, int ensize_K, int reduced_ndim,
+                    int base_ncells, int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster,
+                    int minN, int maxN, double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed,
+                    int *pred, int *n_pred, double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used,
+                    int *path);
+
 /* ---- a11: SHARP_unlimited ---------------------------------------------------------- */
 /* R/SHARP_unlimited.R:29-242.  Whole call on one GPU: blocks are device (or host) matrices sharing m
  * genes; p = ceiling(log2(sum ncb)/0.04); shared projectors; per-block SHARP(); cross-block sMetaC on

@@ -230,14 +230,21 @@ def sMetaC(rerowColor, sE1, folds=None, hmethod=None, finalN_cluster=None, minN_
     return {"finalColor": fin, "tf": tf[: nC.value].copy(), "warn": rc}
 
 
+def _is_sparse(x):
+    return hasattr(x, "tocsc") and hasattr(x, "nnz")
+
+
 def testlog(scExp, ncells, p, sncells=100, n_cores=None, cells=None):
     """R/SHARP.R:877-924.  The reference draws the test cells with the unseeded global RNG (:884), so its
     result is not reproducible; pass `cells` (0-based indices) to fix them."""
     sncells = min(sncells, ncells)
     if cells is None:
         cells = np.random.default_rng().permutation(ncells)[:sncells]
-    sE = np.asarray(scExp, np.float64)[:, np.asarray(cells)]
-    pr = ranM(scExp, p, 5)
+    if _is_sparse(scExp):
+        sE = np.asfortranarray(scExp[:, np.asarray(cells)].toarray(), dtype=np.float64)
+    else:
+        sE = np.asarray(scExp, np.float64)[:, np.asarray(cells)]
+    pr = ranM2(scExp.shape[0], p, 5)
     msil = []
     for k in (1, 2):
         E1 = pr.project(sE, logflag=(k == 2))
@@ -261,7 +268,16 @@ def _enresults(pred, x0, viE, ncells, ngenes, p, K, t0, paras, forview, key="N.p
 
 def _run_sharp(X, K, p, base_ncells, partition_ncells, hmethod, N_cluster, enpN, indN, minN, maxN, sil_thre,
                height_Ntimes, flag, rM, rN_seed, forview):
-    X = np.asfortranarray(X, dtype=np.float64)
+    sparse = _is_sparse(X)
+    if sparse:                                                            # dgCMatrix-style input: only the non-zeros are uploaded
+        X = X.tocsc()
+        if X.nnz >= 2**31:
+            raise SharpError("sparse input: more than 2^31 - 1 stored entries (the limit of a dgCMatrix as well)")
+        cp = np.ascontiguousarray(X.indptr, np.int32)
+        ri = np.ascontiguousarray(X.indices, np.int32)
+        xv = np.ascontiguousarray(X.data, np.float64)
+    else:
+        X = np.asfortranarray(X, dtype=np.float64)
     m, n = X.shape
     pred = np.zeros(n, np.int32)
     p_eff = p if p else int(np.ceil(np.log2(n) / 0.04))
@@ -269,7 +285,9 @@ def _run_sharp(X, K, p, base_ncells, partition_ncells, hmethod, N_cluster, enpN,
     capc = max(int(maxN or 0), 40, (n + 4999) // 5000) + 2
     x0 = np.zeros(n * capc) if forview else None
     npred, x0c, pu, Ku, path = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
-    rc = check(lib().sharp_SHARP(_dp(X), m, C.c_longlong(n), C.c_longlong(m), int(K or 0), int(p or 0),
+    entry = ((lib().sharp_SHARP_csc, (_ip(cp), _ip(ri), _dp(xv), m, C.c_longlong(n))) if sparse else
+             (lib().sharp_SHARP, (_dp(X), m, C.c_longlong(n), C.c_longlong(m))))
+    rc = check(entry[0](*entry[1], int(K or 0), int(p or 0),
                                  int(base_ncells or 0), int(partition_ncells or 0), _hmethod(hmethod), int(N_cluster or 0),
                                  int(enpN or 0), int(indN or 0), int(minN or 0), int(maxN or 0),
                                  C.c_double(-1.0 if sil_thre is None else sil_thre),
@@ -293,7 +311,14 @@ def SHARP(scExp, exp_type=None, ensize_K=None, reduced_ndim=None, base_ncells=No
     if scExp is None:
         raise SharpError("No expression data is provided!")
     _lib.ensure_init()
-    X = np.array(scExp, dtype=np.float64, copy=True)
+    sparse = _is_sparse(scExp)
+    if sparse:                                                            # scipy.sparse stands in for the Matrix package's dgCMatrix
+        X = scExp.tocsc().astype(np.float64)
+        if not X.has_canonical_format:
+            X = X.copy()
+            X.sum_duplicates()
+    else:
+        X = np.asarray(scExp, dtype=np.float64)                           # never modified in place (8 GB at cfg2)
     ngenes, ncells = X.shape
     if prep is None:
         prep = ncells < 1e4                                               # :74-80
@@ -302,13 +327,24 @@ def SHARP(scExp, exp_type=None, ensize_K=None, reduced_ndim=None, base_ncells=No
         if first.size < len(gene_names):
             warnings.warn(f"{len(gene_names) - first.size} duplicated genes are found and then are removed!")
             X = X[np.sort(first)]
-    if prep:                                                              # :99-106
+    if prep and sparse:                                                   # :99-106 on the stored entries
+        if (X.data < 0).any():
+            warnings.warn("Your expression matrix contain negative values! SHARP will replace negative values with 0!")
+            X = X.copy()
+            X.data[X.data < 0] = 0.0
+        X = X[np.asarray(X.sum(1)).ravel() != 0]
+    elif prep:
         if (X < 0).any():
             warnings.warn("Your expression matrix contain negative values! SHARP will replace negative values with 0!")
-            X[X < 0] = 0
+            X = np.where(X < 0, 0.0, X)
         X = X[X.sum(1) != 0]
     if exp_type is not None and exp_type not in ("CPM", "TPM"):           # :110-114
-        X = X / X.sum(0, keepdims=True) * 1e6
+        if sparse:
+            X = X.tocsc(copy=True)
+            colsum = np.asarray(X.sum(0)).ravel()
+            X.data = X.data / np.repeat(colsum, np.diff(X.indptr)) * 1e6
+        else:
+            X = X / X.sum(0, keepdims=True) * 1e6
     if rN_seed is not None:                                               # :169-179
         if not isinstance(rN_seed, (int, float, np.integer, np.floating)):
             raise SharpError("The rN.seed should be a numeric!")

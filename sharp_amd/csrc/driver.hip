@@ -12,6 +12,8 @@
 #include <cstring>
 #include <numeric>
 #include <random>
+#include <thread>
+#include <vector>
 
 #include "meta.hpp"
 #include "projector.hpp"
@@ -101,6 +103,24 @@ __global__ void round1_kernel(double *__restrict__ E, long long count) {
 }
 
 inline int colour_of(int j) { return j > 40 ? ((j - 1) % 40) + 1 : j; }   // R/getrowColor.R:59-68
+
+// dgCMatrix slab -> dense fp32 block: one wave per cell scatters the cell's (row index, value) pairs into its zeroed column.
+// Out-of-range row indices are counted, never written.
+__global__ void csc_expand_kernel(const long long *__restrict__ colptr, const int *__restrict__ rowidx, const float *__restrict__ val,
+                                  long long e_base, long long ncell, int m, float *__restrict__ dX, long long ld, int *__restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x) >> 6;
+    const long long nwave = (static_cast<long long>(gridDim.x) * blockDim.x) >> 6;
+    for (long long c = wave; c < ncell; c += nwave) {
+        const long long e0 = colptr[c] - e_base, e1 = colptr[c + 1] - e_base;
+        float *col = dX + c * ld;
+        for (long long e = e0 + lane; e < e1; e += 64) {
+            const int g = rowidx[e];
+            if (g >= 0 && g < m) col[g] = val[e];
+            else atomicAdd(bad, 1);
+        }
+    }
+}
 
 __global__ void gather_rows_kernel(const double *__restrict__ src, const int *__restrict__ row_of, long long n, int p, double *__restrict__ dst) {
     const long long tot = n * p;
@@ -407,14 +427,144 @@ using namespace sharp;
 
 namespace {
 
+// Host matrix (fp64, genes x cells, column-major: what R hands to .C()) -> fp32 block in HBM.  The caller's memory is
+// pageable, so the block is cut into slabs of cells: host threads narrow a slab into one of two pinned staging buffers while the
+// previous slab's DMA is in flight (PCIe carries 4 B per value instead of 8; the narrowing runs at host memory bandwidth).
+struct UploadStage {
+    float *pinned[2] = {nullptr, nullptr};
+    size_t cap = 0;                       // floats per staging buffer
+    hipEvent_t done[2] = {nullptr, nullptr};
+    void ensure(size_t count) {
+        if (count <= cap) return;
+        for (int q = 0; q < 2; ++q) {
+            if (pinned[q]) (void)hipHostFree(pinned[q]);
+            SHARP_HIP_CHECK(hipHostMalloc((void **)&pinned[q], count * sizeof(float), hipHostMallocDefault));
+            if (!done[q]) SHARP_HIP_CHECK(hipEventCreateWithFlags(&done[q], hipEventDisableTiming));
+        }
+        cap = count;
+    }
+};
+UploadStage &upload_stage() { static UploadStage u; return u; }
+// The resident copy of a host matrix is kept between calls like every other workspace (freshly allocated HBM costs ≈ 30 ms per GB
+// at first touch; run_Mtimes_SHARP and testlog + SHARP call in on the same matrix again and again).
+DevBuf<float> &host_block() { static DevBuf<float> b; return b; }
+
 void upload_as_float(const double *X, int m, long long n, long long ld, DevBuf<float> &dX, long long &ldd) {
     ldd = (static_cast<long long>(m) + 3) / 4 * 4;
-    std::vector<float> h(static_cast<size_t>(ldd) * n, 0.0f);
-    for (long long c = 0; c < n; ++c)
-        for (int g = 0; g < m; ++g) h[c * ldd + g] = static_cast<float>(X[c * ld + g]);
-    dX.alloc(h.size());
-    dX.upload(h.data(), h.size());
+    {
+        HostTimer ht("upload_alloc");
+        dX.ensure(static_cast<size_t>(ldd) * n);
+    }
+    if (n <= 0) return;
+    HostTimer ht("upload_narrow_and_copy");
+    const size_t slab_floats = static_cast<size_t>(32) << 20;                         // 128 MB per staging buffer
+    const long long slab = std::max<long long>(1, std::min<long long>(n, static_cast<long long>(slab_floats / ldd)));
+    UploadStage &U = upload_stage();
+    U.ensure(static_cast<size_t>(slab) * ldd);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("SHARP_UPLOAD_THREADS")) hw = static_cast<unsigned>(std::max(1, atoi(e)));
+    const int nthr = static_cast<int>(std::max(1u, std::min(hw ? hw : 4u, 32u)));
+    hipStream_t s = ctx().stream;
+    int q = 0;
+    bool used[2] = {false, false};
+    for (long long c0 = 0; c0 < n; c0 += slab, q ^= 1) {
+        const long long nc = std::min(slab, n - c0);
+        if (used[q]) SHARP_HIP_CHECK(hipEventSynchronize(U.done[q]));                  // the DMA that last read this buffer
+        float *dst = U.pinned[q];
+        auto narrow = [&](int t) {
+            const long long a = nc * t / nthr, b = nc * (t + 1) / nthr;
+            for (long long c = a; c < b; ++c) {
+                const double *src = X + (c0 + c) * ld;
+                float *d = dst + c * ldd;
+                for (int g = 0; g < m; ++g) d[g] = static_cast<float>(src[g]);
+                for (long long g = m; g < ldd; ++g) d[g] = 0.0f;
+            }
+        };
+        if (nthr == 1 || nc < nthr) { for (int t = 0; t < nthr; ++t) narrow(t); }
+        else {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nthr; ++t) th.emplace_back(narrow, t);
+            narrow(0);
+            for (auto &x : th) x.join();
+        }
+        SHARP_HIP_CHECK(hipMemcpyAsync(dX.p + c0 * ldd, dst, static_cast<size_t>(nc) * ldd * sizeof(float), hipMemcpyHostToDevice, s));
+        SHARP_HIP_CHECK(hipEventRecord(U.done[q], s));
+        used[q] = true;
+    }
     stream_sync();
+}
+
+// Compressed sparse column input (R's dgCMatrix: @p column pointers, @i 0-based row indices, @x values; canonical form, no
+// duplicated entries) -> the same dense fp32 block in HBM that the dense entry points build, so everything downstream is unchanged.
+// Only the non-zeros cross PCIe (8 B each: int32 index + fp32 value), slab by slab through the pinned staging buffers.
+void upload_csc_as_float(const int *colptr, const int *rowidx, const double *val, int m, long long n, float *dX, long long ldd) {
+    if (n <= 0) return;
+    if (!colptr || (!rowidx && colptr[n] > 0) || (!val && colptr[n] > 0)) throw Error(SHARP_ERR_ARG, "sparse input: null pointer");
+    if (colptr[0] < 0) throw Error(SHARP_ERR_ARG, "sparse input: negative column pointer");
+    for (long long c = 0; c < n; ++c)
+        if (colptr[c + 1] < colptr[c]) throw Error(SHARP_ERR_ARG, "sparse input: column pointers must be non-decreasing");
+    HostTimer ht("upload_csc");
+    Ctx &cx = ctx();
+    hipStream_t s = cx.stream;
+    SHARP_HIP_CHECK(hipMemsetAsync(dX, 0, static_cast<size_t>(ldd) * n * sizeof(float), s));
+    std::vector<long long> cp(static_cast<size_t>(n) + 1);
+    for (long long c = 0; c <= n; ++c) cp[c] = colptr[c];
+    DevBuf<long long> dcp(cp.size());
+    dcp.upload(cp.data(), cp.size());
+    DevBuf<int> dbad(1);
+    dbad.zero();
+    const long long slab_e = 16LL << 20;                                   // entries per slab: 64 MB of indices + 64 MB of values
+    UploadStage &U = upload_stage();
+    U.ensure(static_cast<size_t>(slab_e) * 2);                             // [indices | values] share one staging buffer
+    DevBuf<int> didx[2];
+    DevBuf<float> dval[2];
+    for (int k = 0; k < 2; ++k) { const size_t cap = static_cast<size_t>(std::max<long long>(1, std::min<long long>(slab_e, cp[n] - cp[0]))); didx[k].alloc(cap); dval[k].alloc(cap); }
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("SHARP_UPLOAD_THREADS")) hw = static_cast<unsigned>(std::max(1, atoi(e)));
+    const int nthr = static_cast<int>(std::max(1u, std::min(hw ? hw : 4u, 32u)));
+    int q = 0;
+    bool used[2] = {false, false};
+    long long c0 = 0;
+    while (c0 < n) {
+        // whole cells per slab; a single cell never exceeds m <= 2^31 entries but may exceed the slab: grow the slab for it
+        long long c1 = c0;
+        const long long e0 = cp[c0];
+        while (c1 < n && cp[c1 + 1] - e0 <= slab_e) ++c1;
+        if (c1 == c0) { c1 = c0 + 1; U.ensure(static_cast<size_t>(cp[c1] - e0) * 2); for (int k = 0; k < 2; ++k) used[k] = false; SHARP_HIP_CHECK(hipStreamSynchronize(s)); }
+        const long long ne = cp[c1] - e0;
+        if (ne > 0) {
+            if (used[q]) SHARP_HIP_CHECK(hipEventSynchronize(U.done[q]));
+            int *hi = reinterpret_cast<int *>(U.pinned[q]);
+            float *hv = U.pinned[q] + ne;
+            auto pack = [&](int t) {
+                const long long a = ne * t / nthr, b = ne * (t + 1) / nthr;
+                std::memcpy(hi + a, rowidx + e0 + a, static_cast<size_t>(b - a) * sizeof(int));
+                for (long long e = a; e < b; ++e) hv[e] = static_cast<float>(val[e0 + e]);
+            };
+            if (nthr == 1 || ne < (1 << 16)) { for (int t = 0; t < nthr; ++t) pack(t); }
+            else {
+                std::vector<std::thread> th;
+                for (int t = 1; t < nthr; ++t) th.emplace_back(pack, t);
+                pack(0);
+                for (auto &x : th) x.join();
+            }
+            didx[q].ensure(static_cast<size_t>(ne)); dval[q].ensure(static_cast<size_t>(ne));
+            SHARP_HIP_CHECK(hipMemcpyAsync(didx[q].p, hi, static_cast<size_t>(ne) * sizeof(int), hipMemcpyHostToDevice, s));
+            SHARP_HIP_CHECK(hipMemcpyAsync(dval[q].p, hv, static_cast<size_t>(ne) * sizeof(float), hipMemcpyHostToDevice, s));
+            SHARP_HIP_CHECK(hipEventRecord(U.done[q], s));
+            used[q] = true;
+            const long long ncell = c1 - c0;
+            const int blocks = static_cast<int>(std::min<long long>((ncell + 3) / 4, static_cast<long long>(cx.num_cu) * 16));
+            hipLaunchKernelGGL(csc_expand_kernel, dim3(blocks), dim3(256), 0, s, dcp.p + c0, didx[q].p, dval[q].p, e0, ncell, m,
+                               dX + c0 * ldd, ldd, dbad.p);
+            launch_check("csc_expand_kernel");
+            q ^= 1;
+        }
+        c0 = c1;
+    }
+    int bad = 0;
+    dbad.download(&bad, 1);                                                 // also drains the stream: staging and slabs are free again
+    if (bad) throw Error(SHARP_ERR_ARG, "sparse input: row index outside [0, genes)");
 }
 
 }  // namespace
@@ -458,12 +608,54 @@ int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K,
                 int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
                 double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred, int *n_pred,
                 double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path) {
-    DevBuf<float> dX;
+    DevBuf<float> &dX = host_block();
     long long ldd = 0;
     try {
         ctx();
         if (!X || ld < m || n < 1) throw sharp::Error(SHARP_ERR_ARG, "No expression data is provided!");
         upload_as_float(X, m, n, ld, dX, ldd);
+    }
+    catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
+    catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
+    return sharp_SHARP_dev(dX.p, m, n, ldd, ensize_K, reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
+                           indN_cluster, minN, maxN, sil_thre, height_Ntimes, log_flag, projector, rN_seed, pred, n_pred, viE, x0,
+                           x0_cap_cols, x0_cols, p_used, K_used, path);
+}
+
+/* Gives back what the host-matrix entry points keep between calls: the resident fp32 copy of the last host matrix and the pinned
+ * staging buffers.  The next call simply allocates them again. */
+int sharp_trim(void) {
+    SHARP_API_BEGIN
+    ctx();
+    stream_sync();
+    host_block().release();
+    UploadStage &U = upload_stage();
+    for (int q = 0; q < 2; ++q) if (U.pinned[q]) { (void)hipHostFree(U.pinned[q]); U.pinned[q] = nullptr; }
+    U.cap = 0;
+    SHARP_API_END
+}
+
+/* dgCMatrix entry points (colptr: n+1 ints, rowidx: 0-based, val: fp64; canonical CSC).  sharp_csc_to_dense_dev fills a caller-owned
+ * device block (m x n fp32, column stride ld >= m) that every *_dev entry point then accepts. */
+int sharp_csc_to_dense_dev(const int *colptr, const int *rowidx, const double *val, int m, long long n, float *dX, long long ld) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(dX && ld >= m && m > 0 && n >= 0, "sharp_csc_to_dense_dev: bad block");
+    upload_csc_as_float(colptr, rowidx, val, m, n, dX, ld);
+    SHARP_API_END
+}
+
+int sharp_SHARP_csc(const int *colptr, const int *rowidx, const double *val, int m, long long n, int ensize_K, int reduced_ndim,
+                    int base_ncells, int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN,
+                    int maxN, double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred,
+                    int *n_pred, double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path) {
+    DevBuf<float> &dX = host_block();
+    const long long ldd = (static_cast<long long>(m) + 3) / 4 * 4;
+    try {
+        ctx();
+        if (m <= 0 || n <= 0) throw sharp::Error(SHARP_ERR_ARG, "No expression data is provided!");
+        dX.ensure(static_cast<size_t>(ldd) * n);
+        upload_csc_as_float(colptr, rowidx, val, m, n, dX.p, ldd);
     }
     catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
     catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }

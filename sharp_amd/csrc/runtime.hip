@@ -31,7 +31,12 @@ hipEvent_t Ctx::get_event() {
 hipStream_t Ctx::aux_stream(int i) {
     while (static_cast<int>(aux.size()) <= i) {
         hipStream_t s;
-        SHARP_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        // Streams of one priority share a small pool of hardware queues, dealt out by whatever else the process has created (after
+        // a torch device-to-host copy, two "concurrent" ranges were measured running back to back: 110 ms per step instead of 83).
+        // Streams of different priorities never share a queue, so neighbouring ranges alternate between the two classes.
+        int lo = 0, hi = 0;
+        SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        SHARP_HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, (aux.size() & 1) ? hi : 0));
         aux.push_back(s);
     }
     return aux[i];
@@ -125,7 +130,13 @@ int sharp_init(int device) {
     for (hipStream_t s : c.aux) (void)hipStreamDestroy(s);
     c.aux.clear();
     SHARP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    SHARP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
+    {   // the second stream of the RP stage: its own priority class, hence its own hardware queue (see aux_stream)
+        int lo = 0, hi = 0;
+        SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        int pr = hi;
+        if (const char *e = getenv("SHARP_STREAM2_PRIO")) pr = e[0] == 'l' ? lo : e[0] == 'n' ? 0 : hi;   // tuning knob: low / normal / high
+        SHARP_HIP_CHECK(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, pr));
+    }
     c.device = device;
     c.num_cu = prop.multiProcessorCount;
     c.lds_per_block = prop.sharedMemPerBlock;

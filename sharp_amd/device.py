@@ -33,6 +33,28 @@ def synth_labels(seed, cell0, ncell, G=12):
     return out
 
 
+def csc_to_dev(sp):
+    """scipy.sparse (genes x cells; stands in for R's dgCMatrix) -> resident (cells, genes) float32 cuda tensor.  Only the non-zeros
+    cross PCIe; the dense block is built on the device (sharp_csc_to_dense_dev)."""
+    import torch
+
+    _lib.ensure_init()
+    sp = sp.tocsc()
+    if not sp.has_canonical_format:
+        sp = sp.copy()
+        sp.sum_duplicates()
+    m, n = sp.shape
+    if sp.nnz >= 2**31:
+        raise ValueError("sparse input: more than 2^31 - 1 stored entries")
+    dX = torch.empty((n, m), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    cp = np.ascontiguousarray(sp.indptr, np.int32)
+    ri = np.ascontiguousarray(sp.indices, np.int32)
+    xv = np.ascontiguousarray(sp.data, np.float64)
+    check(lib().sharp_csc_to_dense_dev(_ip(cp), _ip(ri), _dp(xv), m, C.c_longlong(n), C.c_void_p(dX.data_ptr()), C.c_longlong(m)))
+    return dX
+
+
 def SHARP_dev(dX, ensize_K=0, reduced_ndim=0, base_ncells=0, partition_ncells=0, hmethod=1, N_cluster=0, enpN_cluster=0,
               indN_cluster=0, minN_cluster=0, maxN_cluster=0, sil_thre=-1.0, height_Ntimes=0.0, flag=True, projector=0,
               rN_seed=0.5):
