@@ -25,13 +25,14 @@ def _gather_tables(means_list, counts_list, p, group=None, device="cpu"):
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    active = dist.is_initialized()          # a world of ONE still runs the collectives: the RCCL path is then exercised on a 1-GPU box
+    world = dist.get_world_size(group) if active else 1
     local_rows = sum(m.shape[0] for m in means_list)
     nblocks_local = len(means_list)
     # header: number of local blocks and rows of each, padded to a fixed size negotiated by one all-reduce
     sizes = torch.tensor([nblocks_local, local_rows], dtype=torch.int64, device=device)
     mx = sizes.clone()
-    if world > 1:
+    if active:
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
     max_blocks, max_rows = int(mx[0]), int(mx[1])
     hdr = torch.zeros(1 + max_blocks, dtype=torch.int64, device=device)
@@ -44,7 +45,7 @@ def _gather_tables(means_list, counts_list, p, group=None, device="cpu"):
         cc = np.concatenate(counts_list, 0).astype(np.float64)     # exact below 2^53
         payload[:local_rows, :p] = torch.from_numpy(mm).to(device)
         payload[:local_rows, p] = torch.from_numpy(cc).to(device)
-    if world > 1:
+    if active:
         hdrs = [torch.zeros_like(hdr) for _ in range(world)]
         pls = [torch.zeros_like(payload) for _ in range(world)]
         dist.all_gather(hdrs, hdr, group=group)

@@ -1,0 +1,53 @@
+"""The N > 1 path on the GPU box: (1) the sharded SHARP_unlimited driver with its collectives running through RCCL (a world of one
+rank: a 1-GPU box cannot host two RCCL ranks) equals the single-call library result; (2) `bench.py --gpus 2` end to end, two ranks
+sharing the GPU over gloo (the bench's test hook), prints one well-formed JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
+def test_sharded_unlimited_through_rccl_world_of_one(tmp_path, oracle):
+    out = str(tmp_path / "rccl.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_worker.py"), _free_port(), out], env=env, timeout=900,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    z = np.load(out)
+    assert float(z["allreduce"]) == 1.0
+    seed, m, nb, nblocks, K = 20261003, 1500, 5200, 3, 3
+    blocks = [oracle.synth_fill(seed, m, b * nb, nb, 5, 250) for b in range(nblocks)]
+    ref = oracle.SHARP_unlimited(blocks, K=K, rN_seed=2103, nthreads=8)
+    assert int(z["p"]) == ref["p"]
+    assert np.array_equal(z["pred"], ref["pred_clusters"])
+
+
+def test_bench_two_ranks_sharing_the_gpu(tmp_path):
+    env = dict(os.environ, SHARP_BENCH_SHARE_GPU="1", SHARP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--cells", "6000"]          # default 20 000 genes: the planted marker programmes need them
+    r = subprocess.run(cmd, env=env, timeout=900, capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                         # rank 0 only, ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "cells/s"
+    assert d["value"] == pytest.approx(2 * 6000 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-3)   # whole-job cells / max-over-ranks time
+    assert d["config"]["workload"].startswith("SHARP_unlimited, 2 blocks")
+    assert d["ari_vs_planted_truth"] > 0.9
