@@ -238,6 +238,7 @@ __global__ __launch_bounds__(HC_THREADS) void hclust_kernel(const HcMeta *__rest
 // D is left untouched; the rounds ping-pong between two scratch matrices.
 // ---------------------------------------------------------------------------------------------
 constexpr int HR_MAXN = 4096;
+constexpr size_t HR_LDS_CU = 160 * 1024;     // LDS of a gfx950 compute unit
 constexpr uint16_t HR_NONE = 0xffffu;
 
 struct HrBest { double v; int i; int tie; };
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                                                                 int *__restrict__ ia_all, int *__restrict__ ib_all,
                                                                 double *__restrict__ h_all, int *__restrict__ status,
                                                                 unsigned char *__restrict__ images, long long image_stride,
-                                                                int lds_bytes, int round, int *__restrict__ remaining) {
+                                                                int lds_bytes, int round, int *__restrict__ remaining, int lds_launch) {
     const HcMeta M = metas[blockIdx.x];
     const int n = M.n, nld = M.nld, method = M.method;
     const double *D = Dall + M.oD;
@@ -309,11 +310,15 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     uint16_t *oldidx = pseq + nal;                             // [nal]     new index -> old index
     uint16_t *newidx = oldidx + nal;                           // [nal]     old index -> new index (survivors)
     uint16_t *plist = newidx + nal;                            // [nal]     first members of the pairs
-    uint16_t *srow = plist + nal;                              // [nal]     new indices of the rows of unmerged clusters
-    int *ctl = reinterpret_cast<int *>(srow + nal);            // [16]: 0 npairs, 1 abort, 2/3 work counters (plain / merged rows), 4 nsingle,
+    uint16_t *colmap = plist + nal;                            // [nal]     old column -> new column, or 0x8000 | (2 rank + member) for the two members of a pair
+    int *ctl = reinterpret_cast<int *>(colmap + nal);            // [16]: 0 npairs, 1 abort, 2/3 work counters (plain / merged rows), 4 nsingle,
                                                                 //       5 cur, 6 na, 7 done, 8 src + 1, 9 nb, 10 state, 11 pending  (5..11: MODE 1/2)
     int *wsum = ctl + 16;                                       // [nwave + 1]
     unsigned char *tie = reinterpret_cast<unsigned char *>(wsum + nwave + 1);   // [nal]
+    // what is left of the workgroup's LDS stages the pair members' entries of the rows being copied (see the rebuild below)
+    const int stage_off = static_cast<int>((tie + nal - sm + 15) & ~static_cast<long>(15));
+    double *stage = reinterpret_cast<double *>(sm + stage_off);
+    const int stage_pairs = lds_launch > stage_off ? (lds_launch - stage_off) / (nwave * 32) : 0;   // 2 rows x 2 members x 8 B per pair and wave
 
     int cur = 0, na = n, done = 0;
     int src = -1;                                               // -1: D (pristine), else scratch index
@@ -384,6 +389,9 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         for (int a = tid; a < na; a += HR_THREADS) {
             partner[a] = HR_NONE;
             if (tie[a]) ctl[1] = 1;
+#ifdef HR_ROUNDS
+            if (tie[a] && blockIdx.x == 0) printf("tie at row %d of %d (done %d): nn %d dnn %.17g\n", a, na, done, (int)nn[a], dnn[a]);
+#endif
         }
         __syncthreads();
         for (int a = tid; a < na; a += HR_THREADS) {
@@ -419,12 +427,16 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
             ia[done + rank] = ida + 1; ib[done + rank] = ib_ + 1;
             crit[done + rank] = h;                               // squared for ward.D2 until the final pass
         }
-        // (3) survivors: everything but the second member of a pair; new index = rank among survivors
+        // (3) new indices: the unmerged clusters keep their relative order in [0, ns), the merged clusters follow in rank order in
+        // [ns, nb).  Every new row is then written as two dense runs of stores.  (With the merged clusters left in place, each
+        // plain row was stored with a hole per merged column, filled later by a scattered 8-byte store: partial-line writes that
+        // cost the HBM 57 % more reads and 34 % more writes than the algorithm needs -- FETCH_SIZE / WRITE_SIZE)
+        // Exact ties abandon the task, so the order of the columns decides nothing.
         {
             const int chunk = (na + HR_THREADS - 1) / HR_THREADS;
             const int lo = tid * chunk, hi = lo + chunk < na ? lo + chunk : na;
             int c = 0;
-            for (int a = lo; a < hi; ++a) c += (partner[a] == HR_NONE || partner[a] > a) ? 1 : 0;
+            for (int a = lo; a < hi; ++a) c += partner[a] == HR_NONE ? 1 : 0;
             int incl = c;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); incl += lane >= d ? t : 0; }
@@ -434,19 +446,19 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
             __syncthreads();
             int pos = wsum[wave] + incl - c;
             for (int a = lo; a < hi; ++a)
-                if (partner[a] == HR_NONE || partner[a] > a) {   // bit 15 of oldidx: the survivor is a merged cluster
-                    newidx[a] = static_cast<uint16_t>(pos);
-                    oldidx[pos++] = static_cast<uint16_t>(a | (partner[a] == HR_NONE ? 0 : 0x8000));
-                }
+                if (partner[a] == HR_NONE) { newidx[a] = static_cast<uint16_t>(pos); colmap[a] = static_cast<uint16_t>(pos); oldidx[pos++] = static_cast<uint16_t>(a); }
+            ns = wsum[nwave];                                   // rows of unmerged clusters (= na - 2 np)
+            for (int q = tid; q < np; q += HR_THREADS) {        // bit 15 of oldidx: the survivor is a merged cluster
+                const int a = plist[q], B = ns + pseq[a];
+                newidx[a] = static_cast<uint16_t>(B);
+                oldidx[B] = static_cast<uint16_t>(a | 0x8000);
+                colmap[a] = static_cast<uint16_t>(0x8000 | (2 * pseq[a]));
+                colmap[partner[a]] = static_cast<uint16_t>(0x8000 | (2 * pseq[a] + 1));
+            }
         }
+        nb = ns + np;
+        if (tid == 0) { ctl[2] = 0; ctl[3] = 0; ctl[4] = ns; }
         __syncthreads();
-        nb = wsum[nwave];                                       // = na - np
-        if (tid == 0) { ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; }
-        __syncthreads();
-        for (int A = tid; A < nb; A += HR_THREADS)
-            if (!(oldidx[A] & 0x8000)) srow[atomicAdd(&ctl[4], 1)] = static_cast<uint16_t>(A);
-        __syncthreads();
-        ns = ctl[4];                                            // rows of unmerged clusters (= nb - np)
         }   // MODE != 2
         if (MODE == 1) {                                        // hand the round over to the rebuild launch
             __syncthreads();
@@ -478,27 +490,27 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                 else if (v == best.v && B != best.i) best.tie = 1;
             };
             if (!am) {
-                for (int B0 = lane; B0 < nb; B0 += 64 * 8) {
+                for (int B0 = lane; B0 < ns; B0 += 64 * 8) {   // columns of unmerged clusters
                     int bb[8];
                     double x[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int B = B0 + 64 * u;
-                        bb[u] = oldidx[B < nb ? B : nb - 1] & 0x7fff;
+                        bb[u] = oldidx[B < ns ? B : ns - 1];
                         x[u] = ra[bb[u]];
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int B = B0 + 64 * u;
-                        if (B < nb && partner[bb[u]] == HR_NONE) {
+                        if (B < ns) {
                             const double v = B == A ? HC_INF : (sq ? x[u] * x[u] : x[u]);   // scratch diagonals hold +inf: no test in later rounds
                             wr[B] = v;
                             if (B != A) consider(v, B);
                         }
                     }
                 }
-                for (int q = lane; q < np; q += 64) {           // merged columns: d(a, k u l) from d(a,k), d(a,l)
-                    const int k1 = plist[q], l1 = partner[k1], B = newidx[k1];
+                for (int B = ns + lane; B < nb; B += 64) {      // merged columns: d(a, k u l) from d(a,k), d(a,l)
+                    const int k1 = oldidx[B] & 0x7fff, l1 = partner[k1];
                     double d1 = ra[k1], d2 = ra[l1];
                     if (sq) { d1 *= d1; d2 *= d2; }
                     const double v = lance_williams(method, d1, d2, dnn[k1], static_cast<double>(csz[k1]), static_cast<double>(csz[l1]), na_);
@@ -569,6 +581,102 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
             if (lane == 1) { nnW[A] = static_cast<uint16_t>(best.i < nb ? best.i : 0); }
             if (lane == 2) { tieW[A] = static_cast<unsigned char>(nb > 2 ? best.tie : 0); }
         };
+#ifdef HR_NO_FIRST_STAGE
+        const int stage_rows = src < 0 ? 0 : (np == 0 ? 2 : std::min(2, 2 * stage_pairs / np));
+#else
+        const int stage_rows = np == 0 ? 2 : std::min(2, 2 * stage_pairs / np);   // rows per wave whose pair entries fit the stage
+#endif
+        // Plain rows, staged form.  The old rows are read ONCE, contiguously (the gathered forms further down skip the pair members'
+        // entries and come back for them after the sweep, by which time the lines have left the L2: the L2's request-size counters
+        // showed every row fetched twice, 12.1 n^2 entries per task instead of 6.05).  An entry of an unmerged column goes straight
+        // to its new column (a dense run of stores per instruction); an entry of a pair member is parked in this wave's LDS stage,
+        // from where the Lance-Williams loop takes it.  NR = 2 rows per wave when the stage holds the round's pairs twice, else 1.
+        // FIRST: the source is the pristine matrix (real diagonal; squared on the fly for ward.D2).
+        auto staged = [&](auto NR_, auto FIRST_, int A0) {
+            constexpr int NR = decltype(NR_)::value;
+            constexpr bool FIRST = decltype(FIRST_)::value;
+            const double *r[NR];
+            double *w[NR], *stg[NR];
+            double mn[NR], sc[NR];
+            int ix[NR], ao[NR];
+#pragma unroll
+            for (int t = 0; t < NR; ++t) {
+                ao[t] = __builtin_amdgcn_readfirstlane(oldidx[A0 + t] & 0x7fff);
+                r[t] = Dsrc + static_cast<long long>(ao[t]) * nld;
+                w[t] = Ddst + static_cast<long long>(A0 + t) * nld;
+                stg[t] = stage + (static_cast<size_t>(wave) * stage_rows + t) * 2 * np;   // a wave's region does not depend on NR (odd last row)
+                mn[t] = HC_INF; sc[t] = HC_INF; ix[t] = 0x7fffffff;
+            }
+            auto upd = [](double &m_, double &s_, int &i_, double v, int B) {
+                s_ = fmin(s_, fmax(m_, v));
+                if (v < m_) { m_ = v; i_ = B; }
+            };
+            int j0 = lane;
+            auto pass = [&](auto U_) {
+                constexpr int U = decltype(U_)::value;
+                for (; j0 + 64 * (U - 1) < na; j0 += 64 * U) {
+                    unsigned cm[U];
+                    double x[NR][U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) cm[u] = colmap[j0 + 64 * u];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int t = 0; t < NR; ++t) x[t][u] = r[t][j0 + 64 * u];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (cm[u] & 0x8000u) {
+#pragma unroll
+                            for (int t = 0; t < NR; ++t) stg[t][cm[u] & 0x7fffu] = (FIRST && sq) ? x[t][u] * x[t][u] : x[t][u];
+                        } else {
+                            const int B = static_cast<int>(cm[u]);
+#pragma unroll
+                            for (int t = 0; t < NR; ++t) {
+                                double v = x[t][u];
+                                if (FIRST) v = B == A0 + t ? HC_INF : (sq ? v * v : v);   // scratch diagonals hold +inf: no test in later rounds
+                                w[t][B] = v;
+                                upd(mn[t], sc[t], ix[t], v, B);
+                            }
+                        }
+                    }
+                    if (U == 1) break;
+                }
+            };
+            pass(std::integral_constant<int, 16>());
+            pass(std::integral_constant<int, 8>());
+            pass(std::integral_constant<int, 4>());
+            pass(std::integral_constant<int, 2>());
+            pass(std::integral_constant<int, 1>());
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double nr_[NR];
+#pragma unroll
+            for (int t = 0; t < NR; ++t) nr_[t] = csz[ao[t]];
+            for (int B = ns + lane; B < nb; B += 64) {          // merged columns: d(a, k u l) from d(a,k), d(a,l)
+                const int rk = B - ns;
+                const int k1 = oldidx[B] & 0x7fff, l1 = partner[k1];
+                const double nk_ = csz[k1], nl_ = csz[l1], hQ = dnn[k1];
+#pragma unroll
+                for (int t = 0; t < NR; ++t) {
+                    const double v = lance_williams(method, stg[t][2 * rk], stg[t][2 * rk + 1], hQ, nk_, nl_, nr_[t]);
+                    w[t][B] = v;
+                    sc[t] = fmin(sc[t], fmax(mn[t], v));
+                    if (v < mn[t] || (v == mn[t] && B < ix[t])) { mn[t] = v; ix[t] = B; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                     // the stage is reused by this wave's next rows
+#pragma unroll
+            for (int t = 0; t < NR; ++t) {
+                HrBest g;
+                g.v = mn[t]; g.i = ix[t]; g.tie = 0;
+                g = hr_wave(g);
+                g.tie |= __ballot(sc[t] == g.v) != 0ull ? 1 : 0; // a lane saw the minimum twice
+                if (lane == 0) { cidN[A0 + t] = cid[ao[t]]; cszN[A0 + t] = csz[ao[t]]; dnnN[A0 + t] = g.v; }
+                if (lane == 1) { nnW[A0 + t] = static_cast<uint16_t>(g.i < nb ? g.i : 0); }
+                if (lane == 2) { tieW[A0 + t] = static_cast<unsigned char>(nb > 2 ? g.tie : 0); }
+            }
+        };
         // work is handed out dynamically (the rows of merged clusters cost about twice a pair of plain rows, and a static
         // split left a quarter of the phase waiting at the barrier): merged rows first, then plain rows two at a time
         for (;;) {
@@ -584,14 +692,28 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
             hr_slow += __builtin_readcyclecounter() - q0;
 #endif
         }
+        if (stage_rows > 0) {
+            const int step = stage_rows;
+            for (;;) {
+                int q = 0;
+                if (lane == 0) q = atomicAdd(wctl + 2, step);
+                q = __builtin_amdgcn_readfirstlane(q);
+                if (q >= ns) break;
+                const bool two = step == 2 && q + 1 < ns;
+                if (src < 0) { if (two) staged(std::integral_constant<int, 2>(), std::true_type(), q); else staged(std::integral_constant<int, 1>(), std::true_type(), q); }
+                else         { if (two) staged(std::integral_constant<int, 2>(), std::false_type(), q); else staged(std::integral_constant<int, 1>(), std::false_type(), q); }
+            }
+        }
+        // the gathered forms: rounds whose pairs do not fit the stage even one row at a time (large tasks with little LDS to spare)
         for (;;) {
+            if (stage_rows > 0) break;
             int q = 0;
             if (lane == 0) q = atomicAdd(wctl + 2, 2);
             q = __builtin_amdgcn_readfirstlane(q);
             if (q >= ns) break;
-            const int A = __builtin_amdgcn_readfirstlane(srow[q]);
+            const int A = q;
             if (q + 1 >= ns) { do_row(A); break; }
-            const int A2 = __builtin_amdgcn_readfirstlane(srow[q + 1]);
+            const int A2 = q + 1;
             const int a1 = __builtin_amdgcn_readfirstlane(oldidx[A] & 0x7fff), a2 = __builtin_amdgcn_readfirstlane(oldidx[A2] & 0x7fff);
 #ifdef HR_TIMING
             const long long q1 = __builtin_readcyclecounter();
@@ -614,20 +736,18 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                 // on these loads (SQ_WAIT_ANY 64 % of the wave cycles), so as many as the registers allow go out together
                 auto pass = [&](auto U_) {
                     constexpr int U = decltype(U_)::value;
-                    for (; B0 + 64 * (U - 1) < nb; B0 += 64 * U) {
+                    for (; B0 + 64 * (U - 1) < ns; B0 += 64 * U) {
                         unsigned mm[U];
                         double x1[U], x2[U];
 #pragma unroll
                         for (int u = 0; u < U; ++u) mm[u] = oldidx[B0 + 64 * u];
 #pragma unroll
-                        for (int u = 0; u < U; ++u) { const unsigned bcol = mm[u] & 0x7fffu; x1[u] = r1[bcol]; x2[u] = r2[bcol]; }
+                        for (int u = 0; u < U; ++u) { x1[u] = r1[mm[u]]; x2[u] = r2[mm[u]]; }
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            if (!(mm[u] & 0x8000u)) {
-                                const int B = B0 + 64 * u;
-                                w1[B] = x1[u]; w2[B] = x2[u];
-                                upd(m1, s1, i1, x1[u], B); upd(m2, s2, i2, x2[u], B);
-                            }
+                            const int B = B0 + 64 * u;
+                            w1[B] = x1[u]; w2[B] = x2[u];
+                            upd(m1, s1, i1, x1[u], B); upd(m2, s2, i2, x2[u], B);
                         }
                         if (U == 1) break;
                     }
@@ -638,8 +758,8 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                 pass(std::integral_constant<int, 2>());
                 pass(std::integral_constant<int, 1>());
                 const double n1 = csz[a1], n2 = csz[a2];
-                for (int q = lane; q < np; q += 64) {           // merged columns: d(a, k u l) from d(a,k), d(a,l)
-                    const int k1 = plist[q], l1 = partner[k1], B = newidx[k1];
+                for (int B = ns + lane; B < nb; B += 64) {      // merged columns: d(a, k u l) from d(a,k), d(a,l)
+                    const int k1 = oldidx[B] & 0x7fff, l1 = partner[k1];
                     const double nk_ = csz[k1], nl_ = csz[l1], hQ = dnn[k1];
                     const double v1 = lance_williams(method, r1[k1], r1[l1], hQ, nk_, nl_, n1);
                     const double v2 = lance_williams(method, r2[k1], r2[l1], hQ, nk_, nl_, n2);
@@ -663,19 +783,19 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
             }
             HrBest b1, b2;
             b1.v = b2.v = HC_INF; b1.i = b2.i = 0x7fffffff; b1.tie = b2.tie = 0;
-            for (int B0 = lane; B0 < nb; B0 += 64 * 8) {
+            for (int B0 = lane; B0 < ns; B0 += 64 * 8) {
                 int bb[8];
                 double x1[8], x2[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int B = B0 + 64 * u;
-                    bb[u] = oldidx[B < nb ? B : nb - 1] & 0x7fff;
+                    bb[u] = oldidx[B < ns ? B : ns - 1];
                     x1[u] = r1[bb[u]]; x2[u] = r2[bb[u]];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int B = B0 + 64 * u;
-                    if (B < nb && partner[bb[u]] == HR_NONE) {
+                    if (B < ns) {
                         const double v1 = B == A ? HC_INF : (sq ? x1[u] * x1[u] : x1[u]);
                         const double v2 = B == A2 ? HC_INF : (sq ? x2[u] * x2[u] : x2[u]);
                         w1[B] = v1; w2[B] = v2;
@@ -685,8 +805,8 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                 }
             }
             const double n1 = csz[a1], n2 = csz[a2];
-            for (int q = lane; q < np; q += 64) {               // merged columns: d(a, k u l) from d(a,k), d(a,l)
-                const int k1 = plist[q], l1 = partner[k1], B = newidx[k1];
+            for (int B = ns + lane; B < nb; B += 64) {          // merged columns: d(a, k u l) from d(a,k), d(a,l)
+                const int k1 = oldidx[B] & 0x7fff, l1 = partner[k1];
                 double d1 = r1[k1], d2 = r1[l1], e1 = r2[k1], e2 = r2[l1];
                 if (sq) { d1 *= d1; d2 *= d2; e1 *= e1; e2 *= e2; }
                 const double nk_ = csz[k1], nl_ = csz[l1], hQ = dnn[k1];
@@ -712,6 +832,9 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         if (blockIdx.x == 0 && tid == 0 && (done == 0 || na < 1200 && na > 1100 || na < 300 && na > 280))
             printf("round na=%d np=%d nb=%d: setup %lld  rebuild %lld (wave0: dual %lld slow %lld)  tail-barrier %lld cycles\n", na, np, nb,
                    hr_t1 - hr_t0, hr_t2 - hr_t1, hr_dual, hr_slow, (long long)__builtin_readcyclecounter() - hr_t2);
+#endif
+#ifdef HR_ROUNDS
+        if (blockIdx.x == 0 && tid == 0) printf("R %d %d %d\n", na, np, nb);      // round sizes of task 0 (traffic model)
 #endif
         done += np; na = nb; cur ^= 1; src = src < 0 ? 0 : (src ^ 1);
         __syncthreads();
@@ -1198,9 +1321,9 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
                     const int max_rounds = max_n + 8;               // every round merges at least one pair
                     for (int r = 0; r < max_rounds; ++r) {
                         hipLaunchKernelGGL(ka, dim3(Ts), dim3(1024), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p, W.height.p,
-                                           W.status.p + R.t0, W.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W.remaining.p);
+                                           W.status.p + R.t0, W.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W.remaining.p, static_cast<int>(lds));
                         hipLaunchKernelGGL(kb, dim3(Ts, wpt), dim3(1024), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p, W.height.p,
-                                           W.status.p + R.t0, W.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W.remaining.p);
+                                           W.status.p + R.t0, W.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W.remaining.p, static_cast<int>(lds));
                         if ((r & 7) == 7) {                         // a finished task costs two empty workgroups per round: look now and then
                             int rem = 0;
                             W.remaining.download(&rem, 1);
@@ -1209,16 +1332,21 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
                     }
                 } else if (Ts <= c.num_cu) {
                     auto k0 = hclust_rnn_kernel<1024, 0>;
+                    // one workgroup per CU: everything the CU has beyond the state stages the pair members' entries
+                    const size_t ldsl = std::max(lds, HR_LDS_CU);
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        static_cast<int>(lds)));
-                    hipLaunchKernelGGL(k0, dim3(Ts), dim3(1024), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
-                                       W.height.p, W.status.p + R.t0, nullptr, 0LL, static_cast<int>(lds), 0, nullptr);
+                                                        static_cast<int>(ldsl)));
+                    hipLaunchKernelGGL(k0, dim3(Ts), dim3(1024), ldsl, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
+                                       W.height.p, W.status.p + R.t0, nullptr, 0LL, static_cast<int>(lds), 0, nullptr, static_cast<int>(ldsl));
                 } else {
                     auto k0 = hclust_rnn_kernel<512, 0>;
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         static_cast<int>(lds)));
-                    hipLaunchKernelGGL(k0, dim3(Ts), dim3(512), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
-                                       W.height.p, W.status.p + R.t0, nullptr, 0LL, static_cast<int>(lds), 0, nullptr);
+                    const size_t ldsl = std::max(lds, HR_LDS_CU / 2);      // two workgroups per CU
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        static_cast<int>(ldsl)));
+                    hipLaunchKernelGGL(k0, dim3(Ts), dim3(512), ldsl, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
+                                       W.height.p, W.status.p + R.t0, nullptr, 0LL, static_cast<int>(lds), 0, nullptr, static_cast<int>(ldsl));
                 }
                 launch_check("hclust_rnn_kernel");
             }
