@@ -177,12 +177,13 @@ def main():
                            "work": "%d tasks x n_t^2 x p flop (upper triangle), f64 MFMA" % T_tasks})
         hms, hcalls = prof.get("hclust", (0.0, 0))
         if hcalls:
-            by = T_tasks * 2000.0 * 2000.0 * 8 * 9.3             # rounds of (read n_a^2 + write n_a'^2): ~9.3 n_t^2 entries per task
+            by = T_tasks * 2000.0 * 2000.0 * 8 * 10.1            # rounds of (read n_a^2 + write n_a'^2) + the round-0 scan: 10.1 n_t^2 entries per task
             th = hms / attr_steps.get("hclust", 1) * 1e-3
             others.append({"kernel": "hclust_rnn_kernel", "bound": "hbm", "achieved": round(by / th / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                            "frac": round(by / th / 8e12, 3), "ms_per_step": round(th * 1e3, 2),
-                           "work": "%d tasks x ~9.3 n_t^2 x 8 B (every round streams the distance matrix into a compacted copy, "
-                                   "~44 rounds); see DESIGN.md 5" % T_tasks})
+                           "work": "%d tasks x 10.1 n_t^2 x 8 B (every round streams the distance matrix into a compacted copy, "
+                                   "45 rounds; measured HBM traffic 131-136 GB per step, profiles/r01_counter_calibration.txt); "
+                                   "see DESIGN.md 5" % T_tasks})
         stages = {k: round(v[0] / attr_steps.get(k, 1), 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0] / attr_steps.get(kv[0], 1))}
         from sharp_amd.api import ARI
 

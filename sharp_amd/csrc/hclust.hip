@@ -381,10 +381,10 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         uint16_t *nnW = outp(nn);
         unsigned char *tieW = outp(tie);
         int np = 0, nb = 0, ns = 0;
-        if (MODE != 2) {
 #ifdef HR_TIMING
         const long long hr_t0 = __builtin_readcyclecounter();
 #endif
+        if (MODE != 2) {
         // (1) reciprocal pairs
         for (int a = tid; a < na; a += HR_THREADS) {
             partner[a] = HR_NONE;
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         __syncthreads();
         if (tid == 0) { ctl[0] = 0; }
 #ifdef HR_TIMING
-        if (blockIdx.x == 0 && tid == 0 && (done == 0 || na < 1200 && na > 1100 || na < 300 && na > 280))
+        if (blockIdx.x == 0 && tid == 0 && (done == 0 || (na < 1200 && na > 1100) || (na < 600 && na > 560) || (na < 300 && na > 280) || (na < 100 && na > 90)))
             printf("round na=%d np=%d nb=%d: setup %lld  rebuild %lld (wave0: dual %lld slow %lld)  tail-barrier %lld cycles\n", na, np, nb,
                    hr_t1 - hr_t0, hr_t2 - hr_t1, hr_dual, hr_slow, (long long)__builtin_readcyclecounter() - hr_t2);
 #endif

@@ -20,7 +20,7 @@ os.makedirs(prof, exist_ok=True)
 
 
 def newest(pattern):
-    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getsize)
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)      # the latest run
     return files[-1] if files else None
 
 
