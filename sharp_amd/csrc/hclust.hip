@@ -677,6 +677,82 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                 if (lane == 2) { tieW[A0 + t] = static_cast<unsigned char>(nb > 2 ? g.tie : 0); }
             }
         };
+        // Rows of merged clusters, staged form (needs the two-row stage): the two old rows a and j of the pair are read once,
+        // contiguously; an unmerged column gets its Lance-Williams value at once, the four entries of a merged column (a, j) x (k, l)
+        // wait in the stage.  (The gathered form in do_row fetches d(a,l), d(j,l) from wherever column l lies: one more 128-byte
+        // line per entry, 2.6 x the row's own bytes.)
+        auto staged_merged = [&](int A) {
+            const int a = __builtin_amdgcn_readfirstlane(oldidx[A] & 0x7fff);
+            const int pa = __builtin_amdgcn_readfirstlane(partner[a]);
+            const double *ra = Dsrc + static_cast<long long>(a) * nld, *rj = Dsrc + static_cast<long long>(pa) * nld;
+            double *wr = Ddst + static_cast<long long>(A) * nld;
+            const double na_ = csz[a], nj_ = csz[pa], hP = dnn[a];
+            const int seqP = pseq[a];
+            double *sa = stage + static_cast<size_t>(wave) * 4 * np, *sj = sa + 2 * np;
+            double mn = HC_INF, sc = HC_INF;
+            int ix = 0x7fffffff;
+            int j0 = lane;
+            auto pass = [&](auto U_) {
+                constexpr int U = decltype(U_)::value;
+                for (; j0 + 64 * (U - 1) < na; j0 += 64 * U) {
+                    unsigned cm[U];
+                    double xa[U], xj[U], nc[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { cm[u] = colmap[j0 + 64 * u]; nc[u] = csz[j0 + 64 * u]; }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { xa[u] = ra[j0 + 64 * u]; xj[u] = rj[j0 + 64 * u]; }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (sq) { xa[u] *= xa[u]; xj[u] *= xj[u]; }
+                        if (cm[u] & 0x8000u) { sa[cm[u] & 0x7fffu] = xa[u]; sj[cm[u] & 0x7fffu] = xj[u]; }
+                        else {
+                            const int B = static_cast<int>(cm[u]);
+                            const double v = lance_williams(method, xa[u], xj[u], hP, na_, nj_, nc[u]);
+                            wr[B] = v;
+                            sc = fmin(sc, fmax(mn, v));
+                            if (v < mn) { mn = v; ix = B; }
+                        }
+                    }
+                    if (U == 1) break;
+                }
+            };
+            pass(std::integral_constant<int, 8>());
+            pass(std::integral_constant<int, 4>());
+            pass(std::integral_constant<int, 2>());
+            pass(std::integral_constant<int, 1>());
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int B = ns + lane; B < nb; B += 64) {
+                const int rk = B - ns;
+                double v = HC_INF;                              // own column: the scratch diagonal
+                if (B != A) {
+                    const int k1 = oldidx[B] & 0x7fff, l1 = partner[k1];
+                    const double d00 = sa[2 * rk], d01 = sa[2 * rk + 1], d10 = sj[2 * rk], d11 = sj[2 * rk + 1];
+                    const double nk_ = csz[k1], nl_ = csz[l1], hQ = dnn[k1];
+                    if (seqP < static_cast<int>(pseq[k1])) {    // (a, j) merges first, then (k, l) against the merged cluster
+                        const double t1 = lance_williams(method, d00, d10, hP, na_, nj_, nk_);
+                        const double t2 = lance_williams(method, d01, d11, hP, na_, nj_, nl_);
+                        v = lance_williams(method, t1, t2, hQ, nk_, nl_, na_ + nj_);
+                    } else {
+                        const double t1 = lance_williams(method, d00, d01, hQ, nk_, nl_, na_);
+                        const double t2 = lance_williams(method, d10, d11, hQ, nk_, nl_, nj_);
+                        v = lance_williams(method, t1, t2, hP, na_, nj_, nk_ + nl_);
+                    }
+                    sc = fmin(sc, fmax(mn, v));
+                    if (v < mn || (v == mn && B < ix)) { mn = v; ix = B; }
+                }
+                wr[B] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            HrBest g;
+            g.v = mn; g.i = ix; g.tie = 0;
+            g = hr_wave(g);
+            g.tie |= __ballot(sc == g.v) != 0ull ? 1 : 0;
+            if (lane == 0) { cidN[A] = cid[a] < cid[pa] ? cid[a] : cid[pa]; cszN[A] = static_cast<uint16_t>(csz[a] + csz[pa]); dnnN[A] = g.v; }
+            if (lane == 1) { nnW[A] = static_cast<uint16_t>(g.i < nb ? g.i : 0); }
+            if (lane == 2) { tieW[A] = static_cast<unsigned char>(nb > 2 ? g.tie : 0); }
+        };
         // work is handed out dynamically (the rows of merged clusters cost about twice a pair of plain rows, and a static
         // split left a quarter of the phase waiting at the barrier): merged rows first, then plain rows two at a time
         for (;;) {
@@ -687,7 +763,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
 #ifdef HR_TIMING
             const long long q0 = __builtin_readcyclecounter();
 #endif
-            do_row(newidx[plist[q]]);
+            if (stage_rows == 2) staged_merged(newidx[plist[q]]); else do_row(newidx[plist[q]]);
 #ifdef HR_TIMING
             hr_slow += __builtin_readcyclecounter() - q0;
 #endif
