@@ -136,7 +136,7 @@ def main():
     if rank == 0:
         p = state["p"]
         # RP matmul = rp_compact_kernel (streams X from HBM: the HBM-bound kernel the roofline is quoted for) feeding
-        # rp_apply_kernel (L2 gather + LDS atomics, writes E) chunk by chunk on two streams.
+        # rp_apply_kernel (L2 gather + LDS atomics, writes E) chunk by chunk.
         cms, ccalls = prof.get("rp_compact", (0.0, 0))
         ams, acalls = prof.get("rp_apply", (0.0, 0))
         sms, scalls = prof.get("rp_stage", (0.0, 0))
@@ -160,7 +160,7 @@ def main():
                     "traffic": None if traffic_compact is None else int(traffic_compact / launches_per_stage),
                     "launch_ms": round(t_launch * 1e3, 4), "cells_per_launch": round(cells_per_launch, 1),
                     "algorithmic_bytes": int(alg_launch),
-                    "stage": {"what": "whole RP matmul (rp_compact + rp_apply overlapped on two streams), per SHARP() call",
+                    "stage": {"what": "whole RP matmul (rp_compact then rp_apply, chunk by chunk; one stream at K*p >= 4096, two below), per SHARP() call",
                               "ms": round(t_stage * 1e3, 4), "algorithmic_bytes": alg_stage,
                               "achieved": round(alg_stage / t_stage / 1e9, 1), "frac": round(alg_stage / t_stage / 8e12, 4),
                               "read_only_frac": round(n * m * 4 / t_stage / 8e12, 4),

@@ -276,8 +276,13 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, const float
                        int fix_bits, double *dE, long long ldE, const int *d_row_map) {
     Ctx &c = ctx();
     SplitWs &W = sws();
-    const char *ser = getenv("SHARP_RP_SERIAL");     // debug: both kernels on the main stream (no overlap)
-    hipStream_t s2 = (ser && ser[0] == '1') ? c.stream : c.stream2;
+    // Two streams (chunk c + 1 is compacted while chunk c is applied) or one.  With many output components (K = 15: 5865) the
+    // apply kernel holds most wave slots, the compaction beside it runs 3x slower (0.54 instead of 0.18 ms per launch) and the
+    // stage takes the same time either way (4.40 vs 4.45 ms): there the kernels run one after the other, each at its own best.
+    // With few components (K = 5) the overlap is worth 4 % of the stage.  SHARP_RP_SERIAL = 1 / 0 forces the choice.
+    const char *ser = getenv("SHARP_RP_SERIAL");
+    const bool serial = ser ? ser[0] == '1' : g.ncomp >= 4096;
+    hipStream_t s2 = serial ? c.stream : c.stream2;
     const int cap = (m + 3) / 4 * 4;                         // worst case: every gene non-zero
     // chunks of cells: two (genes, fix, counts) buffers of <= 2 GB each (sized for the worst case, every gene non-zero);
     // few, equal chunks: each launch pays a tail, and a chunk must give every workgroup several cells
