@@ -1287,12 +1287,12 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
     // Every descriptor of the chunk goes up once; the device work is then enqueued per RANGE of tasks, each range on its
     // own stream: the agglomeration is a memory-latency/scatter-bound kernel and the correlation GEMM an MFMA-bound one,
     // so a range's GEMM, cutree and silhouette statistics run underneath the agglomeration of the other ranges.
-    int NS = T >= 96 ? 2 : 1;   // measured: 2 ranges -4 ms, 3 or more slower than one (the GEMM slows the agglomeration it overlaps)
+    int NS = T >= 194 ? 2 : 1;  // two ranges of more than 96 tasks each (the one-launch agglomeration); 3 or more are slower than one
     {
         // the round-per-launch agglomeration synchronises with the host every few rounds: one range at a time
         const char *mono = getenv("SHARP_HC_MONO"), *seq = getenv("SHARP_HC_SEQ");
         const char *splt = getenv("SHARP_HC_SPLIT");
-        const bool split = splt ? splt[0] == '1' : T <= 64;
+        const bool split = splt ? splt[0] == '1' : T <= 96;
         if (!(mono && mono[0] == '1') && !(seq && seq[0] == '1') && max_n <= HR_MAXN && split) NS = 1;
     }
     if (const char *e = getenv("SHARP_HC_RANGES")) NS = std::max(1, std::min(8, atoi(e)));
@@ -1379,11 +1379,11 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
                 const size_t lds = std::max(state, static_cast<size_t>(npow2) * 16);
                 const char *mono = getenv("SHARP_HC_MONO");       // debug / cross-check: the whole agglomeration in one launch
                 // Few tasks (one projection, the wMetaC / sMetaC similarity tasks, a cross-block sMetaC of thousands of meta-clusters):
-                // one round per pair of launches, every task spread over several workgroups -- 25 tasks of 2000: 5.5 ms against
-                // 13.5 ms in one launch.  Many tasks: one launch is as fast or faster (125 tasks equal, 188 tasks 21 vs 25 ms: the
-                // chip then moves the same 2.3-2.7 TB/s either way and the per-round launches only add their gaps).
+                // one round per pair of launches, every task spread over several workgroups -- 25 tasks of 2000: 4.7 ms against
+                // 10.3 ms in one launch, 50 tasks 6.5 against 11.3.  Many tasks: one launch is as fast (125 tasks: 12.1 vs 12.3 ms)
+                // or faster (the chip is then at its memory limit either way and the per-round launches only add their gaps).
                 const char *splt = getenv("SHARP_HC_SPLIT");     // 1 / 0 force the choice
-                const bool split = splt ? splt[0] == '1' : Ts <= 64;
+                const bool split = splt ? splt[0] == '1' : Ts <= 96;
                 if (!(mono && mono[0] == '1') && split) {
                     const int wpt = std::max(1, std::min(8, (5 * c.num_cu / 2 + Ts - 1) / Ts));
                     W.img.ensure(static_cast<size_t>(Ts) * lds);
@@ -1392,14 +1392,15 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
                     W.remaining.upload(&rem0, 1);
                     auto ka = hclust_rnn_kernel<1024, 1>;
                     auto kb = hclust_rnn_kernel<1024, 2>;
+                    const size_t ldsl = std::max(lds, HR_LDS_CU);       // the rebuild launches stage the pair members' entries like MODE 0
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsl)));
                     const int max_rounds = max_n + 8;               // every round merges at least one pair
                     for (int r = 0; r < max_rounds; ++r) {
                         hipLaunchKernelGGL(ka, dim3(Ts), dim3(1024), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p, W.height.p,
                                            W.status.p + R.t0, W.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W.remaining.p, static_cast<int>(lds));
-                        hipLaunchKernelGGL(kb, dim3(Ts, wpt), dim3(1024), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p, W.height.p,
-                                           W.status.p + R.t0, W.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W.remaining.p, static_cast<int>(lds));
+                        hipLaunchKernelGGL(kb, dim3(Ts, wpt), dim3(1024), ldsl, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p, W.height.p,
+                                           W.status.p + R.t0, W.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W.remaining.p, static_cast<int>(ldsl));
                         if ((r & 7) == 7) {                         // a finished task costs two empty workgroups per round: look now and then
                             int rem = 0;
                             W.remaining.download(&rem, 1);
