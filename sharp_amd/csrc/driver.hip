@@ -36,7 +36,14 @@ struct SharpArgs {
 struct SharpOut {
     std::vector<int> pred;           // 1..G, numbered by first appearance (R/SHARP.R:429-443,828-843)
     int n_pred = 0;
-    DevBuf<double> viE;              // n x p, ORIGINAL cell order, on the device
+    // n x p, ORIGINAL cell order, on the device: a view of a workspace kept between calls (valid until the next call)
+    struct View {
+        double *p = nullptr;
+        void download(double *h, size_t count) const {
+            SHARP_HIP_CHECK(hipMemcpyAsync(h, p, count * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+            SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+        }
+    } viE;
     std::vector<double> x0;          // n x x0_cols column-major
     int x0_cols = 0;
     int p = 0, K = 0, path = 0, rc = 0;
@@ -45,7 +52,7 @@ struct SharpOut {
 namespace {
 
 // big per-call device buffers are kept between calls (hipMalloc/hipFree of multi-GB buffers costs up to tens of ms)
-struct DriverWs { DevBuf<double> E, viE_sh; DevBuf<int> pos; };
+struct DriverWs { DevBuf<double> E, viE_sh, viE_out; DevBuf<int> pos; };
 DriverWs &dws() { static DriverWs w; return w; }
 
 inline bool lex_less_id(int a, int b) {
@@ -154,7 +161,7 @@ void sharp_small_dev(const float *dX, int m, int n, long long ld, const SharpArg
     wmetac_batch(wts, a.want_x0, false, wr);
     out.rc |= wr[0].rc;
     out.pred = wr[0].finalC;
-    if (a.want_viE || true) { out.viE.alloc(static_cast<size_t>(n) * p); ensemble_mean_dev(E.p, ldE, n, p, K, out.viE.p); }   // :416
+    if (a.want_viE || true) { dws().viE_out.ensure(static_cast<size_t>(n) * p); out.viE.p = dws().viE_out.p; ensemble_mean_dev(E.p, ldE, n, p, K, out.viE.p); }   // :416
     if (a.N_cluster <= 0 && n > 10000) merge_small(out.pred);                   // :418-427
     out.n_pred = relabel_first(out.pred);                                       // :429-443
     if (a.want_x0) { out.x0 = wr[0].x0; out.x0_cols = wr[0].ncl; }
@@ -216,6 +223,9 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
         }
     std::vector<HcResult> hr;
     { HostTimer ht("base_clustering_total"); get_opt_hclust_batch(tasks, false, hr); }
+    DevBuf<double> &viE_sh = dws().viE_sh;                                      // enE / K in shuffled order (:750,776)
+    viE_sh.ensure(static_cast<size_t>(n) * p);
+    ensemble_mean_dev(E.p, ldE, n, p, K, viE_sh.p);                             // enqueued now, runs under the host loops below
     // enrp per fold (:627-635); labels "<colour>p<t>" only need to be distinct per (k, t): the colour id does
     std::vector<std::vector<int>> enrp(T);
     for (int t = 0; t < T; ++t) {
@@ -227,9 +237,6 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
             for (int i = 0; i < nt; ++i) enrp[t][static_cast<size_t>(k) * nt + i] = colour_of(r.f[i]);
         }
     }
-    DevBuf<double> &viE_sh = dws().viE_sh;                                      // enE / K in shuffled order (:750,776)
-    viE_sh.ensure(static_cast<size_t>(n) * p);
-    ensemble_mean_dev(E.p, ldE, n, p, K, viE_sh.p);
     // per-fold wMetaC (:692-709)
     std::vector<WmTask> wts(T);
     for (int t = 0; t < T; ++t) {
@@ -260,7 +267,7 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
         for (int i = 0; i < n; ++i) lab[shuffle ? reind[i] - 1 : i] = uid[i] + 1;
         out.pred = lab;
         out.n_pred = relabel_first(out.pred);
-        out.viE.alloc(static_cast<size_t>(n) * p);
+        dws().viE_out.ensure(static_cast<size_t>(n) * p); out.viE.p = dws().viE_out.p;
         if (shuffle) {
             Ctx &c = ctx();
             hipLaunchKernelGGL(gather_rows_kernel, dim3(c.num_cu * 8), dim3(256), 0, c.stream, viE_sh.p, dpos.p, static_cast<long long>(n), p, out.viE.p);
@@ -304,7 +311,7 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
         }
     }
     // viE back to the original cell order (:776-783)
-    out.viE.alloc(static_cast<size_t>(n) * p);
+    dws().viE_out.ensure(static_cast<size_t>(n) * p); out.viE.p = dws().viE_out.p;
     if (shuffle) {
         Ctx &c = ctx();
         hipLaunchKernelGGL(gather_rows_kernel, dim3(c.num_cu * 8), dim3(256), 0, c.stream, viE_sh.p, dpos.p, static_cast<long long>(n), p, out.viE.p);

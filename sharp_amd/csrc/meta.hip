@@ -196,20 +196,38 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
     long long oCid = 0, oW = 0, oS = 0, oCol = 0;
     int maxN = 0, maxAll = 0;
     size_t max_lds = 0;
-    for (int t = 0; t < T; ++t) {
+    // per-fold relabelling on host threads (25 folds x 15 clusterings x 2000 cells at cfg2: 0.8 ms on one thread)
+    std::vector<int> allCs(T, 0), err(T, 0);
+    auto relabel = [&](int t) {
         const WmTask &tk = tasks[t];
-        SHARP_REQUIRE(tk.N >= 2 && tk.C >= 1 && tk.nC, "wMetaC: empty label matrix");
+        if (!(tk.N >= 2 && tk.C >= 1 && tk.nC)) { err[t] = 1; return; }
         std::vector<uint16_t> &cid = cids[t];
         cid.resize(static_cast<size_t>(tk.N) * tk.C);
         int allC = 0;
         std::vector<int> uid;
         for (int col = 0; col < tk.C; ++col) {
             const int nu = first_appearance_ids(tk.nC + static_cast<size_t>(col) * tk.N, tk.N, uid);
-            SHARP_REQUIRE(allC + nu <= 65535, "wMetaC: more than 65535 base clusters");
+            if (allC + nu > 65535) { err[t] = 2; return; }
             for (int i = 0; i < tk.N; ++i) cid[static_cast<size_t>(i) * tk.C + col] = static_cast<uint16_t>(allC + uid[i]);
             for (int q = 0; q < nu; ++q) colof[t].push_back(col);
             allC += nu;
         }
+        allCs[t] = allC;
+    };
+    {
+        const int nthr = std::max(1, std::min({T, 8, static_cast<int>(std::thread::hardware_concurrency())}));
+        if (nthr == 1) { for (int t = 0; t < T; ++t) relabel(t); }
+        else {
+            std::vector<std::thread> th;
+            for (int w = 0; w < nthr; ++w) th.emplace_back([&, w]() { for (int t = w; t < T; t += nthr) relabel(t); });
+            for (auto &x : th) x.join();
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+        const WmTask &tk = tasks[t];
+        SHARP_REQUIRE(err[t] != 1, "wMetaC: empty label matrix");
+        SHARP_REQUIRE(err[t] != 2, "wMetaC: more than 65535 base clusters");
+        const int allC = allCs[t];
         SHARP_REQUIRE(allC >= 3, "wMetaC: fewer than 3 base clusters in the ensemble");
         WmMeta &M = metas[t];
         M.N = tk.N; M.C = tk.C; M.allC = allC; M.pad = 0;
