@@ -1072,22 +1072,35 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const HcMeta *__restr
         fm[labF[i] - 1] = lab[i] - 1;
     }
     __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int c = 0; c < k; ++c) {
-            start[c] = run;
-            for (int f = 0; f < kf; ++f) if (fm[f] == c) order[run++] = f;
-        }
-        start[k] = run;
+    // finest clusters grouped by level cluster (ascending inside a group): counts, a prefix over k <= kf entries, one thread per group
+    for (int c = tid; c <= k; c += ST_THREADS) start[c] = 0;
+    __syncthreads();
+    for (int f = tid; f < kf; f += ST_THREADS) atomicAdd(&start[fm[f] + 1], 1);
+    __syncthreads();
+    if (tid == 0) for (int c = 0; c < k; ++c) start[c + 1] += start[c];
+    // the kf x kf Gram matrix of the finest clusters' sums goes through LDS (the space of sil[], written later): the sums below
+    // re-read it up to (group size) x (group size + kf) times per group, which took 3 of the kernel's 4.5 ms as dependent global loads
+    const bool q_lds = kf * kf <= npow2;
+    if (q_lds) for (int e = tid; e < kf * kf; e += ST_THREADS) sil[e] = Q[static_cast<long long>(e / kf) * kpad + e % kf];
+    __syncthreads();
+    for (int c = tid; c < k; c += ST_THREADS) {
+        int pos = start[c];
+        for (int f = 0; f < kf; ++f) if (fm[f] == c) order[pos++] = f;
     }
     __syncthreads();
     double tot2 = 0.0;
     for (int c = tid; c < k; c += ST_THREADS) {
         double a = 0.0, b = 0.0;
         for (int q = start[c]; q < start[c + 1]; ++q) {
-            const double *qr = Q + static_cast<long long>(order[q]) * kpad;
-            for (int q2 = start[c]; q2 < start[c + 1]; ++q2) a += qr[order[q2]];
-            for (int f = 0; f < kf; ++f) b += qr[f];
+            if (q_lds) {
+                const double *qr = sil + order[q] * kf;
+                for (int q2 = start[c]; q2 < start[c + 1]; ++q2) a += qr[order[q2]];
+                for (int f = 0; f < kf; ++f) b += qr[f];
+            } else {
+                const double *qr = Q + static_cast<long long>(order[q]) * kpad;
+                for (int q2 = start[c]; q2 < start[c + 1]; ++q2) a += qr[order[q2]];
+                for (int f = 0; f < kf; ++f) b += qr[f];
+            }
         }
         cn2[c] = a; ctot[c] = b;
     }
