@@ -642,7 +642,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                     if (U == 1) break;
                 }
             };
-            pass(std::integral_constant<int, 16>());
+            if (NR == 1) pass(std::integral_constant<int, 16>());   // 16 entries per lane in flight either way (128 VGPRs, no scratch)
             pass(std::integral_constant<int, 8>());
             pass(std::integral_constant<int, 4>());
             pass(std::integral_constant<int, 2>());
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                     if (v < mn) { mn = v; ix = B; }
                 };
                 int B0 = lane;
-                // passes of 16, 8, 4, 2, 1 columns per lane, none with bounds tests: the waves spend most of their time parked
+                // passes of 8, 4, 2, 1 columns per lane, none with bounds tests: the waves spend most of their time parked
                 // on these loads (SQ_WAIT_ANY 64 % of the wave cycles), so as many as the registers allow go out together
                 auto pass = [&](auto U_) {
                     constexpr int U = decltype(U_)::value;
@@ -828,7 +828,6 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                         if (U == 1) break;
                     }
                 };
-                pass(std::integral_constant<int, 16>());
                 pass(std::integral_constant<int, 8>());
                 pass(std::integral_constant<int, 4>());
                 pass(std::integral_constant<int, 2>());
