@@ -80,8 +80,8 @@ def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag
     _lib.ensure_init()
     nb, m = dX.shape
     pred = np.zeros(nb, np.int32)
-    means = np.zeros((cap_rows, p))
-    counts = np.zeros(cap_rows, np.int64)
+    means = np.empty((cap_rows, p))                 # only the first G rows are written and returned
+    counts = np.empty(cap_rows, np.int64)
     G = C.c_int()
     check(lib().sharp_unlimited_block_view_dev(C.c_void_p(dX.data_ptr()), m, C.c_longlong(nb), C.c_longlong(dX.stride(0)), p,
                                                projector, ensize_K, C.c_double(rN_seed), int(bool(flag)), _ip(pred), C.byref(G),
