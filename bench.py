@@ -113,8 +113,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof_timed = dev.profile_table()
-    # Attribution pass, outside the timed region: the timed steps run the base-clustering tasks as two ranges on two streams,
-    # so their per-kernel event times overlap; one more step with a single range gives each kernel's own time.
+    # Attribution pass, outside the timed region: chunks of 194 tasks or more run as two ranges on two streams, whose per-kernel
+    # event times overlap; one more step with a single range gives each kernel's own time (at cfg2 the chunks are 188 / 187 tasks:
+    # one range anyway).
     os.environ["SHARP_HC_RANGES"] = "1"
     dev.profile(True)
     step()
@@ -201,7 +202,7 @@ def main():
             "roofline": roof,
             "other_kernels": others,
             "kernel_ms_per_step": stages,
-            "kernel_ms_note": "per-kernel times from one extra un-pipelined step outside the timed region (SHARP_HC_RANGES=1); the timed steps overlap two task ranges, so these add up to more than ms_per_step",
+            "kernel_ms_note": "per-kernel times from one extra step outside the timed region with a single task range per chunk (SHARP_HC_RANGES=1): batches of 194 tasks or more are otherwise run as two overlapping ranges, whose event times overlap",
             "clusters_found": int(state["n_clusters"]),
             "ari_vs_planted_truth": round(float(ARI(truth, state["pred"])["HA"]), 4),
         }
