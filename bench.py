@@ -113,15 +113,17 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof_timed = dev.profile_table()
-    # Attribution pass, outside the timed region: chunks of 194 tasks or more run as two ranges on two streams, whose per-kernel
-    # event times overlap; one more step with a single range gives each kernel's own time (at cfg2 the chunks are 188 / 187 tasks:
-    # one range anyway).
+    # Attribution pass, outside the timed region: in the timed steps the two chunks of base-clustering tasks are in flight together
+    # (SHARP_HC_PIPE) and a chunk of 194 tasks or more runs as two ranges on two streams, so the per-kernel event times overlap and
+    # kernels sharing the chip run slower than alone; one more step with one chunk and one range at a time gives each kernel's own time.
     os.environ["SHARP_HC_RANGES"] = "1"
+    os.environ["SHARP_HC_PIPE"] = "0"
     dev.profile(True)
     step()
     barrier()
     prof = dev.profile_table()
     del os.environ["SHARP_HC_RANGES"]
+    del os.environ["SHARP_HC_PIPE"]
     for kname in ("rp_compact", "rp_apply", "rp_stage"):           # the RP stage is not affected: keep the timed-region statistics
         if kname in prof_timed:
             prof[kname] = prof_timed[kname]
@@ -202,7 +204,7 @@ def main():
             "roofline": roof,
             "other_kernels": others,
             "kernel_ms_per_step": stages,
-            "kernel_ms_note": "per-kernel times from one extra step outside the timed region with a single task range per chunk (SHARP_HC_RANGES=1): batches of 194 tasks or more are otherwise run as two overlapping ranges, whose event times overlap",
+            "kernel_ms_note": "per-kernel times from one extra step outside the timed region with one chunk of base-clustering tasks and one task range at a time (SHARP_HC_PIPE=0, SHARP_HC_RANGES=1); the timed steps keep two chunks in flight, so these add up to more than ms_per_step",
             "clusters_found": int(state["n_clusters"]),
             "ari_vs_planted_truth": round(float(ARI(truth, state["pred"])["HA"]), 4),
         }

@@ -1207,7 +1207,9 @@ struct Workspace {
     DevBuf<RowPrepTask> prep;
     DevBuf<GemmTask> gemm;
 };
-Workspace &ws() { static Workspace w; return w; }
+// Two sets of buffers so that consecutive chunks of tasks can be in flight together (run_chunks); the scratch of the agglomeration
+// itself (S0, S1, img, remaining) is only ever used by one chunk at a time and always comes from set 0.
+Workspace &ws(int slot = 0) { static Workspace w[2]; return w[slot]; }
 
 inline long long rup(long long v, long long a) { return (v + a - 1) / a * a; }
 
@@ -1245,11 +1247,55 @@ void select_level(const HcParams &prm, int n, int kmin, int nk, const double *ms
     if (oind < 1 || oind > nk) { rc |= SHARP_WARN_RANGE; oind = oind < 1 ? 1 : nk; }
 }
 
-void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want_v, std::vector<HcResult> &out) {
+// One chunk of tasks: enqueue_chunk() puts all its device work on streams, finish_chunk() fetches the statistics, selects the
+// levels on the host and fetches the labels.  `pipe` = the chunk is one of several in flight (run on its slot's own stream, ordered
+// against its neighbours by events, see get_opt_hclust_batch); otherwise everything is relative to the library's main stream.
+struct ChunkJob {
+    size_t i0 = 0, i1 = 0;
+    int T = 0, slot = 0;
+    bool pipe = false, first = true;
+    std::vector<HcMeta> metas;
+    std::vector<RowPrepTask> prep;
+    std::vector<GemmTask> g;
+    long long oOut = 0, oM = 0, oLab = 0;
+    int max_n = 0, max_p = 0, max_nk = 0, max_kpad = 0, NS = 1;
+    bool has_next = false;                     // pipelined: another chunk follows (its distance GEMM is enqueued before this one's tail)
+    struct Range { int t0, t1; int off[5], cnt[5]; bool any_sym, any_feat; };
+    std::vector<Range> ranges;
+};
+enum : int { PH_DIST = 1, PH_AGGLO = 2, PH_STATS = 4, PH_ALL = 7 };
+struct PipeEvents {
+    hipEvent_t in = nullptr, out[8] = {nullptr}, gemm[2] = {nullptr, nullptr}, hc[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+};
+PipeEvents &pipe_events() {
+    static PipeEvents e;
+    if (!e.in) {
+        SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.in, hipEventDisableTiming));
+        for (auto &x : e.out) SHARP_HIP_CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+        for (int q = 0; q < 2; ++q) {
+            SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.gemm[q], hipEventDisableTiming));
+            SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.hc[q], hipEventDisableTiming));
+            SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.done[q], hipEventDisableTiming));
+        }
+    }
+    return e;
+}
+
+// Descriptors, workspace and uploads of a chunk (before its first phase).
+void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
     Ctx &c = ctx();
-    Workspace &W = ws();
-    const int T = static_cast<int>(i1 - i0);
-    std::vector<HcMeta> metas(T);
+    Workspace &W = ws(J.slot);
+    Workspace &W0 = ws(0);                     // agglomeration scratch: shared, one chunk's agglomeration runs at a time
+    PipeEvents &EV = pipe_events();
+    const size_t i0 = J.i0;
+    const int T = J.T = static_cast<int>(J.i1 - J.i0);
+    std::vector<HcMeta> &metas = J.metas;
+    metas.assign(T, HcMeta());
+    // a pipelined chunk lives on its slot's stream from its first upload on (the slot's buffers are reused by the chunk after next,
+    // which is on the same stream); its inputs come from the main stream (EV.in, recorded by the caller)
+    hipStream_t chunk_stream = J.pipe ? c.aux_stream(J.slot) : c.stream;
+    if (J.pipe) SHARP_HIP_CHECK(hipStreamWaitEvent(chunk_stream, EV.in, 0));
+    StreamScope chunk_scope(chunk_stream);
     long long oD = 0, oD0 = 0, oCr = 0, oCt = 0, oN = 0, oM = 0, oLab = 0, oK = 0, oCS = 0, oQ = 0, oOut = 0;
     int max_n = 0, max_p = 0, max_nk = 0, max_kpad = 0;
     bool any_sym = false, any_feat = false;
@@ -1288,8 +1334,9 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
         max_kpad = std::max(max_kpad, M.kpad);
         any_sym |= tk.symmetric; any_feat |= !tk.symmetric;
     }
+    J.oOut = oOut; J.oM = oM; J.oLab = oLab; J.max_n = max_n; J.max_p = max_p; J.max_nk = max_nk; J.max_kpad = max_kpad;
     { HostTimer ht("hc_workspace_alloc");
-    W.D.ensure(oD); W.S0.ensure(oD); W.S1.ensure(oD); W.D0.ensure(std::max<long long>(oD0, 1)); W.Cr.ensure(oCr); W.Ct.ensure(oCt); W.nrm.ensure(oN);
+    W.D.ensure(oD); W0.S0.ensure(oD); W0.S1.ensure(oD); W.D0.ensure(std::max<long long>(oD0, 1)); W.Cr.ensure(oCr); W.Ct.ensure(oCt); W.nrm.ensure(oN);
     W.height.ensure(oM); W.ia.ensure(oM); W.ib.ensure(oM); W.lab.ensure(oLab);
     W.H.ensure(oK); W.T.ensure(oK); W.G.ensure(oK); W.CSt.ensure(oCS); W.Q.ensure(oQ); W.out.ensure(oOut); }
     { HostTimer ht("hc_workspace_alloc");
@@ -1308,8 +1355,10 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
         if (!(mono && mono[0] == '1') && !(seq && seq[0] == '1') && max_n <= HR_MAXN && split) NS = 1;
     }
     if (const char *e = getenv("SHARP_HC_RANGES")) NS = std::max(1, std::min(8, atoi(e)));
+    if (J.pipe) NS = 1;                         // the overlap comes from the neighbouring chunks
     NS = std::min(NS, T);
-    std::vector<RowPrepTask> prep(T);
+    std::vector<RowPrepTask> &prep = J.prep;
+    prep.assign(T, RowPrepTask());
     for (int t = 0; t < T; ++t) {
         const HcTask &tk = tasks[i0 + t];
         const HcMeta &M = metas[t];
@@ -1317,9 +1366,12 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
                               W.Ct.p + M.oCt, W.nrm.p + M.oNrm, W.D.p + M.oD};
     }
     W.prep.upload(prep.data(), T);
-    struct Range { int t0, t1; int off[5], cnt[5]; bool any_sym, any_feat; };
-    std::vector<Range> ranges(NS);
-    std::vector<GemmTask> g;
+    typedef ChunkJob::Range Range;
+    J.NS = NS;
+    std::vector<Range> &ranges = J.ranges;
+    ranges.assign(NS, Range());
+    std::vector<GemmTask> &g = J.g;
+    g.clear();
     g.reserve(5 * static_cast<size_t>(T));
     for (int s = 0; s < NS; ++s) {
         Range &R = ranges[s];
@@ -1354,29 +1406,44 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
     }
     W.gemm.upload(g.data(), g.size());
     (void)any_sym; (void)any_feat;
-    static hipEvent_t ev_in = nullptr, ev_out[8] = {nullptr};
-    if (!ev_in) {
-        SHARP_HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
-        for (auto &e : ev_out) SHARP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    if (NS > 1) SHARP_HIP_CHECK(hipEventRecord(EV.in, chunk_stream));     // inputs and descriptors are ready
+}
+
+// Device work of a chunk, in three phases (`phases`: any contiguous set, in order): PH_DIST rows -> distance matrix, PH_AGGLO the
+// agglomeration, PH_STATS cutree and the per-level statistics.  A pipelined chunk has one range on its slot's stream.
+void enqueue_chunk(ChunkJob &J, int phases) {
+    Ctx &c = ctx();
+    Workspace &W = ws(J.slot);
+    Workspace &W0 = ws(0);
+    PipeEvents &EV = pipe_events();
+    const int NS = J.NS, max_n = J.max_n, max_p = J.max_p, max_nk = J.max_nk, max_kpad = J.max_kpad;
     hipStream_t main_stream = c.stream;
-    if (NS > 1) SHARP_HIP_CHECK(hipEventRecord(ev_in, main_stream));     // inputs and descriptors are ready
+    hipStream_t chunk_stream = J.pipe ? c.aux_stream(J.slot) : main_stream;
+    hipEvent_t ev_in = EV.in, *ev_out = EV.out;
 
     for (int s = 0; s < NS; ++s) {
-        const Range &R = ranges[s];
+        const ChunkJob::Range &R = J.ranges[s];
         const int Ts = R.t1 - R.t0;
-        hipStream_t st = NS > 1 ? c.aux_stream(s) : main_stream;
-        if (NS > 1) SHARP_HIP_CHECK(hipStreamWaitEvent(st, ev_in, 0));
+        hipStream_t st = NS > 1 ? c.aux_stream(s) : chunk_stream;
         StreamScope scope(st);
         const HcMeta *dmeta = W.meta.p + R.t0;
+        if (phases & PH_DIST) {
+        if (NS > 1) SHARP_HIP_CHECK(hipStreamWaitEvent(st, ev_in, 0));
+        // pipelined: this chunk's distance GEMM starts when the previous chunk's has finished, i.e. together with the previous
+        // chunk's agglomeration, and fills the CUs that one leaves free (it holds a whole CU per task)
+        if (J.pipe && !J.first) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.slot ^ 1], 0));
         // a3: rows -> centred/normalised (+ 1 - S for similarity input), then D = 1 - U U^T
         row_prep_batched(W.prep.p + R.t0, Ts, max_n, max_p);
         if (R.cnt[0]) gemm_tn_f64_batched(W.gemm.p + R.off[0], R.cnt[0], max_n, max_n, "corr_dist_gemm", true, true);
+        if (J.pipe) SHARP_HIP_CHECK(hipEventRecord(EV.gemm[J.slot], st));
         if (R.any_sym) {
             KernelTimer tm("copy_d");
             hipLaunchKernelGGL(copy_d_kernel, dim3(64, Ts), dim3(256), 0, st, dmeta, W.D.p, W.D0.p);
             launch_check("copy_d_kernel");
         }
+        }
+        if (phases & PH_AGGLO) {
+        if (J.pipe && !J.first) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.hc[J.slot ^ 1], 0));   // one agglomeration at a time (S0 / S1)
         // a4: agglomeration.  Reducible methods go through the bulk-synchronous kernel (streams whole rows between two scratch
         // matrices, D stays pristine); whatever it abandons (exact ties, centroid/median, n > 4096) is done by the
         // sequential NN-list kernel, which skips the tasks whose status is 0 -- no host round trip in between.
@@ -1398,10 +1465,10 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
                 const bool split = splt ? splt[0] == '1' : Ts <= 96;
                 if (!(mono && mono[0] == '1') && split) {
                     const int wpt = std::max(1, std::min(8, (5 * c.num_cu / 2 + Ts - 1) / Ts));
-                    W.img.ensure(static_cast<size_t>(Ts) * lds);
-                    W.remaining.ensure(1);
+                    W0.img.ensure(static_cast<size_t>(Ts) * lds);
+                    W0.remaining.ensure(1);
                     const int rem0 = Ts;
-                    W.remaining.upload(&rem0, 1);
+                    W0.remaining.upload(&rem0, 1);
                     auto ka = hclust_rnn_kernel<1024, 1>;
                     auto kb = hclust_rnn_kernel<1024, 2>;
                     const size_t ldsl = std::max(lds, HR_LDS_CU);       // the rebuild launches stage the pair members' entries like MODE 0
@@ -1409,13 +1476,13 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsl)));
                     const int max_rounds = max_n + 8;               // every round merges at least one pair
                     for (int r = 0; r < max_rounds; ++r) {
-                        hipLaunchKernelGGL(ka, dim3(Ts), dim3(1024), lds, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p, W.height.p,
-                                           W.status.p + R.t0, W.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W.remaining.p, static_cast<int>(lds));
-                        hipLaunchKernelGGL(kb, dim3(Ts, wpt), dim3(1024), ldsl, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p, W.height.p,
-                                           W.status.p + R.t0, W.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W.remaining.p, static_cast<int>(ldsl));
+                        hipLaunchKernelGGL(ka, dim3(Ts), dim3(1024), lds, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p, W.height.p,
+                                           W.status.p + R.t0, W0.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W0.remaining.p, static_cast<int>(lds));
+                        hipLaunchKernelGGL(kb, dim3(Ts, wpt), dim3(1024), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p, W.height.p,
+                                           W.status.p + R.t0, W0.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W0.remaining.p, static_cast<int>(ldsl));
                         if ((r & 7) == 7) {                         // a finished task costs two empty workgroups per round: look now and then
                             int rem = 0;
-                            W.remaining.download(&rem, 1);
+                            W0.remaining.download(&rem, 1);
                             if (rem <= 0) break;
                         }
                     }
@@ -1425,7 +1492,7 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
                     const size_t ldsl = std::max(lds, HR_LDS_CU);
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         static_cast<int>(ldsl)));
-                    hipLaunchKernelGGL(k0, dim3(Ts), dim3(1024), ldsl, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
+                    hipLaunchKernelGGL(k0, dim3(Ts), dim3(1024), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p,
                                        W.height.p, W.status.p + R.t0, nullptr, 0LL, static_cast<int>(lds), 0, nullptr, static_cast<int>(ldsl));
                 } else {
                     auto k0 = hclust_rnn_kernel<512, 0>;
@@ -1434,7 +1501,7 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
                     const size_t ldsl = std::max(lds, HR_LDS_CU / 2);      // two workgroups per CU
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         static_cast<int>(ldsl)));
-                    hipLaunchKernelGGL(k0, dim3(Ts), dim3(512), ldsl, st, dmeta, W.D.p, W.S0.p, W.S1.p, W.ia.p, W.ib.p,
+                    hipLaunchKernelGGL(k0, dim3(Ts), dim3(512), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p,
                                        W.height.p, W.status.p + R.t0, nullptr, 0LL, static_cast<int>(lds), 0, nullptr, static_cast<int>(ldsl));
                 }
                 launch_check("hclust_rnn_kernel");
@@ -1460,6 +1527,13 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
                         acc[3] / Ts, acc[4] / Ts, acc[5] / Ts);
             }
         }
+        if (J.pipe) SHARP_HIP_CHECK(hipEventRecord(EV.hc[J.slot], st));
+        }
+        if (!(phases & PH_STATS)) continue;
+        // pipelined: the next chunk's distance GEMM (already enqueued) is on the critical path -- its agglomeration cannot start
+        // before it -- and this tail is not: it waits for that GEMM and then runs beside the next agglomeration, whose stream has
+        // the higher priority or is served first, on the CUs that one leaves free
+        if (J.pipe && J.has_next) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.slot ^ 1], 0));
         // a5a: labels for every candidate k
         {
             const size_t lds = static_cast<size_t>(max_n) * 4 * 3 + (HC_THREADS / 64 + 1) * 4;
@@ -1495,6 +1569,17 @@ void run_chunk(const std::vector<HcTask> &tasks, size_t i0, size_t i1, bool want
             SHARP_HIP_CHECK(hipStreamWaitEvent(main_stream, ev_out[s], 0));
         }
     }
+    if (J.pipe && (phases & PH_STATS)) SHARP_HIP_CHECK(hipEventRecord(EV.done[J.slot], chunk_stream));
+}
+
+void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, std::vector<HcResult> &out) {
+    Ctx &c = ctx();
+    Workspace &W = ws(J.slot);
+    const size_t i0 = J.i0;
+    const int T = J.T, max_n = J.max_n;
+    const long long oOut = J.oOut, oM = J.oM, oLab = J.oLab;
+    const std::vector<HcMeta> &metas = J.metas;
+    if (J.pipe) SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, pipe_events().done[J.slot], 0));
     std::vector<double> h_out(oOut), h_height(oM);
     if (c.profiling) {      // which agglomeration kernel did the work (tests assert on it)
         const char *seq = getenv("SHARP_HC_SEQ");
@@ -1571,6 +1656,7 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
         if (const char *e = getenv("SHARP_HC_CHUNK")) max_tasks = std::max<size_t>(1, static_cast<size_t>(atoll(e)));
         else if (tasks.size() > ncu) { const size_t nch = (tasks.size() + ncu - 1) / ncu; max_tasks = (tasks.size() + nch - 1) / nch; }
     }
+    std::vector<std::pair<size_t, size_t>> bounds;
     size_t i0 = 0;
     while (i0 < tasks.size()) {
         double bytes = 0;
@@ -1584,9 +1670,42 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
             bytes += b;
             ++i1;
         }
-        run_chunk(tasks, i0, i1, want_v, out);
+        bounds.push_back({i0, i1});
         i0 = i1;
     }
+    // Several chunks: two in flight.  Chunk j + 1's row preparation and distance GEMM (MFMA-bound) run beside chunk j's
+    // agglomeration (HBM-bound, one workgroup per task holding a whole CU: 188 of 256 CUs at cfg2) on the CUs that one leaves free,
+    // chunk j's cutree / cluster sums / silhouette statistics beside chunk j + 1's agglomeration, and the host's level selection and
+    // label download of chunk j under chunk j + 1's device work.  SHARP_HC_PIPE=0: one chunk at a time.
+    const char *pe = getenv("SHARP_HC_PIPE");
+    const bool pipe = bounds.size() > 1 && !(pe && pe[0] == '0');
+    if (!pipe) {
+        for (const auto &b : bounds) {
+            ChunkJob J;
+            J.i0 = b.first; J.i1 = b.second;
+            setup_chunk(tasks, J);
+            enqueue_chunk(J, PH_ALL);
+            finish_chunk(tasks, J, want_v, out);
+        }
+        return;
+    }
+    SHARP_HIP_CHECK(hipEventRecord(pipe_events().in, ctx().stream));        // the tasks' inputs are ready
+    // host order: dist(0) agglo(0) | dist(1) stats(0) agglo(1) | fetch(0) dist(2) stats(1) agglo(2) | fetch(1) ...
+    ChunkJob jobs[2];
+    const size_t nb = bounds.size();
+    for (size_t j = 0; j < nb; ++j) {
+        ChunkJob &J = jobs[j & 1];
+        if (j >= 2) finish_chunk(tasks, J, want_v, out);                    // chunk j - 2 used this slot
+        J.i0 = bounds[j].first; J.i1 = bounds[j].second;
+        J.slot = static_cast<int>(j & 1); J.pipe = true; J.first = j == 0; J.has_next = j + 1 < nb;
+        setup_chunk(tasks, J);
+        enqueue_chunk(J, PH_DIST);
+        if (j >= 1) enqueue_chunk(jobs[(j - 1) & 1], PH_STATS);
+        enqueue_chunk(J, PH_AGGLO);
+    }
+    enqueue_chunk(jobs[(nb - 1) & 1], PH_STATS);
+    if (nb >= 2) finish_chunk(tasks, jobs[(nb - 2) & 1], want_v, out);
+    finish_chunk(tasks, jobs[(nb - 1) & 1], want_v, out);
 }
 
 }  // namespace sharp

@@ -129,7 +129,7 @@ void draw_projector(int m, int p, double seed, std::vector<uint32_t> &rowptr, st
 // ---------------------------------------------------------------------------------------------
 #include "mt_jump_table.inc"
 
-constexpr int PD_THREADS = 256;
+constexpr int PD_THREADS = 640;          // one lane per Mersenne-Twister state word in the jump (624); the draw phases use 227
 constexpr int PD_XS = 19937 + 624 + 227;   // raw words needed to jump: x_0 .. x_(19936+623), rounded up to whole 227-word steps
 constexpr int PD_STAGE = 4096;
 
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(PD_THREADS) void proj_draw_kernel(const uint32_t *_
                                                                uint32_t t1, int flush_every, uint32_t *__restrict__ hits,
                                                                unsigned int cap, unsigned int *__restrict__ nhits,
                                                                int *__restrict__ err) {
-    // One workgroup per (projector, segment of 2^20 draws).  Segment t > 0 first jumps the seed state t * 2^20 draws ahead:
-    // with g_t(x) = x^(t 2^20) mod phi (mt_jump_table.inc), the state window at that offset is w_j = XOR_{i : g_t has x^i}
+    // One workgroup per (projector, segment of 2^MT_JUMP_LOG2 draws).  Segment t > 0 first jumps the seed state t segments ahead:
+    // with g_t(x) = x^(t 2^MT_JUMP_LOG2) mod phi (mt_jump_table.inc), the state window at that offset is w_j = XOR_{i : g_t has x^i}
     // x_(i+j), j = 0..623, over the raw word sequence x -- 20 560 words regenerated into LDS, then 624 independent XOR
     // chains.  All segments of a projector therefore start at once instead of one after the other.
     constexpr int N = 624, M = 397, D = N - M;   // D = 227
@@ -180,21 +180,23 @@ __global__ __launch_bounds__(PD_THREADS) void proj_draw_kernel(const uint32_t *_
             if (tid < D && n0 + N + tid < PD_XS) xs[n0 + N + tid] = xs[n0 + M + tid] ^ pd_tw(xs[n0 + tid], xs[n0 + tid + 1]);
             __syncthreads();
         }
+        // One lane per state word, every coefficient visited: 32 independent LDS reads per polynomial word, masked by the
+        // coefficient, so the reads pipeline (a loop over the set bits only, with its data-dependent trip count, waited for
+        // every read in turn and took 1.2 ms per jump; this form takes the LDS time of 19 937 x 624 word reads).
         const unsigned int *g = mt_jump_poly[seg - 1];
-        uint32_t acc[3] = {0u, 0u, 0u};
+        const int j = tid < N ? tid : 0;
+        uint32_t acc0 = 0u, acc1 = 0u;
         for (int w = 0; w < N; ++w) {
-            uint32_t word = g[w];                                      // same word in every lane: scalar control flow
-            while (word) {
-                const int bit = __builtin_ctz(word);
-                word &= word - 1u;
-                const int i = 32 * w + bit;
+            const uint32_t word = g[w];                                // same word in every lane
+            const uint32_t *x = xs + 32 * w + j;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { const int j = tid + q * PD_THREADS; if (j < N) acc[q] ^= xs[i + j]; }
+            for (int b = 0; b < 32; b += 2) {
+                acc0 ^= x[b] & (0u - ((word >> b) & 1u));
+                acc1 ^= x[b + 1] & (0u - ((word >> (b + 1)) & 1u));
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { const int j = tid + q * PD_THREADS; if (j < N) st[0][j] = acc[q]; }
+        if (tid < N) st[0][tid] = acc0 ^ acc1;
         __syncthreads();
     }
     unsigned int gcount = 0;   // hits already flushed (uniform)
@@ -277,6 +279,34 @@ __global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int
         flat[rowptr[g] + slot] = static_cast<uint16_t>(kk * p + c) | ((w >> 31) ? 0x8000u : 0u);
     }
 }
+// Places the n <= 4*gw codes of one segment (ascending component order) so that the LDS atomics of the apply kernel
+// (rp2.hip) meet few bank conflicts.  A 64-bit LDS atomic is served in groups of 16 contiguous lanes over 16 eight-byte
+// bank pairs (MI355X_MICROARCH.md, LDS: the ds_write_b64 row), i.e. one cycle per group plus one per extra code of the
+// same class = component mod 16 inside the group.  Lane l of a gene's lane group holds positions 4l..4l+3 and its q-th
+// code goes out with atomic instruction q, so the codes are laid down in (class, component) order: the L codes of a
+// class sit at consecutive positions and at most ceil(L/4) of them share an instruction (ascending-component order put
+// ~10 random classes in each instruction: 2.7 cycles per group on average instead of ~1.4).  The order of a gene's
+// codes has no effect on the result: the accumulators are integers.
+__host__ __device__ inline void place_segment(const uint16_t *src, uint32_t n, uint16_t *dst) {
+    unsigned long long cnt[2] = {0ull, 0ull};            // 16 classes x 8-bit counters (n <= 64)
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t c = src[i] & 15u;
+        cnt[c >> 3] += 1ull << ((c & 7u) * 8u);
+    }
+    unsigned long long start[2] = {0ull, 0ull};          // exclusive prefix over the classes
+    uint32_t run = 0;
+    for (uint32_t c = 0; c < 16; ++c) {
+        start[c >> 3] |= static_cast<unsigned long long>(run) << ((c & 7u) * 8u);
+        run += static_cast<uint32_t>(cnt[c >> 3] >> ((c & 7u) * 8u)) & 0xffu;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t c = src[i] & 15u, sh = (c & 7u) * 8u;
+        const uint32_t pos = static_cast<uint32_t>(start[c >> 3] >> sh) & 0xffu;
+        start[c >> 3] += 1ull << sh;
+        dst[pos] = src[i];
+    }
+}
+
 // one thread per gene: order the gene's codes by component (the order of the host build: projector, then column) and
 // write them into the fixed-stride lane-major segments (+ overflow segments)
 __global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, uint16_t *__restrict__ flat, int gw,
@@ -303,11 +333,9 @@ __global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, u
             if (gm < static_cast<uint32_t>(g)) lo = mid + 1; else hi = mid - 1;
         }
     }
-    for (uint32_t i = 0; i < len; ++i) {
-        const uint32_t sgm = i / span, r = i % span;
-        const uint32_t q = r / gw, lane = r % gw;
+    for (uint32_t s0 = 0, sgm = 0; s0 < len; s0 += span, ++sgm) {
         const size_t seg = sgm == 0 ? static_cast<size_t>(g) : extra_base + (sgm - 1);
-        ent[seg * span + 4 * lane + q] = src[i];
+        place_segment(src + s0, len - s0 < span ? len - s0 : span, ent + seg * span);
     }
 }
 __global__ void proj_fill_u16_kernel(uint16_t *p, size_t n, uint16_t v) {
@@ -394,11 +422,9 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
             const uint16_t *src = flat.data() + rowptr[g];
             size_t extra_base = 0;
             if (len > static_cast<uint32_t>(span)) extra_base = ovf_info[ov++].x;
-            for (uint32_t i = 0; i < len; ++i) {
-                const uint32_t sgm = i / span, r = i % span;
-                const uint32_t q = r / grp.gw, lane = r % grp.gw;
+            for (uint32_t s0 = 0, sgm = 0; s0 < len; s0 += span, ++sgm) {
                 const size_t seg = sgm == 0 ? static_cast<size_t>(g) : extra_base + (sgm - 1);
-                ent[seg * span + 4 * lane + q] = src[i];
+                place_segment(src + s0, std::min<uint32_t>(len - s0, span), ent.data() + seg * span);
             }
         }
         grp.ent.alloc(ent.size());

@@ -104,6 +104,27 @@ def test_sharp_large_matches_oracle(sa, oracle):
     assert adjusted_rand_score(truth, res["pred_clusters"]) > 0.5
 
 
+@pytest.mark.parametrize("chunk", [4, 7, 25])
+def test_sharp_large_pipelined_chunks_match_oracle(sa, oracle, monkeypatch, chunk):
+    # the K*T base-clustering tasks cut into 7 / 4 / 1 chunks: with more than one chunk two are in flight at a time
+    # (distance GEMM of chunk j + 1 beside the agglomeration of chunk j, statistics of chunk j beside the agglomeration of
+    # chunk j + 1, on two streams and two workspace sets); SHARP_HC_PIPE=0 runs one chunk at a time.  Same labels either way.
+    m, n, G, nm = 3000, 900, 6, 300
+    X = oracle.synth_fill(SEED, m, 0, n, G, nm)
+    ref = oracle.SHARP(X, K=5, base_ncells=300, partition_ncells=200, rN_seed=2103, nthreads=4)
+    kw = dict(ensize_K=5, base_ncells=300, partition_ncells=200, rN_seed=2103, logflag=False, prep=False)
+    monkeypatch.setenv("SHARP_HC_CHUNK", str(chunk))
+    res = sa.SHARP(X, **kw)
+    res_again = sa.SHARP(X, **kw)                        # the workspace sets are reused
+    monkeypatch.setenv("SHARP_HC_PIPE", "0")
+    res_serial = sa.SHARP(X, **kw)
+    assert res["path"] == "SHARP_large"
+    for r in (res, res_again, res_serial):
+        assert np.array_equal(r["pred_clusters"], ref["pred_clusters"])
+    np.testing.assert_array_equal(res["viE"], res_serial["viE"])
+    np.testing.assert_array_equal(res["x0"], res_serial["x0"])
+
+
 def test_sharp_unlimited_matches_oracle(sa, oracle):
     m, G, nm = 3000, 6, 300
     blocks = [oracle.synth_fill(SEED, m, i * 6000, 6000, G, nm) for i in range(2)]
