@@ -202,9 +202,11 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
                 for (int u = 0; u < U; ++u) {
                     const long long fix = sfix[buf * 64 + grp + u * NG];
                     ap_scatter_codes<GW>(acc, cd[u], fix);
-                    if (novf > 0) {   // rare: a full segment may continue in overflow segments
-                        const uint32_t lastcode = __shfl(cd[u].y >> 16, lane | (GW - 1));
-                        if (lastcode != 0xffffu) {
+                    // rare: a full segment (last code of the group's last lane in use) may continue in overflow segments.  The
+                    // test is a ballot (scalar), not a cross-lane LDS read: that one made every gene wait for all atomics in flight.
+                    const unsigned long long full = novf > 0 ? __ballot(lg == GW - 1 && (cd[u].y >> 16) != 0xffffu) : 0ull;
+                    if (full != 0ull) {
+                        if ((full >> (lane | (GW - 1))) & 1ull) {
                             const uint32_t g = sgen[buf * 64 + grp + u * NG];
                             int lo = 0, hi = novf - 1, hit = -1;
                             while (lo <= hi) {
