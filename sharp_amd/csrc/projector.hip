@@ -262,7 +262,7 @@ __global__ void proj_count_kernel(const uint32_t *__restrict__ hits, unsigned in
     const unsigned int n = nhits[list];
     const uint32_t *h = hits + list * cap;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        atomicAdd(&len[(h[i] & 0x7fffffffu) / p], 1u);
+        atomicAdd(&len[(h[i] & 0x7fffffffu) / p], (h[i] >> 31) ? 0x10000u : 1u);   // low half: positive codes, high half: negative
 }
 // codes (kk*p + c, bit 15 = negative) into the gene's CSR slot range, in arrival order
 __global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int cap, const unsigned int *__restrict__ nhits, int k0,
@@ -279,32 +279,24 @@ __global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int
         flat[rowptr[g] + slot] = static_cast<uint16_t>(kk * p + c) | ((w >> 31) ? 0x8000u : 0u);
     }
 }
-// Places the n <= 4*gw codes of one segment (ascending component order) so that the LDS atomics of the apply kernel
-// (rp2.hip) meet few bank conflicts.  A 64-bit LDS atomic is served in groups of 16 contiguous lanes over 16 eight-byte
-// bank pairs (MI355X_MICROARCH.md, LDS: the ds_write_b64 row), i.e. one cycle per group plus one per extra code of the
-// same class = component mod 16 inside the group.  Lane l of a gene's lane group holds positions 4l..4l+3 and its q-th
-// code goes out with atomic instruction q, so the codes are laid down in (class, component) order: the L codes of a
-// class sit at consecutive positions and at most ceil(L/4) of them share an instruction (ascending-component order put
-// ~10 random classes in each instruction: 2.7 cycles per group on average instead of ~1.4).  The order of a gene's
-// codes has no effect on the result: the accumulators are integers.
-__host__ __device__ inline void place_segment(const uint16_t *src, uint32_t n, uint16_t *dst) {
-    unsigned long long cnt[2] = {0ull, 0ull};            // 16 classes x 8-bit counters (n <= 64)
+// Writes a gene's codes (src: n codes as comp | 0x8000 for negative, any order) into its segments: positive codes into lanes
+// 0, 1, ... (four per lane), negative codes from the next free lane on; lane l lives in segment l / gw (the gene's own segment g,
+// then its overflow segments from extra_base), slots 4 (l % gw) .. + 3.  Untouched slots keep their padding codes.
+__host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint32_t gw, size_t g, size_t extra_base, uint16_t *ent) {
+    const uint32_t span = 4u * gw;
+    uint32_t np = 0;
+    for (uint32_t i = 0; i < n; ++i) np += (src[i] & 0x8000u) ? 0u : 1u;
+    const uint32_t neg0 = (np + 3u) / 4u * 4u;           // first slot (in the gene's lane sequence) of the negative codes
+    uint32_t ip = 0, in = neg0, last = 0;
     for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t c = src[i] & 15u;
-        cnt[c >> 3] += 1ull << ((c & 7u) * 8u);
+        const bool neg = (src[i] & 0x8000u) != 0u;
+        const uint32_t slot = neg ? in++ : ip++;
+        const uint32_t sgm = slot / span, r = slot % span;
+        const size_t seg = sgm == 0 ? g : extra_base + (sgm - 1);
+        ent[seg * span + r] = static_cast<uint16_t>(((src[i] & 0x7fffu) << 3) | (neg ? kCodeNeg : 0u));
+        last = slot > last ? slot : last;
     }
-    unsigned long long start[2] = {0ull, 0ull};          // exclusive prefix over the classes
-    uint32_t run = 0;
-    for (uint32_t c = 0; c < 16; ++c) {
-        start[c >> 3] |= static_cast<unsigned long long>(run) << ((c & 7u) * 8u);
-        run += static_cast<uint32_t>(cnt[c >> 3] >> ((c & 7u) * 8u)) & 0xffu;
-    }
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t c = src[i] & 15u, sh = (c & 7u) * 8u;
-        const uint32_t pos = static_cast<uint32_t>(start[c >> 3] >> sh) & 0xffu;
-        start[c >> 3] += 1ull << sh;
-        dst[pos] = src[i];
-    }
+    if (n && last >= span) ent[g * span + span - 1] |= static_cast<uint16_t>(kCodeMore);
 }
 
 // one thread per gene: order the gene's codes by component (the order of the host build: projector, then column) and
@@ -322,9 +314,8 @@ __global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, u
         while (j > 0 && (src[j - 1] & 0x7fffu) > (v & 0x7fffu)) { src[j] = src[j - 1]; --j; }
         src[j] = v;
     }
-    const uint32_t span = 4u * gw;
     size_t extra_base = 0;
-    if (len > span) {
+    if (novf > 0) {                                      // (genes without overflow segments are simply not found)
         int lo = 0, hi = novf - 1;
         while (lo <= hi) {
             const int mid = (lo + hi) >> 1;
@@ -333,10 +324,7 @@ __global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, u
             if (gm < static_cast<uint32_t>(g)) lo = mid + 1; else hi = mid - 1;
         }
     }
-    for (uint32_t s0 = 0, sgm = 0; s0 < len; s0 += span, ++sgm) {
-        const size_t seg = sgm == 0 ? static_cast<size_t>(g) : extra_base + (sgm - 1);
-        place_segment(src + s0, len - s0 < span ? len - s0 : span, ent + seg * span);
-    }
+    place_gene(src, len, static_cast<uint32_t>(gw), static_cast<size_t>(g), extra_base, ent);
 }
 __global__ void proj_fill_u16_kernel(uint16_t *p, size_t n, uint16_t v) {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) p[i] = v;
@@ -404,10 +392,13 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
         std::vector<uint32_t> ovf_gene;
         std::vector<uint2> ovf_info;
         long long nseg = m;
+        std::vector<uint16_t> lanes(static_cast<size_t>(m));   // lanes of four same-sign codes the gene occupies
         for (int g = 0; g < m; ++g) {
-            const uint32_t len = rowptr[g + 1] - rowptr[g];
-            if (len > static_cast<uint32_t>(span)) {
-                const uint32_t extra = (len - span + span - 1) / span;
+            int np = 0, nn = 0;
+            for (uint32_t q = rowptr[g]; q < rowptr[g + 1]; ++q) { if (flat[q] & 0x8000u) ++nn; else ++np; }
+            lanes[g] = static_cast<uint16_t>(code_lanes(np, nn));
+            if (lanes[g] > grp.gw) {
+                const uint32_t extra = (lanes[g] - grp.gw + grp.gw - 1) / grp.gw;
                 ovf_gene.push_back(static_cast<uint32_t>(g));
                 ovf_info.push_back(make_uint2(static_cast<uint32_t>(nseg), extra));
                 nseg += extra;
@@ -415,17 +406,14 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
         }
         grp.nseg = nseg;
         grp.novf = static_cast<int>(ovf_gene.size());
-        std::vector<uint16_t> ent(static_cast<size_t>(nseg + 1) * span, 0xFFFFu);
+        std::vector<uint16_t> ent(static_cast<size_t>(nseg + 1) * span, static_cast<uint16_t>(kCodePad));
         size_t ov = 0;
         for (int g = 0; g < m; ++g) {
             const uint32_t len = rowptr[g + 1] - rowptr[g];
             const uint16_t *src = flat.data() + rowptr[g];
             size_t extra_base = 0;
-            if (len > static_cast<uint32_t>(span)) extra_base = ovf_info[ov++].x;
-            for (uint32_t s0 = 0, sgm = 0; s0 < len; s0 += span, ++sgm) {
-                const size_t seg = sgm == 0 ? static_cast<size_t>(g) : extra_base + (sgm - 1);
-                place_segment(src + s0, std::min<uint32_t>(len - s0, span), ent.data() + seg * span);
-            }
+            if (lanes[g] > grp.gw) extra_base = ovf_info[ov++].x;
+            place_gene(src, len, static_cast<uint32_t>(grp.gw), static_cast<size_t>(g), extra_base, ent.data());
         }
         grp.ent.alloc(ent.size());
         grp.ent.upload(ent.data(), ent.size());
@@ -503,7 +491,14 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         }
         std::vector<uint32_t> rowptr(static_cast<size_t>(m) + 1, 0);
         int max_len = 0;
-        for (int g = 0; g < m; ++g) { rowptr[g + 1] = rowptr[g] + len[g]; max_len = std::max<int>(max_len, static_cast<int>(len[g])); }
+        std::vector<uint16_t> lanes(static_cast<size_t>(m));   // lanes of four same-sign codes the gene occupies
+        for (int g = 0; g < m; ++g) {
+            const int np = static_cast<int>(len[g] & 0xffffu), nn = static_cast<int>(len[g] >> 16);
+            lanes[g] = static_cast<uint16_t>(code_lanes(np, nn));
+            len[g] = static_cast<unsigned int>(np + nn);
+            rowptr[g + 1] = rowptr[g] + len[g];
+            max_len = std::max<int>(max_len, static_cast<int>(len[g]));
+        }
         grp.nnz = rowptr[m];
         grp.mean_len = static_cast<double>(grp.nnz) / m;
         grp.max_len = max_len;
@@ -514,8 +509,8 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         std::vector<uint2> ovf_info;
         long long nseg = m;
         for (int g = 0; g < m; ++g) {
-            if (len[g] > static_cast<unsigned int>(span)) {
-                const uint32_t extra = (len[g] - span + span - 1) / span;
+            if (lanes[g] > grp.gw) {
+                const uint32_t extra = (lanes[g] - grp.gw + grp.gw - 1) / grp.gw;
                 ovf_gene.push_back(static_cast<uint32_t>(g));
                 ovf_info.push_back(make_uint2(static_cast<uint32_t>(nseg), extra));
                 nseg += extra;
@@ -534,7 +529,7 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         DevBuf<uint16_t> d_flat(static_cast<size_t>(std::max<long long>(grp.nnz, 1)));
         const size_t nent = static_cast<size_t>(nseg + 1) * span;
         grp.ent.alloc(nent);
-        hipLaunchKernelGGL(proj_fill_u16_kernel, dim3(256), dim3(256), 0, c.stream, grp.ent.p, nent, static_cast<uint16_t>(0xFFFFu));
+        hipLaunchKernelGGL(proj_fill_u16_kernel, dim3(256), dim3(256), 0, c.stream, grp.ent.p, nent, static_cast<uint16_t>(kCodePad));
         hipLaunchKernelGGL(proj_fill_kernel, dim3(16, grp.kcount, S), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
                            static_cast<uint32_t>(p), d_rowptr.p, d_fill.p, d_flat.p);
         hipLaunchKernelGGL(proj_layout_kernel, dim3((m + 255) / 256), dim3(256), 0, c.stream, m, d_rowptr.p, d_flat.p, grp.gw,

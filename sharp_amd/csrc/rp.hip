@@ -64,18 +64,6 @@ __device__ __forceinline__ RpStepVals rp_load_step(const float *col, int s, int 
     return r;
 }
 
-template <int GW>
-__device__ __forceinline__ void rp_scatter_codes(unsigned long long *acc, uint2 c, long long fix) {
-    const uint32_t w[4] = {c.x & 0xffffu, c.x >> 16, c.y & 0xffffu, c.y >> 16};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (w[q] != 0xffffu) {   // 0xFFFF = padding
-            const long long v = (w[q] & 0x8000u) ? -fix : fix;
-            atomicAdd(&acc[w[q] & 0x7fffu], static_cast<unsigned long long>(v));
-        }
-    }
-}
-
 // Wave-autonomous structure: each wave compacts, logs and scatters the genes it loaded itself, through
 // its own slice of the LDS slot list, so the only workgroup barriers are the two around the per-cell
 // epilogue.  Per step a wave has ONE dependent L2 round trip: the row-list loads of all its non-zero
@@ -172,11 +160,11 @@ __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
                             const int e = e0 + grp + u * NG;
                             if (e < nnz) {
                                 const long long fix = list[e].fix;
-                                if (ablate < 1) rp_scatter_codes<GW>(acc, cd[u], fix);
+                                if (ablate < 1) scatter_codes<RP_CAP * sizeof(NzSlot)>(cd[u], fix);
                                 else if (cd[u].x == 0xdeadbeefu) acc[0] = 1;
                                 // rare: a full segment may continue in overflow segments
                                 const uint32_t lastcode = __shfl(cd[u].y >> 16, lane | (GW - 1));
-                                if (lastcode != 0xffffu && novf > 0) {
+                                if ((lastcode & kCodeMore) != 0u && novf > 0) {
                                     const uint32_t g = list[e].gene;
                                     int lo = 0, hi = novf - 1, hit = -1;
                                     while (lo <= hi) {
@@ -189,7 +177,7 @@ __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
                                         const uint2 oi = ovf_info[hit];
                                         for (uint32_t sg = 0; sg < oi.y; ++sg) {
                                             const uint2 c = *reinterpret_cast<const uint2 *>(ent + (static_cast<size_t>(oi.x) + sg) * SPAN + 4 * lg);
-                                            rp_scatter_codes<GW>(acc, c, fix);
+                                            scatter_codes<RP_CAP * sizeof(NzSlot)>(c, fix);
                                         }
                                     }
                                 }
@@ -236,6 +224,11 @@ static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float 
     const int nsteps = (m + RP_STEP - 1) / RP_STEP;
     const int step_len = ((m + nsteps - 1) / nsteps + 3) / 4 * 4;
     auto kern = rp_scatter_kernel<GW, VEC>;
+    {   // scatter_codes<RP_CAP * sizeof(NzSlot)>: the dynamic LDS block must start at LDS address 0 (no static LDS in the kernel)
+        hipFuncAttributes fa;
+        SHARP_HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
+        SHARP_REQUIRE(fa.sharedSizeBytes == 0, "rp_scatter_kernel: static LDS in front of the dynamic block");
+    }
     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(lds)));
     int per_cu = 1;   // resident blocks per CU (LDS- and VGPR-limited): size the persistent grid to exactly that

@@ -135,18 +135,6 @@ __global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__r
 }
 
 template <int GW>
-__device__ __forceinline__ void ap_scatter_codes(unsigned long long *acc, uint2 c, long long fix) {
-    const uint32_t w[4] = {c.x & 0xffffu, c.x >> 16, c.y & 0xffffu, c.y >> 16};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (w[q] != 0xffffu) {   // 0xFFFF = padding
-            const long long v = (w[q] & 0x8000u) ? -fix : fix;
-            atomicAdd(&acc[w[q] & 0x7fffu], static_cast<unsigned long long>(v));
-        }
-    }
-}
-
-template <int GW>
 __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     int ncell, long long cell0, int cap, const unsigned int *__restrict__ counts, const uint32_t *__restrict__ genes,
     const long long *__restrict__ fixes, const uint16_t *__restrict__ ent, unsigned int dummy_seg,
@@ -157,9 +145,14 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane / GW, lg = lane % GW;
-    // per-wave scratch: two buffers of 64 (gene, fix) entries
-    long long *sfix = reinterpret_cast<long long *>(acc + ncomp) + wave * 128;
-    uint32_t *sgen = reinterpret_cast<uint32_t *>(reinterpret_cast<long long *>(acc + ncomp) + NW * 128) + wave * 128;
+    // per-wave scratch: two buffers of 64 entries: gene, and the pair (+term, -term) -- a lane picks its signed term with the address
+    long long *sfix = reinterpret_cast<long long *>(acc + ncomp) + wave * 256;
+    uint32_t *sgen = reinterpret_cast<uint32_t *>(reinterpret_cast<long long *>(acc + ncomp) + NW * 256) + wave * 128;
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    auto put_term = [&](int slot, long long f) { *reinterpret_cast<ll2 *>(sfix + 2 * slot) = (ll2){f, -f}; };
+    auto signed_term = [&](int slot, uint32_t code0) -> unsigned long long {
+        return static_cast<unsigned long long>(sfix[2 * slot + static_cast<int>(code0 & kCodeNeg)]);
+    };
     for (int c = tid; c < ncomp; c += AP_THREADS) acc[c] = 0ull;
     __syncthreads();
 
@@ -182,7 +175,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
             uint2 cd[U], cdn[U];
             // prologue: entries of the first batch -> scratch, its row lists in flight, entries of the second batch in flight
             load_entry(wave, gL, fL);
-            sgen[lane] = gL; sfix[lane] = fL;
+            sgen[lane] = gL; put_term(lane, fL);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < U; ++u) cd[u] = *reinterpret_cast<const uint2 *>(ent + static_cast<size_t>(sgen[grp + u * NG]) * SPAN + 4 * lg);
@@ -190,7 +183,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
             for (int b = wave; b < nb; b += NW) {
                 const int nbuf = buf ^ 1;
                 // entries of batch b+NW (loaded one iteration ago) -> the other scratch buffer
-                sgen[nbuf * 64 + lane] = gL; sfix[nbuf * 64 + lane] = fL;
+                sgen[nbuf * 64 + lane] = gL; put_term(nbuf * 64 + lane, fL);
                 __builtin_amdgcn_wave_barrier();
                 // row lists of batch b+NW and entries of batch b+2NW go in flight ...
 #pragma unroll
@@ -198,16 +191,26 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
                     cdn[u] = *reinterpret_cast<const uint2 *>(ent + static_cast<size_t>(sgen[nbuf * 64 + grp + u * NG]) * SPAN + 4 * lg);
                 load_entry(b + 2 * NW, gL, fL);
                 // ... while the atomics of batch b run
+                uint32_t more = 0u;
+                unsigned long long term = signed_term(buf * 64 + grp, cd[0].x);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const long long fix = sfix[buf * 64 + grp + u * NG];
-                    ap_scatter_codes<GW>(acc, cd[u], fix);
-                    // rare: a full segment (last code of the group's last lane in use) may continue in overflow segments.  The
-                    // test is a ballot (scalar), not a cross-lane LDS read: that one made every gene wait for all atomics in flight.
-                    const unsigned long long full = novf > 0 ? __ballot(lg == GW - 1 && (cd[u].y >> 16) != 0xffffu) : 0ull;
-                    if (full != 0ull) {
+                    // the next gene's term is read before this gene's atomics go out: LDS operations return in order, so its
+                    // wait then leaves these four atomics in flight instead of draining them
+                    const unsigned long long tnext = u + 1 < U ? signed_term(buf * 64 + grp + (u + 1) * NG, cd[u + 1 < U ? u + 1 : u].x) : 0ull;
+                    asm volatile("" : "+v"(term));   // the one wait for this gene's term sits here, not in front of every conditional atomic
+                    scatter_codes_signed<0>(cd[u], term);
+                    more |= cd[u].y;
+                    term = tnext;
+                }
+                // rare: a gene may continue in overflow segments (flag in the last slot of its segment: the group's last lane sees
+                // it).  One scalar test per batch.
+                if (__ballot((more & (kCodeMore << 16)) != 0u) != 0ull) {
+                    for (int u = 0; u < U; ++u) {
+                        const unsigned long long full = __ballot((cd[u].y & (kCodeMore << 16)) != 0u);
                         if ((full >> (lane | (GW - 1))) & 1ull) {
-                            const uint32_t g = sgen[buf * 64 + grp + u * NG];
+                            const int slot = buf * 64 + grp + u * NG;
+                            const uint32_t g = sgen[slot];
                             int lo = 0, hi = novf - 1, hit = -1;
                             while (lo <= hi) {
                                 const int mid = (lo + hi) >> 1;
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
                                 const uint2 oi = ovf_info[hit];
                                 for (uint32_t sg = 0; sg < oi.y; ++sg) {
                                     const uint2 c2 = *reinterpret_cast<const uint2 *>(ent + (static_cast<size_t>(oi.x) + sg) * SPAN + 4 * lg);
-                                    ap_scatter_codes<GW>(acc, c2, fix);
+                                    scatter_codes_signed<0>(c2, signed_term(slot, c2.x));
                                 }
                             }
                         }
@@ -260,9 +263,14 @@ static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell
                          const uint32_t *genes, const long long *fixes, double inv_fix, double *dE, long long ldE, const int *row_map,
                          hipStream_t st) {
     Ctx &c = ctx();
-    const size_t lds = static_cast<size_t>(g.ncomp) * 8 + (AP_THREADS / 64) * 128 * 12;
+    const size_t lds = static_cast<size_t>(g.ncomp) * 8 + (AP_THREADS / 64) * 128 * 20;
     auto kern = rp_apply_kernel<GW>;
     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    {   // scatter_codes<0>: the accumulators sit at LDS address 0, i.e. the kernel must not have static LDS in front of the dynamic block
+        hipFuncAttributes fa;
+        SHARP_HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
+        SHARP_REQUIRE(fa.sharedSizeBytes == 0, "rp_apply_kernel: static LDS in front of the accumulators");
+    }
     int per_cu = 1;
     SHARP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), AP_THREADS, lds));
     per_cu = std::max(1, std::min(per_cu, 4));
