@@ -156,30 +156,39 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     for (int c = tid; c < ncomp; c += AP_THREADS) acc[c] = 0ull;
     __syncthreads();
 
-    for (long long ci = blockIdx.x; ci < ncell; ci += gridDim.x) {
-        const int nnz = static_cast<int>(counts[ci]);
-        const int nb = (nnz + 63) >> 6;
-        const uint32_t *gsrc = genes + ci * cap;
-        const long long *fsrc = fixes + ci * cap;
-        auto load_entry = [&](int b, uint32_t &g, long long &f) {   // lane = entry of batch b; unconditional + mask
-            const int e = (b << 6) + lane;
-            const int ec = e < nnz ? e : 0;
-            const uint32_t gg = gsrc[ec];
-            const long long ff = fsrc[ec];
-            g = e < nnz ? gg : dummy_seg;
-            f = e < nnz ? ff : 0ll;
-        };
+    // Per-cell state of this wave.  A cell's first batch is set up (entries -> scratch, row lists and the second batch's entries in
+    // flight) BEFORE the previous cell's barrier and epilogue, so its two dependent global round trips run under them.
+    int nnz = 0, nb = 0, buf = 0;
+    const uint32_t *gsrc = genes;
+    const long long *fsrc = fixes;
+    uint32_t gL = 0u; long long fL = 0ll;
+    uint2 cd[U], cdn[U];
+    auto load_entry = [&](int b, uint32_t &g, long long &f) {   // lane = entry of batch b; unconditional + mask
+        const int e = (b << 6) + lane;
+        const int ec = e < nnz ? e : 0;
+        const uint32_t gg = gsrc[ec];
+        const long long ff = fsrc[ec];
+        g = e < nnz ? gg : dummy_seg;
+        f = e < nnz ? ff : 0ll;
+    };
+    auto begin_cell = [&](long long ci) {
+        nnz = static_cast<int>(counts[ci]);
+        nb = (nnz + 63) >> 6;
+        gsrc = genes + ci * cap;
+        fsrc = fixes + ci * cap;
         if (wave < nb) {
-            int buf = 0;
-            uint32_t gL; long long fL;
-            uint2 cd[U], cdn[U];
-            // prologue: entries of the first batch -> scratch, its row lists in flight, entries of the second batch in flight
+            buf = 0;
             load_entry(wave, gL, fL);
             sgen[lane] = gL; put_term(lane, fL);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < U; ++u) cd[u] = *reinterpret_cast<const uint2 *>(ent + static_cast<size_t>(sgen[grp + u * NG]) * SPAN + 4 * lg);
             load_entry(wave + NW, gL, fL);
+        }
+    };
+    if (static_cast<long long>(blockIdx.x) < ncell) begin_cell(blockIdx.x);
+    for (long long ci = blockIdx.x; ci < ncell; ci += gridDim.x) {
+        if (wave < nb) {
             for (int b = wave; b < nb; b += NW) {
                 const int nbuf = buf ^ 1;
                 // entries of batch b+NW (loaded one iteration ago) -> the other scratch buffer
@@ -234,6 +243,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        if (ci + gridDim.x < ncell) begin_cell(ci + gridDim.x);   // (the scratch buffers are this wave's own and its atomics are issued)
         __syncthreads();   // every wave's atomics for this cell have landed
         const long long cell = cell0 + ci;
         double *erow = E + (row_map ? static_cast<long long>(row_map[cell]) : cell) * ldE + comp0;
