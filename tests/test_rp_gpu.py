@@ -59,6 +59,21 @@ def test_rp_matmul_matches_oracle(sa, oracle, m, n, K, logflag):
         np.testing.assert_allclose(E[:, k * p:(k + 1) * p], ref, rtol=0, atol=2e-12 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("m,n,p,K", [(900, 40, 600, 15),     # K*p = 9000 > 8191 components: two launch groups (13 + 2 projectors)
+                                     (64, 24, 150, 15)])     # sqrt(m) = 8: ~280 codes per gene, every gene runs over several overflow segments
+def test_rp_launch_groups_and_overflow_segments(sa, oracle, m, n, p, K):
+    # the packed row lists: 13-bit components per launch group, lanes of four same-sign codes, overflow segments behind the
+    # fixed-stride ones (sharp_amd/csrc/projector.hpp); host and device builds of the pack must agree with the oracle's dense product
+    X = oracle.synth_fill(SEED, m, 0, n, 3, max(1, m // 4))
+    seeds = [50 + 2103 + k for k in range(1, K + 1)]
+    pr = sa.Projector(m, p, seeds)
+    E = pr.project(X, logflag=True)
+    assert E.shape == (n, K * p)
+    for k in range(K):
+        ref = oracle.project(X, oracle.ranM(m, p, seeds[k]), True)
+        np.testing.assert_allclose(E[:, k * p:(k + 1) * p], ref, rtol=0, atol=2e-12 * np.abs(ref).max())
+
+
 def test_rp_edge_cases(sa, oracle):
     m, p = 777, 50
     pr = sa.Projector(m, p, [2154, 2155])
