@@ -117,8 +117,8 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
         ti = L / ntn; tj = L % ntn;
     }
     const int m0 = ti * FT, n0 = tj * FT;
-    __shared__ double As[GK][FLD];
-    __shared__ double Bs[GK][FLD];
+    __shared__ double As[2][GK][FLD];     // two k tiles: the next one is stored while the current one is read (one barrier per tile)
+    __shared__ double Bs[2][GK][FLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = (wave >> 2) * 64, wc = (wave & 3) * 32;
     v4f64 acc[4][2];
@@ -134,32 +134,37 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
     typedef __attribute__((address_space(1))) const d2 *gd2p;
     d2 ra0 = *(gd2p)(ap), ra1 = *(gd2p)(ap + 2);
     d2 rb0 = *(gd2p)(bp), rb1 = *(gd2p)(bp + 2);
+    As[0][lrow][lcol] = ra0.x; As[0][lrow][lcol + 1] = ra0.y; As[0][lrow][lcol + 2] = ra1.x; As[0][lrow][lcol + 3] = ra1.y;
+    Bs[0][lrow][lcol] = rb0.x; Bs[0][lrow][lcol + 1] = rb0.y; Bs[0][lrow][lcol + 2] = rb1.x; Bs[0][lrow][lcol + 3] = rb1.y;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the first tile is in LDS
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
     for (int k0 = 0; k0 < Kp; k0 += GK) {
-        As[lrow][lcol] = ra0.x; As[lrow][lcol + 1] = ra0.y; As[lrow][lcol + 2] = ra1.x; As[lrow][lcol + 3] = ra1.y;
-        Bs[lrow][lcol] = rb0.x; Bs[lrow][lcol + 1] = rb0.y; Bs[lrow][lcol + 2] = rb1.x; Bs[lrow][lcol + 3] = rb1.y;
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is in LDS
-        __builtin_amdgcn_s_barrier();
-        // next tile (the last iteration re-reads the final tile: unconditional loads keep the waits counted)
+        // next tile into registers (the last iteration re-reads the final tile: unconditional loads keep the waits counted) ...
         const int kn = k0 + GK < Kp ? k0 + GK : k0;
         gcdp an = ap + static_cast<long long>(kn) * t.lda;
         gcdp bn = bp + static_cast<long long>(kn) * t.ldb;
         ra0 = *(gd2p)(an); ra1 = *(gd2p)(an + 2);
         rb0 = *(gd2p)(bn); rb1 = *(gd2p)(bn + 2);
+        // ... while the MFMAs run on the current one
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
             const int kr = kk + (lane >> 4);
             double a[4], b[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[kr][wr + i * 16 + (lane & 15)];
+            for (int i = 0; i < 4; ++i) a[i] = As[buf][kr][wr + i * 16 + (lane & 15)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wc + j * 16 + (lane & 15)];
+            for (int j = 0; j < 2; ++j) b[j] = Bs[buf][kr][wc + j * 16 + (lane & 15)];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        // raw barrier: a __syncthreads() here would also wait (vmcnt(0)) for the prefetch of the next tile
-        __builtin_amdgcn_s_waitcnt(0xc07f);
+        // the other LDS tile was last read before the previous barrier: store the next tile there, one barrier per k tile
+        buf ^= 1;
+        As[buf][lrow][lcol] = ra0.x; As[buf][lrow][lcol + 1] = ra0.y; As[buf][lrow][lcol + 2] = ra1.x; As[buf][lrow][lcol + 3] = ra1.y;
+        Bs[buf][lrow][lcol] = rb0.x; Bs[buf][lrow][lcol + 1] = rb0.y; Bs[buf][lrow][lcol + 2] = rb1.x; Bs[buf][lrow][lcol + 3] = rb1.y;
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0); a raw barrier: __syncthreads() would add waits of its own
         __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
