@@ -1213,6 +1213,11 @@ Workspace &ws(int slot = 0) { static Workspace w[2]; return w[slot]; }
 
 inline long long rup(long long v, long long a) { return (v + a - 1) / a * a; }
 
+// Batches of at most this many tasks run the round-per-launch agglomeration (a task spread over several workgroups); above, one
+// workgroup per task in one launch.  Measured at 2000 observations per task: 75 tasks 8.7 vs 11.7 ms, 125 tasks 11.1 vs 12.1 ms,
+// 150 tasks 14.0 vs 13.2 ms, 175 tasks 15.3 vs 14.4 ms (tools/bench_hc.py, SHARP_HC_SPLIT=1 / 0).
+constexpr int kHcSplitMaxTasks = 136;
+
 // model selection, R/get_opt_hclust.R:162-229
 void select_level(const HcParams &prm, int n, int kmin, int nk, const double *msil, const double *CH, const double *height,
                   int &oind, int &branch, int &rc) {
@@ -1259,6 +1264,7 @@ struct ChunkJob {
     std::vector<GemmTask> g;
     long long oOut = 0, oM = 0, oLab = 0;
     int max_n = 0, max_p = 0, max_nk = 0, max_kpad = 0, NS = 1;
+    bool split = false;                        // round-per-launch agglomeration (few tasks)
     bool has_next = false;                     // pipelined: another chunk follows (its distance GEMM is enqueued before this one's tail)
     struct Range { int t0, t1; int off[5], cnt[5]; bool any_sym, any_feat; };
     std::vector<Range> ranges;
@@ -1351,7 +1357,8 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
         // the round-per-launch agglomeration synchronises with the host every few rounds: one range at a time
         const char *mono = getenv("SHARP_HC_MONO"), *seq = getenv("SHARP_HC_SEQ");
         const char *splt = getenv("SHARP_HC_SPLIT");
-        const bool split = splt ? splt[0] == '1' : T <= 96;
+        const bool split = splt ? splt[0] == '1' : T <= kHcSplitMaxTasks;
+        J.split = split;
         if (!(mono && mono[0] == '1') && !(seq && seq[0] == '1') && max_n <= HR_MAXN && split) NS = 1;
     }
     if (const char *e = getenv("SHARP_HC_RANGES")) NS = std::max(1, std::min(8, atoi(e)));
@@ -1459,10 +1466,10 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                 const char *mono = getenv("SHARP_HC_MONO");       // debug / cross-check: the whole agglomeration in one launch
                 // Few tasks (one projection, the wMetaC / sMetaC similarity tasks, a cross-block sMetaC of thousands of meta-clusters):
                 // one round per pair of launches, every task spread over several workgroups -- 25 tasks of 2000: 4.7 ms against
-                // 10.3 ms in one launch, 50 tasks 6.5 against 11.3.  Many tasks: one launch is as fast (125 tasks: 12.1 vs 12.3 ms)
-                // or faster (the chip is then at its memory limit either way and the per-round launches only add their gaps).
-                const char *splt = getenv("SHARP_HC_SPLIT");     // 1 / 0 force the choice
-                const bool split = splt ? splt[0] == '1' : Ts <= 96;
+                // 10.3 ms in one launch, 50 tasks 6.5 against 11.3.  Many tasks (kHcSplitMaxTasks): one launch is faster (the chip is
+                // then at its memory limit either way and the per-round launches only add their gaps).  SHARP_HC_SPLIT = 1 / 0 forces
+                // the choice; it is made for the whole chunk (a range of a larger chunk stays one launch).
+                const bool split = J.split;
                 if (!(mono && mono[0] == '1') && split) {
                     const int wpt = std::max(1, std::min(8, (5 * c.num_cu / 2 + Ts - 1) / Ts));
                     W0.img.ensure(static_cast<size_t>(Ts) * lds);
