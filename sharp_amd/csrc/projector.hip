@@ -284,8 +284,8 @@ __global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int
 // l lives in segment l / gw (the gene's own segment g, then its overflow segments from extra_base), slots 4 (l % gw) .. + 3, and its
 // slot q goes out with the lane group's q-th atomic instruction.  A 64-bit LDS atomic is served per 16 contiguous lanes over 16
 // eight-byte bank pairs (MI355X_MICROARCH.md, LDS: the ds_write_b64 row): one cycle plus one per extra code of the same class
-// (component mod 16) in the instruction.  So the codes are dealt to the four slot columns class by class, each to a column that
-// does not hold its class yet (and has room in its sign's lanes): SQ_LDS_BANK_CONFLICT -58 % against component order.
+// (component mod 16) in the instruction.  So the codes are dealt to the four slot columns round-robin in class order (the codes of
+// a class land in different columns), within the room of their sign's lanes: SQ_LDS_BANK_CONFLICT -55 % against component order.
 // Unused slots keep kCodePad; every slot of a negative lane carries the sign bit, the consumer reads it from slot 0.
 __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint32_t gw, size_t g, size_t extra_base, uint16_t *ent) {
     const uint32_t span = 4u * gw;
@@ -293,32 +293,47 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
     for (uint32_t i = 0; i < n; ++i) np += (src[i] & 0x8000u) ? 0u : 1u;
     const uint32_t cap[2] = {(np + 3u) / 4u, (n - np + 3u) / 4u};   // lanes per sign
     const uint32_t lane0[2] = {0u, cap[0]};
-    uint32_t cnt[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-    uint32_t colmask[4] = {0u, 0u, 0u, 0u};              // classes present in slot column q
-    uint32_t rot = 0;
+    unsigned long long cnt[2] = {0ull, 0ull};            // codes per (sign, column), 4 x 16 bit
+    unsigned long long colmask = 0ull;                   // classes present per column, 4 x 16 bit
     auto slot_ptr = [&](uint32_t lane, uint32_t q) -> uint16_t * {
         const uint32_t sgm = lane / gw;
         const size_t seg = sgm == 0 ? g : extra_base + (sgm - 1);
         return ent + seg * span + 4u * (lane % gw) + q;
     };
-    for (uint32_t c = 0; c < 16u; ++c)
-        for (uint32_t i = 0; i < n; ++i) {
-            if ((src[i] & 15u) != c) continue;
-            const uint32_t s = (src[i] & 0x8000u) ? 1u : 0u;
-            uint32_t q = 4u;
-            for (uint32_t t = 0; t < 4u && q == 4u; ++t) {
-                const uint32_t qq = (rot + t) & 3u;
-                if (!((colmask[qq] >> c) & 1u) && cnt[s][qq] < cap[s]) q = qq;
-            }
-            for (uint32_t t = 0; t < 4u && q == 4u; ++t) {
-                const uint32_t qq = (rot + t) & 3u;
-                if (cnt[s][qq] < cap[s]) q = qq;        // (4 cap[s] >= the sign's codes: there is room)
-            }
-            *slot_ptr(lane0[s] + cnt[s][q], q) = static_cast<uint16_t>((src[i] & 0x7fffu) << 3);
-            ++cnt[s][q];
-            colmask[q] |= 1u << c;
-            rot = q + 1u;
+    // rank of every code in (class, arrival) order without sorting: per-class counts (16 x 16 bit), their prefix, one more pass
+    unsigned long long start[4] = {0ull, 0ull, 0ull, 0ull};
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t c = src[i] & 15u;
+        start[c >> 2] += 1ull << ((c & 3u) * 16u);
+    }
+    uint32_t run = 0;
+    for (uint32_t c = 0; c < 16u; ++c) {
+        const uint32_t sh = (c & 3u) * 16u;
+        const uint32_t k = static_cast<uint32_t>(start[c >> 2] >> sh) & 0xffffu;
+        start[c >> 2] = (start[c >> 2] & ~(0xffffull << sh)) | (static_cast<unsigned long long>(run) << sh);
+        run += k;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t c = src[i] & 15u, sh = (c & 3u) * 16u;
+        const uint32_t rank = static_cast<uint32_t>(start[c >> 2] >> sh) & 0xffffu;
+        start[c >> 2] += 1ull << sh;
+        const uint32_t s = (src[i] & 0x8000u) ? 1u : 0u;
+        // the codes of a class have consecutive ranks, hence different first-choice columns; a column that is full for the code's
+        // sign, or holds the class already, passes it on (4 cap[s] >= the sign's codes: there is room somewhere)
+        const unsigned long long cs = s ? cnt[1] : cnt[0];
+        uint32_t q = 4u;
+        for (uint32_t t = 0; t < 4u && q == 4u; ++t) {   // first choice: room for the sign and the class not in the column yet
+            const uint32_t qq = (rank + t) & 3u;
+            if ((static_cast<uint32_t>(cs >> (16u * qq)) & 0xffffu) < cap[s] && !((colmask >> (16u * qq + c)) & 1ull)) q = qq;
         }
+        for (uint32_t t = 0; t < 4u && q == 4u; ++t) {
+            const uint32_t qq = (rank + t) & 3u;
+            if ((static_cast<uint32_t>(cs >> (16u * qq)) & 0xffffu) < cap[s]) q = qq;
+        }
+        colmask |= 1ull << (16u * q + c);
+        *slot_ptr(lane0[s] + (static_cast<uint32_t>(cs >> (16u * q)) & 0xffffu), q) = static_cast<uint16_t>((src[i] & 0x7fffu) << 3);
+        if (s) cnt[1] += 1ull << (16u * q); else cnt[0] += 1ull << (16u * q);
+    }
     for (uint32_t l = 0; l < cap[1]; ++l)
         for (uint32_t q = 0; q < 4u; ++q) *slot_ptr(lane0[1] + l, q) |= static_cast<uint16_t>(kCodeNeg);
     if (cap[0] + cap[1] > gw) ent[g * span + span - 1] |= static_cast<uint16_t>(kCodeMore);
