@@ -73,3 +73,6 @@ b = os.path.join(out, tag + "_bench_n1.json")
 if os.path.exists(b) and os.path.getsize(b) > 10:
     shutil.copy(b, os.path.join(prof, tag + "_bench_n1.json"))
     print("bench:", open(b).read()[:200])
+src = os.path.join(out, tag + "_bench_under_rocprof.json")
+if os.path.exists(src) and os.path.getsize(src) > 0:
+    shutil.copy(src, os.path.join(prof, tag + "_bench_under_rocprof.json"))

@@ -13,5 +13,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- $CMD > $OUT/${TAG}_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- $CMD > $OUT/${TAG}_pmc_write.log 2>&1
 cd $REPO
+# the bench line of the SAME process as the kernel-trace pass: its live (HIP-event) launch time of the roofline kernel is what the
+# kernel_stats average has to agree with (events add the launch gap: a few percent)
+grep '^{"metric"' $OUT/${TAG}_kt.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
 timeout 600 python3 bench.py --steps 5 --warmup 2 > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err
 tail -c 600 $OUT/${TAG}_bench_n1.json
