@@ -471,7 +471,7 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
 
 
 // Device build: draws on the GPU (proj_draw_kernel), per-gene counts, then -- after one 80 KB download to size the
-// segments on the host -- fill + layout kernels.  Same packed result as the host build (tests compare both).
+// segments on the host -- fill + layout kernels.  Same row lists as the host build (tests compare the triplets and the projections).
 static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, const double *seeds) {
     SHARP_REQUIRE(m >= 2 && p >= 1 && K >= 1, "projector: need m >= 2, p >= 1, K >= 1");
     SHARP_REQUIRE(p <= kMaxCompPerGroup, "projector: reduced dimension p too large for one launch group");

@@ -6,8 +6,10 @@
 //       and keeps two 1024-gene units in flight behind the one it is compacting.
 //   rp_apply_kernel (stream): per cell, walks the list in 64-entry batches; each GW-lane group gathers a gene's
 //       packed row list (one 8-byte load per lane, L2 resident) and adds +-fix into the per-cell accumulators
-//       in LDS with ds_add_u64; batches are software-pipelined (entries of batch i+2 and row lists of batch
-//       i+1 are in flight while the atomics of batch i run).  Two barriers per cell around the epilogue that
+//       in LDS with ds_add_u64: a code is its accumulator's LDS address after one AND, the lane's signed term
+//       comes from a (+fix, -fix) pair in LDS picked by the lane's sign bit (projector.hpp); batches are
+//       software-pipelined (entries of batch i+2 and row lists of batch i+1 are in flight while the atomics of
+//       batch i run) and the next cell's first batch is set up before the two barriers around the epilogue that
 //       scales by sqrt(s)/sqrt(p) and writes the K*p row of E.
 // Chunk c+1 is compacted while chunk c is applied, so the HBM stream overlaps the L2 gather and the LDS
 // atomics; integer accumulation keeps E bit-reproducible whatever the interleaving.
