@@ -281,7 +281,7 @@ void project_dev(const Projector &pr, const float *dX, int m, int n, long long l
     if (vec) launch_rp<GWV, true>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);      \
     else launch_rp<GWV, false>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map)
         const char *kv = getenv("SHARP_RP_KERNEL");   // "fused": the single-kernel form (always used for unaligned X)
-        if (vec && m >= 8 && !(kv && std::string(kv) == "fused")) {
+        if (vec && m >= 8 && m <= (1 << 20) && !(kv && std::string(kv) == "fused")) {   // (20-bit gene index in the compacted entries)
             project_dev_split(pr, g, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);
             continue;
         }

@@ -40,6 +40,9 @@ __device__ __forceinline__ CpVals cp_load_unit(const float *col, int u, long lon
 }
 
 constexpr int CP_TAB = 256;             // log2(1+x) fixed-point table for integer counts x < CP_TAB
+// compacted entry: bits 19..0 gene, bits 27..20 the count (table entries), bit 31: the 64-bit term is stored beside the word
+constexpr uint32_t kEntryGeneMask = 0xfffffu, kEntryFull = 0x80000000u;
+constexpr int kEntryCountShift = 20;
 
 // fix(x) = round(log2(1+x) * 2^fix_bits) for x = 0..CP_TAB-1, evaluated by the same device libm as the general path
 __global__ void rp_fixtab_kernel(double fix_scale, int log10_mode, long long *__restrict__ tab) {
@@ -54,15 +57,11 @@ __global__ void rp_fixtab_kernel(double fix_scale, int log10_mode, long long *__
 // The order of a cell's list is irrelevant: the consumer adds integers.
 __global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__restrict__ X, int m, long long ld, long long cell0,
                                                                 int ncell, int log_flag, double fix_scale, int cap,
-                                                                const long long *__restrict__ fixtab,
                                                                 unsigned int *__restrict__ counts, uint32_t *__restrict__ genes,
                                                                 long long *__restrict__ fixes) {
     __shared__ uint32_t sg[CP_THREADS / 64][CP_UNIT];
     __shared__ uint32_t sx[CP_THREADS / 64][CP_UNIT];
-    __shared__ long long stab[CP_TAB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < CP_TAB; i += CP_THREADS) stab[i] = fixtab[i];
-    __syncthreads();
     const int units = (m + CP_UNIT - 1) / CP_UNIT;
     const long long total = static_cast<long long>(ncell) * units;
     const long long stride = static_cast<long long>(gridDim.x) * (CP_THREADS / 64);
@@ -119,18 +118,23 @@ __global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__r
             const bool live = e < cntw;
             const float x = __uint_as_float(sx[w][live ? e : 0]);
             const uint32_t gg = sg[w][live ? e : 0];
-            long long fx;
+            // Integer counts below CP_TAB (scRNA counts, the synthetic data) travel as (gene, count) in ONE 32-bit word: the
+            // consumer takes their term from the same 256-entry table; everything else (non-integer or large values, raw mode)
+            // sets kEntryFull and stores its 64-bit term beside the word -- 4 instead of 12 bytes per non-zero written and read.
+            uint32_t entry = gg | kEntryFull;
+            long long fx = 0ll;
+            bool full = true;
             if (log_flag) {
                 const unsigned xi = static_cast<unsigned>(x);
                 const bool tab = static_cast<float>(xi) == x && xi < static_cast<unsigned>(CP_TAB);
-                fx = stab[tab ? xi : 0u];
-                if (__ballot(live && !tab) != 0ull) {      // non-integer or large values: the general path
+                if (tab) { entry = gg | (xi << kEntryCountShift); full = false; }
+                if (__ballot(live && !tab) != 0ull) {      // the general path
                     if (!tab) fx = __double2ll_rn((log_flag == 2 ? log10(1.0 + static_cast<double>(x)) : log2(1.0 + static_cast<double>(x))) * fix_scale);
                 }
             } else {
                 fx = __double2ll_rn(static_cast<double>(x) * fix_scale);
             }
-            if (live) { gout[e] = gg; fout[e] = fx; }
+            if (live) { gout[e] = entry; if (full) fout[e] = fx; }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__r
 template <int GW>
 __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     int ncell, long long cell0, int cap, const unsigned int *__restrict__ counts, const uint32_t *__restrict__ genes,
-    const long long *__restrict__ fixes, const uint16_t *__restrict__ ent, unsigned int dummy_seg,
+    const long long *__restrict__ fixes, const long long *__restrict__ fixtab, const uint16_t *__restrict__ ent, unsigned int dummy_seg,
     const uint32_t *__restrict__ ovf_gene, const uint2 *__restrict__ ovf_info, int novf, int ncomp, double inv_fix, double val,
     double out_scale, double *__restrict__ E, long long ldE, int comp0, const int *__restrict__ row_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -150,6 +154,8 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     // per-wave scratch: two buffers of 64 entries: gene, and the pair (+term, -term) -- a lane picks its signed term with the address
     long long *sfix = reinterpret_cast<long long *>(acc + ncomp) + wave * 256;
     uint32_t *sgen = reinterpret_cast<uint32_t *>(reinterpret_cast<long long *>(acc + ncomp) + NW * 256) + wave * 128;
+    long long *stab = reinterpret_cast<long long *>(reinterpret_cast<uint32_t *>(reinterpret_cast<long long *>(acc + ncomp) + NW * 256) + NW * 128);   // [CP_TAB]
+    for (int i = tid; i < CP_TAB; i += AP_THREADS) stab[i] = fixtab[i];
     typedef long long ll2 __attribute__((ext_vector_type(2)));
     auto put_term = [&](int slot, long long f) { *reinterpret_cast<ll2 *>(sfix + 2 * slot) = (ll2){f, -f}; };
     auto signed_term = [&](int slot, uint32_t code0) -> unsigned long long {
@@ -169,8 +175,10 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
         const int e = (b << 6) + lane;
         const int ec = e < nnz ? e : 0;
         const uint32_t gg = gsrc[ec];
-        const long long ff = fsrc[ec];
-        g = e < nnz ? gg : dummy_seg;
+        long long ff;
+        if (gg & kEntryFull) ff = fsrc[ec];              // rare: a value outside the table
+        else ff = stab[(gg >> kEntryCountShift) & 0xffu];
+        g = e < nnz ? (gg & kEntryGeneMask) : dummy_seg;
         f = e < nnz ? ff : 0ll;
     };
     auto begin_cell = [&](long long ci) {
@@ -275,7 +283,7 @@ static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell
                          const uint32_t *genes, const long long *fixes, double inv_fix, double *dE, long long ldE, const int *row_map,
                          hipStream_t st) {
     Ctx &c = ctx();
-    const size_t lds = static_cast<size_t>(g.ncomp) * 8 + (AP_THREADS / 64) * 128 * 20;
+    const size_t lds = static_cast<size_t>(g.ncomp) * 8 + (AP_THREADS / 64) * 128 * 20 + CP_TAB * 8;
     auto kern = rp_apply_kernel<GW>;
     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     {   // scatter_codes<0>: the accumulators sit at LDS address 0, i.e. the kernel must not have static LDS in front of the dynamic block
@@ -288,6 +296,7 @@ static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell
     per_cu = std::max(1, std::min(per_cu, 4));
     const long long blocks = std::min<long long>(ncell, static_cast<long long>(c.num_cu) * per_cu);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(AP_THREADS), lds, st, ncell, cell0, cap, counts, genes, fixes,
+                       static_cast<const long long *>(sws().fixtab.p),
                        g.ent.p, static_cast<unsigned int>(g.nseg), g.ovf_gene.p, g.ovf_info.p, g.novf, g.ncomp, inv_fix, pr.val,
                        1.0 / std::sqrt(static_cast<double>(pr.p)), dE, ldE, g.k0 * pr.p, row_map);
     launch_check("rp_apply_kernel");
@@ -345,7 +354,7 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, const float
         {
             KernelTimer tc("rp_compact", s2);
             hipLaunchKernelGGL(rp_compact_kernel, dim3(blocks), dim3(CP_THREADS), 0, s2, dX, m, ld, c0, nc, log_flag, fix_scale, cap,
-                               W.fixtab.p, W.counts[q].p, W.genes[q].p, W.fixes[q].p);
+                               W.counts[q].p, W.genes[q].p, W.fixes[q].p);
             launch_check("rp_compact_kernel");
         }
         SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[q], s2));
