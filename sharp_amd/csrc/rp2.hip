@@ -258,8 +258,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
         const long long cell = cell0 + ci;
         double *erow = E + (row_map ? static_cast<long long>(row_map[cell]) : cell) * ldE + comp0;
         for (int c = tid; c < ncomp; c += AP_THREADS) {
-            const long long a = static_cast<long long>(acc[c]);
-            acc[c] = 0ull;
+            const long long a = static_cast<long long>(atomicExch(&acc[c], 0ull));   // read and clear in one LDS operation (ds_wrxchg_rtn_b64)
             erow[c] = out_scale * (val * (static_cast<double>(a) * inv_fix));
         }
         __syncthreads();
