@@ -215,7 +215,7 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
         allCs[t] = allC;
     };
     {
-        const int nthr = std::max(1, std::min({T, 16, static_cast<int>(std::thread::hardware_concurrency())}));
+        const int nthr = std::max(1, std::min({T, 8, static_cast<int>(std::thread::hardware_concurrency())}));
         if (nthr == 1) { for (int t = 0; t < T; ++t) relabel(t); }
         else {
             std::vector<std::thread> th;
