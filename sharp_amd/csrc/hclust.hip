@@ -1217,6 +1217,7 @@ inline long long rup(long long v, long long a) { return (v + a - 1) / a * a; }
 // workgroup per task in one launch.  Measured at 2000 observations per task: 75 tasks 8.7 vs 11.7 ms, 125 tasks 11.1 vs 12.1 ms,
 // 150 tasks 14.0 vs 13.2 ms, 175 tasks 15.3 vs 14.4 ms (tools/bench_hc.py, SHARP_HC_SPLIT=1 / 0).
 constexpr int kHcSplitMaxTasks = 136;
+constexpr int kHcSplitMinObs = 1000;
 
 // model selection, R/get_opt_hclust.R:162-229
 void select_level(const HcParams &prm, int n, int kmin, int nk, const double *msil, const double *CH, const double *height,
@@ -1357,7 +1358,9 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
         // the round-per-launch agglomeration synchronises with the host every few rounds: one range at a time
         const char *mono = getenv("SHARP_HC_MONO"), *seq = getenv("SHARP_HC_SEQ");
         const char *splt = getenv("SHARP_HC_SPLIT");
-        const bool split = splt ? splt[0] == '1' : T <= kHcSplitMaxTasks;
+        // (small tasks -- the similarity matrices of wMetaC and of a per-block sMetaC, a few hundred meta-clusters -- have nothing to
+        // spread over several workgroups: the per-round launches and the host's look every eight rounds only cost, 0.27 ms per SHARP() call)
+        const bool split = splt ? splt[0] == '1' : (T <= kHcSplitMaxTasks && max_n >= kHcSplitMinObs);
         J.split = split;
         if (!(mono && mono[0] == '1') && !(seq && seq[0] == '1') && max_n <= HR_MAXN && split) NS = 1;
     }
