@@ -88,6 +88,17 @@ def test_rp_edge_cases(sa, oracle):
         np.testing.assert_allclose(E[:, k * p:(k + 1) * p], ref, rtol=0, atol=2e-12 * np.abs(ref).max())
     E1 = pr.project(X[:, 1:2], True)
     assert np.array_equal(E1[0], E[1])  # per-cell result independent of the batch it is in
+    # the compacted entries: counts below 256 travel as (gene, count) and take their term from the table, anything else
+    # (counts >= 256, non-integers) carries its own 64-bit term -- both kinds side by side in one cell, on a 1024-gene unit boundary
+    m2 = 2048
+    pr2 = sa.Projector(m2, p, [2154])
+    Y = np.zeros((m2, 3))
+    Y[:, 0] = (np.arange(m2) % 3 == 0) * (np.arange(m2) % 520)            # integers on both sides of 255 / 256
+    Y[:, 1] = np.where(np.arange(m2) % 2 == 0, np.arange(m2) % 300, 0.5)  # table values and non-integers interleaved
+    Y[1020:1030, 2] = [255, 256, 257, 0.25, 1, 2, 65535, 65536, 3.5, 254]
+    E2 = pr2.project(Y, True)
+    ref2 = oracle.project(Y, oracle.ranM(m2, p, 2154), True)
+    np.testing.assert_allclose(E2, ref2, rtol=0, atol=2e-12 * np.abs(ref2).max())
     Ee = pr.project(np.zeros((m, 0)), True)
     assert Ee.shape == (0, 2 * p)
 
