@@ -342,7 +342,7 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
 // one thread per gene: order the gene's codes by component (the order of the host build: projector, then column) and
 // write them into the fixed-stride lane-major segments (+ overflow segments)
 __global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, uint16_t *__restrict__ flat, int gw,
-                                   const uint32_t *__restrict__ ovf_gene, const uint2 *__restrict__ ovf_info, int novf,
+                                   const uint2 *__restrict__ ovf_slot, const uint2 *__restrict__ ovf_info, int novf,
                                    uint16_t *__restrict__ ent) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= m) return;
@@ -355,15 +355,7 @@ __global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, u
         src[j] = v;
     }
     size_t extra_base = 0;
-    if (novf > 0) {                                      // (genes without overflow segments are simply not found)
-        int lo = 0, hi = novf - 1;
-        while (lo <= hi) {
-            const int mid = (lo + hi) >> 1;
-            const uint32_t gm = ovf_gene[mid];
-            if (gm == static_cast<uint32_t>(g)) { extra_base = ovf_info[mid].x; break; }
-            if (gm < static_cast<uint32_t>(g)) lo = mid + 1; else hi = mid - 1;
-        }
-    }
+    if (novf > 0) extra_base = ovf_slot[g].x;
     place_gene(src, len, static_cast<uint32_t>(gw), static_cast<size_t>(g), extra_base, ent);
 }
 __global__ void proj_fill_u16_kernel(uint16_t *p, size_t n, uint16_t v) {
@@ -462,6 +454,13 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
         grp.ovf_gene.alloc(ovf_gene.size());
         grp.ovf_info.alloc(ovf_info.size());
         grp.ovf_gene.upload(ovf_gene.data(), ovf_gene.size());
+        {
+            std::vector<uint2> slot(static_cast<size_t>(m), make_uint2(0u, 0u));
+            for (int q = 0; q < grp.novf; ++q) slot[ovf_gene[q]] = ovf_info[q];
+            grp.ovf_slot.alloc(slot.size());
+            grp.ovf_slot.upload(slot.data(), slot.size());
+            stream_sync();                               // (slot is a local)
+        }
         grp.ovf_info.upload(ovf_info.data(), ovf_info.size());
         stream_sync();
         pr->groups.push_back(std::move(grp));
@@ -563,6 +562,13 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         grp.ovf_gene.alloc(ovf_gene.size());
         grp.ovf_info.alloc(ovf_info.size());
         grp.ovf_gene.upload(ovf_gene.data(), ovf_gene.size());
+        {
+            std::vector<uint2> slot(static_cast<size_t>(m), make_uint2(0u, 0u));
+            for (int q = 0; q < grp.novf; ++q) slot[ovf_gene[q]] = ovf_info[q];
+            grp.ovf_slot.alloc(slot.size());
+            grp.ovf_slot.upload(slot.data(), slot.size());
+            stream_sync();                               // (slot is a local)
+        }
         grp.ovf_info.upload(ovf_info.data(), ovf_info.size());
         DevBuf<uint32_t> d_rowptr(rowptr.size());
         d_rowptr.upload(rowptr.data(), rowptr.size());
@@ -573,7 +579,7 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         hipLaunchKernelGGL(proj_fill_kernel, dim3(16, grp.kcount, S), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
                            static_cast<uint32_t>(p), d_rowptr.p, d_fill.p, d_flat.p);
         hipLaunchKernelGGL(proj_layout_kernel, dim3((m + 255) / 256), dim3(256), 0, c.stream, m, d_rowptr.p, d_flat.p, grp.gw,
-                           grp.ovf_gene.p, grp.ovf_info.p, grp.novf, grp.ent.p);
+                           grp.ovf_slot.p, grp.ovf_info.p, grp.novf, grp.ent.p);
         launch_check("proj_layout_kernel");
         stream_sync();                                   // the temporaries above are released on scope exit
         pr->groups.push_back(std::move(grp));

@@ -72,7 +72,7 @@ __device__ __forceinline__ RpStepVals rp_load_step(const float *col, int s, int 
 template <int GW, bool VEC>
 __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
     const float *__restrict__ X, int m, int n, long long ld, int log_flag, double fix_scale, double inv_fix,
-    double val, double out_scale, const uint16_t *__restrict__ ent, const uint32_t *__restrict__ ovf_gene,
+    double val, double out_scale, const uint16_t *__restrict__ ent, const uint2 *__restrict__ ovf_slot,
     const uint2 *__restrict__ ovf_info, int novf, int ncomp, double *__restrict__ E, long long ldE, int comp0,
     int nsteps, int step_len, int ablate, const int *__restrict__ row_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -166,15 +166,8 @@ __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
                                 const uint32_t lastcode = __shfl(cd[u].y >> 16, lane | (GW - 1));
                                 if ((lastcode & kCodeMore) != 0u && novf > 0) {
                                     const uint32_t g = list[e].gene;
-                                    int lo = 0, hi = novf - 1, hit = -1;
-                                    while (lo <= hi) {
-                                        const int mid = (lo + hi) >> 1;
-                                        const uint32_t gm = ovf_gene[mid];
-                                        if (gm == g) { hit = mid; break; }
-                                        if (gm < g) lo = mid + 1; else hi = mid - 1;
-                                    }
-                                    if (hit >= 0) {
-                                        const uint2 oi = ovf_info[hit];
+                                    const uint2 oi = ovf_slot[g];
+                                    {
                                         for (uint32_t sg = 0; sg < oi.y; ++sg) {
                                             const uint2 c = *reinterpret_cast<const uint2 *>(ent + (static_cast<size_t>(oi.x) + sg) * SPAN + 4 * lg);
                                             scatter_codes<RP_CAP * sizeof(NzSlot)>(c, fix);
@@ -241,7 +234,7 @@ static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float 
     const int ablate = abl ? atoi(abl) : 0;
     KernelTimer t("rp_stage");
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(RP_THREADS), lds, c.stream, dX, m, n, ld, log_flag,
-                       fix_scale, inv_fix, pr.val, out_scale, g.ent.p, g.ovf_gene.p, g.ovf_info.p, g.novf, g.ncomp, dE, ldE, g.k0 * pr.p,
+                       fix_scale, inv_fix, pr.val, out_scale, g.ent.p, g.ovf_slot.p, g.ovf_info.p, g.novf, g.ncomp, dE, ldE, g.k0 * pr.p,
                        nsteps, step_len, ablate, row_map);
     launch_check("rp_scatter_kernel");
 }

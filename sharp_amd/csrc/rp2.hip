@@ -144,7 +144,7 @@ template <int GW>
 __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     int ncell, long long cell0, int cap, const unsigned int *__restrict__ counts, const uint32_t *__restrict__ genes,
     const long long *__restrict__ fixes, const long long *__restrict__ fixtab, const uint16_t *__restrict__ ent, unsigned int dummy_seg,
-    const uint32_t *__restrict__ ovf_gene, const uint2 *__restrict__ ovf_info, int novf, int ncomp, double inv_fix, double val,
+    const uint2 *__restrict__ ovf_slot, const uint2 *__restrict__ ovf_info, int novf, int ncomp, double inv_fix, double val,
     double out_scale, double *__restrict__ E, long long ldE, int comp0, const int *__restrict__ row_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = AP_THREADS / 64, NG = 64 / GW, SPAN = 4 * GW, U = GW;   // a batch = 64 entries = U per group
@@ -230,15 +230,8 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
                         if ((full >> (lane | (GW - 1))) & 1ull) {
                             const int slot = buf * 64 + grp + u * NG;
                             const uint32_t g = sgen[slot];
-                            int lo = 0, hi = novf - 1, hit = -1;
-                            while (lo <= hi) {
-                                const int mid = (lo + hi) >> 1;
-                                const uint32_t gm = ovf_gene[mid];
-                                if (gm == g) { hit = mid; break; }
-                                if (gm < g) lo = mid + 1; else hi = mid - 1;
-                            }
-                            if (hit >= 0) {
-                                const uint2 oi = ovf_info[hit];
+                            const uint2 oi = ovf_slot[g];
+                            {
                                 for (uint32_t sg = 0; sg < oi.y; ++sg) {
                                     const uint2 c2 = *reinterpret_cast<const uint2 *>(ent + (static_cast<size_t>(oi.x) + sg) * SPAN + 4 * lg);
                                     scatter_codes_signed<0>(c2, signed_term(slot, c2.x));
@@ -296,7 +289,7 @@ static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell
     const long long blocks = std::min<long long>(ncell, static_cast<long long>(c.num_cu) * per_cu);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(AP_THREADS), lds, st, ncell, cell0, cap, counts, genes, fixes,
                        static_cast<const long long *>(sws().fixtab.p),
-                       g.ent.p, static_cast<unsigned int>(g.nseg), g.ovf_gene.p, g.ovf_info.p, g.novf, g.ncomp, inv_fix, pr.val,
+                       g.ent.p, static_cast<unsigned int>(g.nseg), g.ovf_slot.p, g.ovf_info.p, g.novf, g.ncomp, inv_fix, pr.val,
                        1.0 / std::sqrt(static_cast<double>(pr.p)), dE, ldE, g.k0 * pr.p, row_map);
     launch_check("rp_apply_kernel");
 }
