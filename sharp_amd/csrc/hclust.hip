@@ -1266,6 +1266,7 @@ struct ChunkJob {
     long long oOut = 0, oM = 0, oLab = 0;
     int max_n = 0, max_p = 0, max_nk = 0, max_kpad = 0, NS = 1;
     bool split = false;                        // round-per-launch agglomeration (few tasks)
+    bool seq_pending = false;                  // the sequential fallback kernel is still to be launched (with the statistics phase)
     bool has_next = false;                     // pipelined: another chunk follows (its distance GEMM is enqueued before this one's tail)
     struct Range { int t0, t1; int off[5], cnt[5]; bool any_sym, any_feat; };
     std::vector<Range> ranges;
@@ -1437,6 +1438,29 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         hipStream_t st = NS > 1 ? c.aux_stream(s) : chunk_stream;
         StreamScope scope(st);
         const HcMeta *dmeta = W.meta.p + R.t0;
+        auto launch_sequential = [&](bool fallback_only) {
+            KernelTimer tm("hclust_sequential");
+            const int nal = (max_n + 1) & ~1;
+            const size_t lds = static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16 + 32 * 12 + 16;
+            SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                static_cast<int>(lds)));
+            const char *abl = getenv("SHARP_HC_ABLATE");
+            const char *tim = getenv("SHARP_HC_TIMING");       // debug: per-phase cycle counts of the merge loop
+            DevBuf<long long> dbg;
+            if (tim) { dbg.alloc(static_cast<size_t>(Ts) * 6); dbg.zero(); }
+            hipLaunchKernelGGL(hclust_kernel, dim3(Ts), dim3(HC_THREADS), lds, st, dmeta, W.D.p, W.ia.p, W.ib.p, W.height.p,
+                               abl ? atoi(abl) : 0, dbg.p, fallback_only ? W.status.p + R.t0 : nullptr);
+            launch_check("hclust_kernel");
+            if (tim) {
+                std::vector<long long> h(static_cast<size_t>(Ts) * 6);
+                dbg.download(h.data(), h.size());
+                double acc[6] = {0, 0, 0, 0, 0, 0};
+                for (int t = 0; t < Ts; ++t) for (int q = 0; q < 6; ++q) acc[q] += static_cast<double>(h[static_cast<size_t>(t) * 6 + q]);
+                fprintf(stderr, "hclust phases T=%d n=%d, mean shader cycles per task: argmin %.0f | loads+LW+stores %.0f | nb reduce %.0f | "
+                                "list+barrier %.0f | rescans %.0f | end barrier %.0f\n", Ts, max_n, acc[0] / Ts, acc[1] / Ts, acc[2] / Ts,
+                        acc[3] / Ts, acc[4] / Ts, acc[5] / Ts);
+            }
+        };
         if (phases & PH_DIST) {
         if (NS > 1) SHARP_HIP_CHECK(hipStreamWaitEvent(st, ev_in, 0));
         // pipelined: this chunk's distance GEMM starts when the previous chunk's has finished, i.e. together with the previous
@@ -1516,26 +1540,11 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                 }
                 launch_check("hclust_rnn_kernel");
             }
-            const int nal = (max_n + 1) & ~1;
-            const size_t lds = static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16 + 32 * 12 + 16;
-            SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                static_cast<int>(lds)));
-            const char *abl = getenv("SHARP_HC_ABLATE");
-            const char *tim = getenv("SHARP_HC_TIMING");       // debug: per-phase cycle counts of the merge loop
-            DevBuf<long long> dbg;
-            if (tim) { dbg.alloc(static_cast<size_t>(Ts) * 6); dbg.zero(); }
-            hipLaunchKernelGGL(hclust_kernel, dim3(Ts), dim3(HC_THREADS), lds, st, dmeta, W.D.p, W.ia.p, W.ib.p, W.height.p,
-                               abl ? atoi(abl) : 0, dbg.p, use_rnn ? W.status.p + R.t0 : nullptr);
-            launch_check("hclust_kernel");
-            if (tim) {
-                std::vector<long long> h(static_cast<size_t>(Ts) * 6);
-                dbg.download(h.data(), h.size());
-                double acc[6] = {0, 0, 0, 0, 0, 0};
-                for (int t = 0; t < Ts; ++t) for (int q = 0; q < 6; ++q) acc[q] += static_cast<double>(h[static_cast<size_t>(t) * 6 + q]);
-                fprintf(stderr, "hclust phases T=%d n=%d, mean shader cycles per task: argmin %.0f | loads+LW+stores %.0f | nb reduce %.0f | "
-                                "list+barrier %.0f | rescans %.0f | end barrier %.0f\n", Ts, max_n, acc[0] / Ts, acc[1] / Ts, acc[2] / Ts,
-                        acc[3] / Ts, acc[4] / Ts, acc[5] / Ts);
-            }
+            // whatever the bulk-synchronous kernel abandoned (status != 0): the sequential kernel.  When it is only the fallback, a
+            // pipelined chunk with a successor launches it with its statistics phase: its (normally idle) workgroups would otherwise
+            // take CU slots from the successor's distance GEMM, which is on the critical path.
+            if (!use_rnn || !(J.pipe && J.has_next)) launch_sequential(use_rnn);
+            else J.seq_pending = true;
         }
         if (J.pipe) SHARP_HIP_CHECK(hipEventRecord(EV.hc[J.slot], st));
         }
@@ -1544,6 +1553,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         // before it -- and this tail is not: it waits for that GEMM and then runs beside the next agglomeration, whose stream has
         // the higher priority or is served first, on the CUs that one leaves free
         if (J.pipe && J.has_next) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.slot ^ 1], 0));
+        if (J.seq_pending) { launch_sequential(true); J.seq_pending = false; }
         // a5a: labels for every candidate k
         {
             const size_t lds = static_cast<size_t>(max_n) * 4 * 3 + (HC_THREADS / 64 + 1) * 4;
