@@ -3,6 +3,7 @@
 // RAII device buffers and per-kernel HIP-event timing.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
 
 #include <cstdint>
 #include <cstdio>
@@ -134,6 +135,11 @@ struct StreamScope {
 };
 
 inline void stream_sync() { SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream)); }
+
+// fn(0) .. fn(n-1) on the calling thread plus up to max_threads - 1 workers of a persistent pool (items handed out dynamically).
+// For the short host loops between kernels (per-fold relabelling and votes): starting std::threads anew cost more than the loops.
+// fn must not call HIP and must not throw.
+void host_parallel_for(int n, int max_threads, const std::function<void(int)> &fn);
 inline void launch_check(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) throw Error(SHARP_ERR, std::string("launch of ") + what + " failed: " + hipGetErrorString(e));

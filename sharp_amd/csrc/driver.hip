@@ -228,15 +228,15 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
     ensemble_mean_dev(E.p, ldE, n, p, K, viE_sh.p);                             // enqueued now, runs under the host loops below
     // enrp per fold (:627-635); labels "<colour>p<t>" only need to be distinct per (k, t): the colour id does
     std::vector<std::vector<int>> enrp(T);
-    for (int t = 0; t < T; ++t) {
+    for (const HcResult &r : hr) out.rc |= r.rc;
+    host_parallel_for(T, 8, [&](int t) {
         const int nt = fst[t + 1] - fst[t];
         enrp[t].resize(static_cast<size_t>(nt) * K);
         for (int k = 0; k < K; ++k) {
             const HcResult &r = hr[static_cast<size_t>(k) * T + t];
-            out.rc |= r.rc;
             for (int i = 0; i < nt; ++i) enrp[t][static_cast<size_t>(k) * nt + i] = colour_of(r.f[i]);
         }
-    }
+    });
     // per-fold wMetaC (:692-709)
     std::vector<WmTask> wts(T);
     for (int t = 0; t < T; ++t) {

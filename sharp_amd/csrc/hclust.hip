@@ -1620,7 +1620,8 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
     std::vector<int> chosen(T);
     std::vector<long long> poff(T);
     long long ptot = 0;
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < T; ++t) { poff[t] = ptot; ptot += metas[t].n; }
+    host_parallel_for(T, T >= 16 ? 8 : 1, [&](int t) {     // (each task writes its own result only)
         const HcTask &tk = tasks[i0 + t];
         const HcMeta &M = metas[t];
         HcResult &R = out[i0 + t];
@@ -1637,8 +1638,7 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
             R.maxsil = *std::max_element(R.msil.begin(), R.msil.end());
         }
         chosen[t] = oind - 1;
-        poff[t] = ptot; ptot += M.n;
-    }
+    });
     W.chosen.ensure(T); W.packoff.ensure(T); W.packed.ensure(ptot);
     W.chosen.upload(chosen.data(), T);
     W.packoff.upload(poff.data(), T);
@@ -1648,13 +1648,13 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
     W.packed.download(h_packed.data(), ptot);
     std::vector<int> h_lab;
     if (want_v) { h_lab.resize(oLab); W.lab.download(h_lab.data(), oLab); }
-    for (int t = 0; t < T; ++t) {
+    host_parallel_for(T, T >= 16 ? 8 : 1, [&](int t) {
         const HcMeta &M = metas[t];
         HcResult &R = out[i0 + t];
         R.f.assign(h_packed.begin() + poff[t], h_packed.begin() + poff[t] + M.n);
         R.optN = *std::max_element(R.f.begin(), R.f.end());
         if (want_v) R.v.assign(h_lab.begin() + M.oLab, h_lab.begin() + M.oLab + static_cast<long long>(M.nk) * M.n);
-    }
+    });
 }
 
 }  // namespace

@@ -215,13 +215,7 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
         allCs[t] = allC;
     };
     {
-        const int nthr = std::max(1, std::min({T, 8, static_cast<int>(std::thread::hardware_concurrency())}));
-        if (nthr == 1) { for (int t = 0; t < T; ++t) relabel(t); }
-        else {
-            std::vector<std::thread> th;
-            for (int w = 0; w < nthr; ++w) th.emplace_back([&, w]() { for (int t = w; t < T; t += nthr) relabel(t); });
-            for (auto &x : th) x.join();
-        }
+        host_parallel_for(T, 8, relabel);
     }
     for (int t = 0; t < T; ++t) {
         const WmTask &tk = tasks[t];
@@ -354,16 +348,7 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
         }
     };
     {
-        unsigned hw = std::thread::hardware_concurrency();
-        const int nthr = T >= 4 ? static_cast<int>(std::min<unsigned>(std::min<unsigned>(hw ? hw : 4, 16), static_cast<unsigned>(T))) : 1;
-        if (nthr <= 1) {
-            for (int t = 0; t < T; ++t) vote_fold(t);
-        } else {
-            std::vector<std::thread> pool;
-            for (int w = 0; w < nthr; ++w)
-                pool.emplace_back([&, w] { for (int t = w; t < T; t += nthr) vote_fold(t); });
-            for (auto &th : pool) th.join();
-        }
+        host_parallel_for(T, T >= 4 ? 16 : 1, vote_fold);
     }
 }
 

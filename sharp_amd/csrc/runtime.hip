@@ -1,7 +1,10 @@
 // runtime.hip -- context, error string, profiling and device-memory helpers of the C ABI.
 #include <cstring>
 #include <ctime>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <sstream>
 
 #include "common.hpp"
@@ -75,6 +78,74 @@ KernelTimer::~KernelTimer() {
     if (c.pending.size() > 4096) {
         try { c.resolve_pending(); } catch (...) {}
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent host worker pool (host_parallel_for).  Created on first use and never destroyed: the workers sleep on a
+// condition variable between jobs and die with the process.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct HostPool {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int)> *fn = nullptr;
+    std::atomic<int> next{0};
+    int n = 0, participants = 0, pending = 0;
+    unsigned long generation = 0;
+
+    explicit HostPool(int nworkers) {
+        for (int w = 0; w < nworkers; ++w) workers.emplace_back([this, w] { run(w); });
+    }
+    void drain() {
+        for (;;) {
+            const int i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n) break;
+            (*fn)(i);
+        }
+    }
+    void run(int w) {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return generation != seen; });
+                seen = generation;
+                if (w >= participants) continue;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+    void parallel_for(int count, int max_threads, const std::function<void(int)> &f) {
+        const int helpers = std::min<int>(static_cast<int>(workers.size()), std::min(max_threads, count) - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            fn = &f; n = count; next.store(0, std::memory_order_relaxed);
+            participants = helpers; pending = helpers;
+            ++generation;
+        }
+        cv_work.notify_all();
+        drain();                                          // the caller works too
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        fn = nullptr;
+    }
+};
+}  // namespace
+
+void host_parallel_for(int n, int max_threads, const std::function<void(int)> &fn) {
+    if (n <= 0) return;
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 4;
+    if (n == 1 || max_threads <= 1 || hw <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    static HostPool *pool = new HostPool(static_cast<int>(std::min<unsigned>(hw - 1, 15)));   // leaked on purpose
+    static std::mutex one_job;                            // one job at a time (the library is driven from one thread anyway)
+    std::lock_guard<std::mutex> lk(one_job);
+    pool->parallel_for(n, max_threads, fn);
 }
 
 static double now_s() {
