@@ -1198,7 +1198,27 @@ __global__ void pack_labels_kernel(const HcMeta *__restrict__ metas, const int *
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+// grow-only pinned host buffer: the per-chunk result downloads (heights 3 MB, labels 1.5 MB at cfg2) go through it at PCIe speed
+// instead of through the driver's staging of pageable memory
+template <typename T>
+struct PinnedBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    void ensure(size_t count) {
+        if (count <= n) return;
+        if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
+        SHARP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), count * sizeof(T), hipHostMallocDefault));
+        n = count;
+    }
+};
+
 struct Workspace {
+    PinnedBuf<double> h_out, h_height;
+    PinnedBuf<int> h_packed;
     DevBuf<double> D, D0, S0, S1, Cr, Ct, nrm, height, H, T, G, CSt, Q, out;
     DevBuf<int> ia, ib, lab, chosen, packed, status, remaining;
     DevBuf<unsigned char> img;          // LDS state images of the round-per-launch agglomeration
@@ -1600,7 +1620,8 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
     const long long oOut = J.oOut, oM = J.oM, oLab = J.oLab;
     const std::vector<HcMeta> &metas = J.metas;
     if (J.pipe) SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, pipe_events().done[J.slot], 0));
-    std::vector<double> h_out(oOut), h_height(oM);
+    W.h_out.ensure(std::max<long long>(oOut, 1)); W.h_height.ensure(std::max<long long>(oM, 1));
+    double *h_out = W.h_out.p, *h_height = W.h_height.p;
     if (c.profiling) {      // which agglomeration kernel did the work (tests assert on it)
         const char *seq = getenv("SHARP_HC_SEQ");
         int fallback = T;
@@ -1614,8 +1635,8 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
         c.stats["host:hclust_tasks_sequential"].launches += fallback;
     }
     HostTimer ht_tail("hc_download_select");
-    W.out.download(h_out.data(), oOut);
-    W.height.download(h_height.data(), oM);
+    W.out.download(h_out, oOut);
+    W.height.download(h_height, oM);
     // model selection on the host (a few dozen numbers per task)
     std::vector<int> chosen(T);
     std::vector<long long> poff(T);
@@ -1626,9 +1647,9 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
         const HcMeta &M = metas[t];
         HcResult &R = out[i0 + t];
         R.rc = 0; R.nk = M.nk;
-        R.msil.assign(h_out.begin() + M.oOut, h_out.begin() + M.oOut + M.nk);
-        R.CHind.assign(h_out.begin() + M.oOut + M.nk, h_out.begin() + M.oOut + 2 * M.nk);
-        R.height.assign(h_height.begin() + M.oM, h_height.begin() + M.oM + M.n - 1);
+        R.msil.assign(h_out + M.oOut, h_out + M.oOut + M.nk);
+        R.CHind.assign(h_out + M.oOut + M.nk, h_out + M.oOut + 2 * M.nk);
+        R.height.assign(h_height + M.oM, h_height + M.oM + M.n - 1);
         int oind = 1;
         if (tk.prm.N_cluster > 0) {
             R.branch = 0; R.maxsil = R.msil[0];
@@ -1644,14 +1665,15 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
     W.packoff.upload(poff.data(), T);
     hipLaunchKernelGGL(pack_labels_kernel, dim3(8, T), dim3(256), 0, c.stream, W.meta.p, W.lab.p, W.chosen.p, W.packoff.p, W.packed.p);
     launch_check("pack_labels_kernel");
-    std::vector<int> h_packed(ptot);
-    W.packed.download(h_packed.data(), ptot);
+    W.h_packed.ensure(std::max<long long>(ptot, 1));
+    int *h_packed = W.h_packed.p;
+    W.packed.download(h_packed, ptot);
     std::vector<int> h_lab;
     if (want_v) { h_lab.resize(oLab); W.lab.download(h_lab.data(), oLab); }
     host_parallel_for(T, T >= 16 ? 8 : 1, [&](int t) {
         const HcMeta &M = metas[t];
         HcResult &R = out[i0 + t];
-        R.f.assign(h_packed.begin() + poff[t], h_packed.begin() + poff[t] + M.n);
+        R.f.assign(h_packed + poff[t], h_packed + poff[t] + M.n);
         R.optN = *std::max_element(R.f.begin(), R.f.end());
         if (want_v) R.v.assign(h_lab.begin() + M.oLab, h_lab.begin() + M.oLab + static_cast<long long>(M.nk) * M.n);
     });
