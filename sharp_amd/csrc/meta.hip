@@ -159,6 +159,8 @@ inline bool lex_less(int a, int b) {   // order of R's table() levels: the ids a
 }
 
 struct MetaWs {
+    uint16_t *h_cid = nullptr;       // pinned, grow-only: the relabelled ensembles are written here and uploaded from here
+    size_t h_cid_n = 0;
     DevBuf<uint16_t> cid;
     DevBuf<double> w, S, means, U, Ut, nrm, Smat;
     DevBuf<int> col, start, members;
@@ -191,7 +193,15 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
     MetaWs &W = mws();
     // R = unique(x): global cluster ids in column-major first-appearance order (R/wMetaC.R:60-67)
     std::vector<WmMeta> metas(T);
-    std::vector<std::vector<uint16_t>> cids(T);
+    // the relabelled label matrices of all folds, back to back, in pinned memory (offsets known before the relabelling)
+    std::vector<long long> cid_off(T + 1, 0);
+    for (int t = 0; t < T; ++t) cid_off[t + 1] = cid_off[t] + static_cast<long long>(std::max(tasks[t].N, 0)) * std::max(tasks[t].C, 0);
+    if (static_cast<size_t>(cid_off[T]) > W.h_cid_n) {
+        if (W.h_cid) { (void)hipHostFree(W.h_cid); W.h_cid = nullptr; W.h_cid_n = 0; }
+        SHARP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&W.h_cid), static_cast<size_t>(cid_off[T]) * sizeof(uint16_t), hipHostMallocDefault));
+        W.h_cid_n = static_cast<size_t>(cid_off[T]);
+    }
+    uint16_t *const hc = W.h_cid;
     std::vector<std::vector<int>> colof(T);
     long long oCid = 0, oW = 0, oS = 0, oCol = 0;
     int maxN = 0, maxAll = 0;
@@ -201,8 +211,7 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
     auto relabel = [&](int t) {
         const WmTask &tk = tasks[t];
         if (!(tk.N >= 2 && tk.C >= 1 && tk.nC)) { err[t] = 1; return; }
-        std::vector<uint16_t> &cid = cids[t];
-        cid.resize(static_cast<size_t>(tk.N) * tk.C);
+        uint16_t *cid = hc + cid_off[t];
         int allC = 0;
         std::vector<int> uid;
         for (int col = 0; col < tk.C; ++col) {
@@ -236,13 +245,9 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
     SHARP_REQUIRE(max_lds <= 150 * 1024, "wMetaC: N x C label block does not fit in LDS");
     W.cid.ensure(oCid); W.w.ensure(oW); W.S.ensure(oS); W.col.ensure(oCol); W.meta.ensure(T);
     {
-        std::vector<uint16_t> hc(oCid);
         std::vector<int> hcol(oCol);
-        for (int t = 0; t < T; ++t) {
-            std::copy(cids[t].begin(), cids[t].end(), hc.begin() + metas[t].oCid);
-            std::copy(colof[t].begin(), colof[t].end(), hcol.begin() + metas[t].oCol);
-        }
-        W.cid.upload(hc.data(), oCid);
+        for (int t = 0; t < T; ++t) std::copy(colof[t].begin(), colof[t].end(), hcol.begin() + metas[t].oCol);   // (metas[t].oCid == cid_off[t])
+        W.cid.upload(hc, oCid);
         W.col.upload(hcol.data(), oCol);
         W.meta.upload(metas.data(), T);
         stream_sync();
@@ -290,7 +295,7 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
             R.S.assign(h_S.begin() + metas[t].oS, h_S.begin() + metas[t].oS + static_cast<long long>(R.allC) * R.allC);
             R.tf = tf;
         }
-        const std::vector<uint16_t> &cid = cids[t];
+        const uint16_t *cid = hc + cid_off[t];
         R.finalC.resize(N);
         std::vector<int> second(N, -1), uv(C), uc(C);
         // rank of every meta id in R's table() level order (ids compared as character strings)
