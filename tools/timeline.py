@@ -8,8 +8,11 @@ import sys
 root = sys.argv[1]
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
 pick = int(sys.argv[3]) if len(sys.argv) > 3 else -2
+import os
+
 rows = []
-for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
+files = sorted(glob.glob(root + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
+for f in files[-1:]:                                      # the newest run only (gpurun_out/ accumulates earlier ones)
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), r["Kernel_Name"]))
 rows.sort()
