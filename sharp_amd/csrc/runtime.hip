@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <unistd.h>
 #include <sstream>
 
 #include "common.hpp"
@@ -142,9 +143,14 @@ void host_parallel_for(int n, int max_threads, const std::function<void(int)> &f
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 4;
     if (n == 1 || max_threads <= 1 || hw <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-    static HostPool *pool = new HostPool(static_cast<int>(std::min<unsigned>(hw - 1, 15)));   // leaked on purpose
+    static HostPool *pool = nullptr;                      // leaked on purpose
+    static pid_t pool_pid = 0;
     static std::mutex one_job;                            // one job at a time (the library is driven from one thread anyway)
     std::lock_guard<std::mutex> lk(one_job);
+    if (!pool || pool_pid != getpid()) {                  // (a forked child has the object but not the threads: start its own)
+        pool = new HostPool(static_cast<int>(std::min<unsigned>(hw - 1, 15)));
+        pool_pid = getpid();
+    }
     pool->parallel_for(n, max_threads, fn);
 }
 
