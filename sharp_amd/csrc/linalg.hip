@@ -39,15 +39,25 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_kernel(const GemmTask *__rest
         for (int b = 0; b < 2; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const int lrow = tid >> 4;          // 0..15  (k within the tile)
     const int lcol = (tid & 15) * 4;    // 0..60  (4 consecutive m / n)
-    for (int k0 = 0; k0 < t.K; k0 += GK) {
+    // the next k tile is fetched into registers while the MFMAs of the current one run (the same products in the same order as
+    // without it: only the global-load latency, which every k tile used to pay in full, moves under the arithmetic)
+    double ra[4], rb[4];
+    auto fetch = [&](int k0) {
         const int k = k0 + lrow;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int mm = m0 + lcol + q, nn = n0 + lcol + q;
-            As[lrow][lcol + q] = (k < t.K && mm < t.M) ? ((gcdp)t.At)[static_cast<long long>(k) * t.lda + mm] : 0.0;
-            Bs[lrow][lcol + q] = (k < t.K && nn < t.N) ? ((gcdp)t.Bt)[static_cast<long long>(k) * t.ldb + nn] : 0.0;
+            ra[q] = (k < t.K && mm < t.M) ? ((gcdp)t.At)[static_cast<long long>(k) * t.lda + mm] : 0.0;
+            rb[q] = (k < t.K && nn < t.N) ? ((gcdp)t.Bt)[static_cast<long long>(k) * t.ldb + nn] : 0.0;
         }
-        __syncthreads();
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < t.K; k0 += GK) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { As[lrow][lcol + q] = ra[q]; Bs[lrow][lcol + q] = rb[q]; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is in LDS
+        __builtin_amdgcn_s_barrier();
+        if (k0 + GK < t.K) fetch(k0 + GK);
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
             const int kr = kk + (lane >> 4);
@@ -62,7 +72,9 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_kernel(const GemmTask *__rest
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        // raw barrier: a __syncthreads() here would also wait (vmcnt(0)) for the prefetch of the next tile
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
