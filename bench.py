@@ -7,14 +7,20 @@ steps, then exactly K timed steps bracketed by barrier + device synchronisation 
 ranks, rank 0 prints ONE JSON line.
 
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
-  N = 1 : BASELINE.json configs[1]: one SHARP() call on 50 000 cells x 20 000 genes, ensize.K = 15
-          (SHARP_large: projectors, RP matmul, 375 base-clustering tasks, 25 wMetaC, sMetaC).
-  N > 1 : SHARP_unlimited with one such block per GPU (same per-GPU work: weak scaling); the only
-          data-path collective is the all-gather of the per-block centroid table before the final sMetaC.
-The JSON carries `roofline` for the RP scatter kernel (HBM-bound; algorithmic bytes per SURVEY.md 8d) with
-the kernel's duration measured live by HIP events on the library's stream, and `cpu_baseline`: the fp64 CPU
-oracle (a port of the reference's R path, not R itself) timed on the host cores on a bounded sample."""
+  N = 1 (default, --config cfg2): BASELINE.json configs[1]: one SHARP() call on 50 000 cells x 20 000 genes,
+          ensize.K = 15 (SHARP_large: projectors, RP matmul, 375 base-clustering tasks, 25 wMetaC, sMetaC).
+  N = 1, --config cfg3: BASELINE.json configs[2]: SHARP_unlimited on 500 000 cells x 20 000 genes as 10 blocks, K = 5.
+          (The default run also times cfg3 once, after the timed region, and reports it under "other_configs".)
+  N > 1 : BASELINE.json configs[3]: SHARP_unlimited on 1.3 M cells x 27 000 genes, ensize.K = 5, split into N blocks,
+          one per GPU (162 500 cells each at N = 8), p = 508 from the global count: the total problem is fixed
+          ("scaling": "strong").  The only data-path collective is the all-gather of the per-block centroid table
+          before the final sMetaC (sharp_amd/dist.py).
+The JSON carries `roofline` for the RP matmul stage (rp_compact_kernel + rp_apply_kernel; HBM-bound: X is read once for
+all K projectors) from HIP events on the library's streams inside the timed region, the same stage at the
+K = 5 shapes of cfg3 and of cfg4's per-GPU share (`roofline.by_config`), and `cpu_baseline`: the fp64 CPU oracle (a
+port of the reference's R path, not R itself) timed on the host cores on a bounded sample."""
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -26,10 +32,35 @@ if ROOT not in sys.path:
 
 DATA_SEED = 20261003
 RN_SEED = 2103
-M_GENES = 20000
-CELLS_PER_GPU = 50000
-K_RP = 15
 G_TRUE, N_MARK = 12, 1000
+CFG2 = dict(cells=50000, genes=20000, K=15)
+CFG3 = dict(cells=500000, genes=20000, K=5, blocks=10)
+CFG4 = dict(cells=1300000, genes=27000, K=5)
+METRIC = "cells/sec end-to-end SHARP (fixed genes, n.RP); ARI vs reference labels"
+
+
+def rp_stage_numbers(prof, n, m, K, p, steps_of):
+    """Roofline numbers of the RP matmul stage from the library's HIP-event table: per SHARP() call the stage reads
+    n*m*4 B of X (once for all K projectors) and writes n*K*p*4 B of E (SURVEY.md 8d's algorithmic bytes)."""
+    cms, ccalls = prof.get("rp_compact", (0.0, 0))
+    ams, acalls = prof.get("rp_apply", (0.0, 0))
+    sms, scalls = prof.get("rp_stage", (0.0, 0))
+    if not scalls:
+        return None
+    t_stage = sms / scalls * 1e-3
+    read_b, write_b = n * m * 4, n * K * p * 4
+    out = {"ms": round(t_stage * 1e3, 4), "cells": n, "genes": m, "n_RP": K, "reduced_dim": p,
+           "algorithmic_read_bytes": read_b, "algorithmic_write_bytes": write_b,
+           "achieved_read": round(read_b / t_stage / 1e9, 1), "frac_read": round(read_b / t_stage / 8e12, 4),
+           "frac_read_write": round((read_b + write_b) / t_stage / 8e12, 4), "launches_per_stage": round((ccalls + acalls) / scalls, 2)}
+    if ccalls:
+        tl = cms / ccalls * 1e-3
+        bl = read_b / (ccalls / scalls)
+        out["rp_compact_kernel"] = {"launch_ms": round(tl * 1e3, 4), "algorithmic_bytes": int(bl), "achieved": round(bl / tl / 1e9, 1),
+                                    "frac": round(bl / tl / 8e12, 4)}
+    if acalls:
+        out["rp_apply_kernel"] = {"launch_ms": round(ams / acalls, 4)}
+    return out
 
 
 def main():
@@ -37,9 +68,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cells", type=int, default=CELLS_PER_GPU, help="cells per GPU (default: the configs[1] size)")
-    ap.add_argument("--genes", type=int, default=M_GENES)
+    ap.add_argument("--config", choices=["cfg2", "cfg3"], default="cfg2", help="N = 1 workload (N > 1 always runs cfg4)")
+    ap.add_argument("--cells", type=int, default=0, help="override the TOTAL number of cells of the workload (tests)")
+    ap.add_argument("--genes", type=int, default=0, help="override the number of genes (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the cfg3 / cfg4-share measurements after the timed region")
     args = ap.parse_args()
 
     import numpy as np
@@ -69,39 +102,87 @@ def main():
     import sharp_amd
     from sharp_amd import device as dev
     from sharp_amd import dist as sdist
+    from sharp_amd.api import ARI
 
     sharp_amd.init(local_rank)
-    n, m = args.cells, args.genes
-
-    # ---- synthetic block of this rank, generated on the device (counter-based: identical on CPU and GPU)
-    dX = torch.empty((n, m), dtype=torch.float32, device="cuda")
-    dev.synth_fill(dX, DATA_SEED, rank * n, G_TRUE, N_MARK)
-    truth = dev.synth_labels(DATA_SEED, rank * n, n, G_TRUE)
-    torch.cuda.synchronize()
+    lib = sharp_amd.lib()
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        sharp_amd.lib().sharp_synchronize()
+        lib.sharp_synchronize()
 
-    ncb = [n] * world
+    def synth_block(cell0, n, m):
+        x = torch.empty((n, m), dtype=torch.float32, device="cuda")
+        dev.synth_fill(x, DATA_SEED, cell0, G_TRUE, N_MARK)
+        return x
+
+    def unlimited_call(blocks, K):
+        """sharp_SHARP_unlimited_dev on resident blocks -> (pred, n_pred, p)"""
+        B = len(blocks)
+        ptrs = (C.c_void_p * B)(*[b.data_ptr() for b in blocks])
+        ncb = np.array([b.shape[0] for b in blocks], np.int64)
+        ldb = np.array([b.stride(0) for b in blocks], np.int64)
+        pred = np.zeros(int(ncb.sum()), np.int32)
+        npred, pu = C.c_int(), C.c_int()
+        rc = lib.sharp_SHARP_unlimited_dev(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), ldb.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                           B, blocks[0].shape[1], K, 0, 0, 0, C.c_double(RN_SEED), pred.ctypes.data_as(C.POINTER(C.c_int)),
+                                           C.byref(npred), C.byref(pu))
+        if rc not in (0, 16, 32, 48):
+            raise RuntimeError(lib.sharp_last_error().decode())
+        return pred, npred.value, pu.value
+
+    # ---- workload of this run: synthetic blocks generated on the device (counter-based: identical on CPU and GPU)
     state = {}
+    if world > 1:
+        cfg, tag = dict(CFG4), "cfg4"
+    else:
+        cfg, tag = (dict(CFG2), "cfg2") if args.config == "cfg2" else (dict(CFG3), "cfg3")
+    if args.cells:
+        cfg["cells"] = args.cells
+    if args.genes:
+        cfg["genes"] = args.genes
+    n_total, m, K = cfg["cells"], cfg["genes"], cfg["K"]
+    if world > 1:
+        # block r of the N: cells [c0, c1) of the one synthetic data set; rank r owns block r
+        bounds = [n_total * r // world for r in range(world + 1)]
+        ncb = [bounds[r + 1] - bounds[r] for r in range(world)]
+        dX = synth_block(bounds[rank], ncb[rank], m)
+        truth = dev.synth_labels(DATA_SEED, bounds[rank], ncb[rank], G_TRUE)
 
-    def step():
-        if world == 1:
-            pred, info = dev.SHARP_dev(dX, ensize_K=K_RP, rN_seed=RN_SEED)
-            state["p"], state["pred"], state["n_clusters"] = info["reduced.dim"], pred, info["N.pred_cluster"]
-        else:
-            p = sdist.global_reduced_dim(n * world)
-            proj = sharp_amd.Projector(m, p, [50 + RN_SEED + k for k in range(1, K_RP + 1)])
+        def step():
+            p = sdist.global_reduced_dim(n_total)                    # R/SHARP_unlimited.R:65-66: from the GLOBAL cell count
+            proj = sharp_amd.Projector(m, p, [50 + RN_SEED + k for k in range(1, K + 1)])   # :97-104, regenerated on every rank
 
             def run_block(blk, p_):
-                return dev.unlimited_block_dev(blk, p_, proj.handle, K_RP, RN_SEED)
+                return dev.unlimited_block_dev(blk, p_, proj.handle, K, RN_SEED)
 
             out, nfin, p = sdist.unlimited_sharded([dX], [rank], ncb, run_block, dev.unlimited_merge, device=xdev)
             proj.close()
             state["p"], state["pred"], state["n_clusters"] = p, out[rank], nfin
+        workload = ("SHARP_unlimited on synthetic %d cells x %d genes, %d blocks (one per GPU, %d cells each), ensize.K=%d, rN.seed=%d"
+                    % (n_total, m, world, ncb[0], K, RN_SEED))
+    elif tag == "cfg2":
+        dX = synth_block(0, n_total, m)
+        truth = dev.synth_labels(DATA_SEED, 0, n_total, G_TRUE)
+
+        def step():
+            pred, info = dev.SHARP_dev(dX, ensize_K=K, rN_seed=RN_SEED)
+            state["p"], state["pred"], state["n_clusters"] = info["reduced.dim"], pred, info["N.pred_cluster"]
+        workload = "SHARP() on synthetic %d cells x %d genes, ensize.K=%d, SHARP_large path, rN.seed=%d" % (n_total, m, K, RN_SEED)
+    else:
+        B = cfg["blocks"]
+        nb = n_total // B
+        blocks = [synth_block(b * nb, nb, m) for b in range(B)]
+        truth = np.concatenate([dev.synth_labels(DATA_SEED, b * nb, nb, G_TRUE) for b in range(B)])
+
+        def step():
+            pred, npred, p = unlimited_call(blocks, K)
+            state["p"], state["pred"], state["n_clusters"] = p, pred, npred
+        workload = ("SHARP_unlimited on synthetic %d cells x %d genes as %d blocks of %d, ensize.K=%d, rN.seed=%d"
+                    % (n_total, m, B, nb, K, RN_SEED))
+    torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -124,82 +205,64 @@ def main():
     prof = dev.profile_table()
     del os.environ["SHARP_HC_RANGES"]
     del os.environ["SHARP_HC_PIPE"]
-    for kname in ("rp_compact", "rp_apply", "rp_stage"):           # the RP stage is not affected: keep the timed-region statistics
-        if kname in prof_timed:
-            prof[kname] = prof_timed[kname]
-    attr_steps = {k: (args.steps if k in ("rp_compact", "rp_apply", "rp_stage") else 1) for k in prof}
+    dev.profile(False)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     ms_per_step = dt / args.steps * 1e3
-    cells_per_s = n * world * args.steps / dt
+    cells_per_s = n_total * args.steps / dt
 
     if rank == 0:
         p = state["p"]
-        # RP matmul = rp_compact_kernel (streams X from HBM: the HBM-bound kernel the roofline is quoted for) feeding
-        # rp_apply_kernel (L2 gather + LDS atomics, writes E) chunk by chunk.
-        cms, ccalls = prof.get("rp_compact", (0.0, 0))
-        ams, acalls = prof.get("rp_apply", (0.0, 0))
-        sms, scalls = prof.get("rp_stage", (0.0, 0))
+        n_local = int(dX.shape[0]) if tag != "cfg3" else n_total // cfg["blocks"]     # cells per SHARP() call (per block)
+        # the RP matmul as BASELINE.json's north_star defines it: the whole stage (the compaction kernel streams X, the apply kernel does
+        # the sparse-ternary accumulation and writes E), timed inside the timed region by HIP events on the library's streams
+        st = rp_stage_numbers(prof_timed, n_local, m, K, p, args.steps)
         roof = None
-        if ccalls and scalls:
-            launches_per_stage = ccalls / scalls                    # chunks of cells per SHARP() call
-            cells_per_launch = n / launches_per_stage
-            t_launch = cms / ccalls * 1e-3                          # live HIP events on the stream the kernel runs on
-            alg_launch = cells_per_launch * m * 4                   # X is read once for all K projectors
-            t_stage = sms / scalls * 1e-3
-            alg_stage = n * (m * 4 + K_RP * p * 4)                  # + K*p*4 B of E per cell, written by rp_apply_kernel
-            traffic = traffic_compact = None                      # PMC-measured HBM bytes (profiles/rp_traffic.json, tools/profile_round.sh)
+        if st:
+            traffic, tsrc = None, None
             tf = os.path.join(ROOT, "profiles", "rp_traffic.json")
-            if os.path.exists(tf) and n == CELLS_PER_GPU and m == M_GENES:
+            if tag == "cfg2" and os.path.exists(tf) and n_total == CFG2["cells"] and m == CFG2["genes"]:
                 tj = json.load(open(tf))
-                traffic = tj.get("hbm_bytes_per_launch")             # both kernels, one SHARP() call
-                traffic_compact = tj.get("hbm_bytes_per_kernel_per_SHARP_call", {}).get("sharp::rp_compact_kernel")
-            ach = alg_launch / t_launch / 1e9
-            roof = {"kernel": "rp_compact_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(ach / 8000.0, 4),
-                    "traffic": None if traffic_compact is None else int(traffic_compact / launches_per_stage),
-                    "launch_ms": round(t_launch * 1e3, 4), "cells_per_launch": round(cells_per_launch, 1),
-                    "algorithmic_bytes": int(alg_launch),
-                    "stage": {"what": "whole RP matmul (rp_compact then rp_apply, chunk by chunk; one stream at K*p >= 4096, two below), per SHARP() call",
-                              "ms": round(t_stage * 1e3, 4), "algorithmic_bytes": alg_stage,
-                              "achieved": round(alg_stage / t_stage / 1e9, 1), "frac": round(alg_stage / t_stage / 8e12, 4),
-                              "read_only_frac": round(n * m * 4 / t_stage / 8e12, 4),
-                              "rp_apply_launch_ms": round(ams / max(acalls, 1), 4), "hbm_bytes_measured": traffic}}
+                traffic = tj.get("hbm_bytes_per_launch")
+                tsrc = "profiles/rp_traffic.json: rocprofv3 --pmc passes of this command on the builder's box (not measured in this run)"
+            roof = {"kernel": "RP matmul stage = rp_compact_kernel + rp_apply_kernel, per SHARP() call (per block)", "bound": "hbm",
+                    "achieved": st["achieved_read"], "peak": 8000.0, "unit": "GB/s", "frac": st["frac_read"],
+                    "traffic": traffic, "traffic_source": tsrc,
+                    "what": "algorithmic bytes = X read once for all K projectors (cells x genes x 4 B, SURVEY.md 8d: the HBM-read roofline "
+                            "north_star names) / stage time from HIP events in the timed region",
+                    "stage": st}
+        stages = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         # the two other heavy kernels, for context (from the single-range attribution step)
         others = []
-        T_tasks = K_RP * len(range(0, n, 2000)) if n >= 5000 else K_RP
-        gms, gcalls = prof.get("corr_dist_gemm", (0.0, 0))
-        if gcalls:
-            fl = T_tasks * 2000.0 * 2000.0 * p                   # upper triangle of n_t^2 * p * 2 flop per task
-            tg = gms / attr_steps.get("corr_dist_gemm", 1) * 1e-3
-            others.append({"kernel": "gemm_tn_f64_fast_kernel", "bound": "mfma", "achieved": round(fl / tg / 1e12, 1), "peak": 78.6,
-                           "unit": "TFLOP/s", "frac": round(fl / tg / 78.6e12, 3), "ms_per_step": round(tg * 1e3, 2),
-                           "work": "%d tasks x n_t^2 x p flop (upper triangle), f64 MFMA" % T_tasks})
-        hms, hcalls = prof.get("hclust", (0.0, 0))
-        if hcalls:
-            by = T_tasks * 2000.0 * 2000.0 * 8 * 10.1            # rounds of (read n_a^2 + write n_a'^2) + the round-0 scan: 10.1 n_t^2 entries per task
-            th = hms / attr_steps.get("hclust", 1) * 1e-3
-            others.append({"kernel": "hclust_rnn_kernel", "bound": "hbm", "achieved": round(by / th / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(by / th / 8e12, 3), "ms_per_step": round(th * 1e3, 2),
-                           "work": "%d tasks x 10.1 n_t^2 x 8 B (every round streams the distance matrix into a compacted copy, "
-                                   "45 rounds; measured HBM traffic 131-136 GB per step, profiles/r01_counter_calibration.txt); "
-                                   "see DESIGN.md 5" % T_tasks})
-        stages = {k: round(v[0] / attr_steps.get(k, 1), 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0] / attr_steps.get(kv[0], 1))}
-        from sharp_amd.api import ARI
-
+        if tag == "cfg2":
+            T_tasks = K * len(range(0, n_total, 2000))
+            gms, gcalls = prof.get("corr_dist_gemm", (0.0, 0))
+            if gcalls:
+                fl = T_tasks * 2000.0 * 2000.0 * p                   # upper triangle of n_t^2 * p * 2 flop per task
+                tg = gms * 1e-3
+                others.append({"kernel": "gemm_tn_f64_fast_kernel", "bound": "mfma", "achieved": round(fl / tg / 1e12, 1), "peak": 78.6,
+                               "unit": "TFLOP/s", "frac": round(fl / tg / 78.6e12, 3), "ms_per_step": round(tg * 1e3, 2),
+                               "work": "%d tasks x n_t^2 x p flop (upper triangle), f64 MFMA" % T_tasks})
+            hms, hcalls = prof.get("hclust", (0.0, 0))
+            if hcalls:
+                by = T_tasks * 2000.0 * 2000.0 * 8 * 10.1            # rounds of (read n_a^2 + write n_a'^2) + the round-0 scan
+                th = hms * 1e-3
+                others.append({"kernel": "hclust_rnn_kernel", "bound": "hbm", "achieved": round(by / th / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round(by / th / 8e12, 3), "ms_per_step": round(th * 1e3, 2),
+                               "work": "%d tasks x 10.1 n_t^2 x 8 B as the kernel streams it (every round rewrites the distance matrix "
+                                       "compacted); the distance matrices themselves are %d x n_t^2 x 8 B = %.1f GB"
+                                       % (T_tasks, T_tasks, T_tasks * 2000.0 * 2000.0 * 8 / 1e9)})
         result = {
-            "metric": "cells/sec end-to-end SHARP (fixed genes, n.RP); ARI vs reference labels",
+            "metric": METRIC,
             "value": round(cells_per_s, 1), "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("SHARP() on synthetic %d cells x %d genes, ensize.K=%d, SHARP_large path, rN.seed=%d"
-                                    % (n, m, K_RP, RN_SEED)) if world == 1 else
-                                   ("SHARP_unlimited, %d blocks of %d cells x %d genes (one per GPU), ensize.K=%d, rN.seed=%d"
-                                    % (world, n, m, K_RP, RN_SEED)),
-                       "cells_per_gpu": n, "genes": m, "n_RP": K_RP, "reduced_dim": p, "x_storage": "fp32 in HBM",
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "baseline_config": {"cfg2": "configs[1]", "cfg3": "configs[2]", "cfg4": "configs[3]"}[tag],
+                       "cells_total": n_total, "cells_per_gpu": int(dX.shape[0]) if tag != "cfg3" else n_total, "cells_per_block": n_local, "genes": m, "n_RP": K,
+                       "reduced_dim": p, "x_storage": "fp32 in HBM (synthetic counts are fp32-exact)",
                        "parallelism": "1 block per GPU" if world > 1 else "single GPU"},
             "roofline": roof,
             "other_kernels": others,
@@ -208,15 +271,76 @@ def main():
             "clusters_found": int(state["n_clusters"]),
             "ari_vs_planted_truth": round(float(ARI(truth, state["pred"])["HA"]), 4),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"], result["parity"] = cpu_baseline(np, dX, m)
+        if world == 1 and tag == "cfg2" and not args.no_extra and not args.cells and not args.genes:
+            del dX
+            torch.cuda.empty_cache()
+            result["other_configs"], by_cfg = extra_configs(np, torch, sharp_amd, dev, lib, synth_block, unlimited_call, ARI)
+            if roof:
+                roof["by_config"] = by_cfg
+            dX = synth_block(0, n_total, m)
+        if world == 1 and tag == "cfg2" and not args.no_cpu_baseline:
+            result["cpu_baseline"], result["parity"] = cpu_baseline(np, dX, m, K)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(np, dX, m):
+def extra_configs(np, torch, sharp_amd, dev, lib, synth_block, unlimited_call, ARI):
+    """After the timed region of the default run: BASELINE.json's largest single-GPU configuration (cfg3) end to end, and the RP matmul
+    stage at the K = 5 shapes (a block of cfg3; one GPU's share of cfg4), so that the driver's box produces these numbers too."""
+    out, by_cfg = {}, {}
+    # ---- cfg3: 500 000 x 20 000 as 10 blocks, SHARP_unlimited, K = 5
+    m, K, B = CFG3["genes"], CFG3["K"], CFG3["blocks"]
+    nb = CFG3["cells"] // B
+    blocks = [synth_block(b * nb, nb, m) for b in range(B)]
+    truth = np.concatenate([dev.synth_labels(DATA_SEED, b * nb, nb, G_TRUE) for b in range(B)])
+    torch.cuda.synchronize()
+    unlimited_call(blocks, K)                                            # warm-up (workspaces)
+    dev.profile(True)
+    reps = 2
+    lib.sharp_synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pred, npred, p = unlimited_call(blocks, K)
+    lib.sharp_synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    prof = dev.profile_table()
+    dev.profile(False)
+    out["cfg3"] = {"workload": "SHARP_unlimited on synthetic %d cells x %d genes as %d blocks, ensize.K=%d (BASELINE.json configs[2])"
+                               % (CFG3["cells"], m, B, K),
+                   "value": round(CFG3["cells"] / dt, 1), "unit": "cells/s", "seconds_per_call": round(dt, 4), "calls_timed": reps,
+                   "reduced_dim": p, "clusters_found": int(npred), "ari_vs_planted_truth": round(float(ARI(truth, pred)["HA"]), 4)}
+    by_cfg["cfg3_block"] = rp_stage_numbers(prof, nb, m, K, p, reps)
+    del blocks
+    torch.cuda.empty_cache()
+    # ---- cfg4's per-GPU share at N = 8: one 162 500 x 27 000 block, K = 5, p = 508: the RP stage alone, and the block step
+    m, K = CFG4["genes"], CFG4["K"]
+    nb, p = CFG4["cells"] // 8, 508
+    x = synth_block(0, nb, m)
+    proj = sharp_amd.Projector(m, p, [50 + RN_SEED + k for k in range(1, K + 1)])
+    dev.unlimited_block_dev(x, p, proj.handle, K, RN_SEED)              # warm-up
+    dev.profile(True)
+    lib.sharp_synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pr, mn, cn = dev.unlimited_block_dev(x, p, proj.handle, K, RN_SEED)
+    lib.sharp_synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    prof = dev.profile_table()
+    dev.profile(False)
+    proj.close()
+    out["cfg4_share"] = {"workload": "one GPU's block of BASELINE.json configs[3] at N = 8: %d cells x %d genes, ensize.K=%d, p=%d, "
+                                     "sharp_unlimited_block_dev (projectors resident)" % (nb, m, K, p),
+                         "value": round(nb / dt, 1), "unit": "cells/s", "seconds_per_call": round(dt, 4), "calls_timed": reps,
+                         "clusters_found": int(mn.shape[0])}
+    by_cfg["cfg4_share"] = rp_stage_numbers(prof, nb, m, K, p, reps)
+    del x
+    torch.cuda.empty_cache()
+    return out, by_cfg
+
+
+def cpu_baseline(np, dX, m, K):
     """The oracle (CPU port of the reference path) on a bounded sample of the same workload, on the host
     cores of this box; plus the GPU-vs-oracle label agreement on that sample."""
     from oracle import pyoracle as orc
@@ -226,17 +350,18 @@ def cpu_baseline(np, dX, m):
     orc.build()
     cores = os.cpu_count() or 1
     ns = 4000                                          # 2 folds x 15 projections = 30 base-clustering tasks
-    cores = min(cores, 2 * K_RP)                       # the oracle parallelises over the K*T task grid only
+    cores = min(cores, 2 * K)                          # the oracle parallelises over the K*T task grid only
     Xs = dX[:ns].cpu().numpy().T.astype(np.float64)    # (genes, cells)
     t0 = time.perf_counter()
-    ref = orc.SHARP(Xs, K=K_RP, base_ncells=1, rN_seed=RN_SEED, nthreads=cores, want_view=False)
+    ref = orc.SHARP(Xs, K=K, base_ncells=1, rN_seed=RN_SEED, nthreads=cores, want_view=False)
     t = time.perf_counter() - t0
-    pred, _ = dev.SHARP_dev(dX[:ns], ensize_K=K_RP, base_ncells=1, rN_seed=RN_SEED)
+    pred, _ = dev.SHARP_dev(dX[:ns], ensize_K=K, base_ncells=1, rN_seed=RN_SEED)
     ari = float(ARI(ref["pred_clusters"], pred)["HA"])
     base = {"value": round(ns / t, 2), "unit": "cells/s", "cores": cores, "kind": "port",
             "sample": "oracle SHARP_large on the first %d cells x %d genes of the same data (2 folds x %d RPs, OpenMP over "
-                      "the K*T task grid), %.1f s" % (ns, m, K_RP, t)}
-    return base, {"ari_gpu_vs_oracle_on_sample": round(ari, 4), "sample_cells": ns}
+                      "the K*T task grid), %.1f s" % (ns, m, K, t)}
+    return base, {"ari_gpu_vs_oracle_on_sample": round(ari, 4), "sample_cells": ns,
+                  "full_size": "tests/test_configs_gpu.py::test_full_size_block_matches_oracle: a whole 50 000 x 20 000 block, labels identical"}
 
 
 if __name__ == "__main__":

@@ -24,8 +24,10 @@
  *   - functions ending in _dev take DEVICE pointers (HBM-resident data, e.g. from
  *     hipMalloc or a torch tensor's data_ptr()) and run on the library's stream.
  *   - single-threaded callers (R's main thread); the library never calls back.
- *   - the `sharp_C_*` variants use R's .C() convention (every argument a pointer,
- *     void return, int* status out) so glue needs no R headers.
+ *   - the `sharp_C_*` entry points at the end of this header are the same calls in R's .C()
+ *     convention (every argument a pointer, void return, int* status out), so the reference's
+ *     R functions can call the library with no glue compiled against R.h (r/sharp_hip.R);
+ *     r/sharp_glue.c is the .Call shim that avoids .C()'s argument copies.
  */
 #ifndef SHARP_HIP_H
 #define SHARP_HIP_H
@@ -58,7 +60,7 @@ int sharp_profile_get(const char *name, double *total_ms, long long *launches);
 int sharp_profile_dump(char *buf, int buflen);
 
 /* ---- a1: ranM / ranM2 / projector half of RPmat ---------------------------- */
-/* R/ranM.R:11-33, R/ranM2.R:44-68, R/RPmat.R:82-99.
+/* R/ranM.R:11-33, R/ranM2.R:11-35, R/RPmat.R:14-31.
  * Builds K sparse ternary projectors R_k (m x p) with R's own RNG stream:
  * set.seed(seeds[k]); sample(c(sqrt(s),0,-sqrt(s)), m*p, TRUE, c(1/2s,1-1/s,1/2s));
  * byrow fill.  seeds[k] must be integer-valued (50 + rN.seed + k at the call sites
@@ -74,7 +76,7 @@ int sharp_projector_info(int handle, int *m, int *p, int *K, long long *nnz_tota
 int sharp_projector_triplets(int handle, int k, int *gene, int *col, signed char *sign, long long *nnz);
 
 /* ---- a2: RP matmul  E1 = t( 1/sqrt(p) * t(R_k) %*% log2(X+1) ) -------------- */
-/* R/RPmat.R:100, R/SHARP.R:343-345,363,569-571,579-585.
+/* R/RPmat.R:32, R/SHARP.R:343-345,363,569-571,579-585.
  * Host variant: X double, m x n column-major with leading dimension ld (>= m).
  * E: n x (K*p) row-major, component k*p + c = projector k, column c.
  * X is staged to the device as fp32 (exact for counts < 2^24; otherwise rounded to
@@ -147,6 +149,12 @@ int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K,
                 int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
                 double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred,
                 int *n_pred, double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path);
+
+/* allrpinfo of the most recent call that took the SHARP_small path (R/SHARP.R:350-387,446: per random projection k its tag, the
+ * rowColor of every cell, N.cluster and indE = the projected matrix): enrp n x K column-major colour indices (1..40, the index into the
+ * reference's colorL), indE n x (K p) row-major with projection k in columns [k p, (k+1) p).  Any output may be NULL (sizes only).
+ * Valid until the next sharp_SHARP* call; an error if the last call took the SHARP_large path (the reference returns no allrpinfo there). */
+int sharp_last_rpinfo(int *n, int *K, int *p, int *enrp, double *indE);
 
 /* Releases the resident fp32 copy of the last host matrix and the pinned staging buffers that sharp_SHARP / sharp_SHARP_csc keep
  * between calls (the analogue of R's gc() after a SHARP() run; no reference counterpart). */
@@ -232,6 +240,64 @@ int sharp_dev_alloc(long long bytes, void **dptr);
 int sharp_dev_free(void *dptr);
 int sharp_dev_upload(void *dptr, const void *host, long long bytes);
 int sharp_dev_download(void *host, const void *dptr, long long bytes);
+
+/* ---- the same entry points in R's .C() calling convention (sharp_amd/csrc/dotc.hip) -------------------------------------------
+ * What R's  .C("sharp_C_SHARP", as.double(scExp), nrow(scExp), as.double(ncol(scExp)), ..., status = integer(1))  binds: every
+ * argument is a pointer into a vector R owns (double* for numeric, int* for integer / logical, char** for character), the return is
+ * void and *status receives what the plain entry point returns.  Dimensions that can exceed 2^31 - 1 (numbers of cells) travel as
+ * double.  R cannot pass NULL, so optional outputs are buffers of length >= 1 selected by bits of *want.  "Missing" arguments are 0
+ * (negative for sil.thre) as above.  `flashmark` (R/get_opt_hclust.R:76-83): TRUE takes flashClust(d, "ward") = the ward.D criterion;
+ * with any other hmethod the reference's test `hmethod == "ward.D" || "ward.D2"` is an R error, reproduced as SHARP_ERR_ARG.
+ * r/sharp_hip.R holds the R side of every one of these. */
+void sharp_C_init(int *device, int *status);
+void sharp_C_shutdown(int *status);
+void sharp_C_trim(int *status);
+void sharp_C_device_count(int *count, int *status);
+void sharp_C_last_error(char **msg, int *len);                     /* copies the message into the caller's string of *len bytes */
+/* R/ranM.R:11-33, R/ranM2.R:11-35, R/RPmat.R:14-31 */
+void sharp_C_projector_create(int *m, int *p, int *K, double *seeds, int *handle, int *status);
+void sharp_C_projector_destroy(int *handle, int *status);
+/* nnz: in = capacity of gene/col/sign (0: count only), out = non-zeros of projector *k; sign[i] = +1 / -1 */
+void sharp_C_projector_triplets(int *handle, int *k, int *gene, int *col, int *sign, double *nnz, int *status);
+/* R/RPmat.R:32: X m x n column-major, E n x (K p) row-major */
+void sharp_C_project(int *proj, double *X, int *m, int *n, int *log_flag, double *E, int *status);
+/* R/get_opt_hclust.R:33-244; mat n x p ROW-major; want: 1 v, 2 msil + CHind, 4 height */
+void sharp_C_get_opt_hclust(double *mat, int *n, int *p, int *hmethod, int *N_cluster, int *minN, int *maxN, double *sil_thre,
+                            double *height_Ntimes, int *flashmark, int *f, int *v, double *msil, double *CHind, double *maxsil,
+                            double *height, int *optN, int *nk, int *branch, int *want, int *status);
+/* R/getrowColor.R:17-121 */
+void sharp_C_getrowColor(double *E, int *n, int *p, int *hmethod, int *indN_cluster, int *minN, int *maxN, double *sil_thre,
+                         double *height_Ntimes, int *flashmark, int *rowColor, double *maxsil, int *status);
+/* R/wMetaC.R:15-226; want: 1 x0 (room for N * (maxN + 2)) */
+void sharp_C_wMetaC(int *nC, int *N, int *C, int *hmethod, int *enN_cluster, int *minN, int *maxN, double *sil_thre,
+                    double *height_Ntimes, int *finalC, double *x0, int *ncl, int *want, int *status);
+/* R/sMetaC.R:17-210; n as double; tf: room for n entries */
+void sharp_C_sMetaC(int *labels, double *sE1, double *n, int *p, int *hmethod, int *finalN_cluster, int *minN, int *maxN,
+                    double *sil_thre, double *height_Ntimes, int *finalColor, int *tf, int *nC, int *status);
+/* R/SHARP.R:44-318 (and :339-454, :478-851); want: 1 viE, 2 x0; info[5] = n_pred, x0_cols, p_used, K_used, path */
+void sharp_C_SHARP(double *X, int *m, double *n, int *ensize_K, int *reduced_ndim, int *base_ncells, int *partition_ncells, int *hmethod,
+                   int *N_cluster, int *enpN_cluster, int *indN_cluster, int *minN, int *maxN, double *sil_thre, double *height_Ntimes,
+                   int *flashmark, int *log_flag, int *projector, double *rN_seed, int *pred, double *viE, double *x0, int *x0_cap_cols,
+                   int *info, int *want, int *status);
+void sharp_C_SHARP_csc(int *colptr, int *rowidx, double *val, int *m, double *n, int *ensize_K, int *reduced_ndim, int *base_ncells,
+                       int *partition_ncells, int *hmethod, int *N_cluster, int *enpN_cluster, int *indN_cluster, int *minN, int *maxN,
+                       double *sil_thre, double *height_Ntimes, int *flashmark, int *log_flag, int *projector, double *rN_seed, int *pred,
+                       double *viE, double *x0, int *x0_cap_cols, int *info, int *want, int *status);
+/* allrpinfo (R/SHARP.R:350-387,446); dims[3] = n, K, p; want: 1 enrp, 2 indE */
+void sharp_C_last_rpinfo(int *dims, int *enrp, double *indE, int *want, int *status);
+/* R/SHARP_unlimited.R:29-242; Xcat: the blocks one after the other (each m x ncb[b] column-major), ncb as doubles; want: 1 viE;
+ * info[2] = n_pred, p_used */
+void sharp_C_SHARP_unlimited(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *N_cluster, int *minN, int *maxN,
+                             double *rN_seed, int *pred, double *viE, int *info, int *want, int *status);
+/* R/SHARP_unlimited2.R:29-292 */
+void sharp_C_SHARP_unlimited2(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *reduced_ndim, int *partition_ncells,
+                              int *hmethod, int *N_cluster, int *enpN, int *indN, int *minN, int *maxN, double *sil_thre,
+                              double *height_Ntimes, int *flag, double *rN_seed, int *pred, double *viE, int *info, int *want, int *status);
+/* R/SHARP_unlimited.R:163-183 on gathered centroid tables; counts, ncells as doubles */
+void sharp_C_unlimited_merge(double *means, double *counts, int *nC, int *p, double *ncells, int *N_cluster, int *minN, int *maxN,
+                             int *final_id, int *n_final, int *status);
+/* R/get_marker_genes.R:120-152 */
+void sharp_C_marker_genes(double *X, int *m, double *n, int *label, int *n_cluster, double *theta, int *ng, double *out, int *status);
 
 #ifdef __cplusplus
 }

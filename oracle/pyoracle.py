@@ -242,6 +242,18 @@ def SHARP_unlimited(blocks, K=0, N_cluster=0, minN=0, maxN=0, rN_seed=2103, nthr
     return dict(rc=rc, pred_clusters=pred, viE=viE, p=po.value)
 
 
+def unlimited_merge(means, counts, ncells, N_cluster=0, minN=0, maxN=0):
+    """The tail of SHARP_unlimited from the per-(block, cluster) centroids on (R/SHARP_unlimited.R:163-183)."""
+    means = np.ascontiguousarray(means, np.float64)
+    counts = np.ascontiguousarray(counts, np.int64)
+    nC, p = means.shape
+    fid = np.zeros(nC, np.int32)
+    nf = C.c_int()
+    rc = lib().oracle_unlimited_merge(_dp(means), _p(counts, C.c_longlong), nC, p, C.c_longlong(int(ncells)), int(N_cluster or 0),
+                                      int(minN), int(maxN), _ip(fid), C.byref(nf))
+    return dict(rc=rc, final_id=fid, n_final=nf.value)
+
+
 def SHARP_unlimited2(blocks, K=0, reduced_ndim=0, partition_ncells=0, hmethod="ward.D", N_cluster=0, enpN=0, indN=0, minN=0,
                      maxN=0, sil_thre=-1.0, height_Ntimes=0.0, flag=True, rN_seed=2103, nthreads=1, want_view=False):
     m = blocks[0].shape[0]

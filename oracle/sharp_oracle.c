@@ -139,8 +139,8 @@ void oracle_sample_perm(uint32_t seed, int n, int *out) {
 }
 
 /* ------------------------------------------------------------------------- */
-/* ranM / ranM2 / projector half of RPmat   (R/ranM.R:11-33, R/ranM2.R:44-68, */
-/* R/RPmat.R:82-99).                                                          */
+/* ranM / ranM2 / projector half of RPmat   (R/ranM.R:11-33, R/ranM2.R:11-35, */
+/* R/RPmat.R:14-31).                                                          */
 /*   x0 = sample(c(sqrt(s),0,-sqrt(s)), m*p, TRUE, prob=c(1/(2s),1-1/s,1/(2s)))*/
 /*   Matrix(x0, nrow=m, byrow=TRUE): element i = r*p + c  ->  R[r,c].         */
 /* sample() with prob and 3 candidates = ProbSampleReplace (inversion, one    */
@@ -174,7 +174,7 @@ void oracle_ranM(int m, int p, double seedn, int8_t *tern) {
 }
 
 /* ------------------------------------------------------------------------- */
-/* RP matmul (R/RPmat.R:100, R/SHARP.R:343-345,363,569-571,579-585):          */
+/* RP matmul (R/RPmat.R:32, R/SHARP.R:343-345,363,569-571,579-585):          */
 /*   E1 = t( (1/sqrt(p)) * (t(R) %*% L) ),  L = log2(X+1) if logflag.         */
 /* X: genes x cells, column-major (cell contiguous), like R.                  */
 /* E: cells x p, row-major (= R's p x n projmat, column-major).               */
@@ -553,6 +553,9 @@ int oracle_get_opt_hclust(const double *mat_in, int n, int p, int hmethod, int N
         int nk = kmax - minN + 1;
         if (nk < 1) { rc = OR_ERR_ARG; goto done; }
         *nk_out = nk;
+        /* the levels are independent: OpenMP over them when called from serial code (a cross-block sMetaC at 1e7 cells tries
+           1801 levels); inside the task-parallel loops of SHARP_large nested parallelism is off and this runs serially */
+        #pragma omp parallel for schedule(dynamic, 1)
         for (int c = 0; c < nk; c++) {                     /* :129-154 */
             int k = minN + c;
             int *vc = v + (size_t)c * n;
@@ -759,6 +762,54 @@ int oracle_wMetaC(const int *nC, int N, int C, int hmethod, int enN, int minN, i
     return rc;
 }
 
+/* The part of sMetaC after the centroids (R/sMetaC.R:67-151): S = cor(centroids), the k-range rule by the number of   */
+/* cells, get_opt_hclust(S), the second-best override.  aG: nC x p row-major centroids; tf_out[nC].                     */
+static int smetac_core(const double *aG, int nC, int p, long long ncells_ll, int hmethod, int finalN, int minN, int maxN,
+                       double sil_thre, double height_Ntimes, int *tf_out) {
+    int rc = OR_OK;
+    /* S = cor between centroids, diag 1 (:67-85) */
+    double *S = (double *)xmalloc(sizeof(double) * (size_t)nC * (size_t)nC);
+    for (int a = 0; a < nC; a++) {
+        S[(size_t)a * nC + a] = 1.0;
+        for (int b = a + 1; b < nC; b++) S[(size_t)a * nC + b] = S[(size_t)b * nC + a] = r_cor_vec(aG + (size_t)a * p, aG + (size_t)b * p, p);
+    }
+    /* k-range adjustment (:103-119) */
+    long long ncells = ncells_ll; int mm = (int)(ncells / 10000);
+    if (ncells < 1000000) {
+        int baseN = mm > 2 ? mm : 2; if (baseN > 10) baseN = 10;
+        int mx = maxN < nC ? maxN : nC;
+        if (minN == 2 && mx - baseN >= 3) minN = baseN;
+    } else {
+        int mm3 = (int)(ncells / 50000), mm2 = (int)(ncells / 5000);
+        if (mm2 > maxN) maxN = mm2;
+        if (mm3 > minN) minN = mm3;
+    }
+    int kmax = maxN < nC - 1 ? maxN : nC - 1, nk = kmax - minN + 1; if (nk < 1) nk = 1;
+    int *f = (int *)xmalloc(sizeof(int) * (size_t)nC);
+    int *v = (int *)xmalloc(sizeof(int) * (size_t)nC * (size_t)nk);
+    double *msil = (double *)xmalloc(sizeof(double) * (size_t)nk), *ch = (double *)xmalloc(sizeof(double) * (size_t)nk);
+    double *height = (double *)xmalloc(sizeof(double) * (size_t)nC);
+    double maxsil; int optN, nko, br;
+    rc |= oracle_get_opt_hclust(S, nC, nC, hmethod, finalN, minN, maxN, sil_thre, height_Ntimes,
+                                f, v, msil, ch, &maxsil, height, &optN, &nko, &br);   /* :128-129 */
+    int *tf = f;
+    int nuf = 0; { int mxf = 0; for (int t = 0; t < nC; t++) if (f[t] > mxf) mxf = f[t]; nuf = mxf; }
+    if (nko > 1 && nuf == 2 && maxsil > sil_thre) {        /* :139-148 */
+        double *s0 = (double *)xmalloc(sizeof(double) * (size_t)nko);
+        memcpy(s0, msil, sizeof(double) * (size_t)nko);
+        qsort(s0, (size_t)nko, sizeof(double), cmp_dbl);
+        double s1 = s0[nko - 2];
+        free(s0);
+        /* s2 = which(s0 == s1): if several columns tie R would pick a matrix (quirk 9);
+           take the first. */
+        int s2 = 0; for (int c = 0; c < nko; c++) if (msil[c] == s1) { s2 = c; break; }
+        tf = v + (size_t)s2 * nC;
+    }
+    for (int t = 0; t < nC; t++) tf_out[t] = tf[t];
+    free(S); free(f); free(v); free(msil); free(ch); free(height);
+    return rc;
+}
+
 /* ------------------------------------------------------------------------- */
 /* sMetaC (R/sMetaC.R:17-210).  labels[n]: ints, equal <=> same string;       */
 /* sE1: n x p row-major.  finalN: 0 = NULL.  Outputs finalColor[n] (tf value), */
@@ -793,47 +844,9 @@ int oracle_sMetaC(const int *labels, const double *sE1, int n, int p, int hmetho
     double *aG = (double *)xmalloc(sizeof(double) * (size_t)nC * (size_t)p);
     for (int t = 0; t < nC; t++) for (int k = 0; k < p; k++) aG[(size_t)t * p + k] = (double)(acc[(size_t)t * p + k] / cnt[t]);
     free(acc);
-    /* S = cor between centroids, diag 1 (:67-85) */
-    double *S = (double *)xmalloc(sizeof(double) * (size_t)nC * (size_t)nC);
-    for (int a = 0; a < nC; a++) {
-        S[(size_t)a * nC + a] = 1.0;
-        for (int b = a + 1; b < nC; b++) S[(size_t)a * nC + b] = S[(size_t)b * nC + a] = r_cor_vec(aG + (size_t)a * p, aG + (size_t)b * p, p);
-    }
-    /* k-range adjustment (:103-119) */
-    int ncells = n, mm = ncells / 10000;
-    if (ncells < 1000000) {
-        int baseN = mm > 2 ? mm : 2; if (baseN > 10) baseN = 10;
-        int mx = maxN < nC ? maxN : nC;
-        if (minN == 2 && mx - baseN >= 3) minN = baseN;
-    } else {
-        int mm3 = ncells / 50000, mm2 = ncells / 5000;
-        if (mm2 > maxN) maxN = mm2;
-        if (mm3 > minN) minN = mm3;
-    }
-    int kmax = maxN < nC - 1 ? maxN : nC - 1, nk = kmax - minN + 1; if (nk < 1) nk = 1;
-    int *f = (int *)xmalloc(sizeof(int) * (size_t)nC);
-    int *v = (int *)xmalloc(sizeof(int) * (size_t)nC * (size_t)nk);
-    double *msil = (double *)xmalloc(sizeof(double) * (size_t)nk), *ch = (double *)xmalloc(sizeof(double) * (size_t)nk);
-    double *height = (double *)xmalloc(sizeof(double) * (size_t)nC);
-    double maxsil; int optN, nko, br;
-    rc |= oracle_get_opt_hclust(S, nC, nC, hmethod, finalN, minN, maxN, sil_thre, height_Ntimes,
-                                f, v, msil, ch, &maxsil, height, &optN, &nko, &br);   /* :128-129 */
-    int *tf = f;
-    int nuf = 0; { int mxf = 0; for (int t = 0; t < nC; t++) if (f[t] > mxf) mxf = f[t]; nuf = mxf; }
-    if (nko > 1 && nuf == 2 && maxsil > sil_thre) {        /* :139-148 */
-        double *s0 = (double *)xmalloc(sizeof(double) * (size_t)nko);
-        memcpy(s0, msil, sizeof(double) * (size_t)nko);
-        qsort(s0, (size_t)nko, sizeof(double), cmp_dbl);
-        double s1 = s0[nko - 2];
-        free(s0);
-        /* s2 = which(s0 == s1): if several columns tie R would pick a matrix (quirk 9);
-           take the first. */
-        int s2 = 0; for (int c = 0; c < nko; c++) if (msil[c] == s1) { s2 = c; break; }
-        tf = v + (size_t)s2 * nC;
-    }
-    for (int t = 0; t < nC; t++) tf_out[t] = tf[t];
-    for (int i = 0; i < n; i++) finalColor[i] = tf[uid[i]];  /* :182 */
-    free(uid); free(ulab); free(cnt); free(aG); free(S); free(f); free(v); free(msil); free(ch); free(height);
+    rc |= smetac_core(aG, nC, p, (long long)n, hmethod, finalN, minN, maxN, sil_thre, height_Ntimes, tf_out);
+    for (int i = 0; i < n; i++) finalColor[i] = tf_out[uid[i]];  /* :182 */
+    free(uid); free(ulab); free(cnt); free(aG);
     return rc;
 }
 
@@ -1131,6 +1144,41 @@ int oracle_SHARP_unlimited(const double *Xcat, int m, int nb, const int *ncb, in
     if (viE_out) memcpy(viE_out, E1, sizeof(double) * (size_t)ncells * (size_t)p);
     if (p_out) *p_out = p;
     free(tern); free(fColor); free(E1);
+    return rc;
+}
+
+/* The tail of SHARP_unlimited from the per-(block, cluster) centroids on (R/SHARP_unlimited.R:163-183), for checking a    */
+/* sharded run's merge step on ITS OWN centroid tables: sMetaC only ever uses colMeans per label (R/sMetaC.R:58-63), so     */
+/* means (nC x p row-major, block order then first appearance inside the block) and counts are all it needs.  ncells = the  */
+/* TOTAL number of cells (decides the k range, R/sMetaC.R:103-119, and the default maxN, R/SHARP_unlimited.R:75-77).        */
+/* final_id[nC]: 1-based id of every row, numbered by decreasing cluster size.                                             */
+int oracle_unlimited_merge(const double *means, const long long *counts, int nC, int p, long long ncells, int N_cluster,
+                           int minN, int maxN, int *final_id, int *n_final) {
+    if (minN <= 0) minN = 2;                                                 /* :70-72 */
+    if (maxN <= 0) { long long c = (ncells + 4999) / 5000; maxN = c > 40 ? (int)c : 40; }   /* :75-77 */
+    int rc = smetac_core(means, nC, p, ncells, 1, N_cluster, minN, maxN, 0.35, 2.0, final_id);   /* :163 */
+    int mx = 0; for (int q = 0; q < nC; q++) if (final_id[q] > mx) mx = final_id[q];
+    long long *cnt = (long long *)xcalloc((size_t)mx + 1, sizeof(long long));
+    for (int q = 0; q < nC; q++) cnt[final_id[q]] += counts[q];
+    if (N_cluster <= 0 && ncells > 10000) {                                  /* :168-177 */
+        int mn = -1;
+        for (int q = 1; q <= mx; q++) if (cnt[q] > 0 && cnt[q] < 10) { mn = q; break; }
+        if (mn >= 0) {
+            for (int q = 0; q < nC; q++) if (cnt[final_id[q]] < 10) final_id[q] = mn;
+            for (int q = 0; q <= mx; q++) cnt[q] = 0;
+            for (int q = 0; q < nC; q++) cnt[final_id[q]] += counts[q];
+        }
+    }
+    /* x = sort(table(finalrowColor), decreasing = TRUE): by size, ties in the string order of the ids (:180-183); sizes can
+       exceed an int only beyond 2^31 cells, which the int pairs of cmp_size_then_lex do not cover */
+    int (*pairs)[2] = (int (*)[2])xmalloc(sizeof(int) * 2 * (size_t)(mx + 1)); int np = 0;
+    for (int q = 1; q <= mx; q++) if (cnt[q]) { pairs[np][0] = (int)cnt[q]; pairs[np][1] = q; np++; }
+    qsort(pairs, (size_t)np, sizeof(int) * 2, cmp_size_then_lex);
+    int *map = (int *)xcalloc((size_t)mx + 1, sizeof(int));
+    for (int q = 0; q < np; q++) map[pairs[q][1]] = q + 1;
+    for (int q = 0; q < nC; q++) final_id[q] = map[final_id[q]];
+    *n_final = np;
+    free(cnt); free(pairs); free(map);
     return rc;
 }
 

@@ -1,0 +1,153 @@
+/* sharp_glue.c -- .Call shim between R and libsharp_hip.so (include/sharp_hip.h) for the reference package's hot path.
+ *
+ *     R CMD SHLIB sharp_glue.c -I../include -L../sharp_amd -lsharp_hip          (needs R's headers: not built in the build image,
+ *                                                                                which has no R; the .C() route in sharp_hip.R
+ *                                                                                needs no compiled glue at all)
+ *
+ * Unlike .C(), .Call passes R's vectors by reference: the 8 GB of a 50 000 x 20 000 numeric matrix are read in place by the
+ * library's threaded upload (sharp_SHARP) instead of being duplicated first.  Errors become R errors (the reference's stop()),
+ * the two warning bits R warnings.  Called from R's main thread only; the library never calls back into R.
+ * Parameter vectors (built in r/sharp_hip.R::.sharp_run):
+ *   ipar = ensize.K, reduced.ndim, base.ncells, partition.ncells, hmethod, N.cluster, enpN.cluster, indN.cluster, minN.cluster,
+ *          maxN.cluster, flashmark, flag (log transform), rM handle          (0 = missing -> the reference default inside the library)
+ *   dpar = sil.thre (< 0 = missing), height.Ntimes (0 = missing), rN.seed (0.5 = the reference's "not reproducible" sentinel) */
+#include <math.h>
+#include <string.h>
+
+#include <R.h>
+#include <Rinternals.h>
+
+#include "sharp_hip.h"
+
+static void chk(int rc) {
+    if (rc == SHARP_OK) return;
+    if ((rc & ~(SHARP_WARN_RANGE | SHARP_WARN_NA_VOTE)) == 0) {
+        if (rc & SHARP_WARN_RANGE) warning("SHARP: the model selection left the range of candidate cluster numbers (clamped)");
+        if (rc & SHARP_WARN_NA_VOTE) warning("SHARP: wMetaC's single-cluster fallback met a cell with one vote value");
+        return;
+    }
+    error("%s", sharp_last_error());
+}
+
+/* R/get_opt_hclust.R:76-83: flashmark = TRUE means flashClust(d, "ward") = the ward.D criterion; any other hmethod is an R error there */
+static int method_with_flashmark(int hmethod, int flashmark) {
+    if (!flashmark) return hmethod;
+    if ((hmethod > 0 ? hmethod : 1) != 1) error("invalid 'y' type in 'x || y'");
+    return 1;
+}
+
+SEXP R_sharp_init(SEXP dev) { chk(sharp_init(asInteger(dev))); return R_NilValue; }
+SEXP R_sharp_trim(void) { chk(sharp_trim()); return R_NilValue; }
+
+static SEXP sharp_result(SEXP pred, SEXP viE, SEXP x0, int n, int x0c, int p, int K, int path, int forview) {
+    const char *names[] = {"pred", "viE", "x0", "p", "K", "path", ""};
+    SEXP out = PROTECT(mkNamed(VECSXP, names));
+    SET_VECTOR_ELT(out, 0, pred);
+    if (forview) {
+        /* viE arrives n x p row-major = a p x n R matrix: hand back its transpose, cells x p, like enE/K (R/SHARP.R:416,776-783) */
+        SEXP v = PROTECT(allocMatrix(REALSXP, n, p));
+        const double *s = REAL(viE);
+        double *d = REAL(v);
+        for (int i = 0; i < n; ++i) for (int c = 0; c < p; ++c) d[(size_t)c * n + i] = s[(size_t)i * p + c];
+        SET_VECTOR_ELT(out, 1, v);
+        SEXP x = PROTECT(allocMatrix(REALSXP, n, x0c));
+        memcpy(REAL(x), REAL(x0), sizeof(double) * (size_t)n * (size_t)x0c);
+        SET_VECTOR_ELT(out, 2, x);
+        UNPROTECT(2);
+    }
+    SET_VECTOR_ELT(out, 3, ScalarInteger(p));
+    SET_VECTOR_ELT(out, 4, ScalarInteger(K));
+    SET_VECTOR_ELT(out, 5, ScalarInteger(path));
+    UNPROTECT(1);
+    return out;
+}
+
+/* SHARP(): X is an R numeric matrix genes x cells (column-major doubles) -- exactly the layout the ABI takes (R/SHARP.R:251-280) */
+SEXP R_sharp_SHARP(SEXP X, SEXP ipar, SEXP dpar, SEXP forview_) {
+    const int m = nrows(X), n = ncols(X), *ip = INTEGER(ipar), forview = asLogical(forview_);
+    const double *dp = REAL(dpar);
+    const int hm = method_with_flashmark(ip[4], ip[10]);
+    const int pmax = ip[1] > 0 ? ip[1] : (int)ceil(log2((double)n) / 0.04);
+    int capc = (ip[9] > 40 ? ip[9] : 40);
+    if ((n + 4999) / 5000 > capc) capc = (n + 4999) / 5000;
+    capc += 2;
+    SEXP pred = PROTECT(allocVector(INTSXP, n));
+    SEXP viE = PROTECT(allocVector(REALSXP, forview ? (R_xlen_t)n * pmax : 1));
+    SEXP x0 = PROTECT(allocVector(REALSXP, forview ? (R_xlen_t)n * capc : 1));
+    int npred = 0, p = 0, K = 0, path = 0, x0c = 0;
+    chk(sharp_SHARP(REAL(X), m, n, m, ip[0], ip[1], ip[2], ip[3], hm, ip[5], ip[6], ip[7], ip[8], ip[9], dp[0], dp[1], ip[11], ip[12], dp[2],
+                    INTEGER(pred), &npred, forview ? REAL(viE) : NULL, forview ? REAL(x0) : NULL, capc, &x0c, &p, &K, &path));
+    SEXP out = sharp_result(pred, viE, x0, n, x0c, p, K, path, forview);
+    UNPROTECT(3);
+    return out;
+}
+
+/* scExp held as a Matrix::dgCMatrix: the three slots go over as they are, nothing is densified on the host */
+SEXP R_sharp_SHARP_csc(SEXP Xp, SEXP Xi, SEXP Xx, SEXP dim, SEXP ipar, SEXP dpar, SEXP forview_) {
+    const int m = INTEGER(dim)[0], n = INTEGER(dim)[1], *ip = INTEGER(ipar), forview = asLogical(forview_);
+    const double *dp = REAL(dpar);
+    const int hm = method_with_flashmark(ip[4], ip[10]);
+    const int pmax = ip[1] > 0 ? ip[1] : (int)ceil(log2((double)n) / 0.04);
+    int capc = (ip[9] > 40 ? ip[9] : 40);
+    if ((n + 4999) / 5000 > capc) capc = (n + 4999) / 5000;
+    capc += 2;
+    SEXP pred = PROTECT(allocVector(INTSXP, n));
+    SEXP viE = PROTECT(allocVector(REALSXP, forview ? (R_xlen_t)n * pmax : 1));
+    SEXP x0 = PROTECT(allocVector(REALSXP, forview ? (R_xlen_t)n * capc : 1));
+    int npred = 0, p = 0, K = 0, path = 0, x0c = 0;
+    chk(sharp_SHARP_csc(INTEGER(Xp), INTEGER(Xi), REAL(Xx), m, n, ip[0], ip[1], ip[2], ip[3], hm, ip[5], ip[6], ip[7], ip[8], ip[9], dp[0],
+                        dp[1], ip[11], ip[12], dp[2], INTEGER(pred), &npred, forview ? REAL(viE) : NULL, forview ? REAL(x0) : NULL, capc,
+                        &x0c, &p, &K, &path));
+    SEXP out = sharp_result(pred, viE, x0, n, x0c, p, K, path, forview);
+    UNPROTECT(3);
+    return out;
+}
+
+/* SHARP_unlimited(): blocks = list of numeric matrices sharing the gene axis (R/SHARP_unlimited.R:96-183);
+ * ipar = ensize.K, N.cluster, minN.cluster, maxN.cluster */
+SEXP R_sharp_unlimited(SEXP blocks, SEXP ipar, SEXP seed, SEXP viewflag_) {
+    const int nb = LENGTH(blocks), *ip = INTEGER(ipar), viewflag = asLogical(viewflag_);
+    if (nb < 1) error("No expression data is provided!");
+    const int m = nrows(VECTOR_ELT(blocks, 0));
+    const double **ptrs = (const double **)R_alloc((size_t)nb, sizeof(double *));
+    long long *ncb = (long long *)R_alloc((size_t)nb, sizeof(long long));
+    long long ncells = 0;
+    for (int b = 0; b < nb; ++b) {
+        SEXP B = VECTOR_ELT(blocks, b);
+        if (!isReal(B) || nrows(B) != m) error("The input should be a LIST of partitioned scRNA-seq expression matrices!");
+        ptrs[b] = REAL(B); ncb[b] = ncols(B); ncells += ncb[b];
+    }
+    const int p = (int)ceil(log2((double)ncells) / 0.04);
+    SEXP pred = PROTECT(allocVector(INTSXP, (R_xlen_t)ncells));
+    SEXP viE = PROTECT(allocVector(REALSXP, viewflag ? (R_xlen_t)ncells * p : 1));
+    int npred = 0, pu = 0;
+    chk(sharp_SHARP_unlimited_view(ptrs, ncb, nb, m, ip[0], ip[1], ip[2], ip[3], asReal(seed), INTEGER(pred), &npred, &pu,
+                                   viewflag ? REAL(viE) : NULL));
+    const char *names[] = {"pred", "viE", "p", ""};
+    SEXP out = PROTECT(mkNamed(VECSXP, names));
+    SET_VECTOR_ELT(out, 0, pred);
+    if (viewflag) {
+        SEXP v = PROTECT(allocMatrix(REALSXP, (int)ncells, pu));
+        const double *s = REAL(viE);
+        double *d = REAL(v);
+        for (long long i = 0; i < ncells; ++i) for (int c = 0; c < pu; ++c) d[(size_t)c * (size_t)ncells + (size_t)i] = s[(size_t)i * pu + c];
+        SET_VECTOR_ELT(out, 1, v);
+        UNPROTECT(1);
+    }
+    SET_VECTOR_ELT(out, 2, ScalarInteger(pu));
+    UNPROTECT(3);
+    return out;
+}
+
+static const R_CallMethodDef call_methods[] = {
+    {"R_sharp_init", (DL_FUNC)&R_sharp_init, 1},
+    {"R_sharp_trim", (DL_FUNC)&R_sharp_trim, 0},
+    {"R_sharp_SHARP", (DL_FUNC)&R_sharp_SHARP, 4},
+    {"R_sharp_SHARP_csc", (DL_FUNC)&R_sharp_SHARP_csc, 7},
+    {"R_sharp_unlimited", (DL_FUNC)&R_sharp_unlimited, 4},
+    {NULL, NULL, 0}};
+
+void R_init_sharp_glue(DllInfo *dll) {
+    R_registerRoutines(dll, NULL, call_methods, NULL, NULL);
+    R_useDynamicSymbols(dll, TRUE);      /* the sharp_C_* symbols of libsharp_hip.so are looked up by name through .C() */
+}

@@ -89,13 +89,13 @@ def ranM(scdata, p, seedn):
 
 
 def ranM2(m, p, seedn):
-    """R/ranM2.R:44-68 -- as ranM but takes the number of features."""
+    """R/ranM2.R:11-35 -- as ranM but takes the number of features."""
     _seed_check(seedn)
     return Projector(m, p, [seedn])
 
 
 def RPmat(scdata, p, seedn):
-    """R/RPmat.R:82-115 -- list(R = projector, projmat = 1/sqrt(p) * t(R) %*% scdata) (p x n)."""
+    """R/RPmat.R:14-47 -- list(R = projector, projmat = 1/sqrt(p) * t(R) %*% scdata) (p x n)."""
     pr = ranM(scdata, p, seedn)
     E = pr.project(scdata, logflag=False)
     return {"R": pr, "projmat": E.T.copy()}
@@ -112,11 +112,18 @@ colorL = ["red", "purple", "blue", "yellow", "green", "orange", "brown", "gray",
           "deeppink", "lightcoral", "lightcyan"]
 
 
-def _hmethod(h):
+def _hmethod(h, flashmark=False):
+    """hclust method code.  flashmark (R/get_opt_hclust.R:76-83): TRUE takes flashClust(d, "ward"), the ward.D criterion -- the same
+    merges as hclust(d, "ward.D") --, and the guard `hmethod == "ward.D" || "ward.D2"` is an R error for every other method
+    (`||` on a character string), reproduced here."""
     if h is None:
-        return 1
+        h = "ward.D"
     if h not in HMETHODS:
         raise SharpError(f"invalid clustering method '{h}'")
+    if flashmark:
+        if h != "ward.D":
+            raise SharpError("invalid 'y' type in 'x || y'")
+        return 1
     return HMETHODS[h]
 
 
@@ -152,7 +159,7 @@ def get_opt_hclust(mat, hmethod=None, N_cluster=None, minN_cluster=None, maxN_cl
     optN = C.c_int()
     nko = C.c_int()
     br = C.c_int()
-    rc = check(lib().sharp_get_opt_hclust(_dp(a), n, p, _hmethod(hmethod), Ncl, minN, maxN, C.c_double(sil),
+    rc = check(lib().sharp_get_opt_hclust(_dp(a), n, p, _hmethod(hmethod, flashmark), Ncl, minN, maxN, C.c_double(sil),
                                           C.c_double(hN), _ip(f), _ip(v), _dp(msil), _dp(ch), C.byref(maxsil),
                                           _dp(height), C.byref(optN), C.byref(nko), C.byref(br)), allow=16)
     k = nko.value
@@ -168,7 +175,7 @@ def getrowColor(Emat, hmethod=None, indN_cluster=None, minN_cluster=2, maxN_clus
     n, p = a.shape
     rc_ = np.zeros(n, np.int32)
     maxsil = C.c_double()
-    check(lib().sharp_getrowColor(_dp(a), n, p, _hmethod(hmethod), int(indN_cluster or 0), int(minN_cluster),
+    check(lib().sharp_getrowColor(_dp(a), n, p, _hmethod(hmethod, flashmark), int(indN_cluster or 0), int(minN_cluster),
                                   int(maxN_cluster), C.c_double(sil_thre),
                                   C.c_double(1.0 if height_Ntimes is None else height_Ntimes), _ip(rc_), C.byref(maxsil)),
           allow=16)
@@ -252,13 +259,15 @@ def testlog(scExp, ncells, p, sncells=100, n_cores=None, cells=None):
     return bool(msil[0] < 0.75 and msil[0] >= 0.95 * msil[1])
 
 
-def _enresults(pred, x0, viE, ncells, ngenes, p, K, t0, paras, forview, key="N.pred_cluster"):
+def _enresults(pred, x0, viE, ncells, ngenes, p, K, t0, paras, forview, key="N.pred_cluster", allrpinfo=None):
     import time as _t
 
     uy = np.unique(pred)
     out = {"pred_clusters": pred, "unique_pred_clusters": uy, "distr_pred_clusters": {int(u): int((pred == u).sum()) for u in uy},
            key: int(uy.size)}
     if forview:
+        if allrpinfo is not None:                                             # SHARP_small only (R/SHARP.R:445-449)
+            out["allrpinfo"] = allrpinfo
         out["x0"] = x0
         out["viE"] = viE
     out.update({"N.cells": ncells, "N.genes": ngenes, "reduced.dim": p, "ensize.K": K,
@@ -266,8 +275,24 @@ def _enresults(pred, x0, viE, ncells, ngenes, p, K, t0, paras, forview, key="N.p
     return out
 
 
+def _allrpinfo():
+    """allrpinfo of the SHARP_small run that just finished (R/SHARP.R:350-387,446): per random projection its tag "_RP<p>_<k>",
+    the rowColor of every cell (colour names), N.cluster and indE = the projected cells x p matrix."""
+    n, K, p = C.c_int(), C.c_int(), C.c_int()
+    check(lib().sharp_last_rpinfo(C.byref(n), C.byref(K), C.byref(p), None, None))
+    enrp = np.zeros((K.value, n.value), np.int32)
+    indE = np.zeros((n.value, K.value * p.value))
+    check(lib().sharp_last_rpinfo(None, None, None, _ip(enrp), _dp(indE)))
+    out = []
+    for k in range(K.value):
+        rc_ = [colorL[j - 1] for j in enrp[k]]
+        out.append({"tag": "_RP%d_%d" % (p.value, k + 1), "rowColor": rc_, "N.cluster": len(set(rc_)),
+                    "indE": indE[:, k * p.value:(k + 1) * p.value].copy()})
+    return out
+
+
 def _run_sharp(X, K, p, base_ncells, partition_ncells, hmethod, N_cluster, enpN, indN, minN, maxN, sil_thre,
-               height_Ntimes, flag, rM, rN_seed, forview):
+               height_Ntimes, flag, rM, rN_seed, forview, flashmark=False):
     sparse = _is_sparse(X)
     if sparse:                                                            # dgCMatrix-style input: only the non-zeros are uploaded
         X = X.tocsc()
@@ -288,7 +313,7 @@ def _run_sharp(X, K, p, base_ncells, partition_ncells, hmethod, N_cluster, enpN,
     entry = ((lib().sharp_SHARP_csc, (_ip(cp), _ip(ri), _dp(xv), m, C.c_longlong(n))) if sparse else
              (lib().sharp_SHARP, (_dp(X), m, C.c_longlong(n), C.c_longlong(m))))
     rc = check(entry[0](*entry[1], int(K or 0), int(p or 0),
-                                 int(base_ncells or 0), int(partition_ncells or 0), _hmethod(hmethod), int(N_cluster or 0),
+                                 int(base_ncells or 0), int(partition_ncells or 0), _hmethod(hmethod, flashmark), int(N_cluster or 0),
                                  int(enpN or 0), int(indN or 0), int(minN or 0), int(maxN or 0),
                                  C.c_double(-1.0 if sil_thre is None else sil_thre),
                                  C.c_double(0.0 if height_Ntimes is None else height_Ntimes), int(bool(flag)),
@@ -296,7 +321,8 @@ def _run_sharp(X, K, p, base_ncells, partition_ncells, hmethod, N_cluster, enpN,
                                  C.byref(npred), _dp(viE), _dp(x0), capc, C.byref(x0c), C.byref(pu), C.byref(Ku),
                                  C.byref(path)), allow=48)
     x0m = x0[: n * x0c.value].reshape(x0c.value, n).T.copy() if forview else None
-    return pred, x0m, viE, pu.value, Ku.value, path.value, rc
+    info = _allrpinfo() if forview and path.value == 0 else None          # SHARP_small only (R/SHARP.R:446)
+    return pred, x0m, viE, pu.value, Ku.value, path.value, rc, info
 
 
 def SHARP(scExp, exp_type=None, ensize_K=None, reduced_ndim=None, base_ncells=None, partition_ncells=None, hmethod=None,
@@ -359,15 +385,15 @@ def SHARP(scExp, exp_type=None, ensize_K=None, reduced_ndim=None, base_ncells=No
         flag = testlog(X, ncells, p, 100 if sncells is None else sncells, n_cores, testlog_cells)   # :211-224
     else:
         flag = True                                                       # :225-228
-    pred, x0, viE, pu, Ku, path, rc = _run_sharp(X, ensize_K, p, base_ncells, partition_ncells, hmethod, N_cluster,
-                                                 enpN_cluster, indN_cluster, minN_cluster, maxN_cluster, sil_thre,
-                                                 height_Ntimes, flag, rM, rN_seed, forview)
+    pred, x0, viE, pu, Ku, path, rc, rpinfo = _run_sharp(X, ensize_K, p, base_ncells, partition_ncells, hmethod, N_cluster,
+                                                         enpN_cluster, indN_cluster, minN_cluster, maxN_cluster, sil_thre,
+                                                         height_Ntimes, flag, rM, rN_seed, forview, flashmark)
     paras = {"ensize.K": Ku, "reduced.ndim": pu, "base.ncells": base_ncells or 5000,
              "partition.ncells": partition_ncells or 2000, "logmark": flag, "hmethod": hmethod or "ward.D",
              "N.cluster": N_cluster, "minN.cluster": minN_cluster or 2,
              "maxN.cluster": maxN_cluster or max(40, -(-ncells // 5000)), "sil.thre": 0.35 if sil_thre is None else sil_thre,
              "height.Ntimes": height_Ntimes or 2, "n.cores": n_cores}
-    out = _enresults(pred, x0, viE, ncells, ngenes, pu, Ku, t0, paras, forview)
+    out = _enresults(pred, x0, viE, ncells, ngenes, pu, Ku, t0, paras, forview, allrpinfo=rpinfo)
     out["warn"] = rc
     out["path"] = "SHARP_large" if path else "SHARP_small"
     return out
@@ -382,10 +408,10 @@ def SHARP_small(scExp, ncells=None, ensize_K=15, reduced_ndim=None, hmethod="war
     t0 = _t.time()
     _lib.ensure_init()
     n = np.shape(scExp)[1]
-    pred, x0, viE, pu, Ku, _, rc = _run_sharp(scExp, ensize_K, reduced_ndim, n + 1, None, hmethod, N_cluster, None,
-                                              indN_cluster, minN_cluster, maxN_cluster, sil_thre, height_Ntimes, flag, None,
-                                              rN_seed, forview)
-    return _enresults(pred, x0, viE, n, np.shape(scExp)[0], pu, Ku, t0, {}, forview)
+    pred, x0, viE, pu, Ku, _, rc, rpinfo = _run_sharp(scExp, ensize_K, reduced_ndim, n + 1, None, hmethod, N_cluster, None,
+                                                      indN_cluster, minN_cluster, maxN_cluster, sil_thre, height_Ntimes, flag, None,
+                                                      rN_seed, forview, flashmark)
+    return _enresults(pred, x0, viE, n, np.shape(scExp)[0], pu, Ku, t0, {}, forview, allrpinfo=rpinfo)
 
 
 def SHARP_large(scExp, ncells=None, ensize_K=5, reduced_dim=None, partition_ncells=2000, hmethod="ward.D", N_cluster=None,
@@ -397,9 +423,9 @@ def SHARP_large(scExp, ncells=None, ensize_K=5, reduced_dim=None, partition_ncel
     t0 = _t.time()
     _lib.ensure_init()
     n = np.shape(scExp)[1]
-    pred, x0, viE, pu, Ku, _, rc = _run_sharp(scExp, ensize_K, reduced_dim, 1, partition_ncells, hmethod, N_cluster,
-                                              enpN_cluster, indN_cluster, minN_cluster, maxN_cluster, sil_thre, height_Ntimes,
-                                              flag, rM, rN_seed, forview)
+    pred, x0, viE, pu, Ku, _, rc, _info = _run_sharp(scExp, ensize_K, reduced_dim, 1, partition_ncells, hmethod, N_cluster,
+                                                     enpN_cluster, indN_cluster, minN_cluster, maxN_cluster, sil_thre, height_Ntimes,
+                                                     flag, rM, rN_seed, forview, flashmark)
     return _enresults(pred, x0, viE, n, np.shape(scExp)[0], pu, Ku, t0, {}, forview)
 
 

@@ -55,6 +55,11 @@ namespace {
 struct DriverWs { DevBuf<double> E, viE_sh, viE_out; DevBuf<int> pos; };
 DriverWs &dws() { static DriverWs w; return w; }
 
+// allrpinfo of the last SHARP_small run (R/SHARP.R:350-387,446): the colour index of every cell under every random projection; the
+// projections themselves (indE) are still in dws().E until the next SHARP call
+struct LastSmall { bool valid = false; int n = 0, K = 0, p = 0; long long ldE = 0; std::vector<int> enrp; };
+LastSmall &last_small() { static LastSmall l; return l; }
+
 inline bool lex_less_id(int a, int b) {
     char sa[16], sb[16];
     snprintf(sa, sizeof sa, "%d", a);
@@ -155,6 +160,7 @@ void sharp_small_dev(const float *dX, int m, int n, long long ld, const SharpArg
     get_opt_hclust_batch(tasks, false, hr);                                     // :366 getrowColor
     std::vector<int> enrp(static_cast<size_t>(n) * K);
     for (int k = 0; k < K; ++k) { out.rc |= hr[k].rc; for (int i = 0; i < n; ++i) enrp[static_cast<size_t>(k) * n + i] = colour_of(hr[k].f[i]); }
+    { LastSmall &L = last_small(); L.valid = true; L.n = n; L.K = K; L.p = p; L.ldE = ldE; L.enrp = enrp; }
     WmTask wt; wt.nC = enrp.data(); wt.N = n; wt.C = K; wt.prm = base; wt.prm.N_cluster = a.N_cluster;   // :401
     std::vector<WmTask> wts{wt};
     std::vector<WmResult> wr;
@@ -185,6 +191,7 @@ static std::vector<int> fold_starts(int n, int ng) {
 // ---------------------------------------------------------------------------------------------
 void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, int ng, HcParams base, SharpOut &out) {
     HostTimer ht_all("sharp_large_total");
+    last_small().valid = false;                                                 // E is about to be overwritten
     const bool shuffle = n < 100000;                                            // :504-507
     std::vector<int> reind;                                                     // shuffled position i holds cell reind[i]-1
     std::vector<int> pos(n);                                                    // cell -> shuffled position
@@ -350,17 +357,17 @@ void sharp_front_dev(const float *dX, int m, long long n_, long long ld, SharpAr
     }
     if (a.fpart) {                                                              // SHARP_fpart has no small path
         if (K <= 0) K = 5;
-        SHARP_REQUIRE(part >= 3 && part <= kHcMaxN, "partition.ncells must be between 3 and 7168");
+        SHARP_REQUIRE(part >= 3 && part <= kHcMaxN, "partition.ncells must be between 3 and 16384");
         out.path = 1;
         sharp_large_dev(dX, m, n, ld, a, K, p, part, base, out);
     } else if (n < base_ncells) {
         if (K <= 0) K = 15;                                                     // :254-257
-        SHARP_REQUIRE(n <= kHcMaxN, "SHARP_small: more than 7168 cells in one unpartitioned clustering task");
+        SHARP_REQUIRE(n <= kHcMaxN, "SHARP_small: more than 16384 cells in one unpartitioned clustering task");
         out.path = 0;
         sharp_small_dev(dX, m, n, ld, a, K, p, base, out);
     } else {
         if (K <= 0) K = 5;                                                      // :268-271
-        SHARP_REQUIRE(part >= 3 && part <= kHcMaxN, "partition.ncells must be between 3 and 7168");
+        SHARP_REQUIRE(part >= 3 && part <= kHcMaxN, "partition.ncells must be between 3 and 16384");
         out.path = 1;
         sharp_large_dev(dX, m, n, ld, a, K, p, part, base, out);
     }
@@ -627,6 +634,26 @@ int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K,
     return sharp_SHARP_dev(dX.p, m, n, ldd, ensize_K, reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
                            indN_cluster, minN, maxN, sil_thre, height_Ntimes, log_flag, projector, rN_seed, pred, n_pred, viE, x0,
                            x0_cap_cols, x0_cols, p_used, K_used, path);
+}
+
+/* allrpinfo of the most recent SHARP_small run (R/SHARP.R:350-387: per random projection k the rowColor of every cell and the projected
+ * matrix indE = tmp$mat).  enrp: n x K column-major colour indices; indE: n x (K p) row-major, projection k in columns [k p, (k+1) p). */
+int sharp_last_rpinfo(int *n, int *K, int *p, int *enrp, double *indE) {
+    SHARP_API_BEGIN
+    ctx();
+    LastSmall &L = last_small();
+    SHARP_REQUIRE(L.valid, "sharp_last_rpinfo: the last SHARP call did not take the SHARP_small path (allrpinfo exists there only, R/SHARP.R:446)");
+    if (n) *n = L.n;
+    if (K) *K = L.K;
+    if (p) *p = L.p;
+    if (enrp) std::copy(L.enrp.begin(), L.enrp.end(), enrp);
+    if (indE) {
+        const size_t w = static_cast<size_t>(L.K) * L.p * sizeof(double);
+        SHARP_HIP_CHECK(hipMemcpy2DAsync(indE, w, dws().E.p, static_cast<size_t>(L.ldE) * sizeof(double), w, static_cast<size_t>(L.n),
+                                         hipMemcpyDeviceToHost, ctx().stream));
+        stream_sync();
+    }
+    SHARP_API_END
 }
 
 /* Gives back what the host-matrix entry points keep between calls: the resident fp32 copy of the last host matrix and the pinned

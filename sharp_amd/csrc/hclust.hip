@@ -95,17 +95,22 @@ __device__ __forceinline__ double lance_williams(int method, double d1, double d
 // a4: agglomeration.  State in LDS: disnn (nearest neighbour to the right), nn, membr, flag.
 // D is the full symmetric matrix in HBM (row reads coalesced; the mirrored column write is strided).
 // ---------------------------------------------------------------------------------------------
+// GS: the nearest-neighbour state lives in global memory (gstate, gstride bytes per task) instead of LDS: tasks of more than
+// kHcLdsMaxN observations (a cross-block sMetaC over thousands of block-level clusters).  Same code, same order of operations; the
+// workgroup barriers order the global accesses as they order the LDS ones (all waves of a workgroup share the CU's L1).
+template <bool GS>
 __global__ __launch_bounds__(HC_THREADS) void hclust_kernel(const HcMeta *__restrict__ metas, double *__restrict__ Dall,
                                                             int *__restrict__ ia_all, int *__restrict__ ib_all,
                                                             double *__restrict__ h_all, int ablate, long long *__restrict__ dbg,
-                                                            const int *__restrict__ only_if) {
+                                                            const int *__restrict__ only_if, unsigned char *gstate, long long gstride) {
     if (only_if && only_if[blockIdx.x] == 0) return;      // the bulk-synchronous kernel already did this task
     const HcMeta M = metas[blockIdx.x];
     const int n = M.n, nld = M.nld, method = M.method;
     double *D = Dall + M.oD;
     int *ia = ia_all + M.oM, *ib = ib_all + M.oM;
     double *crit = h_all + M.oM;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_lds[];
+    unsigned char *const sm = GS ? gstate + static_cast<long long>(blockIdx.x) * gstride : sm_lds;
     const int nal = (n + 1) & ~1;
     double *disnn = reinterpret_cast<double *>(sm);
     double *pv = disnn + nal;                 // [32]
@@ -280,7 +285,9 @@ __device__ __forceinline__ HrBest hr_wave(HrBest x) {
 // previous round's transition, finds and ranks the reciprocal pairs, builds the column maps and stores it back; MODE 2
 // (gridDim.y workgroups per task) loads it read-only and rebuilds its share of the rows (work is handed out by counters in
 // the image), writing the new rows' nearest neighbours straight into the image.
-template <int HR_THREADS, int MODE>
+// GS (MODE 1 / 2 only): tasks beyond HR_MAXN observations, whose state does not fit a CU's LDS -- the state arrays ARE the global
+// image (no copy in or out; the same code addresses them), only the stage of the rebuild stays in LDS.
+template <int HR_THREADS, int MODE, bool GS = false>
 __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__restrict__ metas, const double *__restrict__ Dall,
                                                                 double *__restrict__ S0all, double *__restrict__ S1all,
                                                                 int *__restrict__ ia_all, int *__restrict__ ib_all,
@@ -295,11 +302,12 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     double *crit = h_all + M.oM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = HR_THREADS / 64;
     unsigned char *img = MODE ? images + static_cast<long long>(blockIdx.x) * image_stride : nullptr;
-    if (method == 6 || method == 7 || n > HR_MAXN) {            // centroid / median are not reducible; large n: LDS
+    if (method == 6 || method == 7 || n > (GS ? kHcMaxN : HR_MAXN)) {   // centroid / median are not reducible; large n: LDS
         if (MODE != 2 && (MODE == 0 || round == 0) && tid == 0) { status[blockIdx.x] = 1; if (MODE == 1) atomicSub(remaining, 1); }
         return;
     }
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_lds[];
+    unsigned char *const sm = GS ? img : sm_lds;               // where the state arrays live
     const int nal = (n + 3) & ~3;
     double *dnnA = reinterpret_cast<double *>(sm);             // [2][nal]  NN distance (also the pair's height)
     uint16_t *cidA = reinterpret_cast<uint16_t *>(dnnA + 2 * nal);   // [2][nal]  smallest original member
@@ -316,18 +324,20 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     int *wsum = ctl + 16;                                       // [nwave + 1]
     unsigned char *tie = reinterpret_cast<unsigned char *>(wsum + nwave + 1);   // [nal]
     // what is left of the workgroup's LDS stages the pair members' entries of the rows being copied (see the rebuild below)
-    const int stage_off = static_cast<int>((tie + nal - sm + 15) & ~static_cast<long>(15));
-    double *stage = reinterpret_cast<double *>(sm + stage_off);
+    const int stage_off = GS ? 0 : static_cast<int>((tie + nal - sm + 15) & ~static_cast<long>(15));
+    double *stage = reinterpret_cast<double *>(sm_lds + stage_off);
     const int stage_pairs = lds_launch > stage_off ? (lds_launch - stage_off) / (nwave * 32) : 0;   // 2 rows x 2 members x 8 B per pair and wave
 
     int cur = 0, na = n, done = 0;
     int src = -1;                                               // -1: D (pristine), else scratch index
     const bool fresh = MODE == 0 || (MODE == 1 && round == 0);
     if (!fresh) {                                               // the state image of the previous launches
-        const uint4 *gi = reinterpret_cast<const uint4 *>(img);
-        uint4 *li = reinterpret_cast<uint4 *>(sm);
-        for (int q = tid; q < lds_bytes / 16; q += HR_THREADS) li[q] = gi[q];
-        __syncthreads();
+        if (!GS) {
+            const uint4 *gi = reinterpret_cast<const uint4 *>(img);
+            uint4 *li = reinterpret_cast<uint4 *>(sm);
+            for (int q = tid; q < lds_bytes / 16; q += HR_THREADS) li[q] = gi[q];
+            __syncthreads();
+        }
         if (ctl[10] != 0 || (MODE == 2 && !ctl[11])) return;   // finished / abandoned, or nothing pending
         cur = ctl[5]; na = ctl[6]; done = ctl[7]; src = ctl[8] - 1;
         if (MODE == 1 && ctl[11]) {                             // apply the transition of the round that MODE 2 just rebuilt
@@ -365,10 +375,11 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     }   // fresh
 
     // where the results of a rebuilt row go: the LDS arrays (MODE 0) or the global image (MODE 2)
-    auto outp = [&](auto *lds_ptr) { return MODE == 2 ? reinterpret_cast<decltype(lds_ptr)>(img + (reinterpret_cast<unsigned char *>(lds_ptr) - sm)) : lds_ptr; };
+    auto outp = [&](auto *lds_ptr) { return (MODE == 2 && !GS) ? reinterpret_cast<decltype(lds_ptr)>(img + (reinterpret_cast<unsigned char *>(lds_ptr) - sm)) : lds_ptr; };
     int *wctl = outp(ctl);
     auto store_image = [&]() {
         __syncthreads();
+        if (GS) return;
         uint4 *gi = reinterpret_cast<uint4 *>(img);
         const uint4 *li = reinterpret_cast<const uint4 *>(sm);
         for (int q = tid; q < lds_bytes / 16; q += HR_THREADS) gi[q] = li[q];
@@ -962,13 +973,13 @@ __global__ __launch_bounds__(HC_THREADS) void cutree_kernel(const HcMeta *__rest
     int *lab = lab_all + M.oLab;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     int *absorbed = reinterpret_cast<int *>(sm);   // merge step at which i stops being a representative
-    int *parent = absorbed + n;
-    int *rank = parent + n;
-    int *wsum = rank + n;                          // [HC_THREADS/64 + 1]
+    int *wsum = absorbed + n;                      // [HC_THREADS/64 + 1]
+    uint16_t *parent = reinterpret_cast<uint16_t *>(wsum + HC_THREADS / 64 + 1);   // (n <= kHcMaxN < 65536)
+    uint16_t *rank = parent + n;
     const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += HC_THREADS) { absorbed[i] = 0x7fffffff; parent[i] = i; }
+    for (int i = tid; i < n; i += HC_THREADS) { absorbed[i] = 0x7fffffff; parent[i] = static_cast<uint16_t>(i); }
     __syncthreads();
-    for (int s = tid; s < n - 1; s += HC_THREADS) { absorbed[ib[s] - 1] = s; parent[ib[s] - 1] = ia[s] - 1; }
+    for (int s = tid; s < n - 1; s += HC_THREADS) { absorbed[ib[s] - 1] = s; parent[ib[s] - 1] = static_cast<uint16_t>(ia[s] - 1); }
     __syncthreads();
     const int chunk = (n + HC_THREADS - 1) / HC_THREADS;
     for (int L = 0; L < M.nk; ++L) {
@@ -987,7 +998,7 @@ __global__ __launch_bounds__(HC_THREADS) void cutree_kernel(const HcMeta *__rest
         if (tid == 0) { int run = 0; for (int q = 0; q < HC_THREADS / 64; ++q) { const int t = wsum[q]; wsum[q] = run; run += t; } }
         __syncthreads();
         int run = wsum[w] + inc - local;
-        for (int i = b0; i < b1; ++i) { if (absorbed[i] >= nm) rank[i] = ++run; }
+        for (int i = b0; i < b1; ++i) { if (absorbed[i] >= nm) rank[i] = static_cast<uint16_t>(++run); }
         __syncthreads();
         for (int i = tid; i < n; i += HC_THREADS) {
             int r = i;
@@ -1031,12 +1042,17 @@ __global__ void copy_d_kernel(const HcMeta *__restrict__ metas, const double *__
 // A level-k cluster is a union of finest clusters; its sums add the finest columns in ascending order.
 // ---------------------------------------------------------------------------------------------
 constexpr int ST_THREADS = 512;
-constexpr int ST_MAXK = 512;
+constexpr size_t ST_LDS_MAX = 160 * 1024;
+// LDS of one stats workgroup: sil[npow2] (median by bitonic sort), part[ST_THREADS], and seven per-cluster arrays of kcap entries
+inline size_t stats_lds_bytes(int max_n, int kcap) {
+    int npow2 = 1; while (npow2 < max_n) npow2 <<= 1;
+    return static_cast<size_t>(npow2) * 8 + ST_THREADS * 8 + 2 * static_cast<size_t>(kcap) * 8 + (5 * static_cast<size_t>(kcap) + 8) * 4;
+}
 
 __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const HcMeta *__restrict__ metas, const int *__restrict__ lab_all,
                                                            const double *__restrict__ T_all, const double *__restrict__ G_all,
                                                            const double *__restrict__ Q_all, const double *__restrict__ nrm_all,
-                                                           double *__restrict__ out_all, int count, int max_nk) {
+                                                           double *__restrict__ out_all, int count, int max_nk, int kcap) {
     // One workgroup per (task, level).  The levels of a task all read the task's G (n x kpad): the linear workgroup id is
     // dealt so that the eight tasks of a group sit on the eight XCDs (workgroups go round-robin to XCDs) and G is
     // fetched into one L2 once instead of once per level (34 GB -> 0.3 GB of HBM reads per step).
@@ -1056,14 +1072,14 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const HcMeta *__restr
     double *sil = reinterpret_cast<double *>(sm);            // npow2
     double *part = sil + npow2;                              // ST_THREADS
     double *cn2 = part + ST_THREADS;                         // k  : |sum_c|^2
-    double *ctot = cn2 + ST_MAXK;                            // k  : sum_c . total
-    int *cnt = reinterpret_cast<int *>(ctot + ST_MAXK);      // k
-    int *cntF = cnt + ST_MAXK;                               // kf
-    int *fm = cntF + ST_MAXK;                                // kf : level cluster (0-based) of finest cluster f
-    int *start = fm + ST_MAXK;                               // k + 1
-    int *order = start + ST_MAXK + 1;                        // kf : finest clusters grouped by level cluster
+    double *ctot = cn2 + kcap;                               // k  : sum_c . total
+    int *cnt = reinterpret_cast<int *>(ctot + kcap);         // k
+    int *cntF = cnt + kcap;                                  // kf
+    int *fm = cntF + kcap;                                   // kf : level cluster (0-based) of finest cluster f
+    int *start = fm + kcap;                                  // k + 1
+    int *order = start + kcap + 1;                           // kf : finest clusters grouped by level cluster
     const int tid = threadIdx.x;
-    for (int c = tid; c < ST_MAXK; c += ST_THREADS) { cnt[c] = 0; cntF[c] = 0; }
+    for (int c = tid; c < kcap; c += ST_THREADS) { cnt[c] = 0; cntF[c] = 0; }
     __syncthreads();
     for (int i = tid; i < n; i += ST_THREADS) {
         atomicAdd(&cnt[lab[i] - 1], 1);
@@ -1222,6 +1238,7 @@ struct Workspace {
     DevBuf<double> D, D0, S0, S1, Cr, Ct, nrm, height, H, T, G, CSt, Q, out;
     DevBuf<int> ia, ib, lab, chosen, packed, status, remaining;
     DevBuf<unsigned char> img;          // LDS state images of the round-per-launch agglomeration
+    DevBuf<unsigned char> seqstate;     // nearest-neighbour state of the sequential kernel for tasks beyond kHcLdsMaxN observations
     DevBuf<long long> packoff;
     DevBuf<HcMeta> meta;
     DevBuf<RowPrepTask> prep;
@@ -1331,7 +1348,7 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
         const HcTask &tk = tasks[i0 + t];
         HcMeta &M = metas[t];
         SHARP_REQUIRE(tk.n >= 3, "get_opt_hclust: need at least 3 observations");
-        SHARP_REQUIRE(tk.n <= kHcMaxN, "get_opt_hclust: more than 7168 observations in one clustering task is not supported");
+        SHARP_REQUIRE(tk.n <= kHcMaxN, "get_opt_hclust: more than 16384 observations in one clustering task is not supported");
         SHARP_REQUIRE(tk.prm.hmethod >= 1 && tk.prm.hmethod <= 8, "get_opt_hclust: unknown agglomeration method");
         M.n = tk.n; M.p = tk.symmetric ? tk.n : tk.p; M.nld = static_cast<int>(rup(tk.n, 128));
         M.method = tk.prm.hmethod; M.symmetric = tk.symmetric ? 1 : 0; M.pad0 = 0;
@@ -1344,7 +1361,6 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
             M.kmax = std::min(tk.prm.maxN, tk.n - 1);
             SHARP_REQUIRE(M.kmin >= 2 && M.kmax >= M.kmin, "get_opt_hclust: empty range of cluster numbers (minN.cluster..maxN.cluster)");
         }
-        SHARP_REQUIRE(M.kmax <= ST_MAXK, "get_opt_hclust: more than 512 candidate clusters is not supported");
         M.nk = M.kmax - M.kmin + 1;
         M.kpad = static_cast<int>(rup(M.kmax, 16));
         M.oD = oD; oD += static_cast<long long>(M.nld) * M.nld;
@@ -1363,6 +1379,9 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
         any_sym |= tk.symmetric; any_feat |= !tk.symmetric;
     }
     J.oOut = oOut; J.oM = oM; J.oLab = oLab; J.max_n = max_n; J.max_p = max_p; J.max_nk = max_nk; J.max_kpad = max_kpad;
+    SHARP_REQUIRE(stats_lds_bytes(max_n, std::max(max_kpad, 64)) <= ST_LDS_MAX,
+                  "get_opt_hclust: this many observations with this many candidate cluster numbers does not fit the silhouette kernel "
+                  "(LDS: 8 B per observation rounded up to a power of two + 36 B per candidate cluster)");
     { HostTimer ht("hc_workspace_alloc");
     W.D.ensure(oD); W0.S0.ensure(oD); W0.S1.ensure(oD); W.D0.ensure(std::max<long long>(oD0, 1)); W.Cr.ensure(oCr); W.Ct.ensure(oCt); W.nrm.ensure(oN);
     W.height.ensure(oM); W.ia.ensure(oM); W.ib.ensure(oM); W.lab.ensure(oLab);
@@ -1383,7 +1402,7 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
         // spread over several workgroups: the per-round launches and the host's look every eight rounds only cost, 0.27 ms per SHARP() call)
         const bool split = splt ? splt[0] == '1' : (T <= kHcSplitMaxTasks && max_n >= kHcSplitMinObs);
         J.split = split;
-        if (!(mono && mono[0] == '1') && !(seq && seq[0] == '1') && max_n <= HR_MAXN && split) NS = 1;
+        if (!(seq && seq[0] == '1') && ((!(mono && mono[0] == '1') && split) || max_n > HR_MAXN)) NS = 1;
     }
     if (const char *e = getenv("SHARP_HC_RANGES")) NS = std::max(1, std::min(8, atoi(e)));
     if (J.pipe) NS = 1;                         // the overlap comes from the neighbouring chunks
@@ -1461,15 +1480,22 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         auto launch_sequential = [&](bool fallback_only) {
             KernelTimer tm("hclust_sequential");
             const int nal = (max_n + 1) & ~1;
-            const size_t lds = static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16 + 32 * 12 + 16;
-            SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                static_cast<int>(lds)));
+            const size_t lds = (static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16 + 32 * 12 + 16 + 15) / 16 * 16;
             const char *abl = getenv("SHARP_HC_ABLATE");
             const char *tim = getenv("SHARP_HC_TIMING");       // debug: per-phase cycle counts of the merge loop
             DevBuf<long long> dbg;
             if (tim) { dbg.alloc(static_cast<size_t>(Ts) * 6); dbg.zero(); }
-            hipLaunchKernelGGL(hclust_kernel, dim3(Ts), dim3(HC_THREADS), lds, st, dmeta, W.D.p, W.ia.p, W.ib.p, W.height.p,
-                               abl ? atoi(abl) : 0, dbg.p, fallback_only ? W.status.p + R.t0 : nullptr);
+            if (max_n <= kHcLdsMaxN) {
+                SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    static_cast<int>(lds)));
+                hipLaunchKernelGGL(hclust_kernel<false>, dim3(Ts), dim3(HC_THREADS), lds, st, dmeta, W.D.p, W.ia.p, W.ib.p, W.height.p,
+                                   abl ? atoi(abl) : 0, dbg.p, fallback_only ? W.status.p + R.t0 : nullptr, nullptr, 0LL);
+            } else {                                            // state in global memory (W.seqstate is per slot, like D)
+                W.seqstate.ensure(static_cast<size_t>(J.T) * lds);
+                hipLaunchKernelGGL(hclust_kernel<true>, dim3(Ts), dim3(HC_THREADS), 0, st, dmeta, W.D.p, W.ia.p, W.ib.p, W.height.p,
+                                   abl ? atoi(abl) : 0, dbg.p, fallback_only ? W.status.p + R.t0 : nullptr,
+                                   W.seqstate.p + static_cast<size_t>(R.t0) * lds, static_cast<long long>(lds));
+            }
             launch_check("hclust_kernel");
             if (tim) {
                 std::vector<long long> h(static_cast<size_t>(Ts) * 6);
@@ -1503,7 +1529,8 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         // sequential NN-list kernel, which skips the tasks whose status is 0 -- no host round trip in between.
         {
             const char *seq = getenv("SHARP_HC_SEQ");           // debug / cross-check: the sequential kernel only
-            const bool use_rnn = !(seq && seq[0] == '1') && max_n <= HR_MAXN;
+            const bool use_rnn = !(seq && seq[0] == '1');
+            const bool gs = max_n > HR_MAXN;                    // state arrays in global memory (always round per launch)
             KernelTimer tm("hclust");
             if (use_rnn) {
                 const int nal = (max_n + 3) & ~3;
@@ -1516,22 +1543,29 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                 // 10.3 ms in one launch, 50 tasks 6.5 against 11.3.  Many tasks (kHcSplitMaxTasks): one launch is faster (the chip is
                 // then at its memory limit either way and the per-round launches only add their gaps).  SHARP_HC_SPLIT = 1 / 0 forces
                 // the choice; it is made for the whole chunk (a range of a larger chunk stays one launch).
-                const bool split = J.split;
-                if (!(mono && mono[0] == '1') && split) {
-                    const int wpt = std::max(1, std::min(8, (5 * c.num_cu / 2 + Ts - 1) / Ts));
+                const bool split = J.split || gs;
+                if ((!(mono && mono[0] == '1') || gs) && split) {
+                    // workgroups per task in the rebuild launches: eight when there are tens of tasks (measured, 25 - 136 tasks of 2000);
+                    // a lone big task (a per-block or cross-block sMetaC of thousands of clusters) gets up to a quarter of the chip
+                    int wpt = std::max(1, std::min(8, (5 * c.num_cu / 2 + Ts - 1) / Ts));
+                    if (Ts <= 8) wpt = std::max(wpt, std::min(64, c.num_cu / (4 * Ts)));
+                    if (const char *e = getenv("SHARP_HC_WPT")) wpt = std::max(1, atoi(e));
                     W0.img.ensure(static_cast<size_t>(Ts) * lds);
                     W0.remaining.ensure(1);
                     const int rem0 = Ts;
                     W0.remaining.upload(&rem0, 1);
-                    auto ka = hclust_rnn_kernel<1024, 1>;
-                    auto kb = hclust_rnn_kernel<1024, 2>;
-                    const size_t ldsl = std::max(lds, HR_LDS_CU);       // the rebuild launches stage the pair members' entries like MODE 0
-                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+                    auto ka = gs ? hclust_rnn_kernel<1024, 1, true> : hclust_rnn_kernel<1024, 1, false>;
+                    auto kb = gs ? hclust_rnn_kernel<1024, 2, true> : hclust_rnn_kernel<1024, 2, false>;
+                    // the rebuild launches stage the pair members' entries like MODE 0: whatever the CU has beyond the state (all of it
+                    // when the state is global)
+                    const size_t ldsa = gs ? 0 : lds;
+                    const size_t ldsl = gs ? HR_LDS_CU : std::max(lds, HR_LDS_CU);
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsa)));
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsl)));
                     const int max_rounds = max_n + 8;               // every round merges at least one pair
                     for (int r = 0; r < max_rounds; ++r) {
-                        hipLaunchKernelGGL(ka, dim3(Ts), dim3(1024), lds, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p, W.height.p,
-                                           W.status.p + R.t0, W0.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W0.remaining.p, static_cast<int>(lds));
+                        hipLaunchKernelGGL(ka, dim3(Ts), dim3(1024), ldsa, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p, W.height.p,
+                                           W.status.p + R.t0, W0.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W0.remaining.p, static_cast<int>(ldsa));
                         hipLaunchKernelGGL(kb, dim3(Ts, wpt), dim3(1024), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p, W.height.p,
                                            W.status.p + R.t0, W0.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W0.remaining.p, static_cast<int>(ldsl));
                         if ((r & 7) == 7) {                         // a finished task costs two empty workgroups per round: look now and then
@@ -1576,7 +1610,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         if (J.seq_pending) { launch_sequential(true); J.seq_pending = false; }
         // a5a: labels for every candidate k
         {
-            const size_t lds = static_cast<size_t>(max_n) * 4 * 3 + (HC_THREADS / 64 + 1) * 4;
+            const size_t lds = static_cast<size_t>(max_n) * 8 + (HC_THREADS / 64 + 1) * 4 + 16;
             SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cutree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 static_cast<int>(lds)));
             KernelTimer tm("cutree");
@@ -1594,14 +1628,14 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         if (R.cnt[4]) gemm_tn_f64_batched(W.gemm.p + R.off[4], R.cnt[4], max_kpad, max_n, "dist_cluster_sums_gemm");
         // a5b: silhouette medians + CH per level
         {
-            int npow2 = 1; while (npow2 < max_n) npow2 <<= 1;
-            const size_t lds = static_cast<size_t>(npow2) * 8 + ST_THREADS * 8 + 2 * ST_MAXK * 8 + (5 * ST_MAXK + 8) * 4;
+            const int kcap = std::max(J.max_kpad, 64);
+            const size_t lds = stats_lds_bytes(max_n, kcap);
             SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 static_cast<int>(lds)));
             KernelTimer tm("sil_ch_stats");
             const long long blocks = static_cast<long long>((Ts + 7) / 8) * 8 * max_nk;
             hipLaunchKernelGGL(stats_kernel, dim3(static_cast<unsigned>(blocks)), dim3(ST_THREADS), lds, st, dmeta, W.lab.p, W.T.p,
-                               W.G.p, W.Q.p, W.nrm.p, W.out.p, Ts, max_nk);
+                               W.G.p, W.Q.p, W.nrm.p, W.out.p, Ts, max_nk, kcap);
             launch_check("stats_kernel");
         }
         if (NS > 1) {
@@ -1616,7 +1650,7 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
     Ctx &c = ctx();
     Workspace &W = ws(J.slot);
     const size_t i0 = J.i0;
-    const int T = J.T, max_n = J.max_n;
+    const int T = J.T;
     const long long oOut = J.oOut, oM = J.oM, oLab = J.oLab;
     const std::vector<HcMeta> &metas = J.metas;
     if (J.pipe) SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, pipe_events().done[J.slot], 0));
@@ -1625,7 +1659,7 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
     if (c.profiling) {      // which agglomeration kernel did the work (tests assert on it)
         const char *seq = getenv("SHARP_HC_SEQ");
         int fallback = T;
-        if (!(seq && seq[0] == '1') && max_n <= HR_MAXN) {
+        if (!(seq && seq[0] == '1')) {
             std::vector<int> st(T);
             W.status.download(st.data(), T);
             fallback = 0;

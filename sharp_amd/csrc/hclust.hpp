@@ -34,7 +34,12 @@ struct HcResult {
     int optN = 0, nk = 0, branch = 0;
 };
 
-constexpr int kHcMaxN = 7168;   // LDS-resident nearest-neighbour state per task
+// Observations per clustering task.  Up to kHcLdsMaxN (sequential kernel) / 4096 (bulk-synchronous kernel) the agglomeration state
+// of a task lives in its workgroup's LDS; beyond, up to kHcMaxN, the same kernels keep it in global memory (the cross-block sMetaC
+// of SHARP_unlimited over thousands of block-level clusters, R/SHARP_unlimited.R:163; the per-block sMetaC of a block of hundreds of
+// folds).  kHcMaxN: the silhouette medians are sorted in LDS (8 B per observation, rounded up to a power of two) and indices are 15-bit.
+constexpr int kHcLdsMaxN = 7168;
+constexpr int kHcMaxN = 16384;
 
 void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::vector<HcResult> &out);
 

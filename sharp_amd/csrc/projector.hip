@@ -1,5 +1,5 @@
 // projector.hip -- host construction of the ranM() projectors (R/ranM.R:11-33,
-// R/ranM2.R:44-68, R/RPmat.R:82-99) and upload as packed gene-major row lists.
+// R/ranM2.R:11-35, R/RPmat.R:14-31) and upload as packed gene-major row lists.
 #include "projector.hpp"
 
 #include <algorithm>

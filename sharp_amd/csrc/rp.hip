@@ -1,5 +1,5 @@
 // rp.hip -- the sparse-ternary random-projection matmul:
-//   E1 = t( 1/sqrt(p) * t(R_k) %*% log2(X+1) )      R/RPmat.R:100, R/SHARP.R:343-345,569-585
+//   E1 = t( 1/sqrt(p) * t(R_k) %*% log2(X+1) )      R/RPmat.R:32, R/SHARP.R:343-345,569-585
 // for ALL K projectors in one pass over X (the reference re-reads and re-logs X once
 // per k, R/SHARP.R:554-571).
 //

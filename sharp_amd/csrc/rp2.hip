@@ -1,4 +1,4 @@
-// rp2.hip -- the RP matmul (R/RPmat.R:100, R/SHARP.R:343-345,569-585) as a two-kernel
+// rp2.hip -- the RP matmul (R/RPmat.R:32, R/SHARP.R:343-345,569-585) as a two-kernel
 // producer/consumer pipeline over chunks of cells, on two HIP streams:
 //   rp_compact_kernel (stream2): streams X once (the only HBM-bound part), compacts the non-zeros of every
 //       cell wave-locally (ballot prefix), evaluates fp64 log2(1+x) -> 44-bit fixed point for them and appends

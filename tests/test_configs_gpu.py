@@ -1,0 +1,255 @@
+"""BASELINE.json configs 3, 4 and 5 at their full sizes on one MI355X, and the edges of the path they reach:
+
+  cfg3  500 000 cells x 20 000 genes as 10 blocks, SHARP_unlimited, K = 5, p = 474      -- whole, one call and block by block
+  cfg4  1.3 M cells x 27 000 genes, 8 blocks of 162 500 (one per GPU in the 8-GPU run), p = 508 -- all eight shares in turn
+        on this GPU through sharp_unlimited_block_dev, then sharp_unlimited_merge at ncells = 1.3 M (the n >= 1e6 branch of
+        sMetaC, R/sMetaC.R:110-119), checked against the oracle's merge on the same centroid tables
+  cfg5  10 M cells x 20 000 genes, 200 streamed blocks of 50 000 (25 per GPU in the 8-GPU run), p = 582 -- all 200 generated
+        on the fly into one buffer, then the merge at ncells = 1e7 (k = 200 .. 2000: 1801 candidate levels) against the oracle
+  one full-size block (50 000 x 20 000, K = 5, cfg3's reduced dimension) label for label against the oracle
+  sharp_sMetaC at n = 1.2 M cells against the oracle; clustering tasks beyond the LDS-resident limits (> 4096, > 7168 rows)
+
+The oracle is the CPU restatement of the reference (oracle/); where it would need hours (whole configs) the checks are the
+size-independent properties of the path: determinism, numbering rules, agreement of the one-call and the sharded form,
+recovery of the planted clusters."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+from sklearn.metrics import adjusted_rand_score
+
+pytestmark = pytest.mark.gpu
+SEED, RN = 20261003, 2103
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    import sharp_amd
+    from sharp_amd import device
+
+    sharp_amd.init(0)
+    return sharp_amd, device, torch
+
+
+def _purity(truth, pred):
+    """fraction of cells whose predicted cluster's majority planted label is their own"""
+    tab = np.zeros((pred.max() + 1, truth.max() + 1), np.int64)
+    np.add.at(tab, (pred, truth), 1)
+    return tab.max(1).sum() / truth.size
+
+
+def _block_steps(sa, dev, torch, m, nb, nblocks, p, K=5):
+    """every block in turn through sharp_unlimited_block_dev (what a rank of the sharded run does with its blocks); the blocks
+    are generated into ONE device buffer.  Returns per-block labels, centroid tables, counts, planted labels, seconds."""
+    proj = sa.Projector(m, p, [50 + RN + k for k in range(1, K + 1)])
+    dX = torch.empty((nb, m), dtype=torch.float32, device="cuda")
+    preds, means, counts, truth = [], [], [], []
+    t_run = 0.0
+    try:
+        for b in range(nblocks):
+            dev.synth_fill(dX, SEED, b * nb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pr, mn, cn = dev.unlimited_block_dev(dX, p, proj.handle, K, RN)
+            t_run += time.perf_counter() - t0
+            assert pr.min() == 1 and pr.max() == mn.shape[0] == cn.size and cn.sum() == nb
+            first = [int(np.argmax(pr == j)) for j in range(1, pr.max() + 1)]
+            assert first == sorted(first)                                 # block labels by first appearance (R/SHARP.R:828-843)
+            np.testing.assert_array_equal(np.bincount(pr)[1:], cn)
+            preds.append(pr); means.append(mn); counts.append(cn)
+            truth.append(dev.synth_labels(SEED, b * nb, nb))
+    finally:
+        proj.close()
+        del dX
+        torch.cuda.empty_cache()
+    return preds, means, counts, truth, t_run
+
+
+def _apply_merge(preds, means, fid):
+    first = np.concatenate([[0], np.cumsum([mn.shape[0] for mn in means])])
+    return np.concatenate([np.asarray(fid)[first[b] + preds[b] - 1] for b in range(len(preds))])
+
+
+def test_cfg3_whole_and_sharded(env):
+    sa, dev, torch = env
+    lib = sa.lib()
+    nb, m, B = 50000, 20000, 10                       # BASELINE.json configs[2]
+    blocks = []
+    for b in range(B):
+        x = torch.empty((nb, m), dtype=torch.float32, device="cuda")
+        dev.synth_fill(x, SEED, b * nb)
+        blocks.append(x)
+    ptrs = (C.c_void_p * B)(*[x.data_ptr() for x in blocks])
+    ncb = np.full(B, nb, np.int64)
+    ldb = np.full(B, m, np.int64)
+
+    def run():
+        pred = np.zeros(B * nb, np.int32)
+        npred, pu = C.c_int(), C.c_int()
+        torch.cuda.synchronize()
+        rc = lib.sharp_SHARP_unlimited_dev(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), ldb.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                           B, m, 5, 0, 0, 0, C.c_double(RN), pred.ctypes.data_as(C.POINTER(C.c_int)), C.byref(npred),
+                                           C.byref(pu))
+        assert rc in (0, 16, 32, 48), lib.sharp_last_error()
+        return pred, npred.value, pu.value
+
+    p1, n1, p = run()
+    t0 = time.perf_counter()
+    p2, n2, _ = run()
+    dt = time.perf_counter() - t0
+    print("cfg3: %.3f s per call = %.0f cells/s, %d clusters" % (dt, B * nb / dt, n1))
+    assert p == 474 == int(np.ceil(np.log2(B * nb) / 0.04))               # R/SHARP_unlimited.R:65-66
+    assert np.array_equal(p1, p2) and n1 == n2 == p1.max() and p1.min() == 1
+    sizes = np.bincount(p1)[1:]
+    assert np.all(np.diff(sizes) <= 0)                                    # ids by decreasing size (:180-183)
+    assert (sizes < 10).sum() <= 1                                        # < 10-cell clusters merged (:168-177)
+    truth = np.concatenate([dev.synth_labels(SEED, b * nb, nb) for b in range(B)])
+    assert adjusted_rand_score(truth, p1) > 0.9
+    # the sharded form (block step per block, then the merge on the gathered centroid tables) gives the same labels
+    proj = sa.Projector(m, p, [50 + RN + k for k in range(1, 6)])
+    preds, means, counts = [], [], []
+    for b in range(B):
+        pr, mn, cn = dev.unlimited_block_dev(blocks[b], p, proj.handle, 5, RN)
+        preds.append(pr); means.append(mn); counts.append(cn)
+    proj.close()
+    fid, nf = dev.unlimited_merge(np.concatenate(means, 0), np.concatenate(counts, 0), B * nb)
+    assert nf == n1 and np.array_equal(_apply_merge(preds, means, fid), p1)
+    del blocks
+    torch.cuda.empty_cache()
+
+
+def test_cfg4_shares_and_merge_at_1p3M_cells(env, oracle):
+    sa, dev, torch = env
+    nb, m, B, p = 162500, 27000, 8, 508                                   # BASELINE.json configs[3]: 1.3 M x 27 000, one block per GPU
+    ncells = nb * B
+    assert p == int(np.ceil(np.log2(ncells) / 0.04))
+    preds, means, counts, truth, t_run = _block_steps(sa, dev, torch, m, nb, B, p)
+    print("cfg4: %d shares of %d cells: %.3f s per share = %.0f cells/s per GPU" % (B, nb, t_run / B, nb * B / t_run))
+    M, Cn = np.concatenate(means, 0), np.concatenate(counts, 0)
+    fid, nf = dev.unlimited_merge(M, Cn, ncells)
+    ref = oracle.unlimited_merge(M, Cn, ncells)
+    assert ref["rc"] in (0, 16) and nf == ref["n_final"] and np.array_equal(fid, ref["final_id"])
+    # n >= 1e6 (R/sMetaC.R:110-119): the candidate numbers of clusters start at floor(n / 50000) = 26 and go to 260 (or nC - 1)
+    assert 26 <= nf <= min(260, M.shape[0] - 1)
+    pred = _apply_merge(preds, means, fid)
+    sizes = np.bincount(pred)[1:]
+    assert pred.min() == 1 and pred.max() == nf and np.all(np.diff(sizes) <= 0)
+    t = np.concatenate(truth)
+    # >= 26 clusters are forced on 12 planted ones: the merge does not mix what the blocks kept apart
+    assert _purity(t, pred) > _purity(t, np.concatenate([preds[b] + 1000 * b for b in range(B)])) - 0.01
+    # every share on its own recovers the planted clusters
+    for b in range(B):
+        assert adjusted_rand_score(truth[b], preds[b]) > 0.9
+
+
+def test_cfg5_two_hundred_streamed_blocks_and_merge_at_1e7_cells(env, oracle):
+    sa, dev, torch = env
+    nb, m, B, p = 50000, 20000, 200, 582                                  # BASELINE.json configs[4]: 10 M x 20 000, 25 blocks per GPU
+    ncells = nb * B
+    assert p == int(np.ceil(np.log2(ncells) / 0.04))
+    preds, means, counts, truth, t_run = _block_steps(sa, dev, torch, m, nb, B, p)
+    M, Cn = np.concatenate(means, 0), np.concatenate(counts, 0)
+    t0 = time.perf_counter()
+    fid, nf = dev.unlimited_merge(M, Cn, ncells)
+    t_merge = time.perf_counter() - t0
+    print("cfg5: 200 blocks %.2f s (%.0f cells/s on one GPU; a rank of the 8-GPU run does 25: %.2f s), merge of %d rows %.3f s"
+          % (t_run, ncells / t_run, t_run / 8, M.shape[0], t_merge))
+    # k = floor(1e7 / 50000) .. floor(1e7 / 5000) = 200 .. 2000 (capped by nC - 1): up to 1801 candidate levels
+    assert 200 <= nf <= min(2000, M.shape[0] - 1)
+    t0 = time.perf_counter()
+    ref = oracle.unlimited_merge(M, Cn, ncells)
+    print("oracle merge: %.1f s" % (time.perf_counter() - t0))
+    assert ref["rc"] in (0, 16) and nf == ref["n_final"] and np.array_equal(fid, ref["final_id"])
+    pred = _apply_merge(preds, means, fid)
+    sizes = np.bincount(pred)[1:]
+    assert pred.max() == nf and np.all(np.diff(sizes) <= 0)
+    # >= 200 clusters are forced on 12 planted ones: the merge joins block-level clusters of the same planted cluster, it does not mix
+    # what the blocks kept apart
+    t = np.concatenate(truth)
+    assert _purity(t, pred) > _purity(t, np.concatenate([preds[b] + 100 * b for b in range(B)])) - 0.01
+    assert min(adjusted_rand_score(truth[b], preds[b]) for b in range(0, B, 20)) > 0.9
+
+
+def test_full_size_block_matches_oracle(env, oracle):
+    """One 50 000 x 20 000 block, ensize.K = 5, p = 474 (a block of cfg3), SHARP_large: labels identical to the oracle's."""
+    sa, dev, torch = env
+    n, m, K, p = 50000, 20000, 5, 474
+    dX = torch.empty((n, m), dtype=torch.float32, device="cuda")
+    dev.synth_fill(dX, SEED, 0)
+    pred, info = dev.SHARP_dev(dX, ensize_K=K, reduced_ndim=p, rN_seed=RN)
+    assert info["path"] == "SHARP_large"
+    X = dX.cpu().numpy().T.astype(np.float64)                             # (genes, cells), column-major: 8 GB
+    del dX
+    torch.cuda.empty_cache()
+    cores = min(os.cpu_count() or 1, 64)                                  # 125 tasks; every thread holds a 320 MB fold copy
+    t0 = time.perf_counter()
+    ref = oracle.SHARP(X, K=K, reduced_ndim=p, rN_seed=RN, nthreads=cores, want_view=False)
+    print("oracle: %.1f s on %d threads (%.0f cells/s)" % (time.perf_counter() - t0, cores, n / (time.perf_counter() - t0)))
+    assert ref["rc"] in (0, 16)
+    assert np.array_equal(pred, ref["pred_clusters"])
+
+
+def test_smetac_at_1p2M_cells_matches_oracle(env, oracle):
+    """sharp_sMetaC with n >= 1e6 (R/sMetaC.R:110-119: maxN = max(maxN, n/5000), minN = max(minN, n/50000))."""
+    sa, dev, torch = env
+    rng = np.random.default_rng(12)
+    n, p, nlab, G = 1200000, 8, 300, 30
+    cen = rng.standard_normal((G, p)) * 3
+    lab_centre = rng.integers(0, G, nlab)
+    labels = rng.integers(0, nlab, n).astype(np.int32)
+    labels[:nlab] = rng.permutation(nlab)                                 # every id present
+    E = cen[lab_centre[labels]] + 0.3 * rng.standard_normal((n, p)) + 0.2 * rng.standard_normal((nlab, p))[labels]
+    ref = oracle.sMetaC(labels, E, maxN=40)
+    res = sa.sMetaC(labels, E, maxN_cluster=40)
+    assert ref["rc"] in (0, 16) and ref["nC"] == nlab
+    assert np.array_equal(res["tf"], ref["tf"])
+    assert np.array_equal(res["finalColor"], ref["finalColor"])
+    assert 24 <= res["tf"].max() <= 240                                   # k range 24 .. 240
+
+
+@pytest.mark.parametrize("n", [4500, 8000])
+def test_similarity_task_beyond_the_lds_limits(env, oracle, n, monkeypatch):
+    """get_opt_hclust on an n x n similarity with n > 4096 (bulk-synchronous kernel) and n > 7168 (sequential kernel): the
+    state of the agglomeration lives in global memory there.  Rows = cluster centroids as a cross-block sMetaC sees them."""
+    sa, dev, torch = env
+    rng = np.random.default_rng(n)
+    G, p = 25, 60
+    cen = rng.standard_normal((G, p))
+    Z = cen[rng.integers(0, G, n)] + 0.35 * rng.standard_normal((n, p))
+    S = np.corrcoef(Z)
+    np.fill_diagonal(S, 1.0)
+    S = (S + S.T) / 2
+    ref = oracle.get_opt_hclust(S, minN=2, maxN=40, sil_thre=0.35)
+    dev.profile(True)
+    res = sa.get_opt_hclust(S, minN_cluster=2, maxN_cluster=40, sil_thre=0.35)
+    prof = dev.profile_table()
+    assert prof["host:hclust_tasks_bulk_synchronous"][1] == 1             # no exact ties: the bulk-synchronous kernel did it
+    assert res["branch"] == ref["branch"] and res["optN_cluster"] == ref["optN"]
+    np.testing.assert_allclose(res["height"], ref["height"], rtol=1e-9)
+    assert np.array_equal(res["v"], ref["v"])                             # every cutree level
+    np.testing.assert_allclose(res["msil"], ref["msil"], atol=1e-10)
+    np.testing.assert_allclose(res["CHind"], ref["CHind"], rtol=1e-8)
+    assert np.array_equal(res["f"], ref["f"])
+    if n > 7168:                                                          # the sequential kernel with its state in global memory
+        monkeypatch.setenv("SHARP_HC_SEQ", "1")
+        seq = sa.get_opt_hclust(S, minN_cluster=2, maxN_cluster=40, sil_thre=0.35)
+        np.testing.assert_allclose(seq["height"], ref["height"], rtol=1e-12)
+        assert np.array_equal(seq["v"], ref["v"]) and np.array_equal(seq["f"], ref["f"])
+
+
+def test_unlimited_merge_beyond_7168_rows(env, oracle):
+    """sharp_unlimited_merge on 9000 (block, cluster) rows -- cfg5's 200 blocks x 40 clusters would be 8000 (R/SHARP_unlimited.R:163)."""
+    sa, dev, torch = env
+    rng = np.random.default_rng(5)
+    nC, p, G = 9000, 64, 40
+    cen = rng.standard_normal((G, p))
+    M = cen[rng.integers(0, G, nC)] + 0.3 * rng.standard_normal((nC, p))
+    Cn = rng.integers(5, 200, nC).astype(np.int64)          # < 1e6 cells in all: the k range stays 10 .. 40
+    ncells = int(Cn.sum())
+    fid, nf = dev.unlimited_merge(M, Cn, ncells)
+    ref = oracle.unlimited_merge(M, Cn, ncells)
+    assert nf == ref["n_final"] and np.array_equal(fid, ref["final_id"])

@@ -41,13 +41,35 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path):
     env = dict(os.environ, SHARP_BENCH_SHARE_GPU="1", SHARP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--cells", "6000"]          # default 20 000 genes: the planted marker programmes need them
+           "--cells", "12000", "--genes", "20000"]   # N > 1 runs cfg4's shape (1.3 M x 27 000 split N ways); here 12 000 cells in all, 6000 per rank
     r = subprocess.run(cmd, env=env, timeout=900, capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                         # rank 0 only, ONE line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "cells/s"
-    assert d["value"] == pytest.approx(2 * 6000 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-3)   # whole-job cells / max-over-ranks time
-    assert d["config"]["workload"].startswith("SHARP_unlimited, 2 blocks")
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong" and d["unit"] == "cells/s"
+    assert d["value"] == pytest.approx(12000 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-3)      # whole-job cells / max-over-ranks time
+    assert d["config"]["workload"].startswith("SHARP_unlimited on synthetic 12000 cells x 20000 genes, 2 blocks")
+    assert d["config"]["baseline_config"] == "configs[3]" and d["config"]["n_RP"] == 5 and d["config"]["cells_per_gpu"] == 6000
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["ari_vs_planted_truth"] > 0.9
+
+
+def test_bench_default_line_names_cfg2_and_carries_the_other_configs():
+    """`python bench.py` (N = 1): the headline is BASELINE.json configs[1]; the same line carries cfg3 end to end and the RP-stage roofline
+    at the K = 5 shapes (cfg3's block, cfg4's per-GPU share), and the CPU baseline."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"], env=env, timeout=1200,
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["baseline_config"] == "configs[1]"
+    assert d["config"]["workload"].startswith("SHARP() on synthetic 50000 cells x 20000 genes, ensize.K=15")
+    rf = d["roofline"]
+    assert rf["kernel"].startswith("RP matmul stage") and rf["peak"] == 8000.0
+    assert rf["frac"] == pytest.approx(50000 * 20000 * 4 / (rf["stage"]["ms"] * 1e-3) / 8e12, rel=2e-3)
+    assert set(rf["by_config"]) == {"cfg3_block", "cfg4_share"} and rf["by_config"]["cfg4_share"]["reduced_dim"] == 508
+    assert d["other_configs"]["cfg3"]["reduced_dim"] == 474 and d["other_configs"]["cfg3"]["ari_vs_planted_truth"] > 0.9
+    assert d["cpu_baseline"]["kind"] == "port" and d["parity"]["ari_gpu_vs_oracle_on_sample"] >= 0.99

@@ -208,6 +208,9 @@ def test_sharp_unlimited3_streams_a_directory_of_blocks(sa, oracle, digit_free_d
     res = sa.SHARP_unlimited(parts, rN_seed=2103)
     assert np.array_equal(res3["pred_clusters"], res["pred_clusters"])
     assert np.array_equal(res3["viE"], res["viE"])
+    ref = oracle.SHARP_unlimited(parts, rN_seed=2103, nthreads=8, want_view=True)      # and both equal the oracle on these partitions
+    assert np.array_equal(res3["pred_clusters"], ref["pred_clusters"])
+    np.testing.assert_allclose(res3["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
     assert res3["bytes_streamed"] == sum(sizes) * m * 4
     with pytest.raises(sa.SharpError, match="should be a folder"):
         sa.SHARP_unlimited3({"dir": os.path.join(d, "missing"), "ncells": 10, "ngenes": m})
@@ -225,6 +228,23 @@ def test_view_reduction_above_1e5_cells(sa, oracle):
     ref = oracle.project(E1.T, oracle.ranM(420, 50, 50 + seed + K + 1), False)     # (1/sqrt(50)) * t(z0) %*% t(E1), cells x 50
     assert got.shape == (300, 50)
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6 * np.abs(ref).max())
+
+
+def test_ARI_five_indices_match_oracle(sa, oracle):
+    """R/ARI.R:20-42 -> clues::adjustedRand(label, res$pred_clusters): Rand, HA, MA, FM, Jaccard; labels may be strings."""
+    rng = np.random.default_rng(21)
+    for n, ga, gb in [(500, 4, 6), (3000, 12, 9), (50, 2, 2)]:
+        a = rng.integers(1, ga + 1, n)
+        b = np.where(rng.random(n) < 0.7, (a * 7) % gb + 1, rng.integers(1, gb + 1, n))
+        ref = oracle.adjusted_rand(a, b)
+        for got in (sa.ARI(a, b), sa.ARI(a, {"pred_clusters": b}),
+                    sa.ARI(np.array(["type_%d" % v for v in a]), np.array(["c%d" % v for v in b]))):   # cell-type names vs cluster names
+            assert sorted(got) == sorted(ref)
+            for key in ref:
+                assert abs(got[key] - ref[key]) < 1e-12, (key, got[key], ref[key])
+        assert abs(ref["HA"] - adjusted_rand_score(a, b)) < 1e-12
+    same = sa.ARI(a, a)
+    assert all(abs(same[k] - 1.0) < 1e-15 for k in same)
 
 
 def test_run_Mtimes_SHARP(sa, oracle):
