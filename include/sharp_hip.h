@@ -79,8 +79,8 @@ int sharp_projector_triplets(int handle, int k, int *gene, int *col, signed char
 /* R/RPmat.R:32, R/SHARP.R:343-345,363,569-571,579-585.
  * Host variant: X double, m x n column-major with leading dimension ld (>= m).
  * E: n x (K*p) row-major, component k*p + c = projector k, column c.
- * X is staged to the device as fp32 (exact for counts < 2^24; otherwise rounded to
- * fp32 -- see DESIGN.md "Numerics").  log_flag: 1 = log2(x+1) (flag TRUE), 0 = raw. */
+ * X is kept on the device as fp32 when every value is fp32-exact, else as fp64 (sharp_x_storage(),
+ * DESIGN.md "Numerics").  log_flag: 1 = log2(x+1) (flag TRUE), 0 = raw. */
 int sharp_project(int proj, const double *X, int m, int n, long long ld, int log_flag, double *E);
 /* Device variant: dX fp32 (m x n, leading dimension ld elements, 16-byte aligned columns
  * when ld % 4 == 0), dE fp64 n x ldE row-major (ldE >= K*p). */
@@ -144,11 +144,17 @@ int sharp_SHARP_dev(const float *dX, int m, long long n, long long ld, int ensiz
                     int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
                     double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred,
                     int *n_pred, double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path);
-/* host matrix: X double, m x n column-major (ld >= m); staged as fp32 */
+/* host matrix: X double, m x n column-major (ld >= m); kept in HBM as fp32 when that is exact, else as fp64 (sharp_x_storage) */
 int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells,
                 int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
                 double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred,
                 int *n_pred, double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path);
+
+/* How the most recent host-matrix entry point (sharp_SHARP, sharp_SHARP_csc, sharp_SHARP_unlimited*, sharp_project) stored its block
+ * in HBM: 32 = fp32, chosen when every value survives the round trip through float (counts, UMI data: half the bytes of the one pass
+ * over X); 64 = fp64 (TPM / CPM-like doubles), so that log2(X + 1) and the projection see the numbers the reference computes with
+ * (R/SHARP.R:110-117,343-345).  0: nothing uploaded yet.  The environment variable SHARP_X_STORAGE = fp32 | fp64 forces the choice. */
+int sharp_x_storage(void);
 
 /* allrpinfo of the most recent call that took the SHARP_small path (R/SHARP.R:350-387,446: per random projection k its tag, the
  * rowColor of every cell, N.cluster and indE = the projected matrix): enrp n x K column-major colour indices (1..40, the index into the
@@ -156,15 +162,16 @@ int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K,
  * Valid until the next sharp_SHARP* call; an error if the last call took the SHARP_large path (the reference returns no allrpinfo there). */
 int sharp_last_rpinfo(int *n, int *K, int *p, int *enrp, double *indE);
 
-/* Releases the resident fp32 copy of the last host matrix and the pinned staging buffers that sharp_SHARP / sharp_SHARP_csc keep
+/* Releases the resident copy of the last host matrix and the pinned staging buffers that sharp_SHARP / sharp_SHARP_csc keep
  * between calls (the analogue of R's gc() after a SHARP() run; no reference counterpart). */
 int sharp_trim(void);
 
 /* Sparse input: the reference takes whatever `log2(scExp + 1)` and `%*%` accept (R/SHARP.R:343-345,579), which includes the
  * Matrix package's dgCMatrix -- the usual container of scRNA-seq counts.  colptr = @p (n + 1 ints), rowidx = @i (0-based),
- * val = @x; canonical CSC (no duplicated entries).  Only the non-zeros cross PCIe; the block is expanded to the same dense fp32
- * layout on the device, so results are bit-identical to the dense entry points.  sharp_csc_to_dense_dev fills a caller-owned
- * device block (m x n fp32, column stride ld >= m) for the *_dev entry points. */
+ * val = @x; canonical CSC (no duplicated entries).  Only the non-zeros cross PCIe; the dense block (fp32 or fp64 like the dense
+ * entry points choose, sharp_x_storage) is built on the device, so results are bit-identical to the dense entry points.
+ * sharp_csc_to_dense_dev fills a caller-owned device block (m x n fp32, column stride ld >= m; values narrowed to fp32) for the
+ * *_dev entry points. */
 int sharp_csc_to_dense_dev(const int *colptr, const int *rowidx, const double *val, int m, long long n, float *dX, long long ld);
 int sharp_SHARP_csc(const int *colptr, const int *rowidx, const double *val, int m, long long n, int ensize_K, int reduced_ndim,
                     int base_ncells, int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster,
@@ -234,6 +241,12 @@ int sharp_marker_genes_dev(const float *dX, int m, long long n, long long ld, co
 int sharp_synth_fill_dev(unsigned seed, int m, long long cell0, int ncell, int G, int nmark,
                          float *dX, long long ld);
 int sharp_synth_labels(unsigned seed, long long cell0, int ncell, int G, int *labels);
+
+/* Test entry for the fp64 MFMA GEMM kernels behind the correlation distance and the per-cluster sums (tests/test_linalg_gpu.py):
+ * C (M x N row-major) = sum_k At[k][i] * Bt[k][j], At K x M and Bt K x N row-major host arrays.  epilogue: 0 plain, 1 = 1 - clamp(v)
+ * with a zero diagonal (correlation distance), 2 = clamp(v) with a unit diagonal; symmetric: Bt is ignored (C = At^T At, upper
+ * triangle computed and mirrored); fast: the 128 x 128-tile kernel on zero-padded copies, else the generic 64 x 64 kernel. */
+int sharp_gemm_tn_f64(const double *At, const double *Bt, double *C, int M, int N, int K, int epilogue, int symmetric, int fast);
 
 /* ---- device memory helpers for non-torch hosts (R glue, tests) -------------- */
 int sharp_dev_alloc(long long bytes, void **dptr);

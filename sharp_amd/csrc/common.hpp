@@ -49,6 +49,22 @@ void set_error(const std::string &msg);
     }                                                        \
     return SHARP_OK;
 
+// An expression block resident in HBM: genes x cells, column-major (a cell is a contiguous vector of ld values), stored as fp32
+// (counts and every other fp32-exact input: half the bytes of the one pass over X) or as fp64 (TPM / CPM-like doubles, which fp32
+// would perturb by 6e-8 relative: the reference computes log2(X + 1) and the projection in double, R/SHARP.R:343-345).
+struct XRef {
+    const void *p = nullptr;
+    bool f64 = false;
+    // fixed-point bits of the RP accumulation in log mode: 44 while |log2(1 + x)| < 128 (every fp32 value); an fp64 block with values
+    // beyond FLT_MAX gets 41 (|log2(1 + x)| < 1024, < 2^11 terms per sum)
+    int log_fix_bits = 44;
+    XRef() = default;
+    XRef(const float *q) : p(q), f64(false) {}      // (implicit: the *_dev entry points take fp32 blocks)
+    XRef(const double *q) : p(q), f64(true) {}
+    const float *f32() const { return static_cast<const float *>(p); }
+    const double *d64() const { return static_cast<const double *>(p); }
+};
+
 struct KernelStat {
     double ms = 0;
     long long launches = 0;

@@ -18,6 +18,7 @@
 #include "meta.hpp"
 #include "projector.hpp"
 #include "rrng.hpp"
+#include "upload.hpp"
 
 namespace sharp {
 
@@ -116,24 +117,6 @@ __global__ void round1_kernel(double *__restrict__ E, long long count) {
 
 inline int colour_of(int j) { return j > 40 ? ((j - 1) % 40) + 1 : j; }   // R/getrowColor.R:59-68
 
-// dgCMatrix slab -> dense fp32 block: one wave per cell scatters the cell's (row index, value) pairs into its zeroed column.
-// Out-of-range row indices are counted, never written.
-__global__ void csc_expand_kernel(const long long *__restrict__ colptr, const int *__restrict__ rowidx, const float *__restrict__ val,
-                                  long long e_base, long long ncell, int m, float *__restrict__ dX, long long ld, int *__restrict__ bad) {
-    const int lane = threadIdx.x & 63;
-    const long long wave = (blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x) >> 6;
-    const long long nwave = (static_cast<long long>(gridDim.x) * blockDim.x) >> 6;
-    for (long long c = wave; c < ncell; c += nwave) {
-        const long long e0 = colptr[c] - e_base, e1 = colptr[c + 1] - e_base;
-        float *col = dX + c * ld;
-        for (long long e = e0 + lane; e < e1; e += 64) {
-            const int g = rowidx[e];
-            if (g >= 0 && g < m) col[g] = val[e];
-            else atomicAdd(bad, 1);
-        }
-    }
-}
-
 __global__ void gather_rows_kernel(const double *__restrict__ src, const int *__restrict__ row_of, long long n, int p, double *__restrict__ dst) {
     const long long tot = n * p;
     for (long long q = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; q < tot; q += static_cast<long long>(gridDim.x) * blockDim.x) {
@@ -147,7 +130,7 @@ __global__ void gather_rows_kernel(const double *__restrict__ src, const int *__
 // ---------------------------------------------------------------------------------------------
 // SHARP_small (R/SHARP.R:339-454)
 // ---------------------------------------------------------------------------------------------
-void sharp_small_dev(const float *dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, HcParams base, SharpOut &out) {
+void sharp_small_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, HcParams base, SharpOut &out) {
     auto pr = projector_for(a, m, p, K);
     const long long ldE = static_cast<long long>(pr->K) * p;
     DevBuf<double> &E = dws().E;
@@ -189,7 +172,7 @@ static std::vector<int> fold_starts(int n, int ng) {
 // ---------------------------------------------------------------------------------------------
 // SHARP_large (R/SHARP.R:478-851)
 // ---------------------------------------------------------------------------------------------
-void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, int ng, HcParams base, SharpOut &out) {
+void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, int ng, HcParams base, SharpOut &out) {
     HostTimer ht_all("sharp_large_total");
     last_small().valid = false;                                                 // E is about to be overwritten
     const bool shuffle = n < 100000;                                            // :504-507
@@ -334,8 +317,8 @@ void sharp_large_dev(const float *dX, int m, int n, long long ld, const SharpArg
 // ---------------------------------------------------------------------------------------------
 // SHARP front door (R/SHARP.R:44-318) for a prepared matrix resident on the device
 // ---------------------------------------------------------------------------------------------
-void sharp_front_dev(const float *dX, int m, long long n_, long long ld, SharpArgs a, SharpOut &out) {
-    SHARP_REQUIRE(dX, "No expression data is provided!");
+void sharp_front_dev(XRef dX, int m, long long n_, long long ld, SharpArgs a, SharpOut &out) {
+    SHARP_REQUIRE(dX.p, "No expression data is provided!");
     SHARP_REQUIRE(n_ >= 3 && n_ < (1LL << 31) && m >= 2, "SHARP: need at least 3 cells and 2 genes");
     const int n = static_cast<int>(n_);
     if (a.rN_seed != 0.5) SHARP_REQUIRE(std::fmod(a.rN_seed, 1.0) == 0.0, "The rN.seed should be an integer!");   // :169-179
@@ -379,7 +362,7 @@ void sharp_front_dev(const float *dX, int m, long long n_, long long ld, SharpAr
 // ---------------------------------------------------------------------------------------------
 // one block: y[[i]] = SHARP(mat, reduced.ndim = p, prep = FALSE, logflag = FALSE, rM = rM, ensize.K, rN.seed)
 // (:135) and the colMeans of its viE per predicted cluster -- all sMetaC ever uses of E1 (:163, R/sMetaC.R:58-63)
-void unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int K, double rN_seed,
+void unlimited_block_dev(XRef dX, int m, long long nb, long long ld, int p, int projector, int K, double rN_seed,
                          std::vector<int> &pred, std::vector<double> &means, std::vector<long long> &counts, double *viE_host,
                          int flag = 1, const SharpArgs *fpart_args = nullptr) {
     SharpArgs a;
@@ -441,158 +424,19 @@ using namespace sharp;
 
 namespace {
 
-// Host matrix (fp64, genes x cells, column-major: what R hands to .C()) -> fp32 block in HBM.  The caller's memory is
-// pageable, so the block is cut into slabs of cells: host threads narrow a slab into one of two pinned staging buffers while the
-// previous slab's DMA is in flight (PCIe carries 4 B per value instead of 8; the narrowing runs at host memory bandwidth).
-struct UploadStage {
-    float *pinned[2] = {nullptr, nullptr};
-    size_t cap = 0;                       // floats per staging buffer
-    hipEvent_t done[2] = {nullptr, nullptr};
-    void ensure(size_t count) {
-        if (count <= cap) return;
-        for (int q = 0; q < 2; ++q) {
-            if (pinned[q]) (void)hipHostFree(pinned[q]);
-            SHARP_HIP_CHECK(hipHostMalloc((void **)&pinned[q], count * sizeof(float), hipHostMallocDefault));
-            if (!done[q]) SHARP_HIP_CHECK(hipEventCreateWithFlags(&done[q], hipEventDisableTiming));
-        }
-        cap = count;
-    }
-};
-UploadStage &upload_stage() { static UploadStage u; return u; }
-// The resident copy of a host matrix is kept between calls like every other workspace (freshly allocated HBM costs ≈ 30 ms per GB
+// The resident copy of a host matrix is kept between calls like every other workspace (freshly allocated HBM costs ~ 30 ms per GB
 // at first touch; run_Mtimes_SHARP and testlog + SHARP call in on the same matrix again and again).
-DevBuf<float> &host_block() { static DevBuf<float> b; return b; }
+HostBlock &host_block() { static HostBlock b; return b; }
 
-void upload_as_float(const double *X, int m, long long n, long long ld, DevBuf<float> &dX, long long &ldd) {
-    ldd = (static_cast<long long>(m) + 3) / 4 * 4;
-    {
-        HostTimer ht("upload_alloc");
-        dX.ensure(static_cast<size_t>(ldd) * n);
-    }
-    if (n <= 0) return;
-    HostTimer ht("upload_narrow_and_copy");
-    const size_t slab_floats = static_cast<size_t>(32) << 20;                         // 128 MB per staging buffer
-    const long long slab = std::max<long long>(1, std::min<long long>(n, static_cast<long long>(slab_floats / ldd)));
-    UploadStage &U = upload_stage();
-    U.ensure(static_cast<size_t>(slab) * ldd);
-    unsigned hw = std::thread::hardware_concurrency();
-    if (const char *e = getenv("SHARP_UPLOAD_THREADS")) hw = static_cast<unsigned>(std::max(1, atoi(e)));
-    const int nthr = static_cast<int>(std::max(1u, std::min(hw ? hw : 4u, 32u)));
-    hipStream_t s = ctx().stream;
-    int q = 0;
-    bool used[2] = {false, false};
-    for (long long c0 = 0; c0 < n; c0 += slab, q ^= 1) {
-        const long long nc = std::min(slab, n - c0);
-        if (used[q]) SHARP_HIP_CHECK(hipEventSynchronize(U.done[q]));                  // the DMA that last read this buffer
-        float *dst = U.pinned[q];
-        auto narrow = [&](int t) {
-            const long long a = nc * t / nthr, b = nc * (t + 1) / nthr;
-            for (long long c = a; c < b; ++c) {
-                const double *src = X + (c0 + c) * ld;
-                float *d = dst + c * ldd;
-                for (int g = 0; g < m; ++g) d[g] = static_cast<float>(src[g]);
-                for (long long g = m; g < ldd; ++g) d[g] = 0.0f;
-            }
-        };
-        if (nthr == 1 || nc < nthr) { for (int t = 0; t < nthr; ++t) narrow(t); }
-        else {
-            std::vector<std::thread> th;
-            for (int t = 1; t < nthr; ++t) th.emplace_back(narrow, t);
-            narrow(0);
-            for (auto &x : th) x.join();
-        }
-        SHARP_HIP_CHECK(hipMemcpyAsync(dX.p + c0 * ldd, dst, static_cast<size_t>(nc) * ldd * sizeof(float), hipMemcpyHostToDevice, s));
-        SHARP_HIP_CHECK(hipEventRecord(U.done[q], s));
-        used[q] = true;
-    }
-    stream_sync();
-}
-
-// Compressed sparse column input (R's dgCMatrix: @p column pointers, @i 0-based row indices, @x values; canonical form, no
-// duplicated entries) -> the same dense fp32 block in HBM that the dense entry points build, so everything downstream is unchanged.
-// Only the non-zeros cross PCIe (8 B each: int32 index + fp32 value), slab by slab through the pinned staging buffers.
-void upload_csc_as_float(const int *colptr, const int *rowidx, const double *val, int m, long long n, float *dX, long long ldd) {
-    if (n <= 0) return;
-    if (!colptr || (!rowidx && colptr[n] > 0) || (!val && colptr[n] > 0)) throw Error(SHARP_ERR_ARG, "sparse input: null pointer");
-    if (colptr[0] < 0) throw Error(SHARP_ERR_ARG, "sparse input: negative column pointer");
-    for (long long c = 0; c < n; ++c)
-        if (colptr[c + 1] < colptr[c]) throw Error(SHARP_ERR_ARG, "sparse input: column pointers must be non-decreasing");
-    HostTimer ht("upload_csc");
-    Ctx &cx = ctx();
-    hipStream_t s = cx.stream;
-    SHARP_HIP_CHECK(hipMemsetAsync(dX, 0, static_cast<size_t>(ldd) * n * sizeof(float), s));
-    std::vector<long long> cp(static_cast<size_t>(n) + 1);
-    for (long long c = 0; c <= n; ++c) cp[c] = colptr[c];
-    DevBuf<long long> dcp(cp.size());
-    dcp.upload(cp.data(), cp.size());
-    DevBuf<int> dbad(1);
-    dbad.zero();
-    const long long slab_e = 16LL << 20;                                   // entries per slab: 64 MB of indices + 64 MB of values
-    UploadStage &U = upload_stage();
-    U.ensure(static_cast<size_t>(slab_e) * 2);                             // [indices | values] share one staging buffer
-    DevBuf<int> didx[2];
-    DevBuf<float> dval[2];
-    for (int k = 0; k < 2; ++k) { const size_t cap = static_cast<size_t>(std::max<long long>(1, std::min<long long>(slab_e, cp[n] - cp[0]))); didx[k].alloc(cap); dval[k].alloc(cap); }
-    unsigned hw = std::thread::hardware_concurrency();
-    if (const char *e = getenv("SHARP_UPLOAD_THREADS")) hw = static_cast<unsigned>(std::max(1, atoi(e)));
-    const int nthr = static_cast<int>(std::max(1u, std::min(hw ? hw : 4u, 32u)));
-    int q = 0;
-    bool used[2] = {false, false};
-    long long c0 = 0;
-    while (c0 < n) {
-        // whole cells per slab; a single cell never exceeds m <= 2^31 entries but may exceed the slab: grow the slab for it
-        long long c1 = c0;
-        const long long e0 = cp[c0];
-        while (c1 < n && cp[c1 + 1] - e0 <= slab_e) ++c1;
-        if (c1 == c0) { c1 = c0 + 1; U.ensure(static_cast<size_t>(cp[c1] - e0) * 2); for (int k = 0; k < 2; ++k) used[k] = false; SHARP_HIP_CHECK(hipStreamSynchronize(s)); }
-        const long long ne = cp[c1] - e0;
-        if (ne > 0) {
-            if (used[q]) SHARP_HIP_CHECK(hipEventSynchronize(U.done[q]));
-            int *hi = reinterpret_cast<int *>(U.pinned[q]);
-            float *hv = U.pinned[q] + ne;
-            auto pack = [&](int t) {
-                const long long a = ne * t / nthr, b = ne * (t + 1) / nthr;
-                std::memcpy(hi + a, rowidx + e0 + a, static_cast<size_t>(b - a) * sizeof(int));
-                for (long long e = a; e < b; ++e) hv[e] = static_cast<float>(val[e0 + e]);
-            };
-            if (nthr == 1 || ne < (1 << 16)) { for (int t = 0; t < nthr; ++t) pack(t); }
-            else {
-                std::vector<std::thread> th;
-                for (int t = 1; t < nthr; ++t) th.emplace_back(pack, t);
-                pack(0);
-                for (auto &x : th) x.join();
-            }
-            didx[q].ensure(static_cast<size_t>(ne)); dval[q].ensure(static_cast<size_t>(ne));
-            SHARP_HIP_CHECK(hipMemcpyAsync(didx[q].p, hi, static_cast<size_t>(ne) * sizeof(int), hipMemcpyHostToDevice, s));
-            SHARP_HIP_CHECK(hipMemcpyAsync(dval[q].p, hv, static_cast<size_t>(ne) * sizeof(float), hipMemcpyHostToDevice, s));
-            SHARP_HIP_CHECK(hipEventRecord(U.done[q], s));
-            used[q] = true;
-            const long long ncell = c1 - c0;
-            const int blocks = static_cast<int>(std::min<long long>((ncell + 3) / 4, static_cast<long long>(cx.num_cu) * 16));
-            hipLaunchKernelGGL(csc_expand_kernel, dim3(blocks), dim3(256), 0, s, dcp.p + c0, didx[q].p, dval[q].p, e0, ncell, m,
-                               dX + c0 * ldd, ldd, dbad.p);
-            launch_check("csc_expand_kernel");
-            q ^= 1;
-        }
-        c0 = c1;
-    }
-    int bad = 0;
-    dbad.download(&bad, 1);                                                 // also drains the stream: staging and slabs are free again
-    if (bad) throw Error(SHARP_ERR_ARG, "sparse input: row index outside [0, genes)");
-}
-
-}  // namespace
-
-extern "C" {
-
-int sharp_SHARP_dev(const float *dX, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells,
-                    int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
-                    double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred, int *n_pred,
-                    double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path) {
+// the body shared by the host-matrix, CSC and device entry points of SHARP()
+int sharp_run_block(XRef dX, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells, int partition_ncells,
+                    int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN, double sil_thre,
+                    double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred, int *n_pred, double *viE, double *x0,
+                    int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path) {
     int warn = 0;
     SHARP_API_BEGIN
     ctx();
-    SHARP_REQUIRE(pred, "sharp_SHARP_dev: null output");
+    SHARP_REQUIRE(pred, "sharp_SHARP: null output");
     SharpArgs a;
     a.K = ensize_K; a.reduced_ndim = reduced_ndim; a.base_ncells = base_ncells; a.partition_ncells = partition_ncells;
     a.hmethod = hmethod; a.N_cluster = N_cluster; a.enpN = enpN_cluster; a.indN = indN_cluster; a.minN = minN; a.maxN = maxN;
@@ -605,7 +449,7 @@ int sharp_SHARP_dev(const float *dX, int m, long long n, long long ld, int ensiz
     if (n_pred) *n_pred = o.n_pred;
     if (viE) o.viE.download(viE, static_cast<size_t>(n) * o.p);
     if (x0) {
-        SHARP_REQUIRE(o.x0_cols <= x0_cap_cols, "sharp_SHARP_dev: x0 buffer has too few columns");
+        SHARP_REQUIRE(o.x0_cols <= x0_cap_cols, "sharp_SHARP: x0 buffer has too few columns");
         std::copy(o.x0.begin(), o.x0.end(), x0);
     }
     if (x0_cols) *x0_cols = o.x0_cols;
@@ -618,23 +462,39 @@ int sharp_SHARP_dev(const float *dX, int m, long long n, long long ld, int ensiz
     return warn;
 }
 
+}  // namespace
+
+extern "C" {
+
+int sharp_SHARP_dev(const float *dX, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells,
+                    int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
+                    double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred, int *n_pred,
+                    double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path) {
+    return sharp_run_block(XRef(dX), m, n, ld, ensize_K, reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
+                           indN_cluster, minN, maxN, sil_thre, height_Ntimes, log_flag, projector, rN_seed, pred, n_pred, viE, x0,
+                           x0_cap_cols, x0_cols, p_used, K_used, path);
+}
+
 int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells,
                 int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
                 double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred, int *n_pred,
                 double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path) {
-    DevBuf<float> &dX = host_block();
-    long long ldd = 0;
+    HostBlock &hb = host_block();
     try {
         ctx();
         if (!X || ld < m || n < 1) throw sharp::Error(SHARP_ERR_ARG, "No expression data is provided!");
-        upload_as_float(X, m, n, ld, dX, ldd);
+        upload_block(X, m, n, ld, hb);
     }
     catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
     catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
-    return sharp_SHARP_dev(dX.p, m, n, ldd, ensize_K, reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
+    return sharp_run_block(hb.ref(), m, n, hb.ld, ensize_K, reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
                            indN_cluster, minN, maxN, sil_thre, height_Ntimes, log_flag, projector, rN_seed, pred, n_pred, viE, x0,
                            x0_cap_cols, x0_cols, p_used, K_used, path);
 }
+
+/* 32 or 64: how the most recent host-matrix entry point (sharp_SHARP, sharp_SHARP_csc, sharp_SHARP_unlimited*, sharp_project) stored
+ * its block in HBM -- fp32 when every value survives the round trip through float, else fp64 (0: no upload yet). */
+int sharp_x_storage(void) { return upload_last_storage(); }
 
 /* allrpinfo of the most recent SHARP_small run (R/SHARP.R:350-387: per random projection k the rowColor of every cell and the projected
  * matrix indE = tmp$mat).  enrp: n x K column-major colour indices; indE: n x (K p) row-major, projection k in columns [k p, (k+1) p). */
@@ -663,9 +523,7 @@ int sharp_trim(void) {
     ctx();
     stream_sync();
     host_block().release();
-    UploadStage &U = upload_stage();
-    for (int q = 0; q < 2; ++q) if (U.pinned[q]) { (void)hipHostFree(U.pinned[q]); U.pinned[q] = nullptr; }
-    U.cap = 0;
+    upload_release_staging();
     SHARP_API_END
 }
 
@@ -675,7 +533,7 @@ int sharp_csc_to_dense_dev(const int *colptr, const int *rowidx, const double *v
     SHARP_API_BEGIN
     ctx();
     SHARP_REQUIRE(dX && ld >= m && m > 0 && n >= 0, "sharp_csc_to_dense_dev: bad block");
-    upload_csc_as_float(colptr, rowidx, val, m, n, dX, ld);
+    upload_csc_into_f32(colptr, rowidx, val, m, n, dX, ld);
     SHARP_API_END
 }
 
@@ -683,17 +541,15 @@ int sharp_SHARP_csc(const int *colptr, const int *rowidx, const double *val, int
                     int base_ncells, int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN,
                     int maxN, double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred,
                     int *n_pred, double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path) {
-    DevBuf<float> &dX = host_block();
-    const long long ldd = (static_cast<long long>(m) + 3) / 4 * 4;
+    HostBlock &hb = host_block();
     try {
         ctx();
         if (m <= 0 || n <= 0) throw sharp::Error(SHARP_ERR_ARG, "No expression data is provided!");
-        dX.ensure(static_cast<size_t>(ldd) * n);
-        upload_csc_as_float(colptr, rowidx, val, m, n, dX.p, ldd);
+        upload_block_csc(colptr, rowidx, val, m, n, hb);
     }
     catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
     catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
-    return sharp_SHARP_dev(dX.p, m, n, ldd, ensize_K, reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
+    return sharp_run_block(hb.ref(), m, n, hb.ld, ensize_K, reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
                            indN_cluster, minN, maxN, sil_thre, height_Ntimes, log_flag, projector, rN_seed, pred, n_pred, viE, x0,
                            x0_cap_cols, x0_cols, p_used, K_used, path);
 }
@@ -746,9 +602,12 @@ int sharp_unlimited_merge(const double *means, const long long *counts, int nC, 
     SHARP_API_END
 }
 
-int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
-                                   int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used,
-                                   double *viE) {
+}  // extern "C"
+
+// SHARP_unlimited on resident blocks (fp32 or fp64 each)
+static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                         int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used,
+                         double *viE) {
     SHARP_API_BEGIN
     ctx();
     SHARP_REQUIRE(dX_blocks && ncb && ldb && pred, "The input should be a LIST of partitioned scRNA-seq expression matrices!");
@@ -795,10 +654,10 @@ int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long lon
 
 // SHARP_unlimited2 (R/SHARP_unlimited2.R:29-292): SHARP_fpart per block, then ONE sMetaC over the fold-level ensemble
 // clusters of all blocks -- which, like every sMetaC, only needs their centroids in E1 = enE/K.
-int sharp_SHARP_unlimited2_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
-                               int ensize_K, int reduced_ndim, int partition_ncells, int hmethod, int N_cluster, int enpN, int indN,
-                               int minN, int maxN, double sil_thre, double height_Ntimes, int flag, double rN_seed, int *pred,
-                               int *n_pred, int *p_used, double *viE) {
+static int unlimited2_run(const XRef *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                          int ensize_K, int reduced_ndim, int partition_ncells, int hmethod, int N_cluster, int enpN, int indN,
+                          int minN, int maxN, double sil_thre, double height_Ntimes, int flag, double rN_seed, int *pred,
+                          int *n_pred, int *p_used, double *viE) {
     SHARP_API_BEGIN
     ctx();
     SHARP_REQUIRE(dX_blocks && ncb && ldb && pred && nblocks >= 1, "No expression data is provided!");
@@ -849,26 +708,63 @@ int sharp_SHARP_unlimited2_dev(const float *const *dX_blocks, const long long *n
     SHARP_API_END
 }
 
+namespace {
+// host blocks of a list-of-matrices call: each is stored as fp32 or fp64 on its own merits
+struct HostBlocks {
+    std::vector<HostBlock> bufs;
+    std::vector<XRef> refs;
+    std::vector<long long> lds;
+    int upload(const double *const *X_blocks, const long long *ncb, int nblocks, int m) {
+        try {
+            ctx();
+            if (!X_blocks || !ncb || nblocks < 1) throw sharp::Error(SHARP_ERR_ARG, "No expression data is provided!");
+            bufs.resize(nblocks);
+            int any64 = 0;
+            for (int b = 0; b < nblocks; ++b) {
+                upload_block(X_blocks[b], m, ncb[b], m, bufs[b]);
+                refs.push_back(bufs[b].ref());
+                lds.push_back(bufs[b].ld);
+                any64 |= bufs[b].f64;
+            }
+            (void)any64;
+        }
+        catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
+        catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
+        return SHARP_OK;
+    }
+};
+std::vector<XRef> f32_refs(const float *const *dX_blocks, int nblocks) {
+    std::vector<XRef> r;
+    for (int b = 0; dX_blocks && b < nblocks; ++b) r.emplace_back(dX_blocks[b]);
+    return r;
+}
+}  // namespace
+
+extern "C" {
+
+int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                                   int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used,
+                                   double *viE) {
+    const std::vector<XRef> refs = f32_refs(dX_blocks, nblocks);
+    return unlimited_run(dX_blocks ? refs.data() : nullptr, ncb, ldb, nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred, p_used, viE);
+}
+
+int sharp_SHARP_unlimited2_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                               int ensize_K, int reduced_ndim, int partition_ncells, int hmethod, int N_cluster, int enpN, int indN,
+                               int minN, int maxN, double sil_thre, double height_Ntimes, int flag, double rN_seed, int *pred,
+                               int *n_pred, int *p_used, double *viE) {
+    const std::vector<XRef> refs = f32_refs(dX_blocks, nblocks);
+    return unlimited2_run(dX_blocks ? refs.data() : nullptr, ncb, ldb, nblocks, m, ensize_K, reduced_ndim, partition_ncells, hmethod, N_cluster,
+                          enpN, indN, minN, maxN, sil_thre, height_Ntimes, flag, rN_seed, pred, n_pred, p_used, viE);
+}
+
 int sharp_SHARP_unlimited2(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int reduced_ndim,
                            int partition_ncells, int hmethod, int N_cluster, int enpN, int indN, int minN, int maxN, double sil_thre,
                            double height_Ntimes, int flag, double rN_seed, int *pred, int *n_pred, int *p_used, double *viE) {
-    std::vector<DevBuf<float>> bufs(nblocks > 0 ? nblocks : 0);
-    std::vector<const float *> ptrs;
-    std::vector<long long> lds;
-    try {
-        ctx();
-        if (!X_blocks || !ncb || nblocks < 1) throw sharp::Error(SHARP_ERR_ARG, "No expression data is provided!");
-        for (int b = 0; b < nblocks; ++b) {
-            long long ldd = 0;
-            upload_as_float(X_blocks[b], m, ncb[b], m, bufs[b], ldd);
-            ptrs.push_back(bufs[b].p);
-            lds.push_back(ldd);
-        }
-    }
-    catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
-    catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
-    return sharp_SHARP_unlimited2_dev(ptrs.data(), ncb, lds.data(), nblocks, m, ensize_K, reduced_ndim, partition_ncells, hmethod,
-                                      N_cluster, enpN, indN, minN, maxN, sil_thre, height_Ntimes, flag, rN_seed, pred, n_pred, p_used, viE);
+    HostBlocks H;
+    if (const int rc = H.upload(X_blocks, ncb, nblocks, m)) return rc;
+    return unlimited2_run(H.refs.data(), ncb, H.lds.data(), nblocks, m, ensize_K, reduced_ndim, partition_ncells, hmethod,
+                          N_cluster, enpN, indN, minN, maxN, sil_thre, height_Ntimes, flag, rN_seed, pred, n_pred, p_used, viE);
 }
 
 int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
@@ -879,23 +775,9 @@ int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *nc
 
 int sharp_SHARP_unlimited_view(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,
                                int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used, double *viE) {
-    std::vector<DevBuf<float>> bufs(nblocks > 0 ? nblocks : 0);
-    std::vector<const float *> ptrs;
-    std::vector<long long> lds;
-    try {
-        ctx();
-        if (!X_blocks || !ncb || nblocks < 1) throw sharp::Error(SHARP_ERR_ARG, "No expression data is provided!");
-        for (int b = 0; b < nblocks; ++b) {
-            long long ldd = 0;
-            upload_as_float(X_blocks[b], m, ncb[b], m, bufs[b], ldd);
-            ptrs.push_back(bufs[b].p);
-            lds.push_back(ldd);
-        }
-    }
-    catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
-    catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
-    return sharp_SHARP_unlimited_view_dev(ptrs.data(), ncb, lds.data(), nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred,
-                                          n_pred, p_used, viE);
+    HostBlocks H;
+    if (const int rc = H.upload(X_blocks, ncb, nblocks, m)) return rc;
+    return unlimited_run(H.refs.data(), ncb, H.lds.data(), nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred, p_used, viE);
 }
 
 int sharp_SHARP_unlimited(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,

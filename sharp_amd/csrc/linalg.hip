@@ -4,6 +4,9 @@
 // silhouette / CH (hclust.hip).
 #include "linalg.hpp"
 
+#include <algorithm>
+#include <vector>
+
 namespace sharp {
 
 // Pointers read out of a descriptor in memory are generic (flat) to the compiler: flat loads count on lgkmcnt as well as
@@ -13,6 +16,11 @@ typedef __attribute__((address_space(1))) double *gdp;          // global double
 
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// Workgroup barrier for the LDS tiles: waits for this wave's LDS operations only (lgkmcnt(0)) -- a __syncthreads() would also wait
+// (vmcnt(0)) for the global prefetch of the next k tile -- and orders memory accesses for the COMPILER too: the plain
+// __builtin_amdgcn_s_barrier() is not a memory operation to LLVM, which may then move LDS loads and stores across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------
 // GEMM: 64x64 tile per 256-thread workgroup, each wave a 32x32 quadrant = 2x2 MFMA 16x16 tiles.
@@ -55,8 +63,7 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_kernel(const GemmTask *__rest
     for (int k0 = 0; k0 < t.K; k0 += GK) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { As[lrow][lcol + q] = ra[q]; Bs[lrow][lcol + q] = rb[q]; }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is in LDS
-        __builtin_amdgcn_s_barrier();
+        lds_barrier();   // lgkmcnt(0): the tile is in LDS
         if (k0 + GK < t.K) fetch(k0 + GK);
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
@@ -73,8 +80,7 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_kernel(const GemmTask *__rest
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         // raw barrier: a __syncthreads() here would also wait (vmcnt(0)) for the prefetch of the next tile
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_s_barrier();
+        lds_barrier();
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -148,8 +154,7 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
     d2 rb0 = *(gd2p)(bp), rb1 = *(gd2p)(bp + 2);
     As[0][lrow][lcol] = ra0.x; As[0][lrow][lcol + 1] = ra0.y; As[0][lrow][lcol + 2] = ra1.x; As[0][lrow][lcol + 3] = ra1.y;
     Bs[0][lrow][lcol] = rb0.x; Bs[0][lrow][lcol + 1] = rb0.y; Bs[0][lrow][lcol + 2] = rb1.x; Bs[0][lrow][lcol + 3] = rb1.y;
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the first tile is in LDS
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();   // lgkmcnt(0): the first tile is in LDS
     int buf = 0;
     for (int k0 = 0; k0 < Kp; k0 += GK) {
         // next tile into registers (the last iteration re-reads the final tile: unconditional loads keep the waits counted) ...
@@ -176,8 +181,7 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
         buf ^= 1;
         As[buf][lrow][lcol] = ra0.x; As[buf][lrow][lcol + 1] = ra0.y; As[buf][lrow][lcol + 2] = ra1.x; As[buf][lrow][lcol + 3] = ra1.y;
         Bs[buf][lrow][lcol] = rb0.x; Bs[buf][lrow][lcol + 1] = rb0.y; Bs[buf][lrow][lcol + 2] = rb1.x; Bs[buf][lrow][lcol + 3] = rb1.y;
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0); a raw barrier: __syncthreads() would add waits of its own
-        __builtin_amdgcn_s_barrier();
+        lds_barrier();   // lgkmcnt(0); a raw barrier: __syncthreads() would add waits of its own
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -338,3 +342,37 @@ void row_prep_batched(const RowPrepTask *d_tasks, int count, int max_n, int max_
 }
 
 }  // namespace sharp
+
+using namespace sharp;
+
+extern "C" {
+
+/* Test entry for the fp64 MFMA GEMM kernels (tests/test_linalg_gpu.py): C (M x N, row-major) = sum_k At[k][.] Bt[k][.] for host
+ * operands At (K x M) and Bt (K x N), row-major.  fast = 1 runs the 128 x 128-tile kernel on zero-padded copies (what the
+ * correlation-distance stage feeds it), fast = 0 the generic 64 x 64 kernel on the operands as they are. */
+int sharp_gemm_tn_f64(const double *At, const double *Bt, double *C, int M, int N, int K, int epilogue, int symmetric, int fast) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(At && Bt && C && M > 0 && N > 0 && K > 0, "sharp_gemm_tn_f64: bad arguments");
+    SHARP_REQUIRE(!symmetric || (M == N), "sharp_gemm_tn_f64: symmetric needs M == N");
+    const long long lda = fast ? (M + 127) / 128 * 128 : M, ldb = fast ? (N + 127) / 128 * 128 : N;
+    const int Kp = fast ? (K + 15) / 16 * 16 : K;
+    std::vector<double> ha(static_cast<size_t>(Kp) * lda, 0.0), hb(static_cast<size_t>(Kp) * ldb, 0.0);
+    for (int k = 0; k < K; ++k) {
+        for (int i = 0; i < M; ++i) ha[static_cast<size_t>(k) * lda + i] = At[static_cast<size_t>(k) * M + i];
+        for (int j = 0; j < N; ++j) hb[static_cast<size_t>(k) * ldb + j] = Bt[static_cast<size_t>(k) * N + j];
+    }
+    DevBuf<double> dA(ha.size()), dB(hb.size()), dC(static_cast<size_t>(M) * N);
+    dA.upload(ha.data(), ha.size());
+    dB.upload(hb.data(), hb.size());
+    dC.zero();
+    GemmTask t{dA.p, symmetric ? dA.p : dB.p, dC.p, M, N, K, lda, symmetric ? lda : ldb, N, epilogue, symmetric, fast};
+    DevBuf<GemmTask> dt(1);
+    dt.upload(&t, 1);
+    gemm_tn_f64_batched(dt.p, 1, M, N, "test_gemm", fast != 0, symmetric != 0);
+    dC.download(C, static_cast<size_t>(M) * N);
+    SHARP_API_END
+}
+
+}  // extern "C"
+

@@ -14,6 +14,7 @@
 //     whatever the wave scheduling (fp64 atomics would not be);
 //   * the epilogue converts to fp64, applies sqrt(s)/sqrt(p) and writes the K*p row of E.
 #include "projector.hpp"
+#include "upload.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -196,14 +197,23 @@ __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
 }
 
 // Raw (no log) mode needs a data-dependent fixed-point scale: max |x| over the block.
-__global__ void absmax_kernel(const float *__restrict__ X, int m, int n, long long ld, unsigned int *out) {
+// (fp64 blocks: the maximum rounded UP to fp32 -- the scale only needs a bound)
+template <typename T>
+__global__ void absmax_kernel(const T *__restrict__ X, int m, int n, long long ld, unsigned int *out) {
     float mx = 0.f;
     const long long total = static_cast<long long>(m) * n;
     for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < total;
          i += static_cast<long long>(gridDim.x) * blockDim.x) {
         const long long c = i / m;
         const int g = static_cast<int>(i - c * m);
-        mx = fmaxf(mx, fabsf(X[c * ld + g]));
+        const T v = X[c * ld + g];
+        const T a = v < T(0) ? -v : v;
+        float f = __uint_as_float(0x7f800000u);                                      // NaN counts as non-finite (+inf)
+        if (a == a) {
+            f = static_cast<float>(a);
+            if (static_cast<T>(f) < a) f = __uint_as_float(__float_as_uint(f) + 1u);   // the next fp32 up
+        }
+        mx = fmaxf(mx, f);
     }
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o));
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));  // non-negative floats order as uints
@@ -239,23 +249,25 @@ static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float 
     launch_check("rp_scatter_kernel");
 }
 
-void project_dev_split(const Projector &pr, const ProjectorGroup &g, const float *dX, int m, int n, long long ld, int log_flag,
+void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, int m, int n, long long ld, int log_flag,
                        int fix_bits, double *dE, long long ldE, const int *d_row_map);   // rp2.hip
 
-void project_dev(const Projector &pr, const float *dX, int m, int n, long long ld, int log_flag, double *dE, long long ldE,
+void project_dev(const Projector &pr, XRef X, int m, int n, long long ld, int log_flag, double *dE, long long ldE,
                  const int *d_row_map) {
+    const float *dX = X.f32();
     SHARP_REQUIRE(m == pr.m, "project: gene count differs from the projector's");
     SHARP_REQUIRE(ld >= m, "project: leading dimension smaller than m");
     SHARP_REQUIRE(ldE >= static_cast<long long>(pr.K) * pr.p, "project: ldE smaller than K*p");
     if (n <= 0) return;
     Ctx &c = ctx();
-    int fix_bits = RP_FIX_BITS;
+    int fix_bits = std::min(RP_FIX_BITS, X.log_fix_bits);
     if (!log_flag) {
         DevBuf<unsigned int> mx(1);
         mx.zero();
         {
             KernelTimer t("rp_absmax");
-            hipLaunchKernelGGL(absmax_kernel, dim3(c.num_cu * 4), dim3(256), 0, c.stream, dX, m, n, ld, mx.p);
+            if (X.f64) hipLaunchKernelGGL(absmax_kernel<double>, dim3(c.num_cu * 4), dim3(256), 0, c.stream, X.d64(), m, n, ld, mx.p);
+            else hipLaunchKernelGGL(absmax_kernel<float>, dim3(c.num_cu * 4), dim3(256), 0, c.stream, dX, m, n, ld, mx.p);
             launch_check("absmax_kernel");
         }
         unsigned int bits = 0;
@@ -267,15 +279,16 @@ void project_dev(const Projector &pr, const float *dX, int m, int n, long long l
         std::frexp(static_cast<double>(f), &e);          // |x| < 2^e
         fix_bits = std::min(52, 62 - 12 - std::max(e, 0)); // up to 2^11 terms + sign
     }
-    const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dX) & 15u) == 0);
+    const bool vec = (ld % (X.f64 ? 2 : 4) == 0) && ((reinterpret_cast<uintptr_t>(X.p) & 15u) == 0);
+    SHARP_REQUIRE(!X.f64 || (vec && m >= 8 && m <= (1 << 20)), "project: an fp64 block must be 16-byte aligned with an even leading dimension");
     for (const auto &g : pr.groups) {
         const int gw = g.gw;
 #define SHARP_RP_CASE(GWV)                                                                          \
     if (vec) launch_rp<GWV, true>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);      \
     else launch_rp<GWV, false>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map)
         const char *kv = getenv("SHARP_RP_KERNEL");   // "fused": the single-kernel form (always used for unaligned X)
-        if (vec && m >= 8 && m <= (1 << 20) && !(kv && std::string(kv) == "fused")) {   // (20-bit gene index in the compacted entries)
-            project_dev_split(pr, g, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);
+        if (vec && m >= 8 && m <= (1 << 20) && (X.f64 || !(kv && std::string(kv) == "fused"))) {   // (20-bit gene index in the compacted entries)
+            project_dev_split(pr, g, X, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);
             continue;
         }
         if (gw == 16) { SHARP_RP_CASE(16); }
@@ -348,15 +361,11 @@ int sharp_project(int proj, const double *X, int m, int n, long long ld, int log
     auto pr = get_projector(proj);
     SHARP_REQUIRE(X && E, "sharp_project: null buffer");
     SHARP_REQUIRE(ld >= m, "sharp_project: ld < m");
-    const long long ldd = (static_cast<long long>(m) + 3) / 4 * 4;
-    std::vector<float> h(static_cast<size_t>(ldd) * n, 0.0f);
-    for (long long c = 0; c < n; ++c)
-        for (int g = 0; g < m; ++g) h[c * ldd + g] = static_cast<float>(X[c * ld + g]);
-    DevBuf<float> dX(h.size());
-    dX.upload(h.data(), h.size());
+    HostBlock hb;                                       // fp32 when exact, else fp64 (upload.hpp)
+    upload_block(X, m, n, ld, hb);
     const long long ldE = static_cast<long long>(pr->K) * pr->p;
     DevBuf<double> dE(static_cast<size_t>(ldE) * n);
-    project_dev(*pr, dX.p, m, n, ldd, log_flag, dE.p, ldE, nullptr);
+    project_dev(*pr, hb.ref(), m, n, hb.ld, log_flag, dE.p, ldE, nullptr);
     dE.download(E, static_cast<size_t>(ldE) * n);
     SHARP_API_END
 }

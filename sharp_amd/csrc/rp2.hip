@@ -24,17 +24,31 @@ constexpr int CP_THREADS = 256;
 constexpr int CP_UNIT = 1024;           // genes per wave unit = 64 lanes x 4 float4
 constexpr int AP_THREADS = 512;
 
-struct CpVals { float4 v[4]; };
+// One unit = 1024 genes = 16 values per lane, fetched with 16-byte loads: fp32 blocks as 4 x float4 (lane l, load j: genes
+// 4 (l + 64 j) ..), fp64 blocks as 8 x double2 (genes 2 (l + 64 j) ..).  gene_of(q) is the gene of a lane's q-th value.
+template <typename T> struct CpVals { T v[16]; };
+template <typename T> struct CpLayout;
+template <> struct CpLayout<float> {
+    static constexpr int VEC = 4, LOADS = 4;
+    __device__ static __forceinline__ int gene_of(int lane, int q) { return 4 * lane + 256 * (q >> 2) + (q & 3); }
+};
+template <> struct CpLayout<double> {
+    static constexpr int VEC = 2, LOADS = 8;
+    __device__ static __forceinline__ int gene_of(int lane, int q) { return 2 * lane + 128 * (q >> 1) + (q & 1); }
+};
 
-__device__ __forceinline__ CpVals cp_load_unit(const float *col, int u, long long ld, int lane) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    CpVals r;
+template <typename T>
+__device__ __forceinline__ CpVals<T> cp_load_unit(const T *col, int u, long long ld, int lane) {
+    typedef T tv __attribute__((ext_vector_type(CpLayout<T>::VEC)));
+    constexpr int V = CpLayout<T>::VEC;
+    CpVals<T> r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int g = u * CP_UNIT + 4 * (lane + 64 * j);
-        const int gc = g + 3 < ld ? g : 0;      // unconditional, clamped into the column (ld % 4 == 0, ld >= m)
-        const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(col + gc));
-        r.v[j] = make_float4(t.x, t.y, t.z, t.w);
+    for (int j = 0; j < CpLayout<T>::LOADS; ++j) {
+        const int g = u * CP_UNIT + V * (lane + 64 * j);
+        const int gc = g + V - 1 < ld ? g : 0;      // unconditional, clamped into the column (ld % V == 0, ld >= m)
+        const tv t = __builtin_nontemporal_load(reinterpret_cast<const tv *>(col + gc));
+#pragma unroll
+        for (int e = 0; e < V; ++e) r.v[V * j + e] = t[e];
     }
     return r;
 }
@@ -55,40 +69,42 @@ __global__ void rp_fixtab_kernel(double fix_scale, int log10_mode, long long *__
 // lane appends (gene, x) to the wave's LDS window; then one lane per non-zero turns x into the fixed-point term
 // (table for integer counts, fp64 log2 otherwise -- same bits either way) and the list goes out coalesced.
 // The order of a cell's list is irrelevant: the consumer adds integers.
-__global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__restrict__ X, int m, long long ld, long long cell0,
+// T = the storage type of the block: float (counts, fp32-exact data) or double (TPM-like values: the term is log2(1 + x) of the
+// double itself, as the reference computes it).
+template <typename T>
+__global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const T *__restrict__ X, int m, long long ld, long long cell0,
                                                                 int ncell, int log_flag, double fix_scale, int cap,
                                                                 unsigned int *__restrict__ counts, uint32_t *__restrict__ genes,
                                                                 long long *__restrict__ fixes) {
     __shared__ uint32_t sg[CP_THREADS / 64][CP_UNIT];
-    __shared__ uint32_t sx[CP_THREADS / 64][CP_UNIT];
+    __shared__ T sx[CP_THREADS / 64][CP_UNIT];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int units = (m + CP_UNIT - 1) / CP_UNIT;
     const long long total = static_cast<long long>(ncell) * units;
     const long long stride = static_cast<long long>(gridDim.x) * (CP_THREADS / 64);
     long long it = static_cast<long long>(blockIdx.x) * (CP_THREADS / 64) + w;
     if (it >= total) return;
-    auto fetch = [&](long long q) -> CpVals {
+    auto fetch = [&](long long q) -> CpVals<T> {
         const long long qq = q < total ? q : total - 1;
         const long long c = qq / units;
-        return cp_load_unit(X + (cell0 + c) * ld, static_cast<int>(qq - c * units), ld, lane);
+        return cp_load_unit<T>(X + (cell0 + c) * ld, static_cast<int>(qq - c * units), ld, lane);
     };
-    CpVals b1 = fetch(it), b2 = fetch(it + stride);
+    CpVals<T> b1 = fetch(it), b2 = fetch(it + stride);
     for (; it < total; it += stride) {
-        const CpVals b0 = b1;
+        const CpVals<T> b0 = b1;
         b1 = b2;
         b2 = fetch(it + 2 * stride);
         const long long c = it / units;
         const int u = static_cast<int>(it - c * units);
-        const float vals[16] = {b0.v[0].x, b0.v[0].y, b0.v[0].z, b0.v[0].w, b0.v[1].x, b0.v[1].y, b0.v[1].z, b0.v[1].w,
-                                b0.v[2].x, b0.v[2].y, b0.v[2].z, b0.v[2].w, b0.v[3].x, b0.v[3].y, b0.v[3].z, b0.v[3].w};
-        const int gbase = u * CP_UNIT + 4 * lane;          // gene of candidate q: gbase + 256*(q>>2) + (q&3)
+        const T *vals = b0.v;
+        const int ubase = u * CP_UNIT;                     // gene of candidate q: ubase + CpLayout<T>::gene_of(lane, q)
         unsigned nzm = 0;
         if (u * CP_UNIT + CP_UNIT <= m) {                  // wave-uniform: only the last unit of a cell is ragged
 #pragma unroll
-            for (int q = 0; q < 16; ++q) nzm |= vals[q] != 0.0f ? (1u << q) : 0u;
+            for (int q = 0; q < 16; ++q) nzm |= vals[q] != T(0) ? (1u << q) : 0u;
         } else {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) nzm |= (gbase + 256 * (q >> 2) + (q & 3) < m && vals[q] != 0.0f) ? (1u << q) : 0u;
+            for (int q = 0; q < 16; ++q) nzm |= (ubase + CpLayout<T>::gene_of(lane, q) < m && vals[q] != T(0)) ? (1u << q) : 0u;
         }
         const int mine = __popc(nzm);
         int incl = mine;                                   // inclusive prefix sum over the wave
@@ -104,8 +120,8 @@ __global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__r
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if ((nzm >> q) & 1u) {
-                sg[w][pos] = static_cast<uint32_t>(gbase + 256 * (q >> 2) + (q & 3));
-                sx[w][pos] = __float_as_uint(vals[q]);
+                sg[w][pos] = static_cast<uint32_t>(ubase + CpLayout<T>::gene_of(lane, q));
+                sx[w][pos] = vals[q];
                 ++pos;
             }
         }
@@ -116,7 +132,7 @@ __global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__r
         for (int e0 = 0; e0 < cntw; e0 += 64) {            // one lane per non-zero
             const int e = e0 + lane;
             const bool live = e < cntw;
-            const float x = __uint_as_float(sx[w][live ? e : 0]);
+            const T x = sx[w][live ? e : 0];
             const uint32_t gg = sg[w][live ? e : 0];
             // Integer counts below CP_TAB (scRNA counts, the synthetic data) travel as (gene, count) in ONE 32-bit word: the
             // consumer takes their term from the same 256-entry table; everything else (non-integer or large values, raw mode)
@@ -125,8 +141,8 @@ __global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const float *__r
             long long fx = 0ll;
             bool full = true;
             if (log_flag) {
-                const unsigned xi = static_cast<unsigned>(x);
-                const bool tab = static_cast<float>(xi) == x && xi < static_cast<unsigned>(CP_TAB);
+                const unsigned xi = (x >= T(0) && x < T(CP_TAB)) ? static_cast<unsigned>(x) : 0u;
+                const bool tab = static_cast<T>(xi) == x && x < T(CP_TAB);
                 if (tab) { entry = gg | (xi << kEntryCountShift); full = false; }
                 if (__ballot(live && !tab) != 0ull) {      // the general path
                     if (!tab) fx = __double2ll_rn((log_flag == 2 ? log10(1.0 + static_cast<double>(x)) : log2(1.0 + static_cast<double>(x))) * fix_scale);
@@ -295,7 +311,7 @@ static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell
 }
 
 // X must be 16-byte aligned with ld % 4 == 0.  One projector group (K*p <= 12288) per call.
-void project_dev_split(const Projector &pr, const ProjectorGroup &g, const float *dX, int m, int n, long long ld, int log_flag,
+void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, int m, int n, long long ld, int log_flag,
                        int fix_bits, double *dE, long long ldE, const int *d_row_map) {
     Ctx &c = ctx();
     SplitWs &W = sws();
@@ -345,8 +361,12 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, const float
         const int blocks = static_cast<int>(std::min<long long>((waves + 3) / 4, static_cast<long long>(c.num_cu) * 8));
         {
             KernelTimer tc("rp_compact", s2);
-            hipLaunchKernelGGL(rp_compact_kernel, dim3(blocks), dim3(CP_THREADS), 0, s2, dX, m, ld, c0, nc, log_flag, fix_scale, cap,
-                               W.counts[q].p, W.genes[q].p, W.fixes[q].p);
+            if (dX.f64)
+                hipLaunchKernelGGL(rp_compact_kernel<double>, dim3(blocks), dim3(CP_THREADS), 0, s2, dX.d64(), m, ld, c0, nc, log_flag, fix_scale,
+                                   cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p);
+            else
+                hipLaunchKernelGGL(rp_compact_kernel<float>, dim3(blocks), dim3(CP_THREADS), 0, s2, dX.f32(), m, ld, c0, nc, log_flag, fix_scale,
+                                   cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p);
             launch_check("rp_compact_kernel");
         }
         SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[q], s2));

@@ -3,6 +3,8 @@
 #include <ctime>
 #include <atomic>
 #include <condition_variable>
+#include <exception>
+#include <pthread.h>
 #include <mutex>
 #include <thread>
 #include <unistd.h>
@@ -94,15 +96,24 @@ struct HostPool {
     std::atomic<int> next{0};
     int n = 0, participants = 0, pending = 0;
     unsigned long generation = 0;
+    std::exception_ptr failure;                           // the first exception of a job, rethrown on the caller's thread
 
     explicit HostPool(int nworkers) {
         for (int w = 0; w < nworkers; ++w) workers.emplace_back([this, w] { run(w); });
     }
+    // A throwing item (bad_alloc in a resize, say) must not escape a worker (std::terminate inside the host R / Python process) nor
+    // unwind the caller past the wait for the workers, which still hold `fn`: the first exception is kept, the remaining items are
+    // skipped, everybody finishes, and parallel_for rethrows.
     void drain() {
         for (;;) {
             const int i = next.fetch_add(1, std::memory_order_relaxed);
             if (i >= n) break;
-            (*fn)(i);
+            try { (*fn)(i); }
+            catch (...) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!failure) failure = std::current_exception();
+                next.store(n, std::memory_order_relaxed);
+            }
         }
     }
     void run(int w) {
@@ -127,15 +138,34 @@ struct HostPool {
             std::lock_guard<std::mutex> lk(mu);
             fn = &f; n = count; next.store(0, std::memory_order_relaxed);
             participants = helpers; pending = helpers;
+            failure = nullptr;
             ++generation;
         }
         cv_work.notify_all();
-        drain();                                          // the caller works too
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return pending == 0; });
-        fn = nullptr;
+        drain();                                          // the caller works too (never throws: see drain)
+        std::exception_ptr err;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return pending == 0; });
+            fn = nullptr;
+            err = failure;
+            failure = nullptr;
+        }
+        if (err) std::rethrow_exception(err);
     }
 };
+}  // namespace
+
+namespace {
+// The pool and its job lock live behind pointers so that a forked child can start afresh: the child has the objects but not the
+// threads, and a mutex that another thread of the parent held at fork() time would stay locked forever in the child.
+struct PoolState { HostPool *pool = nullptr; std::mutex *one_job = nullptr; bool atfork = false; };
+PoolState &pool_state() { static PoolState s; return s; }
+void pool_atfork_child() {
+    PoolState &S = pool_state();
+    S.pool = nullptr;                                     // the parent's objects are abandoned in the child (their threads do not exist there)
+    S.one_job = new std::mutex;
+}
 }  // namespace
 
 void host_parallel_for(int n, int max_threads, const std::function<void(int)> &fn) {
@@ -143,15 +173,11 @@ void host_parallel_for(int n, int max_threads, const std::function<void(int)> &f
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 4;
     if (n == 1 || max_threads <= 1 || hw <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-    static HostPool *pool = nullptr;                      // leaked on purpose
-    static pid_t pool_pid = 0;
-    static std::mutex one_job;                            // one job at a time (the library is driven from one thread anyway)
-    std::lock_guard<std::mutex> lk(one_job);
-    if (!pool || pool_pid != getpid()) {                  // (a forked child has the object but not the threads: start its own)
-        pool = new HostPool(static_cast<int>(std::min<unsigned>(hw - 1, 15)));
-        pool_pid = getpid();
-    }
-    pool->parallel_for(n, max_threads, fn);
+    PoolState &S = pool_state();
+    if (!S.atfork) { S.atfork = true; S.one_job = new std::mutex; pthread_atfork(nullptr, nullptr, pool_atfork_child); }
+    std::lock_guard<std::mutex> lk(*S.one_job);           // one job at a time (the library is driven from one thread anyway)
+    if (!S.pool) S.pool = new HostPool(static_cast<int>(std::min<unsigned>(hw - 1, 15)));   // leaked on purpose
+    S.pool->parallel_for(n, max_threads, fn);
 }
 
 static double now_s() {
@@ -193,6 +219,13 @@ int sharp_init(int device) {
     SHARP_API_BEGIN
     Ctx &c = ctx_unchecked();
     if (c.ready && c.device == device) return SHARP_OK;
+    // every workspace the library keeps between calls (distance matrices, E, pinned stages, events, projector handles) lives on the
+    // device of the first sharp_init(): one device per process -- as one process per GPU is how the sharded runs are laid out
+    // (sharp_shutdown() destroys the streams, not the workspaces: a later sharp_init() must name the same device)
+    static int bound_device = -1;
+    if (bound_device >= 0 && bound_device != device)
+        throw Error(SHARP_ERR_ARG, "sharp_init: this process is bound to device " + std::to_string(bound_device) +
+                                   " (its workspaces live there); one device per process -- start one process per GPU");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         throw Error(SHARP_ERR_NO_DEVICE, "libsharp_hip: no HIP device visible (MI355X / gfx950 required; no CPU fallback)");
@@ -215,6 +248,7 @@ int sharp_init(int device) {
         SHARP_HIP_CHECK(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, pr));
     }
     c.device = device;
+    bound_device = device;
     c.num_cu = prop.multiProcessorCount;
     c.lds_per_block = prop.sharedMemPerBlock;
     c.ready = true;

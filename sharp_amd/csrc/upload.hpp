@@ -1,0 +1,34 @@
+// upload.hpp -- host matrices (what R hands over: fp64, genes x cells, column-major; or a dgCMatrix's three slots) -> expression
+// blocks in HBM.  A block is stored as fp32 when every value survives the round trip through float (counts, UMI data: half the bytes
+// of the one pass over X) and as fp64 otherwise (TPM / CPM-like doubles), so that log2(X + 1) and the projection see exactly the
+// numbers the reference computes with (R/SHARP.R:110-117,343-345).  SHARP_X_STORAGE = fp32 | fp64 forces the choice.
+#pragma once
+#include "common.hpp"
+
+namespace sharp {
+
+struct HostBlock {               // the resident copy of a host matrix; kept between calls like every other workspace
+    DevBuf<float> f;
+    DevBuf<double> d;
+    bool f64 = false;
+    long long ld = 0;            // column stride in elements (m rounded up to 16 bytes)
+    double max_abs = 0;          // largest |value| of an fp64 block (decides the fixed-point scale of the log-mode accumulation)
+    XRef ref() const {
+        XRef r = f64 ? XRef(d.p) : XRef(f.p);
+        if (f64 && max_abs > 3.4028234663852886e38) r.log_fix_bits = 41;
+        return r;
+    }
+    void release() { f.release(); d.release(); }
+};
+
+// X: m x n column-major doubles, column stride ld >= m (pageable memory).  Threaded narrowing / copying into pinned slabs, DMA'd
+// while the next slab is prepared.
+void upload_block(const double *X, int m, long long n, long long ld, HostBlock &hb);
+// canonical CSC (colptr n + 1 entries, 0-based row indices): only the non-zeros cross PCIe, the dense block is built on the device
+void upload_block_csc(const int *colptr, const int *rowidx, const double *val, int m, long long n, HostBlock &hb);
+// the same into a caller-owned fp32 device block (sharp_csc_to_dense_dev: the *_dev entry points take fp32): values are narrowed
+void upload_csc_into_f32(const int *colptr, const int *rowidx, const double *val, int m, long long n, float *dX, long long ld);
+void upload_release_staging();   // the pinned staging buffers (sharp_trim)
+int upload_last_storage();       // 32 or 64: what the most recent upload_block / upload_block_csc chose (0: none yet)
+
+}  // namespace sharp

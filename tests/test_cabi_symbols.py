@@ -52,6 +52,32 @@ def test_no_device_fails_loudly(so):
     assert b"no device context" in so.sharp_last_error()
 
 
+def test_dotc_convention_without_a_device(so):
+    """The .C()-convention entry points (all-pointer arguments, void return, status out) report the missing device through
+    *status and sharp_C_last_error(char **, int *) -- what r/sharp_hip.R turns into stop()."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    names = [n for n in _declared() if n.startswith("sharp_C_")]
+    assert len(names) >= 20
+    st = (C.c_int * 1)(-1)
+    dev = (C.c_int * 1)(0)
+    so.sharp_C_init.restype = None
+    so.sharp_C_init(dev, st)
+    assert st[0] == 3                                            # SHARP_ERR_NO_DEVICE
+    buf = C.create_string_buffer(b" " * 255)
+    msg = (C.c_char_p * 1)(C.addressof(buf))
+    ln = (C.c_int * 1)(256)
+    so.sharp_C_last_error.restype = None
+    so.sharp_C_last_error(msg, ln)
+    assert b"no HIP device" in buf.value
+    h = (C.c_int * 1)(0)
+    so.sharp_C_projector_create.restype = None
+    so.sharp_C_projector_create((C.c_int * 1)(100), (C.c_int * 1)(10), (C.c_int * 1)(1), (C.c_double * 1)(2154.0), h, st)
+    assert st[0] != 0 and h[0] == 0
+
+
 def test_python_package_has_no_cpu_fallback():
     import torch
 

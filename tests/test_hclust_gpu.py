@@ -167,19 +167,26 @@ def test_bulk_synchronous_and_sequential_agglomeration_agree(sa, oracle, monkeyp
     dev.profile(False)
 
 
-@pytest.mark.parametrize("n,expect_bulk", [(3900, 1), (4200, 0)])
-def test_agglomeration_large_tasks(sa, oracle, n, expect_bulk):
-    """One clustering task near the LDS limits: n <= 4096 observations run in the bulk-synchronous kernel (37 B of LDS state
-    per observation), larger ones (up to 7168) in the sequential kernel.  Sizes like the cross-block sMetaC of a 1.3 M-cell
-    run (about 3 300 meta-clusters)."""
+@pytest.mark.parametrize("n", [3900, 4200])
+def test_agglomeration_large_tasks(sa, oracle, n, monkeypatch):
+    """One clustering task around the LDS limit of the bulk-synchronous kernel (4096 observations: 39 B of LDS state each): below it
+    the state lives in LDS, above it in global memory (same kernel); the sequential kernel (SHARP_HC_SEQ=1) keeps its state in LDS up
+    to 7168.  Sizes like the cross-block sMetaC of a 1.3 M-cell run (about 3 300 meta-clusters)."""
     from sharp_amd import device as dev
 
     rng = np.random.default_rng(5)
     E = rng.standard_normal((n, 40)) + np.repeat(rng.standard_normal((10, 40)) * 3.0, n // 10, axis=0)
     dev.profile(True)
     a = sa.get_opt_hclust(E, maxN_cluster=12)
-    assert _hc_counts(dev) == (expect_bulk, 1 - expect_bulk)
-    dev.profile(False)
+    assert _hc_counts(dev) == (1, 0)
     ref = oracle.get_opt_hclust(E, maxN=12)
     assert np.array_equal(a["f"], ref["f"]) and a["optN_cluster"] == ref["optN"]
     np.testing.assert_allclose(a["height"], ref["height"], rtol=1e-9, atol=1e-12)
+    if n > 4096:
+        monkeypatch.setenv("SHARP_HC_SEQ", "1")
+        dev.profile(True)
+        b = sa.get_opt_hclust(E, maxN_cluster=12)
+        assert _hc_counts(dev) == (0, 1)
+        assert np.array_equal(b["f"], ref["f"])
+        np.testing.assert_allclose(b["height"], ref["height"], rtol=1e-12, atol=1e-14)
+    dev.profile(False)
