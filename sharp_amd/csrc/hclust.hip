@@ -1200,6 +1200,225 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const HcMeta *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// a5b for MANY candidate levels (the cross-block sMetaC of a run of >= 1e6 cells tries k = n/50000 .. n/5000: 1801 levels at 1e7
+// cells, R/sMetaC.R:110-119).  stats_kernel recomputes every level from the finest-level quantities, O(n kf) per level and a
+// per-cluster O(size^2) Gram sum by one thread: 0.4 - 0.75 s for 2200 - 8000 rows.  Consecutive levels differ by ONE merge, so here the
+// per-level cluster sums are carried from the finest level down:
+//   ml_prep_kernel   (one workgroup per task, levels in sequence): |sum_c|^2 of the merged cluster (Gram matrix of the cluster sums
+//                    updated in place), sum_c . total, the between-cluster term of CH;
+//   ml_cells_kernel  (one wave per cell, all levels): the cell's sums of distances / products per cluster live in the wave's LDS and
+//                    follow the merges; per level the silhouette width (own mean, minimum over the other clusters' means) and the
+//                    within term of CH -> s[i][L], w[i][L];
+//   ml_level_kernel  (one workgroup per level): median of s[.][L] (bitonic sort in LDS), sum of w[.][L] in a fixed order, CH.
+// The merges (r1 <- r2 in finest-cluster ids, r1 < r2) come from the host (a replay of the merge list).  Sums of a merged cluster are
+// (sum of r1) + (sum of r2): a different association than stats_kernel's from-scratch sums, equal to rounding.
+// ---------------------------------------------------------------------------------------------
+constexpr int ML_WAVES = 3;          // cells in flight per workgroup: 44 B of LDS per finest cluster and wave
+struct MlMeta {
+    long long oS;                    // n * nk doubles: s[i][L]; w follows at oS + n * nk
+    long long oMerge;                // nk entries of r1 / r2 / cn2 of the merged cluster / B of the level
+    long long oFin;                  // kf entries of cntF (int) / cn2F / ctotF
+};
+
+__global__ __launch_bounds__(1024) void ml_prep_kernel(const HcMeta *__restrict__ metas, const MlMeta *__restrict__ mls, const int *__restrict__ lab_all,
+                                                       double *__restrict__ Q_all, const int *__restrict__ r1_all, const int *__restrict__ r2_all,
+                                                       double *__restrict__ cn2m_all, double *__restrict__ B_all, int *__restrict__ cntF_all,
+                                                       double *__restrict__ cn2F_all, double *__restrict__ tot2_all) {
+    const HcMeta M = metas[blockIdx.x];
+    const MlMeta X = mls[blockIdx.x];
+    const int n = M.n, kf = M.kmax, kpad = M.kpad, nk = M.nk;
+    const int *labF = lab_all + M.oLab + static_cast<long long>(nk - 1) * n;
+    double *Q = Q_all + M.oQ;
+    const int *r1s = r1_all + X.oMerge, *r2s = r2_all + X.oMerge;
+    double *cn2m = cn2m_all + X.oMerge, *Bl = B_all + X.oMerge;
+    int *cntF = cntF_all + X.oFin;
+    double *cn2F = cn2F_all + X.oFin;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    double *cn2 = reinterpret_cast<double *>(sm);        // kf
+    double *ctot = cn2 + kf;                             // kf
+    double *part = ctot + kf;                            // 1024
+    int *cnt = reinterpret_cast<int *>(part + 1024);     // kf
+    const int tid = threadIdx.x;
+    for (int f = tid; f < kf; f += 1024) cnt[f] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) atomicAdd(&cnt[labF[i] - 1], 1);
+    // |S_f|^2 and S_f . total (row sums of the Gram matrix of the finest clusters' sums, ascending)
+    for (int f = tid; f < kf; f += 1024) {
+        const double *qr = Q + static_cast<long long>(f) * kpad;
+        double b = 0.0;
+        for (int g = 0; g < kf; ++g) b += qr[g];
+        ctot[f] = b;
+        cn2[f] = qr[f];
+    }
+    __syncthreads();
+    for (int f = tid; f < kf; f += 1024) { cntF[f] = cnt[f]; cn2F[f] = cn2[f]; }
+    double tot2 = 0.0;
+    for (int f = 0; f < kf; ++f) tot2 += ctot[f];        // |total|^2 (every thread, same order)
+    if (tid == 0) tot2_all[blockIdx.x] = tot2;
+    auto bterm = [&](int r) {
+        double rc = ctot[r] / (sqrt(cn2[r]) * sqrt(tot2));
+        rc = rc > 1.0 ? 1.0 : (rc < -1.0 ? -1.0 : rc);
+        return static_cast<double>(cnt[r]) * (1.0 - rc) * (1.0 - rc);
+    };
+    // between-cluster term at the finest level: fixed assignment of clusters to threads, partial sums added in thread order
+    {
+        double b = 0.0;
+        for (int f = tid; f < kf; f += 1024) b += bterm(f);
+        part[tid] = b;
+        __syncthreads();
+        if (tid == 0) { double B = 0.0; for (int q = 0; q < 1024; ++q) B += part[q]; Bl[nk - 1] = B; part[0] = B; }
+        __syncthreads();
+    }
+    double B = part[0];
+    __syncthreads();
+    for (int L = nk - 2; L >= 0; --L) {
+        const int r1 = r1s[L], r2 = r2s[L];
+        const double cross = Q[static_cast<long long>(r1) * kpad + r2];          // S_r1 . S_r2
+        // Gram matrix of the cluster sums: row and column r1 take r2's (entries of dead clusters are never read again)
+        for (int x = tid; x < kf; x += 1024) {
+            if (x != r1 && x != r2) {
+                const double v = Q[static_cast<long long>(r1) * kpad + x] + Q[static_cast<long long>(r2) * kpad + x];
+                Q[static_cast<long long>(r1) * kpad + x] = v;
+                Q[static_cast<long long>(x) * kpad + r1] = v;
+            }
+        }
+        if (tid == 0) {
+            const double t_old = bterm(r1) + bterm(r2);
+            const double c2 = (cn2[r1] + cn2[r2]) + 2.0 * cross;
+            cn2[r1] = c2; ctot[r1] = ctot[r1] + ctot[r2]; cnt[r1] = cnt[r1] + cnt[r2];
+            Q[static_cast<long long>(r1) * kpad + r1] = c2;
+            B = (B - t_old) + bterm(r1);
+            cn2m[L] = c2; Bl[L] = B;
+        }
+        __syncthreads();
+    }
+}
+
+// One wave per cell.  G / T: n x kpad ROW-major here (a cell's finest-level products / distance sums are one contiguous row).
+__global__ __launch_bounds__(64 * ML_WAVES) void ml_cells_kernel(const HcMeta *__restrict__ metas, const MlMeta *__restrict__ mls, int task,
+                                                                 const int *__restrict__ lab_all, const double *__restrict__ T_all,
+                                                                 const double *__restrict__ G_all, const double *__restrict__ nrm_all,
+                                                                 const int *__restrict__ r1_all, const int *__restrict__ r2_all,
+                                                                 const double *__restrict__ cn2m_all, const int *__restrict__ cntF_all,
+                                                                 const double *__restrict__ cn2F_all, double *__restrict__ S_all) {
+    const HcMeta M = metas[task];
+    const MlMeta X = mls[task];
+    const int n = M.n, kf = M.kmax, kpad = M.kpad, nk = M.nk;
+    const int *labF = lab_all + M.oLab + static_cast<long long>(nk - 1) * n;
+    const double *T = T_all + M.oT, *G = G_all + M.oG, *nrm = nrm_all + M.oNrm;
+    const int *r1s = r1_all + X.oMerge, *r2s = r2_all + X.oMerge;
+    const double *cn2m = cn2m_all + X.oMerge;
+    const int *cntF = cntF_all + X.oFin;
+    const double *cn2F = cn2F_all + X.oFin;
+    double *S = S_all + X.oS, *Wt = S + static_cast<long long>(n) * nk;
+    const bool tfromG = !M.symmetric;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t per_wave = static_cast<size_t>(kf) * (8 + 8 + 2 + 2 + 2);
+    unsigned char *base = sm + ((per_wave + 15) & ~static_cast<size_t>(15)) * wave;
+    double *st = reinterpret_cast<double *>(base);        // sum of distances to the members of cluster r (r = its smallest finest id)
+    double *sg = st + kf;                                 // c_i . (sum of the members' centred rows)
+    uint16_t *cnt = reinterpret_cast<uint16_t *>(sg + kf);
+    uint16_t *live = cnt + kf;                            // the clusters of the current level, any order
+    uint16_t *pos = live + kf;                            // position of r in live[]
+    for (long long i = static_cast<long long>(blockIdx.x) * ML_WAVES + wave; i < n; i += static_cast<long long>(gridDim.x) * ML_WAVES) {
+        const double *Gi = G + i * kpad, *Ti = T + i * kpad;
+        for (int f = lane; f < kf; f += 64) {
+            const double g = Gi[f];
+            sg[f] = g;
+            st[f] = tfromG ? (static_cast<double>(cntF[f]) - g) : Ti[f];
+            cnt[f] = static_cast<uint16_t>(cntF[f]);
+            live[f] = static_cast<uint16_t>(f); pos[f] = static_cast<uint16_t>(f);
+        }
+        int own = labF[i] - 1, k = kf;
+        double cn2own = cn2F[own];
+        const double nr = nrm[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int L = nk - 1; L >= 0; --L) {
+            if (L < nk - 1) {                             // the merge that leads from level L + 1 to level L
+                const int r1 = r1s[L], r2 = r2s[L];
+                if (lane == 0) {
+                    st[r1] = st[r1] + st[r2]; sg[r1] = sg[r1] + sg[r2];
+                    cnt[r1] = static_cast<uint16_t>(cnt[r1] + cnt[r2]);
+                    const int p2 = pos[r2], last = live[k - 1];
+                    live[p2] = static_cast<uint16_t>(last); pos[last] = static_cast<uint16_t>(p2);
+                }
+                --k;
+                if (own == r2 || own == r1) { own = r1; cn2own = cn2m[L]; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            // b = the smallest mean distance to another cluster (a minimum: any order)
+            double bmin = HC_INF;
+            for (int q = lane; q < k; q += 64) {
+                const int r = live[q];
+                if (r != own) { const double bb = st[r] / static_cast<double>(cnt[r]); bmin = bb < bmin ? bb : bmin; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(bmin, o); bmin = y < bmin ? y : bmin; }
+            if (lane == 0) {
+                const int co = cnt[own];
+                const double a = st[own] / static_cast<double>(co - 1);
+                double s = 0.0;
+                if (co > 1 && bmin != a) s = (bmin - a) / fmax(a, bmin);
+                double r = sg[own] / (nr * sqrt(cn2own));
+                r = r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);
+                S[i * nk + L] = s;
+                Wt[i * nk + L] = (1.0 - r) * (1.0 - r);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+__global__ __launch_bounds__(ST_THREADS) void ml_level_kernel(const HcMeta *__restrict__ metas, const MlMeta *__restrict__ mls, int task,
+                                                              const double *__restrict__ S_all, const double *__restrict__ B_all,
+                                                              double *__restrict__ out_all) {
+    const HcMeta M = metas[task];
+    const MlMeta X = mls[task];
+    const int n = M.n, nk = M.nk, L = blockIdx.x, k = M.kmin + L;
+    const double *S = S_all + X.oS, *Wt = S + static_cast<long long>(n) * nk;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    int npow2 = 1; while (npow2 < n) npow2 <<= 1;
+    double *sil = reinterpret_cast<double *>(sm);            // npow2
+    double *part = sil + npow2;                              // ST_THREADS
+    const int tid = threadIdx.x;
+    double wpart = 0.0;
+    for (int i = tid; i < n; i += ST_THREADS) {              // (the same assignment of cells to threads as stats_kernel)
+        sil[i] = S[static_cast<long long>(i) * nk + L];
+        wpart += Wt[static_cast<long long>(i) * nk + L];
+    }
+    for (int i = n + tid; i < npow2; i += ST_THREADS) sil[i] = HC_INF;
+    part[tid] = wpart;
+    __syncthreads();
+    for (int size = 2; size <= npow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (npow2 >> 1); t += ST_THREADS) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const double x = sil[lo], y = sil[hi];
+                if ((x > y) == up) { sil[lo] = y; sil[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        double W = 0.0;
+        for (int q = 0; q < ST_THREADS; ++q) W += part[q];
+        const double B = B_all[X.oMerge + L];
+        const double ch = (B / static_cast<double>(k - 1)) / (W / static_cast<double>(n - k));
+        const double med = (n & 1) ? sil[n / 2] : (sil[n / 2 - 1] + sil[n / 2]) / 2;
+        double *out = out_all + M.oOut;
+        out[L] = med;
+        out[M.nk + L] = ch;
+    }
+}
+
 // gather the chosen label column of every task into one contiguous buffer
 __global__ void pack_labels_kernel(const HcMeta *__restrict__ metas, const int *__restrict__ lab_all, const int *__restrict__ chosen,
                                    const long long *__restrict__ dst_off, int *__restrict__ dst) {
@@ -1239,6 +1458,10 @@ struct Workspace {
     DevBuf<int> ia, ib, lab, chosen, packed, status, remaining;
     DevBuf<unsigned char> img;          // LDS state images of the round-per-launch agglomeration
     DevBuf<unsigned char> seqstate;     // nearest-neighbour state of the sequential kernel for tasks beyond kHcLdsMaxN observations
+    // many-levels statistics (ml_*_kernel)
+    DevBuf<MlMeta> mlmeta;
+    DevBuf<double> mlS, mlcn2m, mlB, mlcn2F, mltot2;
+    DevBuf<int> mlr1, mlr2, mlcntF;
     DevBuf<long long> packoff;
     DevBuf<HcMeta> meta;
     DevBuf<RowPrepTask> prep;
@@ -1254,6 +1477,8 @@ inline long long rup(long long v, long long a) { return (v + a - 1) / a * a; }
 // workgroup per task in one launch.  Measured at 2000 observations per task: 75 tasks 8.7 vs 11.7 ms, 125 tasks 11.1 vs 12.1 ms,
 // 150 tasks 14.0 vs 13.2 ms, 175 tasks 15.3 vs 14.4 ms (tools/bench_hc.py, SHARP_HC_SPLIT=1 / 0).
 constexpr int kHcSplitMaxTasks = 136;
+// more candidate levels than this in a chunk: the incremental per-level statistics (ml_*_kernel) instead of stats_kernel
+constexpr int kMlMinLevels = 256;
 constexpr int kHcSplitMinObs = 1000;
 
 // model selection, R/get_opt_hclust.R:162-229
@@ -1303,6 +1528,9 @@ struct ChunkJob {
     long long oOut = 0, oM = 0, oLab = 0;
     int max_n = 0, max_p = 0, max_nk = 0, max_kpad = 0, NS = 1;
     bool split = false;                        // round-per-launch agglomeration (few tasks)
+    bool ml = false;                           // many candidate levels: the incremental statistics kernels
+    std::vector<MlMeta> mlmetas;
+    int ml_off = 0, ml_cnt = 0, mlt_off = 0, mlt_cnt = 0;   // GEMM descriptors of the row-major G and T
     bool seq_pending = false;                  // the sequential fallback kernel is still to be launched (with the statistics phase)
     bool has_next = false;                     // pipelined: another chunk follows (its distance GEMM is enqueued before this one's tail)
     struct Range { int t0, t1; int off[5], cnt[5]; bool any_sym, any_feat; };
@@ -1379,7 +1607,8 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
         any_sym |= tk.symmetric; any_feat |= !tk.symmetric;
     }
     J.oOut = oOut; J.oM = oM; J.oLab = oLab; J.max_n = max_n; J.max_p = max_p; J.max_nk = max_nk; J.max_kpad = max_kpad;
-    SHARP_REQUIRE(stats_lds_bytes(max_n, std::max(max_kpad, 64)) <= ST_LDS_MAX,
+    SHARP_REQUIRE(max_nk > (getenv("SHARP_ML_MIN_LEVELS") ? std::max(1, atoi(getenv("SHARP_ML_MIN_LEVELS"))) : kMlMinLevels) ||
+                  stats_lds_bytes(max_n, std::max(max_kpad, 64)) <= ST_LDS_MAX,
                   "get_opt_hclust: this many observations with this many candidate cluster numbers does not fit the silhouette kernel "
                   "(LDS: 8 B per observation rounded up to a power of two + 36 B per candidate cluster)");
     { HostTimer ht("hc_workspace_alloc");
@@ -1406,6 +1635,7 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
     }
     if (const char *e = getenv("SHARP_HC_RANGES")) NS = std::max(1, std::min(8, atoi(e)));
     if (J.pipe) NS = 1;                         // the overlap comes from the neighbouring chunks
+    if (J.max_nk > (getenv("SHARP_ML_MIN_LEVELS") ? std::max(1, atoi(getenv("SHARP_ML_MIN_LEVELS"))) : kMlMinLevels)) NS = 1;   // many levels: one range
     NS = std::min(NS, T);
     std::vector<RowPrepTask> &prep = J.prep;
     prep.assign(T, RowPrepTask());
@@ -1453,6 +1683,39 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
             }
             R.cnt[kind] = static_cast<int>(g.size()) - R.off[kind];
         }
+    }
+    // many candidate levels (> kMlMinLevels; SHARP_ML_MIN_LEVELS for tests): G and T of the whole chunk row-major (n x kpad)
+    {
+        int ml_min = kMlMinLevels;
+        if (const char *e = getenv("SHARP_ML_MIN_LEVELS")) ml_min = std::max(1, atoi(e));
+        J.ml = max_nk > ml_min;
+    }
+    if (J.ml) {
+        SHARP_REQUIRE(static_cast<size_t>(max_kpad) * 22 + 64 <= HR_LDS_CU, "get_opt_hclust: too many candidate cluster numbers (more than ~7400)");
+        J.ml_off = static_cast<int>(g.size());
+        for (int t = 0; t < T; ++t) {                      // G = C CS^T  (n x kpad)
+            const HcMeta &M = metas[t];
+            g.push_back(GemmTask{W.Ct.p + M.oCt, W.CSt.p + M.oCSt, W.G.p + M.oG, M.n, M.kpad, M.p, M.nld, M.kpad, M.kpad, 0, 0, 0});
+        }
+        J.ml_cnt = T;
+        J.mlt_off = static_cast<int>(g.size());
+        for (int t = 0; t < T; ++t) {                      // (symmetric) T = D0 H  (n x kpad)
+            const HcMeta &M = metas[t];
+            if (M.symmetric) g.push_back(GemmTask{W.D0.p + M.oD0, W.H.p + M.oH, W.T.p + M.oT, M.n, M.kpad, M.n, M.nld, M.kpad, M.kpad, 0, 0, 0});
+        }
+        J.mlt_cnt = static_cast<int>(g.size()) - J.mlt_off;
+        W.gemm.ensure(g.size());
+        J.mlmetas.assign(T, MlMeta());
+        long long oS = 0, oMg = 0, oFin = 0;
+        for (int t = 0; t < T; ++t) {
+            const HcMeta &M = metas[t];
+            J.mlmetas[t].oS = oS; oS += 2LL * M.n * M.nk;
+            J.mlmetas[t].oMerge = oMg; oMg += M.nk;
+            J.mlmetas[t].oFin = oFin; oFin += M.kmax;
+        }
+        W.mlmeta.ensure(T); W.mlS.ensure(oS); W.mlcn2m.ensure(oMg); W.mlB.ensure(oMg); W.mlr1.ensure(oMg); W.mlr2.ensure(oMg);
+        W.mlcntF.ensure(oFin); W.mlcn2F.ensure(oFin); W.mltot2.ensure(T);
+        W.mlmeta.upload(J.mlmetas.data(), T);
     }
     W.gemm.upload(g.data(), g.size());
     (void)any_sym; (void)any_feat;
@@ -1623,6 +1886,57 @@ void enqueue_chunk(ChunkJob &J, int phases) {
             launch_check("onehot_kernel");
         }
         if (R.cnt[1]) gemm_tn_f64_batched(W.gemm.p + R.off[1], R.cnt[1], max_p, max_kpad, "cluster_sums_gemm");
+        if (J.ml) {
+            // a5b, many levels.  (The chunk is one range here: NS = 1 whenever J.ml, see setup_chunk.)
+            if (R.cnt[3]) gemm_tn_f64_batched(W.gemm.p + R.off[3], R.cnt[3], max_kpad, max_kpad, "cluster_gram_gemm");
+            gemm_tn_f64_batched(W.gemm.p + J.ml_off, J.ml_cnt, max_n, max_kpad, "row_cluster_dot_gemm");
+            if (J.mlt_cnt) gemm_tn_f64_batched(W.gemm.p + J.mlt_off, J.mlt_cnt, max_n, max_kpad, "dist_cluster_sums_gemm");
+            // the merge that leads from level L + 1 to level L, in finest-cluster ids: a replay of the merge list on the host
+            std::vector<int> h_ia(J.oM), h_ib(J.oM);
+            W.ia.download(h_ia.data(), J.oM);
+            W.ib.download(h_ib.data(), J.oM);
+            long long tot_levels = 0;
+            for (int t = 0; t < J.T; ++t) tot_levels += J.metas[t].nk;
+            std::vector<int> h_r1(tot_levels, 0), h_r2(tot_levels, 0);
+            for (int t = 0; t < J.T; ++t) {
+                const HcMeta &M = J.metas[t];
+                const int *ia = h_ia.data() + M.oM, *ib = h_ib.data() + M.oM;
+                std::vector<int> fin(M.n, 0);                    // cell -> finest-cluster id if the cell is a representative at k = kmax
+                std::vector<char> absorbed(M.n, 0);
+                for (int q = 0; q < M.n - M.kmax; ++q) absorbed[ib[q] - 1] = 1;
+                int f = 0;
+                for (int i = 0; i < M.n; ++i) if (!absorbed[i]) fin[i] = f++;   // ids by first appearance = ascending representative
+                for (int L = M.nk - 2; L >= 0; --L) {
+                    const int q = M.n - 1 - (M.kmin + L);         // level k has the merges 0 .. n - k - 1 applied
+                    h_r1[J.mlmetas[t].oMerge + L] = fin[ia[q] - 1];
+                    h_r2[J.mlmetas[t].oMerge + L] = fin[ib[q] - 1];
+                }
+            }
+            W.mlr1.upload(h_r1.data(), tot_levels);
+            W.mlr2.upload(h_r2.data(), tot_levels);
+            {
+                KernelTimer tm("sil_ch_stats");
+                const size_t lds_p = static_cast<size_t>(max_kpad) * 20 + 1024 * 8 + 64;
+                SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ml_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_p)));
+                hipLaunchKernelGGL(ml_prep_kernel, dim3(Ts), dim3(1024), lds_p, st, dmeta, W.mlmeta.p + R.t0, W.lab.p, W.Q.p, W.mlr1.p, W.mlr2.p,
+                                   W.mlcn2m.p, W.mlB.p, W.mlcntF.p, W.mlcn2F.p, W.mltot2.p + R.t0);
+                launch_check("ml_prep_kernel");
+                const size_t per_wave = (static_cast<size_t>(max_kpad) * 22 + 15) & ~static_cast<size_t>(15);
+                const size_t lds_c = per_wave * ML_WAVES;
+                SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ml_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_c)));
+                int npow2 = 1; while (npow2 < max_n) npow2 <<= 1;
+                const size_t lds_l = static_cast<size_t>(npow2) * 8 + ST_THREADS * 8;
+                SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ml_level_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_l)));
+                for (int t = R.t0; t < R.t1; ++t) {
+                    const HcMeta &M = J.metas[t];
+                    const int blocks = std::min((M.n + ML_WAVES - 1) / ML_WAVES, c.num_cu * std::max(1, static_cast<int>(HR_LDS_CU / std::max<size_t>(lds_c, 1))));
+                    hipLaunchKernelGGL(ml_cells_kernel, dim3(blocks), dim3(64 * ML_WAVES), lds_c, st, W.meta.p, W.mlmeta.p, t, W.lab.p, W.T.p, W.G.p, W.nrm.p,
+                                       W.mlr1.p, W.mlr2.p, W.mlcn2m.p, W.mlcntF.p, W.mlcn2F.p, W.mlS.p);
+                    hipLaunchKernelGGL(ml_level_kernel, dim3(M.nk), dim3(ST_THREADS), lds_l, st, W.meta.p, W.mlmeta.p, t, W.mlS.p, W.mlB.p, W.out.p);
+                }
+                launch_check("ml_cells_kernel");
+            }
+        } else {
         if (R.cnt[2]) gemm_tn_f64_batched(W.gemm.p + R.off[2], R.cnt[2], max_kpad, max_n, "row_cluster_dot_gemm");
         if (R.cnt[3]) gemm_tn_f64_batched(W.gemm.p + R.off[3], R.cnt[3], max_kpad, max_kpad, "cluster_gram_gemm");
         if (R.cnt[4]) gemm_tn_f64_batched(W.gemm.p + R.off[4], R.cnt[4], max_kpad, max_n, "dist_cluster_sums_gemm");
@@ -1638,6 +1952,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                                W.G.p, W.Q.p, W.nrm.p, W.out.p, Ts, max_nk, kcap);
             launch_check("stats_kernel");
         }
+        }   // !J.ml
         if (NS > 1) {
             SHARP_HIP_CHECK(hipEventRecord(ev_out[s], st));
             SHARP_HIP_CHECK(hipStreamWaitEvent(main_stream, ev_out[s], 0));

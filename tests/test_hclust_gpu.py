@@ -190,3 +190,38 @@ def test_agglomeration_large_tasks(sa, oracle, n, monkeypatch):
         assert np.array_equal(b["f"], ref["f"])
         np.testing.assert_allclose(b["height"], ref["height"], rtol=1e-12, atol=1e-14)
     dev.profile(False)
+
+
+@pytest.mark.parametrize("kind", ["features", "similarity"])
+def test_many_levels_statistics_match_the_per_level_kernel_and_the_oracle(sa, oracle, kind, monkeypatch):
+    """More than 256 candidate cluster numbers (the cross-block sMetaC of a 1e7-cell run tries 1801) go through the incremental
+    per-level statistics (ml_*_kernel: cluster sums carried from the finest level down, one merge per level) instead of
+    stats_kernel's from-scratch sums; SHARP_ML_MIN_LEVELS forces either on the same task.  Same medians and CH to rounding, same
+    choice; both equal the oracle."""
+    rng = np.random.default_rng(17)
+    n, p, G = 900, 50, 9
+    E = rng.standard_normal((n, p)) + np.repeat(rng.standard_normal((G, p)) * 2.5, n // G, axis=0)
+    if kind == "similarity":
+        mat = np.corrcoef(E)
+        np.fill_diagonal(mat, 1.0)
+        mat = (mat + mat.T) / 2
+    else:
+        mat = E
+    kw = dict(minN_cluster=5, maxN_cluster=300, sil_thre=0.35)
+    monkeypatch.setenv("SHARP_ML_MIN_LEVELS", "100000")
+    a = sa.get_opt_hclust(mat, **kw)                          # stats_kernel
+    monkeypatch.setenv("SHARP_ML_MIN_LEVELS", "8")
+    b = sa.get_opt_hclust(mat, **kw)                          # ml_*_kernel
+    assert a["msil"].size == 296
+    np.testing.assert_allclose(b["msil"], a["msil"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b["CHind"], a["CHind"], rtol=1e-10)
+    assert np.array_equal(a["f"], b["f"]) and a["branch"] == b["branch"]
+    ref = oracle.get_opt_hclust(mat, minN=5, maxN=300, sil_thre=0.35)
+    np.testing.assert_allclose(b["msil"], ref["msil"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(b["CHind"], ref["CHind"], rtol=1e-8)
+    assert np.array_equal(b["f"], ref["f"]) and np.array_equal(b["v"], ref["v"])
+    # the CH branch (a threshold above every median) picks the same level either way
+    monkeypatch.setenv("SHARP_ML_MIN_LEVELS", "8")
+    c = sa.get_opt_hclust(mat, minN_cluster=5, maxN_cluster=300, sil_thre=2.0)
+    refc = oracle.get_opt_hclust(mat, minN=5, maxN=300, sil_thre=2.0)
+    assert c["branch"] == refc["branch"] and np.array_equal(c["f"], refc["f"])
