@@ -72,7 +72,7 @@ __global__ void rp_fixtab_kernel(double fix_scale, int log10_mode, long long *__
 // T = the storage type of the block: float (counts, fp32-exact data) or double (TPM-like values: the term is log2(1 + x) of the
 // double itself, as the reference computes it).
 template <typename T>
-__global__ __launch_bounds__(CP_THREADS) void rp_compact_kernel(const T *__restrict__ X, int m, long long ld, long long cell0,
+__global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 4 : 2) void rp_compact_kernel(const T *__restrict__ X, int m, long long ld, long long cell0,
                                                                 int ncell, int log_flag, double fix_scale, int cap,
                                                                 unsigned int *__restrict__ counts, uint32_t *__restrict__ genes,
                                                                 long long *__restrict__ fixes) {
