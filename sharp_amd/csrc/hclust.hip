@@ -960,6 +960,8 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     }
 }
 
+#include "hclust_lazy.inc"
+
 // ---------------------------------------------------------------------------------------------
 // a5a: cutree for every level k = kmin..kmax (level index L = k - kmin), ids by first appearance.
 // j2 is absorbed by i2 < j2 at its merge step, so a cluster's representative is its smallest member
@@ -1837,6 +1839,17 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                             if (rem <= 0) break;
                         }
                     }
+                } else if (Ts <= c.num_cu && max_n <= HL_MAXN && getenv("SHARP_HC_LAZY") && getenv("SHARP_HC_LAZY")[0] == '1') {
+                    // SHARP_HC_LAZY=1 (an experiment kept for reference): one workgroup per task, rows rewritten only
+                    // when their cluster merges (hclust_lazy.inc) -- half the bytes of hclust_rnn_kernel, same merges, but at four waves
+                    // per CU (a 16 KB LDS row buffer each) it runs at a quarter of the bandwidth: 62 ms against 30 ms at cfg2
+                    const size_t ldsz = hclust_lazy_lds(max_n);
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_lazy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        static_cast<int>(ldsz)));
+                    int theta = 50;
+                    if (const char *e = getenv("SHARP_HC_LAZY_THETA")) theta = std::max(10, std::min(95, atoi(e)));
+                    hipLaunchKernelGGL(hclust_lazy_kernel, dim3(Ts), dim3(HL_THREADS), ldsz, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p,
+                                       W.height.p, W.status.p + R.t0, theta);
                 } else if (Ts <= c.num_cu) {
                     auto k0 = hclust_rnn_kernel<1024, 0>;
                     // one workgroup per CU: everything the CU has beyond the state stages the pair members' entries
