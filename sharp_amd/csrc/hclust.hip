@@ -285,7 +285,10 @@ __device__ __forceinline__ HrBest hr_wave(HrBest x) {
 // previous round's transition, finds and ranks the reciprocal pairs, builds the column maps and stores it back; MODE 2
 // (gridDim.y workgroups per task) loads it read-only and rebuilds its share of the rows (work is handed out by counters in
 // the image), writing the new rows' nearest neighbours straight into the image.
-// GS (MODE 1 / 2 only): tasks beyond HR_MAXN observations, whose state does not fit a CU's LDS -- the state arrays ARE the global
+// MODE 3: picks a task up from its image and runs ALL its remaining rounds in this one launch (one workgroup per task, like MODE 0):
+// once a few hundred clusters are left a round's two launches cost more than its work -- the last ~33 of the 45 rounds of a
+// 2000-observation task took 3.3 ms as 66 launches.
+// GS (MODE 1 / 2 / 3 only): tasks beyond HR_MAXN observations, whose state does not fit a CU's LDS -- the state arrays ARE the global
 // image (no copy in or out; the same code addresses them), only the stage of the rebuild stays in LDS.
 template <int HR_THREADS, int MODE, bool GS = false>
 __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__restrict__ metas, const double *__restrict__ Dall,
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         }
         if (ctl[10] != 0 || (MODE == 2 && !ctl[11])) return;   // finished / abandoned, or nothing pending
         cur = ctl[5]; na = ctl[6]; done = ctl[7]; src = ctl[8] - 1;
-        if (MODE == 1 && ctl[11]) {                             // apply the transition of the round that MODE 2 just rebuilt
+        if ((MODE == 1 || MODE == 3) && ctl[11]) {              // apply the transition of the round that MODE 2 just rebuilt
             done += ctl[0]; na = ctl[9]; cur ^= 1; src = src < 0 ? 0 : (src ^ 1);
             __syncthreads();
             if (tid == 0) { ctl[0] = 0; ctl[11] = 0; }
@@ -1828,7 +1831,17 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsa)));
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsl)));
                     const int max_rounds = max_n + 8;               // every round merges at least one pair
+                    // after `finish_at` rounds (about a quarter of the clusters left at the usual 10 % per round) the rest runs in ONE launch
+                    int finish_at = 15;
+                    if (const char *e = getenv("SHARP_HC_FINISH_AT")) finish_at = atoi(e);
+                    auto kc = gs ? hclust_rnn_kernel<1024, 3, true> : hclust_rnn_kernel<1024, 3, false>;
+                    if (finish_at >= 0) SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsl)));
                     for (int r = 0; r < max_rounds; ++r) {
+                        if (finish_at >= 0 && r == finish_at) {
+                            hipLaunchKernelGGL(kc, dim3(Ts), dim3(1024), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p, W.height.p,
+                                               W.status.p + R.t0, W0.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W0.remaining.p, static_cast<int>(ldsl));
+                            break;
+                        }
                         hipLaunchKernelGGL(ka, dim3(Ts), dim3(1024), ldsa, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p, W.height.p,
                                            W.status.p + R.t0, W0.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W0.remaining.p, static_cast<int>(ldsa));
                         hipLaunchKernelGGL(kb, dim3(Ts, wpt), dim3(1024), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p, W.height.p,

@@ -22,7 +22,7 @@ for tag, (n, m, p) in {"cfg3": (50000, 20000, 474), "cfg5": (50000, 20000, 582),
     dev.unlimited_block_dev(x, p, proj.handle, 5, 2103)
     dev.unlimited_block_dev(x, p, proj.handle, 5, 2103)
     dev.profile(True)
-    reps = 4
+    reps = int(__import__("os").environ.get("BLOCK_REPS", "4"))
     lib.sharp_synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
