@@ -33,6 +33,10 @@ struct SharpArgs {
     // SHARP_fpart (R/SHARP_unlimited2.R:297-544): the large path with log10 (flag = 2), E1 rounded to one decimal before
     // clustering, maxN.cluster = 40 for the base tasks, and NO sMetaC: the per-fold ensemble labels go up to the caller
     bool fpart = false;
+    // SHARP_unlimited with several blocks on this GPU: the block that comes next (same genes, projector, parameters).  Its projection,
+    // row preparation and distance matrices are enqueued on a side stream before this block's agglomeration starts, so that they run
+    // under this block's (HBM-bound, then host-bound) tail; the next call finds them done.
+    XRef next_dX; long long next_n = 0, next_ld = 0;
 };
 struct SharpOut {
     std::vector<int> pred;           // 1..G, numbered by first appearance (R/SHARP.R:429-443,828-843)
@@ -53,7 +57,7 @@ struct SharpOut {
 namespace {
 
 // big per-call device buffers are kept between calls (hipMalloc/hipFree of multi-GB buffers costs up to tens of ms)
-struct DriverWs { DevBuf<double> E, viE_sh, viE_out; DevBuf<int> pos; };
+struct DriverWs { DevBuf<double> E, Eb, viE_sh, viE_out; DevBuf<int> pos, posb; };     // (Eb / posb: the block prepared ahead of time)
 DriverWs &dws() { static DriverWs w; return w; }
 
 // allrpinfo of the last SHARP_small run (R/SHARP.R:350-387,446): the colour index of every cell under every random projection; the
@@ -172,47 +176,134 @@ static std::vector<int> fold_starts(int n, int ng) {
 // ---------------------------------------------------------------------------------------------
 // SHARP_large (R/SHARP.R:478-851)
 // ---------------------------------------------------------------------------------------------
-void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, int ng, HcParams base, SharpOut &out) {
-    HostTimer ht_all("sharp_large_total");
-    last_small().valid = false;                                                 // E is about to be overwritten
-    const bool shuffle = n < 100000;                                            // :504-507
-    std::vector<int> reind;                                                     // shuffled position i holds cell reind[i]-1
-    std::vector<int> pos(n);                                                    // cell -> shuffled position
-    if (shuffle) {
-        RRng rng((a.rN_seed == 0.5) ? static_cast<uint32_t>(std::random_device{}()) : 50u);   // :493-499
-        reind = rng.permutation(n);
-        for (int i = 0; i < n; ++i) pos[reind[i] - 1] = i;
-    } else {
-        std::iota(pos.begin(), pos.end(), 0);
-    }
-    const std::vector<int> fst = fold_starts(n, ng);
-    const int T = static_cast<int>(fst.size()) - 1;
+// The front of a block: shuffle, folds, projection (E rows straight into shuffled order), the K*T base-clustering tasks -- and, for
+// a block prepared ahead of time, their row preparation and distance matrices (hc_prefetch_begin).
+struct LargeFront {
+    XRef dX; int m = 0, n = 0; long long ld = 0; int K = 0, p = 0, ng = 0, flag = 0, projector = 0; double rN_seed = 0; bool fpart = false;
+    HcParams bp;
+    bool shuffle = false;
+    std::vector<int> reind, fst, pos;                                          // (pos: cell -> shuffled position; uploaded from here)
+    int T = 0;
     std::shared_ptr<Projector> pr;
-    { HostTimer ht("projector_build"); pr = projector_for(a, m, p, K); }         // :539-549
-    const long long ldE = static_cast<long long>(pr->K) * p;
-    DevBuf<double> &E = dws().E;
-    { HostTimer ht("alloc_E"); E.ensure(static_cast<size_t>(n) * ldE); }
-    DevBuf<int> &dpos = dws().pos;
-    if (shuffle) { dpos.ensure(n); dpos.upload(pos.data(), n); }
+    long long ldE = 0;
+    double *E = nullptr; int *dpos = nullptr;                                   // device: this block's projection and shuffle map
+    std::vector<HcTask> tasks;
+    std::shared_ptr<HcPrefetch> hc;                                             // distance matrices already enqueued
+    bool matches(XRef X, int m_, int n_, long long ld_, int K_, int p_, int ng_, const SharpArgs &a, const HcParams &b) const {
+        return dX.p == X.p && dX.f64 == X.f64 && m == m_ && n == n_ && ld == ld_ && K == K_ && p == p_ && ng == ng_ && flag == a.flag &&
+               projector == a.projector && rN_seed == a.rN_seed && fpart == a.fpart && bp.hmethod == b.hmethod && bp.N_cluster == b.N_cluster &&
+               bp.minN == b.minN && bp.maxN == b.maxN && bp.sil_thre == b.sil_thre && bp.height_Ntimes == b.height_Ntimes;
+    }
+};
+namespace {
+struct PendingFront { std::unique_ptr<LargeFront> f; hipStream_t stream = nullptr; int parity = 0; };
+PendingFront &pending_front() { static PendingFront p; return p; }
+}  // namespace
+
+static void large_front(LargeFront &F, const SharpArgs &a, bool ahead) {
+    const int n = F.n, m = F.m, K = F.K, p = F.p;
+    F.shuffle = n < 100000;                                                     // :504-507
+    std::vector<int> &pos = F.pos;
+    pos.assign(n, 0);
+    if (F.shuffle) {
+        RRng rng((a.rN_seed == 0.5) ? static_cast<uint32_t>(std::random_device{}()) : 50u);   // :493-499
+        F.reind = rng.permutation(n);
+        for (int i = 0; i < n; ++i) pos[F.reind[i] - 1] = i;
+    }
+    F.fst = fold_starts(n, F.ng);
+    F.T = static_cast<int>(F.fst.size()) - 1;
+    { HostTimer ht("projector_build"); F.pr = projector_for(a, m, p, K); }       // :539-549
+    F.ldE = static_cast<long long>(F.pr->K) * p;
+    DevBuf<double> &E = ahead ? dws().Eb : dws().E;
+    { HostTimer ht("alloc_E"); E.ensure(static_cast<size_t>(n) * F.ldE); }
+    DevBuf<int> &dpos = ahead ? dws().posb : dws().pos;
+    if (F.shuffle) { dpos.ensure(n); dpos.upload(pos.data(), n); }
+    F.E = E.p; F.dpos = F.shuffle ? dpos.p : nullptr;
     // E rows are written straight into shuffled order, so fold t is the contiguous row range [fst[t], fst[t+1])
-    project_dev(*pr, dX, m, n, ld, a.flag, E.p, ldE, shuffle ? dpos.p : nullptr);          // :567-585 for every (k, t)
+    project_dev(*F.pr, F.dX, m, n, F.ld, a.flag, F.E, F.ldE, F.dpos);             // :567-585 for every (k, t)
     if (a.fpart) {                                                              // newE1 = round(newE1, digits = 1)  (unlimited2 :410)
         Ctx &c = ctx();
-        hipLaunchKernelGGL(round1_kernel, dim3(c.num_cu * 8), dim3(256), 0, c.stream, E.p, static_cast<long long>(n) * ldE);
+        hipLaunchKernelGGL(round1_kernel, dim3(c.num_cu * 8), dim3(256), 0, c.stream, F.E, static_cast<long long>(n) * F.ldE);
         launch_check("round1_kernel");
     }
     // K*T base-clustering tasks in one batch (:554-618)
-    std::vector<HcTask> tasks(static_cast<size_t>(K) * T);
+    F.tasks.assign(static_cast<size_t>(K) * F.T, HcTask());
+    for (int k = 0; k < K; ++k)
+        for (int t = 0; t < F.T; ++t) {
+            HcTask &tk = F.tasks[static_cast<size_t>(k) * F.T + t];
+            tk.d_mat = F.E + static_cast<long long>(F.fst[t]) * F.ldE + static_cast<long long>(k) * p;
+            tk.ld = F.ldE; tk.n = F.fst[t + 1] - F.fst[t]; tk.p = p; tk.prm = F.bp;
+        }
+}
+
+void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, int ng, HcParams base, SharpOut &out) {
+    HostTimer ht_all("sharp_large_total");
+    last_small().valid = false;                                                 // E is about to be overwritten
     HcParams bp = base; bp.N_cluster = a.indN;
     if (a.fpart) bp.maxN = 40;                                                  // "for partition clustering" (unlimited2 :421)
-    for (int k = 0; k < K; ++k)
-        for (int t = 0; t < T; ++t) {
-            HcTask &tk = tasks[static_cast<size_t>(k) * T + t];
-            tk.d_mat = E.p + static_cast<long long>(fst[t]) * ldE + static_cast<long long>(k) * p;
-            tk.ld = ldE; tk.n = fst[t + 1] - fst[t]; tk.p = p; tk.prm = bp;
+    // the front: prepared ahead of time by the previous block's call, or now
+    std::unique_ptr<LargeFront> Fp;
+    PendingFront &PF = pending_front();
+    if (PF.f) {
+        if (PF.f->matches(dX, m, n, ld, K, p, ng, a, bp)) {
+            Fp = std::move(PF.f);
+            std::swap(dws().E, dws().Eb);                                       // its buffers become the current block's
+            std::swap(dws().pos, dws().posb);
+        } else {
+            SHARP_HIP_CHECK(hipStreamSynchronize(PF.stream));                   // (a prepared block that is not the one asked for: dropped)
+            PF.f.reset();
         }
+    }
+    if (!Fp) {
+        Fp.reset(new LargeFront);
+        Fp->dX = dX; Fp->m = m; Fp->n = n; Fp->ld = ld; Fp->K = K; Fp->p = p; Fp->ng = ng; Fp->flag = a.flag; Fp->projector = a.projector;
+        Fp->rN_seed = a.rN_seed; Fp->fpart = a.fpart; Fp->bp = bp;
+        large_front(*Fp, a, false);
+    }
+    LargeFront &F = *Fp;
+    const bool shuffle = F.shuffle;
+    const std::vector<int> &reind = F.reind, &fst = F.fst;
+    const int T = F.T;
+    const long long ldE = F.ldE;
+    struct { double *p; } E{F.E};
+    struct { int *p; } dpos{F.dpos};
+    // The NEXT block's front on a side stream.  If this block's own front was prepared ahead, its agglomeration is enqueued first and
+    // the next front waits for it: it then runs under this block's statistics and host-bound tail instead of beside the HBM-bound
+    // agglomeration (which it only slowed down: 259 -> 246 ms for the ten blocks of cfg3 ungated).
+    hipEvent_t after_agglo = nullptr;
+    if (F.hc && a.next_dX.p && !getenv("SHARP_PREFETCH_UNGATED")) { HostTimer ht("base_clustering_total"); after_agglo = hc_prefetch_agglomerate(*F.hc); }
+    if (a.next_dX.p && a.projector && !getenv("SHARP_NO_BLOCK_PREFETCH")) {
+        const int nn = static_cast<int>(a.next_n);
+        const int Tn = (nn + ng - 1) / ng;
+        if (a.next_n >= 5000 && a.next_n < (1LL << 31) && static_cast<long long>(K) * Tn <= ctx().num_cu && Tn > 1) {
+            std::unique_ptr<LargeFront> N(new LargeFront);
+            N->dX = a.next_dX; N->m = m; N->n = nn; N->ld = a.next_ld; N->K = K; N->p = p; N->ng = ng; N->flag = a.flag;
+            N->projector = a.projector; N->rN_seed = a.rN_seed; N->fpart = a.fpart; N->bp = bp;
+            if (a.maxN <= 0 && !a.fpart) N->bp.maxN = std::max(40, (nn + 4999) / 5000);   // the next block's own default (R/SHARP.R:144-146)
+            if (!PF.stream) {
+                // lowest priority: the tail's small kernels (on the critical path) go first whenever they are ready; at equal priority the
+                // next block's distance GEMM kept every CU busy and they waited (the tail took 12 ms instead of 6.6)
+                int lo = 0, hi = 0;
+                SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                SHARP_HIP_CHECK(hipStreamCreateWithPriority(&PF.stream, hipStreamNonBlocking, lo));
+            }
+            {
+                // (the main stream has nothing pending that the next block depends on; its buffers are its own)
+                StreamScope scope(PF.stream);
+                if (after_agglo) SHARP_HIP_CHECK(hipStreamWaitEvent(PF.stream, after_agglo, 0));
+                large_front(*N, a, true);
+                if (hc_prefetch_possible(N->tasks)) N->hc = hc_prefetch_begin(N->tasks, PF.parity ^= 1);
+            }
+            if (N->hc) PF.f = std::move(N);
+            else SHARP_HIP_CHECK(hipStreamSynchronize(PF.stream));              // (cannot be kept: finish it, the projection is simply redone)
+        }
+    }
     std::vector<HcResult> hr;
-    { HostTimer ht("base_clustering_total"); get_opt_hclust_batch(tasks, false, hr); }
+    {
+        HostTimer ht("base_clustering_total");
+        if (F.hc) hc_prefetch_finish(*F.hc, false, hr);
+        else get_opt_hclust_batch(F.tasks, false, hr);
+    }
     DevBuf<double> &viE_sh = dws().viE_sh;                                      // enE / K in shuffled order (:750,776)
     viE_sh.ensure(static_cast<size_t>(n) * p);
     ensemble_mean_dev(E.p, ldE, n, p, K, viE_sh.p);                             // enqueued now, runs under the host loops below
@@ -364,9 +455,11 @@ void sharp_front_dev(XRef dX, int m, long long n_, long long ld, SharpArgs a, Sh
 // (:135) and the colMeans of its viE per predicted cluster -- all sMetaC ever uses of E1 (:163, R/sMetaC.R:58-63)
 void unlimited_block_dev(XRef dX, int m, long long nb, long long ld, int p, int projector, int K, double rN_seed,
                          std::vector<int> &pred, std::vector<double> &means, std::vector<long long> &counts, double *viE_host,
-                         int flag = 1, const SharpArgs *fpart_args = nullptr) {
+                         int flag = 1, const SharpArgs *fpart_args = nullptr, XRef next_dX = XRef(), long long next_n = 0,
+                         long long next_ld = 0) {
     SharpArgs a;
     if (fpart_args) a = *fpart_args;                                            // SHARP_unlimited2: every SHARP_fpart parameter
+    a.next_dX = next_dX; a.next_n = next_n; a.next_ld = next_ld;                // the block after this one (prepared under this one's tail)
     a.K = K; a.reduced_ndim = p; a.flag = flag; a.projector = projector; a.rN_seed = rN_seed; a.want_viE = true;
     a.fpart = fpart_args != nullptr;
     SharpOut o;
@@ -629,8 +722,10 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
             std::vector<int> pb;
             std::vector<double> mb;
             std::vector<long long> cb;
+            const bool more = b + 1 < nblocks;
             unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb,
-                                viE ? viE + static_cast<size_t>(off) * p : nullptr);
+                                viE ? viE + static_cast<size_t>(off) * p : nullptr, 1, nullptr, more ? dX_blocks[b + 1] : XRef(),
+                                more ? ncb[b + 1] : 0, more ? ldb[b + 1] : 0);
             std::copy(pb.begin(), pb.end(), pred + off);
             means.insert(means.end(), mb.begin(), mb.end());
             counts.insert(counts.end(), cb.begin(), cb.end());
@@ -684,8 +779,10 @@ static int unlimited2_run(const XRef *dX_blocks, const long long *ncb, const lon
             std::vector<int> pb;
             std::vector<double> mb;
             std::vector<long long> cb;
+            const bool more = b + 1 < nblocks;
             unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb,
-                                viE ? viE + static_cast<size_t>(off) * p : nullptr, flag ? 2 : 0, &fa);
+                                viE ? viE + static_cast<size_t>(off) * p : nullptr, flag ? 2 : 0, &fa, more ? dX_blocks[b + 1] : XRef(),
+                                more ? ncb[b + 1] : 0, more ? ldb[b + 1] : 0);
             std::copy(pb.begin(), pb.end(), pred + off);
             means.insert(means.end(), mb.begin(), mb.end());
             counts.insert(counts.end(), cb.begin(), cb.end());

@@ -1474,7 +1474,8 @@ struct Workspace {
 };
 // Two sets of buffers so that consecutive chunks of tasks can be in flight together (run_chunks); the scratch of the agglomeration
 // itself (S0, S1, img, remaining) is only ever used by one chunk at a time and always comes from set 0.
-Workspace &ws(int slot = 0) { static Workspace w[2]; return w[slot]; }
+// (slots 2 and 3: batches whose distance matrices are built ahead of time for the NEXT block of a SHARP_unlimited run, hc_prefetch_*)
+Workspace &ws(int slot = 0) { static Workspace w[4]; return w[slot]; }
 
 inline long long rup(long long v, long long a) { return (v + a - 1) / a * a; }
 
@@ -1538,6 +1539,10 @@ struct ChunkJob {
     int ml_off = 0, ml_cnt = 0, mlt_off = 0, mlt_cnt = 0;   // GEMM descriptors of the row-major G and T
     bool seq_pending = false;                  // the sequential fallback kernel is still to be launched (with the statistics phase)
     bool has_next = false;                     // pipelined: another chunk follows (its distance GEMM is enqueued before this one's tail)
+    bool one_range = false;                    // everything on the current stream (a batch prepared ahead of time, hc_prefetch_begin)
+    hipEvent_t mid_event = nullptr;            // recorded behind round `mid_round` of the round-per-launch agglomeration (if it gets that far)
+    int mid_round = 8;
+    bool mid_recorded = false;
     struct Range { int t0, t1; int off[5], cnt[5]; bool any_sym, any_feat; };
     std::vector<Range> ranges;
 };
@@ -1639,7 +1644,7 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
         if (!(seq && seq[0] == '1') && ((!(mono && mono[0] == '1') && split) || max_n > HR_MAXN)) NS = 1;
     }
     if (const char *e = getenv("SHARP_HC_RANGES")) NS = std::max(1, std::min(8, atoi(e)));
-    if (J.pipe) NS = 1;                         // the overlap comes from the neighbouring chunks
+    if (J.pipe || J.one_range) NS = 1;          // the overlap comes from the neighbouring chunks / blocks
     if (J.max_nk > (getenv("SHARP_ML_MIN_LEVELS") ? std::max(1, atoi(getenv("SHARP_ML_MIN_LEVELS"))) : kMlMinLevels)) NS = 1;   // many levels: one range
     NS = std::min(NS, T);
     std::vector<RowPrepTask> &prep = J.prep;
@@ -1837,6 +1842,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                     auto kc = gs ? hclust_rnn_kernel<1024, 3, true> : hclust_rnn_kernel<1024, 3, false>;
                     if (finish_at >= 0) SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsl)));
                     for (int r = 0; r < max_rounds; ++r) {
+                        if (J.mid_event && r == J.mid_round) { SHARP_HIP_CHECK(hipEventRecord(J.mid_event, st)); J.mid_recorded = true; }
                         if (finish_at >= 0 && r == finish_at) {
                             hipLaunchKernelGGL(kc, dim3(Ts), dim3(1024), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p, W.height.p,
                                                W.status.p + R.t0, W0.img.p, static_cast<long long>(lds), static_cast<int>(lds), r, W0.remaining.p, static_cast<int>(ldsl));
@@ -2123,6 +2129,61 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
     enqueue_chunk(jobs[(nb - 1) & 1], PH_STATS);
     if (nb >= 2) finish_chunk(tasks, jobs[(nb - 2) & 1], want_v, out);
     finish_chunk(tasks, jobs[(nb - 1) & 1], want_v, out);
+}
+
+// ---- a batch whose distance matrices are built ahead of time (SHARP_unlimited: the next block's front under the current block's tail)
+struct HcPrefetch {
+    std::vector<HcTask> tasks;
+    ChunkJob J;
+    hipEvent_t ready = nullptr, agglo_done = nullptr;
+    bool agglo_enqueued = false;
+    ~HcPrefetch() { if (ready) (void)hipEventDestroy(ready); if (agglo_done) (void)hipEventDestroy(agglo_done); }
+};
+
+bool hc_prefetch_possible(const std::vector<HcTask> &tasks) {
+    if (tasks.empty() || tasks.size() > static_cast<size_t>(ctx().num_cu) || getenv("SHARP_HC_CHUNK")) return false;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    double bytes = 0;
+    for (const HcTask &t : tasks) {
+        const double nld = static_cast<double>(rup(t.n, 128));
+        bytes += 8.0 * (nld * nld * 4 + 2 * nld * (t.symmetric ? t.n : t.p));
+    }
+    return bytes < 0.25 * static_cast<double>(free_b) || bytes < 8.0e9;
+}
+
+std::shared_ptr<HcPrefetch> hc_prefetch_begin(std::vector<HcTask> tasks, int slot) {
+    auto P = std::make_shared<HcPrefetch>();
+    P->tasks = std::move(tasks);
+    P->J.i0 = 0; P->J.i1 = P->tasks.size();
+    P->J.slot = 2 + (slot & 1);
+    P->J.one_range = true;
+    setup_chunk(P->tasks, P->J);
+    enqueue_chunk(P->J, PH_DIST);                           // on the stream that is current here (the caller's prefetch stream)
+    SHARP_HIP_CHECK(hipEventCreateWithFlags(&P->ready, hipEventDisableTiming));
+    SHARP_HIP_CHECK(hipEventRecord(P->ready, ctx().stream));
+    return P;
+}
+
+hipEvent_t hc_prefetch_agglomerate(HcPrefetch &P) {
+    SHARP_HIP_CHECK(hipStreamWaitEvent(ctx().stream, P.ready, 0));
+    if (!P.agglo_done) SHARP_HIP_CHECK(hipEventCreateWithFlags(&P.agglo_done, hipEventDisableTiming));
+    // round-per-launch form: the event sits behind the large rounds (the first eight move 3/4 of the bytes); the remaining small
+    // rounds leave most of the chip idle, and the next block's front may as well start there
+    if (const char *e = getenv("SHARP_PREFETCH_ROUND")) P.J.mid_round = atoi(e);
+    P.J.mid_event = P.agglo_done;
+    enqueue_chunk(P.J, PH_AGGLO);
+    P.J.mid_event = nullptr;
+    if (!P.J.mid_recorded) SHARP_HIP_CHECK(hipEventRecord(P.agglo_done, ctx().stream));
+    P.agglo_enqueued = true;
+    return P.agglo_done;
+}
+
+void hc_prefetch_finish(HcPrefetch &P, bool want_v, std::vector<HcResult> &out) {
+    out.assign(P.tasks.size(), HcResult());
+    if (!P.agglo_enqueued) hc_prefetch_agglomerate(P);
+    enqueue_chunk(P.J, PH_STATS);
+    finish_chunk(P.tasks, P.J, want_v, out);
 }
 
 }  // namespace sharp

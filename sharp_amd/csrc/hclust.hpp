@@ -1,6 +1,7 @@
 // hclust.hpp -- batched get_opt_hclust (R/get_opt_hclust.R:33-244) on the GPU: distance build,
 // agglomerative tree, cutree for every candidate k, median silhouette, CH index, model selection.
 #pragma once
+#include <memory>
 #include <vector>
 
 #include "common.hpp"
@@ -42,5 +43,19 @@ constexpr int kHcLdsMaxN = 7168;
 constexpr int kHcMaxN = 16384;
 
 void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::vector<HcResult> &out);
+
+// The same batch in two halves, for a caller that overlaps the front of its NEXT block with the tail of the current one
+// (SHARP_unlimited with several blocks per GPU): hc_prefetch_begin uploads the descriptors and enqueues the row preparation and the
+// distance GEMM on the stream that is current at the call (StreamScope) into a workspace slot of its own (slot 0 / 1, alternating);
+// hc_prefetch_finish makes the main stream wait for that, runs the agglomeration and the statistics and fetches the results --
+// exactly what get_opt_hclust_batch does for a batch of one chunk.  Only for batches of at most one task per CU.
+struct HcPrefetch;
+bool hc_prefetch_possible(const std::vector<HcTask> &tasks);
+std::shared_ptr<HcPrefetch> hc_prefetch_begin(std::vector<HcTask> tasks, int slot);
+// (optional, before hc_prefetch_finish) enqueues the agglomeration alone and returns an event recorded behind it on the main stream:
+// what the caller makes the NEXT block's front wait for, so that it runs under the statistics and the host-bound tail, not beside
+// the HBM-bound agglomeration
+hipEvent_t hc_prefetch_agglomerate(HcPrefetch &P);
+void hc_prefetch_finish(HcPrefetch &P, bool want_v, std::vector<HcResult> &out);
 
 }  // namespace sharp

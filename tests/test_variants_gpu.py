@@ -48,7 +48,7 @@ def test_raw_mode_without_log_transform(sa, oracle):
     # flag = FALSE: projection of the raw values (R/SHARP.R:343-345 skipped); fixed-point scale from a max|x| pre-pass
     X = _data(oracle, n=300) * 37.5
     ref = oracle.SHARP(X, K=3, rN_seed=5, flag=False)
-    pred, x0, viE, p, K, path, rc = sa.api._run_sharp(X, 3, None, None, None, None, None, None, None, None, None, None, None, False,
+    pred, x0, viE, p, K, path, rc, _ = sa.api._run_sharp(X, 3, None, None, None, None, None, None, None, None, None, None, None, False,
                                                       None, 5, True)
     assert np.array_equal(pred, ref["pred_clusters"])
     np.testing.assert_allclose(viE, ref["viE"], rtol=0, atol=1e-9 * np.abs(ref["viE"]).max())
