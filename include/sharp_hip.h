@@ -223,6 +223,11 @@ int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long lo
                                    long long *counts, double *viE);
 int sharp_unlimited_merge(const double *means, const long long *counts, int nC, int p, long long ncells, int N_cluster,
                           int minN, int maxN, int *final_id, int *n_final);
+/* One-shot hint for a caller that runs its blocks one call at a time (a rank of the sharded run with several blocks per GPU): the block
+ * of the call AFTER the next one (same genes, projector, parameters), already resident in HBM.  The next sharp_unlimited_block_view_dev
+ * call enqueues that block's projection and distance matrices on a side stream under its own host-bound tail (what
+ * sharp_SHARP_unlimited_dev does between its blocks); the call after it finds them done.  NULL clears the hint.  Results do not change. */
+int sharp_unlimited_next_block_dev(const float *dX_next, long long nb_next, long long ld_next);
 
 /* ---- get_marker_genes (R/get_marker_genes.R:25-264), the per-gene pass :120-152 ---------------- */
 /* X genes x cells column-major (host, leading dimension ld) or dX fp32 on the device; label[n] in 1..n_cluster

@@ -521,6 +521,9 @@ namespace {
 // at first touch; run_Mtimes_SHARP and testlog + SHARP call in on the same matrix again and again).
 HostBlock &host_block() { static HostBlock b; return b; }
 
+struct NextHint { const float *dX = nullptr; long long nb = 0, ld = 0; };
+NextHint &next_hint() { static NextHint h; return h; }
+
 // the body shared by the host-matrix, CSC and device entry points of SHARP()
 int sharp_run_block(XRef dX, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells, int partition_ncells,
                     int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN, double sil_thre,
@@ -647,6 +650,15 @@ int sharp_SHARP_csc(const int *colptr, const int *rowidx, const double *val, int
                            x0_cap_cols, x0_cols, p_used, K_used, path);
 }
 
+/* One-shot hint for a caller that runs its blocks one call at a time (a rank of the sharded run with several blocks): the block that
+ * the NEXT-BUT-ONE call will bring (same genes, projector and parameters as the next call's block), already resident in HBM.  The next
+ * sharp_unlimited_block*_dev call prepares it under its own tail.  dX = NULL clears the hint. */
+int sharp_unlimited_next_block_dev(const float *dX_next, long long nb_next, long long ld_next) {
+    NextHint &h = next_hint();
+    h.dX = dX_next; h.nb = nb_next; h.ld = ld_next;
+    return SHARP_OK;
+}
+
 int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
                                    double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
                                    long long *counts, double *viE) {
@@ -656,7 +668,10 @@ int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long lo
     std::vector<int> pr;
     std::vector<double> mn;
     std::vector<long long> cn;
-    unlimited_block_dev(dX, m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, viE, flag != 0);
+    const NextHint h = next_hint();
+    next_hint() = NextHint();
+    unlimited_block_dev(dX, m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, viE, flag != 0, nullptr,
+                        h.dX ? XRef(h.dX) : XRef(), h.nb, h.ld);
     SHARP_REQUIRE(static_cast<int>(cn.size()) <= cap_rows, "sharp_unlimited_block_view_dev: centroid buffer too small");
     std::copy(pr.begin(), pr.end(), pred);
     std::copy(mn.begin(), mn.end(), means);

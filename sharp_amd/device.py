@@ -72,13 +72,17 @@ def SHARP_dev(dX, ensize_K=0, reduced_ndim=0, base_ncells=0, partition_ncells=0,
                   "path": "SHARP_large" if path.value else "SHARP_small", "warn": rc}
 
 
-def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag=True, viE=None):
+def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag=True, viE=None, next_block=None):
     """One block of SHARP_unlimited: labels, per-cluster means of viE (G x p) and cluster sizes.
 
     flag: the log flag of the block's SHARP() call; viE: optional (nb, p) float64 host array that receives the block's
-    ensemble-mean projection (viewflag)."""
+    ensemble-mean projection (viewflag); next_block: the resident block of the NEXT call (same genes / projector / parameters):
+    its projection and distance matrices are prepared under this call's tail (sharp_unlimited_next_block_dev)."""
     _lib.ensure_init()
     nb, m = dX.shape
+    if next_block is not None:
+        check(lib().sharp_unlimited_next_block_dev(C.c_void_p(next_block.data_ptr()), C.c_longlong(next_block.shape[0]),
+                                                   C.c_longlong(next_block.stride(0))))
     pred = np.zeros(nb, np.int32)
     means = np.empty((cap_rows, p))                 # only the first G rows are written and returned
     counts = np.empty(cap_rows, np.int64)

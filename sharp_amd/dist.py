@@ -64,14 +64,20 @@ def unlimited_sharded(local_blocks, local_block_ids, ncells_per_block, run_block
     local_blocks      : this rank's block objects (passed to run_block)
     local_block_ids   : their global block indices (block b is owned by rank b % world)
     ncells_per_block  : cells of EVERY global block (needed for p and the k-range rules)
-    run_block(block, p) -> (pred (nb,), means (G, p), counts (G,))
+    run_block(block, p[, next_block]) -> (pred (nb,), means (G, p), counts (G,))
     merge(means, counts, ncells_total, N_cluster, minN, maxN) -> (final_id (nC,), n_final)
     Returns {global block id: final labels of that block} for the local blocks, and n_final."""
     ncells_total = int(sum(ncells_per_block))
     p = global_reduced_dim(ncells_total)
     preds, means_list, counts_list = [], [], []
-    for blk in local_blocks:
-        pr, mn, cn = run_block(blk, p)
+    import inspect
+
+    takes_next = len(inspect.signature(run_block).parameters) >= 3      # run_block(block, p, next_block): lets the library prepare the
+    for i, blk in enumerate(local_blocks):                               # rank's next block under the current one's tail
+        if takes_next:
+            pr, mn, cn = run_block(blk, p, local_blocks[i + 1] if i + 1 < len(local_blocks) else None)
+        else:
+            pr, mn, cn = run_block(blk, p)
         preds.append(pr)
         means_list.append(np.asarray(mn, np.float64).reshape(-1, p))
         counts_list.append(np.asarray(cn, np.int64))

@@ -112,8 +112,8 @@ def test_cfg3_whole_and_sharded(env):
     # the sharded form (block step per block, then the merge on the gathered centroid tables) gives the same labels
     proj = sa.Projector(m, p, [50 + RN + k for k in range(1, 6)])
     preds, means, counts = [], [], []
-    for b in range(B):
-        pr, mn, cn = dev.unlimited_block_dev(blocks[b], p, proj.handle, 5, RN)
+    for b in range(B):                                                    # (blocks 5.. with the next block prepared under the current one's tail)
+        pr, mn, cn = dev.unlimited_block_dev(blocks[b], p, proj.handle, 5, RN, next_block=blocks[b + 1] if 5 <= b < B - 1 else None)
         preds.append(pr); means.append(mn); counts.append(cn)
     proj.close()
     fid, nf = dev.unlimited_merge(np.concatenate(means, 0), np.concatenate(counts, 0), B * nb)
