@@ -196,7 +196,7 @@ struct LargeFront {
     }
 };
 namespace {
-struct PendingFront { std::unique_ptr<LargeFront> f; hipStream_t stream = nullptr; int parity = 0; };
+struct PendingFront { std::unique_ptr<LargeFront> f; hipStream_t stream = nullptr; hipEvent_t main_done = nullptr; int parity = 0; };
 PendingFront &pending_front() { static PendingFront p; return p; }
 }  // namespace
 
@@ -289,6 +289,14 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
             }
             {
                 // (the main stream has nothing pending that the next block depends on; its buffers are its own)
+                // This block's own front ran on the main stream (first block of a call): the side stream must not start before it has
+                // finished -- the RP stage's chunk buffers (rp2.hip) are shared, and the next block's compaction would overwrite
+                // entries this block's apply kernels are still reading.  (A front prepared ahead ran on the side stream itself.)
+                if (!F.hc) {
+                    if (!PF.main_done) SHARP_HIP_CHECK(hipEventCreateWithFlags(&PF.main_done, hipEventDisableTiming));
+                    SHARP_HIP_CHECK(hipEventRecord(PF.main_done, ctx().stream));
+                    SHARP_HIP_CHECK(hipStreamWaitEvent(PF.stream, PF.main_done, 0));
+                }
                 StreamScope scope(PF.stream);
                 if (after_agglo) SHARP_HIP_CHECK(hipStreamWaitEvent(PF.stream, after_agglo, 0));
                 large_front(*N, a, true);
