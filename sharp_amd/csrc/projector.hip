@@ -286,8 +286,9 @@ __global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int
 // eight-byte bank pairs (MI355X_MICROARCH.md, LDS: the ds_write_b64 row): one cycle plus one per extra code of the same class
 // (component mod 16) in the instruction.  So the codes are dealt to the four slot columns round-robin in class order (the codes of
 // a class land in different columns), within the room of their sign's lanes: SQ_LDS_BANK_CONFLICT -55 % against component order.
-// Unused slots keep kCodePad; every slot of a negative lane carries the sign bit, the consumer reads it from slot 0.
-__host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint32_t gw, size_t g, size_t extra_base, uint16_t *ent) {
+// The lanes the gene does not use keep kCodePad in every slot; the unused slots of a lane that holds codes get the lane's pad_code
+// (projector.hpp); every slot of a negative lane carries the sign bit, the consumer reads it from slot 0.
+__host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint32_t gw, int ncomp, size_t g, size_t extra_base, uint16_t *ent) {
     const uint32_t span = 4u * gw;
     uint32_t np = 0;
     for (uint32_t i = 0; i < n; ++i) np += (src[i] & 0x8000u) ? 0u : 1u;
@@ -334,14 +335,18 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
         *slot_ptr(lane0[s] + (static_cast<uint32_t>(cs >> (16u * q)) & 0xffffu), q) = static_cast<uint16_t>((src[i] & 0x7fffu) << 3);
         if (s) cnt[1] += 1ull << (16u * q); else cnt[0] += 1ull << (16u * q);
     }
-    for (uint32_t l = 0; l < cap[1]; ++l)
-        for (uint32_t q = 0; q < 4u; ++q) *slot_ptr(lane0[1] + l, q) |= static_cast<uint16_t>(kCodeNeg);
+    for (uint32_t l = 0; l < cap[0] + cap[1]; ++l)       // (every lane of a sign's range holds at least one code)
+        for (uint32_t q = 0; q < 4u; ++q) {
+            uint16_t *sp = slot_ptr(l, q);
+            if (*sp == static_cast<uint16_t>(kCodePad)) *sp = pad_code(ncomp, l % gw);
+            if (l >= lane0[1]) *sp |= static_cast<uint16_t>(kCodeNeg);
+        }
     if (cap[0] + cap[1] > gw) ent[g * span + span - 1] |= static_cast<uint16_t>(kCodeMore);
 }
 
 // one thread per gene: order the gene's codes by component (the order of the host build: projector, then column) and
 // write them into the fixed-stride lane-major segments (+ overflow segments)
-__global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, uint16_t *__restrict__ flat, int gw,
+__global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, uint16_t *__restrict__ flat, int gw, int ncomp,
                                    const uint2 *__restrict__ ovf_slot, const uint2 *__restrict__ ovf_info, int novf,
                                    uint16_t *__restrict__ ent) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -356,7 +361,7 @@ __global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, u
     }
     size_t extra_base = 0;
     if (novf > 0) extra_base = ovf_slot[g].x;
-    place_gene(src, len, static_cast<uint32_t>(gw), static_cast<size_t>(g), extra_base, ent);
+    place_gene(src, len, static_cast<uint32_t>(gw), ncomp, static_cast<size_t>(g), extra_base, ent);
 }
 __global__ void proj_fill_u16_kernel(uint16_t *p, size_t n, uint16_t v) {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) p[i] = v;
@@ -445,7 +450,7 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
             const uint16_t *src = flat.data() + rowptr[g];
             size_t extra_base = 0;
             if (lanes[g] > grp.gw) extra_base = ovf_info[ov++].x;
-            place_gene(src, len, static_cast<uint32_t>(grp.gw), static_cast<size_t>(g), extra_base, ent.data());
+            place_gene(src, len, static_cast<uint32_t>(grp.gw), grp.ncomp, static_cast<size_t>(g), extra_base, ent.data());
         }
         grp.ent.alloc(ent.size());
         grp.ent.upload(ent.data(), ent.size());
@@ -578,7 +583,7 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         hipLaunchKernelGGL(proj_fill_u16_kernel, dim3(256), dim3(256), 0, c.stream, grp.ent.p, nent, static_cast<uint16_t>(kCodePad));
         hipLaunchKernelGGL(proj_fill_kernel, dim3(16, grp.kcount, S), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
                            static_cast<uint32_t>(p), d_rowptr.p, d_fill.p, d_flat.p);
-        hipLaunchKernelGGL(proj_layout_kernel, dim3((m + 255) / 256), dim3(256), 0, c.stream, m, d_rowptr.p, d_flat.p, grp.gw,
+        hipLaunchKernelGGL(proj_layout_kernel, dim3((m + 255) / 256), dim3(256), 0, c.stream, m, d_rowptr.p, d_flat.p, grp.gw, grp.ncomp,
                            grp.ovf_slot.p, grp.ovf_info.p, grp.novf, grp.ent.p);
         launch_check("proj_layout_kernel");
         stream_sync();                                   // the temporaries above are released on scope exit

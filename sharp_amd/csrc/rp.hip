@@ -223,7 +223,7 @@ template <int GW, bool VEC>
 static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float *dX, int m, int n, long long ld,
                       int log_flag, int fix_bits, double *dE, long long ldE, const int *row_map) {
     Ctx &c = ctx();
-    const size_t lds = RP_CAP * sizeof(NzSlot) + static_cast<size_t>(g.ncomp) * 8;
+    const size_t lds = RP_CAP * sizeof(NzSlot) + static_cast<size_t>(g.ncomp + kDumpSlots) * 8;   // + the pad codes' dump accumulators
     const int nsteps = (m + RP_STEP - 1) / RP_STEP;
     const int step_len = ((m + nsteps - 1) / nsteps + 3) / 4 * 4;
     auto kern = rp_scatter_kernel<GW, VEC>;

@@ -4,19 +4,19 @@
 //       cell wave-locally (ballot prefix), evaluates fp64 log2(1+x) -> 44-bit fixed point for them and appends
 //       (gene, fix) to the cell's list in a chunk buffer.  No workgroup barriers: every wave is independent
 //       and keeps two 1024-gene units in flight behind the one it is compacting.
-//   rp_apply_kernel (stream): per cell, walks the list in 64-entry batches; each GW-lane group gathers a gene's
-//       packed row list (one 8-byte load per lane, L2 resident) and adds +-fix into the per-cell accumulators
-//       in LDS with ds_add_u64: a code is its accumulator's LDS address after one AND, the lane's signed term
-//       comes from a (+fix, -fix) pair in LDS picked by the lane's sign bit (projector.hpp); batches are
-//       software-pipelined (entries of batch i+2 and row lists of batch i+1 are in flight while the atomics of
-//       batch i run) and the next cell's first batch is set up before the two barriers around the epilogue that
-//       scales by sqrt(s)/sqrt(p) and writes the K*p row of E.
+//   rp_apply_kernel (stream): per cell, walks the list in 64-entry batches; each GW-lane group takes the entries held by its own
+//       lanes: gene and term of entry u reach the group by DPP row broadcast, each lane fetches its 8 bytes of that gene's packed row
+//       list (L2 resident) and adds +-term into the per-cell accumulators in LDS with ds_add_u64: a code is its accumulator's LDS
+//       address after one AND (projector.hpp).  Four batches are in flight per wave (atomics, row lists, terms, entry words); the
+//       next cell's first batches are set up before the two barriers around the epilogue that scales by sqrt(s)/sqrt(p) and
+//       writes the K*p row of E.  The loop holds no LDS operation but the atomics and waits for no load it has just issued.
 // Chunk c+1 is compacted while chunk c is applied, so the HBM stream overlaps the L2 gather and the LDS
 // atomics; integer accumulation keeps E bit-reproducible whatever the interleaving.
 #include "projector.hpp"
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace sharp {
 
@@ -78,24 +78,37 @@ __global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 4 : 2) void rp_compact
                                                                 long long *__restrict__ fixes) {
     __shared__ uint32_t sg[CP_THREADS / 64][CP_UNIT];
     __shared__ T sx[CP_THREADS / 64][CP_UNIT];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the unit bookkeeping runs on the SALU)
     const int units = (m + CP_UNIT - 1) / CP_UNIT;
     const long long total = static_cast<long long>(ncell) * units;
     const long long stride = static_cast<long long>(gridDim.x) * (CP_THREADS / 64);
-    long long it = static_cast<long long>(blockIdx.x) * (CP_THREADS / 64) + w;
-    if (it >= total) return;
-    auto fetch = [&](long long q) -> CpVals<T> {
-        const long long qq = q < total ? q : total - 1;
-        const long long c = qq / units;
-        return cp_load_unit<T>(X + (cell0 + c) * ld, static_cast<int>(qq - c * units), ld, lane);
+    const long long it0 = static_cast<long long>(blockIdx.x) * (CP_THREADS / 64) + w;
+    if (it0 >= total) return;
+    // (cell, unit) of the unit being worked on and of the unit being fetched (two strides ahead), advanced by (stride / units,
+    // stride % units) with a carry: the two 64-bit divisions per unit this replaces were a quarter of the kernel's vector instructions
+    const int sdiv = static_cast<int>(stride / units), smod = static_cast<int>(stride % units);
+    int c = static_cast<int>(it0 / units), u = static_cast<int>(it0 % units);
+    int fc = c, fu = u;
+    auto advance = [&](int &cc, int &uu) {
+        cc += sdiv;
+        uu += smod;
+        if (uu >= units) { uu -= units; ++cc; }
     };
-    CpVals<T> b1 = fetch(it), b2 = fetch(it + stride);
-    for (; it < total; it += stride) {
+    auto fetch = [&]() -> CpVals<T> {                     // the unit at (fc, fu), clamped to the chunk's last one; then one stride on
+        const bool in = fc < ncell;
+#ifdef SHARP_ABLATE_XSTREAM     // (diagnostic: every cell read from one of 64 columns, i.e. no HBM stream)
+        const CpVals<T> r = cp_load_unit<T>(X + ((cell0 + (in ? fc : ncell - 1)) & 63) * ld, in ? fu : units - 1, ld, lane);
+#else
+        const CpVals<T> r = cp_load_unit<T>(X + (cell0 + (in ? fc : ncell - 1)) * ld, in ? fu : units - 1, ld, lane);
+#endif
+        advance(fc, fu);
+        return r;
+    };
+    CpVals<T> b1 = fetch(), b2 = fetch();
+    for (; c < ncell; advance(c, u)) {
         const CpVals<T> b0 = b1;
         b1 = b2;
-        b2 = fetch(it + 2 * stride);
-        const long long c = it / units;
-        const int u = static_cast<int>(it - c * units);
+        b2 = fetch();
         const T *vals = b0.v;
         const int ubase = u * CP_UNIT;                     // gene of candidate q: ubase + CpLayout<T>::gene_of(lane, q)
         unsigned nzm = 0;
@@ -107,13 +120,16 @@ __global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 4 : 2) void rp_compact
             for (int q = 0; q < 16; ++q) nzm |= (ubase + CpLayout<T>::gene_of(lane, q) < m && vals[q] != T(0)) ? (1u << q) : 0u;
         }
         const int mine = __popc(nzm);
-        int incl = mine;                                   // inclusive prefix sum over the wave
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d);
-            incl += lane >= d ? t : 0;
-        }
-        const int cntw = __shfl(incl, 63);
+        // inclusive prefix sum over the wave: four shifts inside the rows of 16 lanes, then row 0 -> 1 and 2 -> 3, then rows 0-1 -> 2-3
+        // (DPP: no LDS shuffles)
+        int incl = mine;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);   // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);   // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);   // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);   // row_shr:8
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+        const int cntw = __builtin_amdgcn_readlane(incl, 63);
         unsigned int base = 0;
         if (lane == 0) base = atomicAdd(&counts[c], static_cast<unsigned int>(cntw));
         int pos = incl - mine;
@@ -125,10 +141,10 @@ __global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 4 : 2) void rp_compact
                 ++pos;
             }
         }
-        base = __shfl(base, 0);
+        base = __builtin_amdgcn_readfirstlane(base);
         __builtin_amdgcn_wave_barrier();
-        uint32_t *gout = genes + c * cap + base;
-        long long *fout = fixes + c * cap + base;
+        uint32_t *gout = genes + static_cast<long long>(c) * cap + base;
+        long long *fout = fixes + static_cast<long long>(c) * cap + base;
         for (int e0 = 0; e0 < cntw; e0 += 64) {            // one lane per non-zero
             const int e = e0 + lane;
             const bool live = e < cntw;
@@ -156,6 +172,39 @@ __global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 4 : 2) void rp_compact
     }
 }
 
+// compile-time loop: body(std::integral_constant<int, u>) for u = 0 .. N-1 (a DPP control word must be a constant expression)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F &&body) {
+    if constexpr (I < N) {
+        body(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(body);
+    }
+}
+
+// Entry u of a lane group's own GW entries, broadcast to the group's GW lanes without touching the LDS: the group's entries sit in
+// the group's own lanes, a group is (part of) one DPP row of 16 lanes, and `row_newbcast:n` copies lane n of every row to the row's
+// lanes; groups narrower than a row take their own part through the bank mask (one bank = 4 lanes).
+template <int GW, int U_>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t x) {
+    static_assert(GW == 16 || GW == 8 || GW == 4, "a lane group is 4, 8 or 16 lanes");
+    uint32_t v = 0u;
+    if constexpr (GW == 16) {
+        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + U_, 0xf, 0xf, true));
+    } else if constexpr (GW == 8) {
+        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + U_, 0xf, 0x3, true));
+        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(x), 0x150 + 8 + U_, 0xf, 0xc, true));
+    } else {
+        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + U_, 0xf, 0x1, true));
+        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(x), 0x150 + 4 + U_, 0xf, 0x2, true));
+        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(x), 0x150 + 8 + U_, 0xf, 0x4, true));
+        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(x), 0x150 + 12 + U_, 0xf, 0x8, true));
+    }
+    return v;
+}
+
+// A batch = 64 list entries, one per lane; lane group `grp` (GW lanes) works through ITS OWN lanes' entries (u = 0 .. GW-1): gene and
+// term of entry u reach the group's lanes by DPP row broadcast (no LDS scratch: the LDS pipe does the atomics and nothing else),
+// each lane fetches its 8 bytes of that gene's row list and adds the +-term at its four codes.
 template <int GW>
 __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     int ncell, long long cell0, int cap, const unsigned int *__restrict__ counts, const uint32_t *__restrict__ genes,
@@ -163,39 +212,43 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     const uint2 *__restrict__ ovf_slot, const uint2 *__restrict__ ovf_info, int novf, int ncomp, double inv_fix, double val,
     double out_scale, double *__restrict__ E, long long ldE, int comp0, const int *__restrict__ row_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NW = AP_THREADS / 64, NG = 64 / GW, SPAN = 4 * GW, U = GW;   // a batch = 64 entries = U per group
+    constexpr int NW = AP_THREADS / 64, SPAN = 4 * GW, U = GW;   // a batch = 64 entries = U per group
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = lane / GW, lg = lane % GW;
-    // per-wave scratch: two buffers of 64 entries: gene, and the pair (+term, -term) -- a lane picks its signed term with the address
-    long long *sfix = reinterpret_cast<long long *>(acc + ncomp) + wave * 256;
-    uint32_t *sgen = reinterpret_cast<uint32_t *>(reinterpret_cast<long long *>(acc + ncomp) + NW * 256) + wave * 128;
-    long long *stab = reinterpret_cast<long long *>(reinterpret_cast<uint32_t *>(reinterpret_cast<long long *>(acc + ncomp) + NW * 256) + NW * 128);   // [CP_TAB]
-    for (int i = tid; i < CP_TAB; i += AP_THREADS) stab[i] = fixtab[i];
-    typedef long long ll2 __attribute__((ext_vector_type(2)));
-    auto put_term = [&](int slot, long long f) { *reinterpret_cast<ll2 *>(sfix + 2 * slot) = (ll2){f, -f}; };
-    auto signed_term = [&](int slot, uint32_t code0) -> unsigned long long {
-        return static_cast<unsigned long long>(sfix[2 * slot + static_cast<int>(code0 & kCodeNeg)]);
-    };
+    const int lg = lane % GW;
     for (int c = tid; c < ncomp; c += AP_THREADS) acc[c] = 0ull;
     __syncthreads();
 
-    // Per-cell state of this wave.  A cell's first batch is set up (entries -> scratch, row lists and the second batch's entries in
-    // flight) BEFORE the previous cell's barrier and epilogue, so its two dependent global round trips run under them.
-    int nnz = 0, nb = 0, buf = 0;
+    // Per-cell state of this wave: a four-stage pipeline over the cell's batches.  While the atomics of batch b run, the row lists of
+    // batch b+NW, the terms of batch b+2NW (table look-up on the entry words fetched one iteration earlier) and the entry words of batch
+    // b+3NW are in flight: no load is waited for in the iteration that issues it, and the loop holds no LDS operation but the atomics.
+    // A cell's first batches are set up BEFORE the previous cell's barrier and epilogue, so their dependent round trips run under them.
+    int nnz = 0, nb = 0;
     const uint32_t *gsrc = genes;
     const long long *fsrc = fixes;
-    uint32_t gL = 0u; long long fL = 0ll;
+    uint32_t gC = 0u, gL = 0u, wR = 0u;   // genes of the batch being added / of the batch after the next; entry words of the one after that
+    long long fC = 0ll, fL = 0ll;         // their terms
     uint2 cd[U], cdn[U];
-    auto load_entry = [&](int b, uint32_t &g, long long &f) {   // lane = entry of batch b; unconditional + mask
+    auto load_word = [&](int b) -> uint32_t {                  // lane = entry of batch b; unconditional, clamped
         const int e = (b << 6) + lane;
-        const int ec = e < nnz ? e : 0;
-        const uint32_t gg = gsrc[ec];
-        long long ff;
-        if (gg & kEntryFull) ff = fsrc[ec];              // rare: a value outside the table
-        else ff = stab[(gg >> kEntryCountShift) & 0xffu];
-        g = e < nnz ? (gg & kEntryGeneMask) : dummy_seg;
+        return gsrc[e < nnz ? e : 0];
+    };
+    auto decode = [&](int b, uint32_t w, uint32_t &g, long long &f) {
+        const int e = (b << 6) + lane;
+        long long ff = fixtab[(w >> kEntryCountShift) & 0xffu];   // 2 KB, cache resident (a read of an LDS copy would queue behind the atomics)
+        if (__ballot((w & kEntryFull) != 0u) != 0ull) {        // rare, wave-uniform test: a value outside the table
+            if (w & kEntryFull) ff = fsrc[e < nnz ? e : 0];
+        }
+        g = e < nnz ? (w & kEntryGeneMask) : dummy_seg;
         f = e < nnz ? ff : 0ll;
+    };
+    const unsigned char *entb = reinterpret_cast<const unsigned char *>(ent);
+    auto load_lists = [&](uint32_t g, uint2 (&dst)[U]) {
+        const uint32_t gofs = g * static_cast<uint32_t>(SPAN * 2);    // byte offset of the lane's own entry's segment (32 bits: < 2^21 segments)
+        static_for<U>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            dst[u] = *reinterpret_cast<const uint2 *>(entb + (group_bcast<GW, u>(gofs) + static_cast<uint32_t>(8 * lg)));
+        });
     };
     auto begin_cell = [&](long long ci) {
         nnz = static_cast<int>(counts[ci]);
@@ -203,72 +256,78 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
         gsrc = genes + ci * cap;
         fsrc = fixes + ci * cap;
         if (wave < nb) {
-            buf = 0;
-            load_entry(wave, gL, fL);
-            sgen[lane] = gL; put_term(lane, fL);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int u = 0; u < U; ++u) cd[u] = *reinterpret_cast<const uint2 *>(ent + static_cast<size_t>(sgen[grp + u * NG]) * SPAN + 4 * lg);
-            load_entry(wave + NW, gL, fL);
+            const uint32_t w0 = load_word(wave), w1 = load_word(wave + NW);
+            wR = load_word(wave + 2 * NW);
+            decode(wave, w0, gC, fC);
+            decode(wave + NW, w1, gL, fL);
+            load_lists(gC, cd);
         }
+    };
+    // one pipeline step: the atomics of batch b from the row lists in `cur`, the row lists of batch b+NW into `nxt`
+    auto step = [&](int b, uint2 (&cur)[U], uint2 (&nxt)[U]) {
+        const uint32_t gN = gL;
+        const long long fN = fL;
+        load_lists(gN, nxt);
+        decode(b + 2 * NW, wR, gL, fL);
+        asm volatile("" : "+v"(gL));      // the old entry words are dead before the new ones are asked for (else the loop ends on a copy
+        wR = load_word(b + 3 * NW);       // of the word just requested, i.e. on its whole round trip)
+        const uint32_t plo = static_cast<uint32_t>(fC), phi = static_cast<uint32_t>(static_cast<unsigned long long>(fC) >> 32);
+        const long long fneg = -fC;
+        const uint32_t nlo = static_cast<uint32_t>(fneg), nhi = static_cast<uint32_t>(static_cast<unsigned long long>(fneg) >> 32);
+        uint32_t more = 0u;
+        static_for<U>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const bool neg = (cur[u].x & kCodeNeg) != 0u;     // a lane's four codes share their sign
+            // (all four broadcasts with every lane enabled: a DPP read of a disabled lane returns nothing)
+            const uint32_t bpl = group_bcast<GW, u>(plo), bph = group_bcast<GW, u>(phi);
+            const uint32_t bnl = group_bcast<GW, u>(nlo), bnh = group_bcast<GW, u>(nhi);
+#ifdef SHARP_ABLATE_SELECT
+            const uint32_t lo = plo + (neg ? 1u : 0u), hi = phi;
+#else
+            const uint32_t lo = neg ? bnl : bpl, hi = neg ? bnh : bph;
+#endif
+            scatter_codes_signed<0>(cur[u], (static_cast<unsigned long long>(hi) << 32) | lo);
+            more |= cur[u].y;
+        });
+        // rare: a gene may continue in overflow segments (flag in the last slot of its segment: the group's last lane sees it).  One
+        // scalar test per batch.  (Broadcasts again, not LDS shuffles: a returning LDS operation anywhere in the loop makes every
+        // iteration wait for its atomics.)
+        if (__ballot((more & (kCodeMore << 16)) != 0u) != 0ull) {
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const unsigned long long full = __ballot((cur[u].y & (kCodeMore << 16)) != 0u);
+                const uint32_t g = group_bcast<GW, u>(gC);
+                const uint32_t bpl = group_bcast<GW, u>(plo), bph = group_bcast<GW, u>(phi);
+                if ((full >> (lane | (GW - 1))) & 1ull) {
+                    const long long f = static_cast<long long>((static_cast<unsigned long long>(bph) << 32) | bpl);
+                    const uint2 oi = ovf_slot[g];
+                    for (uint32_t sg = 0; sg < oi.y; ++sg) {
+                        const uint2 c2 = *reinterpret_cast<const uint2 *>(ent + (static_cast<size_t>(oi.x) + sg) * SPAN + 4 * lg);
+                        scatter_codes_signed<0>(c2, static_cast<unsigned long long>((c2.x & kCodeNeg) ? -f : f));
+                    }
+                }
+            });
+        }
+        gC = gN;
+        fC = fN;
     };
     if (static_cast<long long>(blockIdx.x) < ncell) begin_cell(blockIdx.x);
     for (long long ci = blockIdx.x; ci < ncell; ci += gridDim.x) {
         if (wave < nb) {
-            for (int b = wave; b < nb; b += NW) {
-                const int nbuf = buf ^ 1;
-                // entries of batch b+NW (loaded one iteration ago) -> the other scratch buffer
-                sgen[nbuf * 64 + lane] = gL; put_term(nbuf * 64 + lane, fL);
-                __builtin_amdgcn_wave_barrier();
-                // row lists of batch b+NW and entries of batch b+2NW go in flight ...
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    cdn[u] = *reinterpret_cast<const uint2 *>(ent + static_cast<size_t>(sgen[nbuf * 64 + grp + u * NG]) * SPAN + 4 * lg);
-                load_entry(b + 2 * NW, gL, fL);
-                // ... while the atomics of batch b run
-                uint32_t more = 0u;
-                unsigned long long term = signed_term(buf * 64 + grp, cd[0].x);
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    // the next gene's term is read before this gene's atomics go out: LDS operations return in order, so its
-                    // wait then leaves these four atomics in flight instead of draining them
-                    const unsigned long long tnext = u + 1 < U ? signed_term(buf * 64 + grp + (u + 1) * NG, cd[u + 1 < U ? u + 1 : u].x) : 0ull;
-                    asm volatile("" : "+v"(term));   // the one wait for this gene's term sits here, not in front of every conditional atomic
-                    scatter_codes_signed<0>(cd[u], term);
-                    more |= cd[u].y;
-                    term = tnext;
-                }
-                // rare: a gene may continue in overflow segments (flag in the last slot of its segment: the group's last lane sees
-                // it).  One scalar test per batch.
-                if (__ballot((more & (kCodeMore << 16)) != 0u) != 0ull) {
-                    for (int u = 0; u < U; ++u) {
-                        const unsigned long long full = __ballot((cd[u].y & (kCodeMore << 16)) != 0u);
-                        if ((full >> (lane | (GW - 1))) & 1ull) {
-                            const int slot = buf * 64 + grp + u * NG;
-                            const uint32_t g = sgen[slot];
-                            const uint2 oi = ovf_slot[g];
-                            {
-                                for (uint32_t sg = 0; sg < oi.y; ++sg) {
-                                    const uint2 c2 = *reinterpret_cast<const uint2 *>(ent + (static_cast<size_t>(oi.x) + sg) * SPAN + 4 * lg);
-                                    scatter_codes_signed<0>(c2, signed_term(slot, c2.x));
-                                }
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) cd[u] = cdn[u];
-                buf = nbuf;
-                __builtin_amdgcn_wave_barrier();
+            for (int b = wave; b < nb; b += 2 * NW) {          // two steps per trip: the two row-list sets swap roles, nothing is copied
+                step(b, cd, cdn);
+                if (b + NW < nb) step(b + NW, cdn, cd);
             }
         }
-        if (ci + gridDim.x < ncell) begin_cell(ci + gridDim.x);   // (the scratch buffers are this wave's own and its atomics are issued)
+        if (ci + gridDim.x < ncell) begin_cell(ci + gridDim.x);   // (its row lists travel under the barrier and the epilogue)
         __syncthreads();   // every wave's atomics for this cell have landed
         const long long cell = cell0 + ci;
         double *erow = E + (row_map ? static_cast<long long>(row_map[cell]) : cell) * ldE + comp0;
         for (int c = tid; c < ncomp; c += AP_THREADS) {
             const long long a = static_cast<long long>(atomicExch(&acc[c], 0ull));   // read and clear in one LDS operation (ds_wrxchg_rtn_b64)
-            erow[c] = out_scale * (val * (static_cast<double>(a) * inv_fix));
+            // streaming store: E is next read by another kernel, and kept out of the L2 it does not push row lists (and the compaction's
+            // entries) out -- apply 344 -> 331 us, the compaction beside it 175 -> 159 us per launch
+            __builtin_nontemporal_store(out_scale * (val * (static_cast<double>(a) * inv_fix)), &erow[c]);
         }
         __syncthreads();
     }
@@ -276,7 +335,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
 
 namespace {
 struct SplitWs {
-    DevBuf<unsigned int> counts[2];
+    DevBuf<unsigned int> counts;         // entries per cell, all chunks of a call (zeroed once per call)
     DevBuf<uint32_t> genes[2];
     DevBuf<long long> fixes[2];
     DevBuf<long long> fixtab;
@@ -291,7 +350,7 @@ static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell
                          const uint32_t *genes, const long long *fixes, double inv_fix, double *dE, long long ldE, const int *row_map,
                          hipStream_t st) {
     Ctx &c = ctx();
-    const size_t lds = static_cast<size_t>(g.ncomp) * 8 + (AP_THREADS / 64) * 128 * 20 + CP_TAB * 8;
+    const size_t lds = static_cast<size_t>(g.ncomp + kDumpSlots) * 8;
     auto kern = rp_apply_kernel<GW>;
     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     {   // scatter_codes<0>: the accumulators sit at LDS address 0, i.e. the kernel must not have static LDS in front of the dynamic block
@@ -302,6 +361,7 @@ static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell
     int per_cu = 1;
     SHARP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), AP_THREADS, lds));
     per_cu = std::max(1, std::min(per_cu, 4));
+    if (const char *e = getenv("SHARP_RP_AP_WGS")) per_cu = std::max(1, std::min(per_cu, atoi(e)));   // tuning knob
     const long long blocks = std::min<long long>(ncell, static_cast<long long>(c.num_cu) * per_cu);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(AP_THREADS), lds, st, ncell, cell0, cap, counts, genes, fixes,
                        static_cast<const long long *>(sws().fixtab.p),
@@ -334,7 +394,7 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
         chunk = (n + nch - 1) / nch;
     }
     for (int q = 0; q < 2; ++q) {
-        W.counts[q].ensure(chunk); W.genes[q].ensure(chunk * cap); W.fixes[q].ensure(chunk * cap);
+        W.genes[q].ensure(chunk * cap); W.fixes[q].ensure(chunk * cap);
         if (!W.ev_compact[q]) { SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_compact[q], hipEventDisableTiming)); SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_apply[q], hipEventDisableTiming)); }
     }
     if (!W.ev_start) SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_start, hipEventDisableTiming));
@@ -349,6 +409,8 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
     KernelTimer t("rp_stage");                                 // the whole stage, measured on the main stream
     SHARP_HIP_CHECK(hipEventRecord(W.ev_start, c.stream));
     SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_start, 0));
+    W.counts.ensure(n);
+    SHARP_HIP_CHECK(hipMemsetAsync(W.counts.p, 0, static_cast<size_t>(n) * 4, s2));
     const int nchunks = static_cast<int>((n + chunk - 1) / chunk);
     const int units = (m + CP_UNIT - 1) / CP_UNIT;
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -356,26 +418,27 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
         const long long c0 = ch * chunk;
         const int nc = static_cast<int>(std::min<long long>(chunk, n - c0));
         if (ch >= 2) SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_apply[q], 0));      // buffer q free again
-        SHARP_HIP_CHECK(hipMemsetAsync(W.counts[q].p, 0, static_cast<size_t>(nc) * 4, s2));
         const long long waves = static_cast<long long>(nc) * units;
-        const int blocks = static_cast<int>(std::min<long long>((waves + 3) / 4, static_cast<long long>(c.num_cu) * 8));
+        int cp_per_cu = 8;
+        if (const char *e = getenv("SHARP_RP_CP_WGS")) cp_per_cu = std::max(1, atoi(e));   // tuning knob
+        const int blocks = static_cast<int>(std::min<long long>((waves + 3) / 4, static_cast<long long>(c.num_cu) * cp_per_cu));
         {
             KernelTimer tc("rp_compact", s2);
             if (dX.f64)
                 hipLaunchKernelGGL(rp_compact_kernel<double>, dim3(blocks), dim3(CP_THREADS), 0, s2, dX.d64(), m, ld, c0, nc, log_flag, fix_scale,
-                                   cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p);
+                                   cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p);
             else
                 hipLaunchKernelGGL(rp_compact_kernel<float>, dim3(blocks), dim3(CP_THREADS), 0, s2, dX.f32(), m, ld, c0, nc, log_flag, fix_scale,
-                                   cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p);
+                                   cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p);
             launch_check("rp_compact_kernel");
         }
         SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[q], s2));
         SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, W.ev_compact[q], 0));
         {
             KernelTimer ta("rp_apply");
-            if (g.gw == 16) launch_apply<16>(g, pr, nc, c0, cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
-            else if (g.gw == 8) launch_apply<8>(g, pr, nc, c0, cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
-            else launch_apply<4>(g, pr, nc, c0, cap, W.counts[q].p, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
+            if (g.gw == 16) launch_apply<16>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
+            else if (g.gw == 8) launch_apply<8>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
+            else launch_apply<4>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
         }
         SHARP_HIP_CHECK(hipEventRecord(W.ev_apply[q], c.stream));
     }
