@@ -260,6 +260,14 @@ void project_dev(const Projector &pr, XRef X, int m, int n, long long ld, int lo
     SHARP_REQUIRE(ldE >= static_cast<long long>(pr.K) * pr.p, "project: ldE smaller than K*p");
     if (n <= 0) return;
     Ctx &c = ctx();
+    {
+        // a projector of density 1/sqrt(m) >= 1/4 is not sparse: the dense form on the MFMA (also SHARP_RP_KERNEL=dense, for cross-checks)
+        const char *kv = getenv("SHARP_RP_KERNEL");
+        if (kv ? std::string(kv) == "dense" : m <= 16) {
+            project_dev_dense(pr, X, m, n, ld, log_flag, dE, ldE, d_row_map);
+            return;
+        }
+    }
     int fix_bits = std::min(RP_FIX_BITS, X.log_fix_bits);
     if (!log_flag) {
         DevBuf<unsigned int> mx(1);

@@ -87,6 +87,19 @@ def test_sharp_small_matches_oracle(sa, oracle):
     assert np.array_equal(r2["pred_clusters"], ref["pred_clusters"])
 
 
+def test_sharp_small_with_the_dense_rp_form_gives_the_same_labels(sa, oracle, monkeypatch):
+    # the dense-projector MFMA form of the RP matmul (rp_dense.hip) under the whole SHARP_small path: E differs from the sparse
+    # kernels' in the last bits (fp64 FMA chains instead of exact fixed-point sums), the labels do not
+    m, n, G, nm = 2000, 300, 6, 200
+    X = oracle.synth_fill(SEED, m, 0, n, G, nm)
+    ref = oracle.SHARP(X, K=5, rN_seed=2103)
+    monkeypatch.setenv("SHARP_RP_KERNEL", "dense")
+    res = sa.SHARP(X, ensize_K=5, rN_seed=2103, logflag=False, prep=False)
+    monkeypatch.delenv("SHARP_RP_KERNEL")
+    assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+    np.testing.assert_allclose(res["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
+
+
 def test_sharp_large_matches_oracle(sa, oracle):
     # the SHARP_large path at reduced fold size: shuffle (set.seed(50); sample(n)), 5 folds with the last two
     # rebalanced, K*T tasks, per-fold wMetaC, cross-fold sMetaC, un-shuffle

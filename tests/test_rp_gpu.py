@@ -134,3 +134,39 @@ def test_rp_is_bit_reproducible_and_linear_in_blocks(sa, oracle):
     assert np.array_equal(Xh, oracle.synth_fill(SEED, m, 0, 8, 12, 1000))  # generator identical on CPU and GPU
     ref = oracle.project(Xh, oracle.ranM(m, p, 2154), True)
     np.testing.assert_allclose(outs[0][:8, :p].cpu().numpy(), ref, rtol=0, atol=2e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("m,n,p,K,logflag,tpm", [(900, 40, 600, 15, True, False),    # two launch groups
+                                                 (64, 24, 150, 15, True, False),     # every gene runs over several overflow segments
+                                                 (1500, 200, 192, 5, True, True),    # an fp64 block (TPM-like values), several 64-cell tiles
+                                                 (1500, 96, 165, 3, False, False)])  # raw values
+def test_rp_dense_mfma_form_matches_oracle(sa, oracle, monkeypatch, m, n, p, K, logflag, tpm):
+    """The dense-projector form of the RP matmul (rp_dense.hip: the projector scattered into a dense +-1 matrix, log2(1 + x) transposed,
+    one f64 MFMA GEMM per launch group) against the oracle's product, and against the sparse kernels on the same input."""
+    X = oracle.synth_fill(SEED, m, 0, n, 3, max(1, m // 4))
+    if tpm:
+        X = X / np.maximum(X.sum(0, keepdims=True), 1.0) * 1e6      # non-fp32-exact doubles: the block is stored as fp64
+    seeds = [50 + 2103 + k for k in range(1, K + 1)]
+    pr = sa.Projector(m, p, seeds)
+    E_sparse = pr.project(X, logflag=logflag)
+    monkeypatch.setenv("SHARP_RP_KERNEL", "dense")
+    E = pr.project(X, logflag=logflag)
+    monkeypatch.delenv("SHARP_RP_KERNEL")
+    assert E.shape == (n, K * p)
+    for k in range(K):
+        ref = oracle.project(X, oracle.ranM(m, p, seeds[k]), logflag)
+        np.testing.assert_allclose(E[:, k * p:(k + 1) * p], ref, rtol=0, atol=2e-12 * np.abs(ref).max())
+    np.testing.assert_allclose(E, E_sparse, rtol=0, atol=2e-12 * np.abs(E_sparse).max())
+
+
+def test_rp_non_sparse_projector_takes_the_dense_form(sa, oracle):
+    """m <= 16 genes: density 1/sqrt(m) >= 1/4, the projector is not sparse and the library itself picks the dense form."""
+    m, n, p = 12, 70, 40
+    rng = np.random.default_rng(5)
+    X = rng.integers(0, 9, size=(m, n)).astype(np.float64)
+    pr = sa.Projector(m, p, [2154, 2155, 2156])
+    E = pr.project(X, logflag=True)
+    for k, sd in enumerate([2154, 2155, 2156]):
+        ref = oracle.project(X, oracle.ranM(m, p, sd), True)
+        np.testing.assert_allclose(E[:, k * p:(k + 1) * p], ref, rtol=0, atol=2e-12 * max(np.abs(ref).max(), 1.0))
+
