@@ -11,9 +11,9 @@ A "step" is one pass of the hot path over one batch of synthetic input already r
           ensize.K = 15 (SHARP_large: projectors, RP matmul, 375 base-clustering tasks, 25 wMetaC, sMetaC).
   N = 1, --config cfg3: BASELINE.json configs[2]: SHARP_unlimited on 500 000 cells x 20 000 genes as 10 blocks, K = 5.
           (The default run also times cfg3 once, after the timed region, and reports it under "other_configs".)
-  N > 1 : BASELINE.json configs[3]: SHARP_unlimited on 1.3 M cells x 27 000 genes, ensize.K = 5, split into N blocks,
-          one per GPU (162 500 cells each at N = 8), p = 508 from the global count: the total problem is fixed
-          ("scaling": "strong").  The only data-path collective is the all-gather of the per-block centroid table
+  N > 1 : BASELINE.json configs[3]: SHARP_unlimited on 1.3 M cells x 27 000 genes, ensize.K = 5, as its EIGHT blocks of
+          162 500 cells whatever N is, block b on GPU b mod N (one per GPU at N = 8), p = 508 from the global count: the
+          total problem and its labels are the same for every N ("scaling": "strong").  The only data-path collective is the all-gather of the per-block centroid table
           before the final sMetaC (sharp_amd/dist.py).
 The JSON carries `roofline` for the RP matmul stage (rp_compact_kernel + rp_apply_kernel; HBM-bound: X is read once for
 all K projectors) from HIP events on the library's streams inside the timed region, the same stage at the
@@ -35,7 +35,7 @@ RN_SEED = 2103
 G_TRUE, N_MARK = 12, 1000
 CFG2 = dict(cells=50000, genes=20000, K=15)
 CFG3 = dict(cells=500000, genes=20000, K=5, blocks=10)
-CFG4 = dict(cells=1300000, genes=27000, K=5)
+CFG4 = dict(cells=1300000, genes=27000, K=5, blocks=8)     # configs[3]: one block per GPU of an 8-GPU node
 METRIC = "cells/sec end-to-end SHARP (fixed genes, n.RP); ARI vs reference labels"
 
 
@@ -145,24 +145,29 @@ def main():
         cfg["genes"] = args.genes
     n_total, m, K = cfg["cells"], cfg["genes"], cfg["K"]
     if world > 1:
-        # block r of the N: cells [c0, c1) of the one synthetic data set; rank r owns block r
-        bounds = [n_total * r // world for r in range(world + 1)]
-        ncb = [bounds[r + 1] - bounds[r] for r in range(world)]
-        dX = synth_block(bounds[rank], ncb[rank], m)
-        truth = dev.synth_labels(DATA_SEED, bounds[rank], ncb[rank], G_TRUE)
+        # The data set is cut into the EIGHT blocks of configs[3] whatever N is (one block per GPU at N = 8; at N = 2 / 4 a rank runs 4 / 2
+        # blocks one after the other, block b on rank b mod N), so every N clusters the same blocks and finds the same labels: strong
+        # scaling of one fixed problem.  (Tests shrink the data set: blocks below 5000 cells would leave the SHARP_large path, so then one per rank.)
+        B = cfg["blocks"] if n_total // cfg["blocks"] >= 5000 and cfg["blocks"] >= world else world
+        bounds = [n_total * b // B for b in range(B + 1)]
+        ncb = [bounds[b + 1] - bounds[b] for b in range(B)]
+        mine = [b for b in range(B) if sdist.block_owner(b, world) == rank]
+        blocks = [synth_block(bounds[b], ncb[b], m) for b in mine]
+        truth = np.concatenate([dev.synth_labels(DATA_SEED, bounds[b], ncb[b], G_TRUE) for b in mine])
+        dX = blocks[0]
 
         def step():
             p = sdist.global_reduced_dim(n_total)                    # R/SHARP_unlimited.R:65-66: from the GLOBAL cell count
             proj = sharp_amd.Projector(m, p, [50 + RN_SEED + k for k in range(1, K + 1)])   # :97-104, regenerated on every rank
 
-            def run_block(blk, p_):
-                return dev.unlimited_block_dev(blk, p_, proj.handle, K, RN_SEED)
+            def run_block(blk, p_, nxt):                             # (nxt: this rank's next block, prepared under this one's tail)
+                return dev.unlimited_block_dev(blk, p_, proj.handle, K, RN_SEED, next_block=nxt)
 
-            out, nfin, p = sdist.unlimited_sharded([dX], [rank], ncb, run_block, dev.unlimited_merge, device=xdev)
+            out, nfin, p = sdist.unlimited_sharded(blocks, mine, ncb, run_block, dev.unlimited_merge, device=xdev)
             proj.close()
-            state["p"], state["pred"], state["n_clusters"] = p, out[rank], nfin
-        workload = ("SHARP_unlimited on synthetic %d cells x %d genes, %d blocks (one per GPU, %d cells each), ensize.K=%d, rN.seed=%d"
-                    % (n_total, m, world, ncb[0], K, RN_SEED))
+            state["p"], state["pred"], state["n_clusters"] = p, np.concatenate([out[b] for b in mine]), nfin
+        workload = ("SHARP_unlimited on synthetic %d cells x %d genes as %d blocks of %d cells, block b on GPU b mod %d, ensize.K=%d, rN.seed=%d"
+                    % (n_total, m, B, ncb[0], world, K, RN_SEED))
     elif tag == "cfg2":
         dX = synth_block(0, n_total, m)
         truth = dev.synth_labels(DATA_SEED, 0, n_total, G_TRUE)
@@ -261,9 +266,9 @@ def main():
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "baseline_config": {"cfg2": "configs[1]", "cfg3": "configs[2]", "cfg4": "configs[3]"}[tag],
-                       "cells_total": n_total, "cells_per_gpu": int(dX.shape[0]) if tag != "cfg3" else n_total, "cells_per_block": n_local, "genes": m, "n_RP": K,
+                       "cells_total": n_total, "cells_per_gpu": (sum(int(b.shape[0]) for b in blocks) if world > 1 else int(dX.shape[0])) if tag != "cfg3" else n_total, "cells_per_block": n_local, "genes": m, "n_RP": K,
                        "reduced_dim": p, "x_storage": "fp32 in HBM (synthetic counts are fp32-exact)",
-                       "parallelism": "1 block per GPU" if world > 1 else "single GPU"},
+                       "parallelism": ("%d blocks, block b on GPU b mod %d; one all-gather of the per-block centroid tables" % (len(ncb), world)) if world > 1 else "single GPU"},
             "roofline": roof,
             "other_kernels": others,
             "kernel_ms_per_step": stages,
