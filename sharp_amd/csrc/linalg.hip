@@ -155,6 +155,10 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
     As[0][lrow][lcol] = ra0.x; As[0][lrow][lcol + 1] = ra0.y; As[0][lrow][lcol + 2] = ra1.x; As[0][lrow][lcol + 3] = ra1.y;
     Bs[0][lrow][lcol] = rb0.x; Bs[0][lrow][lcol + 1] = rb0.y; Bs[0][lrow][lcol + 2] = rb1.x; Bs[0][lrow][lcol + 3] = rb1.y;
     lds_barrier();   // lgkmcnt(0): the first tile is in LDS
+    // The second-dispatched half of the workgroup loses instruction arbitration to the older half at every k tile (priority, then age);
+    // one static priority for it evens that out: 12.00 -> 11.77 ms at cfg2.  (s_setprio 1 / 0 around every MFMA block: 12.6 ms; all
+    // 24 LDS reads of a k tile issued before its 32 MFMAs: 12.15; both: 13.7.)  The guard must be wave-uniform: s_setprio ignores EXEC.
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
     int buf = 0;
     for (int k0 = 0; k0 < Kp; k0 += GK) {
         // next tile into registers (the last iteration re-reads the final tile: unconditional loads keep the waits counted) ...
