@@ -57,7 +57,7 @@ struct SharpOut {
 namespace {
 
 // big per-call device buffers are kept between calls (hipMalloc/hipFree of multi-GB buffers costs up to tens of ms)
-struct DriverWs { DevBuf<double> E, Eb, viE_sh, viE_out; DevBuf<int> pos, posb; };     // (Eb / posb: the block prepared ahead of time)
+struct DriverWs { DevBuf<double> E, Eb, viE_sh, viE_out; DevBuf<int> pos, posb; hipEvent_t mean_go = nullptr, mean_done = nullptr; hipStream_t mean_stream = nullptr; };     // (Eb / posb: the block prepared ahead of time)
 DriverWs &dws() { static DriverWs w; return w; }
 
 // allrpinfo of the last SHARP_small run (R/SHARP.R:350-387,446): the colour index of every cell under every random projection; the
@@ -314,7 +314,28 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
     }
     DevBuf<double> &viE_sh = dws().viE_sh;                                      // enE / K in shuffled order (:750,776)
     viE_sh.ensure(static_cast<size_t>(n) * p);
-    ensemble_mean_dev(E.p, ldE, n, p, K, viE_sh.p);                             // enqueued now, runs under the host loops below
+    // The ensemble mean streams all of E once (HBM-bound, 0.47 ms at cfg2) and is first needed by the final sMetaC: on the side stream
+    // it runs beside the per-fold wMetaC kernels (LDS- and latency-bound) instead of in front of them.
+    hipEvent_t &mean_done = dws().mean_done;
+    {
+        Ctx &c = ctx();
+        hipStream_t &ms = dws().mean_stream;                                    // (a stream of its own: the library's second stream may hold
+        if (!mean_done) {                                                       // the next block's compaction kernels, SHARP_unlimited)
+            SHARP_HIP_CHECK(hipEventCreateWithFlags(&mean_done, hipEventDisableTiming));
+            SHARP_HIP_CHECK(hipEventCreateWithFlags(&dws().mean_go, hipEventDisableTiming));
+            int lo = 0, hi = 0;
+            SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            SHARP_HIP_CHECK(hipStreamCreateWithPriority(&ms, hipStreamNonBlocking, hi));
+        }
+        SHARP_HIP_CHECK(hipEventRecord(dws().mean_go, c.stream));              // E is complete, the base clustering has left the chip
+        hipStream_t run_on = getenv("SHARP_MEAN_INLINE") ? c.stream : ms;      // (A/B knob: in front of the wMetaC kernels as before)
+        SHARP_HIP_CHECK(hipStreamWaitEvent(run_on, dws().mean_go, 0));
+        {
+            StreamScope scope(run_on);
+            ensemble_mean_dev(E.p, ldE, n, p, K, viE_sh.p);
+        }
+        SHARP_HIP_CHECK(hipEventRecord(mean_done, run_on));
+    }
     // enrp per fold (:627-635); labels "<colour>p<t>" only need to be distinct per (k, t): the colour id does
     std::vector<std::vector<int>> enrp(T);
     for (const HcResult &r : hr) out.rc |= r.rc;
@@ -334,6 +355,7 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
     }
     std::vector<WmResult> wr;
     { HostTimer ht("wmetac_total"); wmetac_batch(wts, a.want_x0, false, wr); }
+    SHARP_HIP_CHECK(hipStreamWaitEvent(ctx().stream, mean_done, 0));           // every use of viE_sh is below
     std::vector<int> Slab(n);                                                   // SrowColor in shuffled order
     std::vector<int> stf;                                                       // meta id per (fold, cluster) column of sx0
     std::vector<int> uid(n);
