@@ -74,6 +74,7 @@ struct Ctx {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t main_stream = nullptr;   // `stream` outside every StreamScope
     hipStream_t stream2 = nullptr;   // side stream: producer kernels that overlap with consumers on `stream`
     std::vector<hipStream_t> aux;    // extra streams for pipelined task ranges (created on demand, see aux_stream())
     hipStream_t aux_stream(int i);

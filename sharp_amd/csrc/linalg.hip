@@ -116,8 +116,8 @@ constexpr int FT = 128, FLD = 144;   // 144 doubles per k row: two k rows of a h
 // the lower-triangle tiles of a symmetric product in the grid the kernel ran at 43 TF/s instead of 76, see
 // tools/micro/mfma_f64_loop.hip), and the linear id is dealt so that the eight tasks of a group sit on the eight XCDs
 // (workgroups go round-robin to XCDs): all tiles of a task then share one L2.
-__global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *__restrict__ tasks, int count, int tiles_max) {
-    const long long B = blockIdx.x;
+__global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *__restrict__ tasks, int count, int tiles_max, long long block0) {
+    const long long B = block0 + blockIdx.x;          // (block0: the launch is one slice of the batch, see gemm_tn_f64_batched)
     const long long per_group = 8LL * tiles_max;
     const int zt = static_cast<int>(B / per_group) * 8 + static_cast<int>(B % 8);
     if (zt >= count) return;
@@ -221,8 +221,19 @@ void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_
             const int ntm = (max_M + FT - 1) / FT, ntn = (max_N + FT - 1) / FT;
             const int tiles_max = symmetric ? ntn * (ntn + 1) / 2 : ntm * ntn;
             const long long blocks = static_cast<long long>((nz + 7) / 8) * 8 * tiles_max;
-            hipLaunchKernelGGL(gemm_tn_f64_fast_kernel, dim3(static_cast<unsigned>(blocks)), dim3(512), 0, c.stream, d_tasks + z0, nz,
-                               tiles_max);
+            // On a side stream (the next block of SHARP_unlimited prepared under the current block's tail) the batch goes out in slices
+            // of a few rounds of workgroups: a freed half of a CU always fits the next 512-thread workgroup of this kernel, never the
+            // 1024-thread workgroups of the tail's agglomeration kernels, which then waited -- whatever the stream priorities -- until
+            // the whole batch had been dispatched (2.4 ms instead of 0.2 for the per-fold wMetaC trees).  Between slices the queue drains.
+            long long slice = blocks;
+            if (c.stream != c.main_stream) {
+                const char *e = getenv("SHARP_GEMM_SLICE");                // workgroups per CU in a slice (0: no slices)
+                const int per_cu = e ? atoi(e) : 8;
+                if (per_cu > 0) slice = static_cast<long long>(c.num_cu) * per_cu;
+            }
+            for (long long b0 = 0; b0 < blocks; b0 += slice)
+                hipLaunchKernelGGL(gemm_tn_f64_fast_kernel, dim3(static_cast<unsigned>(std::min(slice, blocks - b0))), dim3(512), 0, c.stream,
+                                   d_tasks + z0, nz, tiles_max, b0);
         }
         else
             hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3((max_N + GT - 1) / GT, (max_M + GT - 1) / GT, nz), dim3(256), 0, c.stream,

@@ -240,6 +240,7 @@ int sharp_init(int device) {
     for (hipStream_t s : c.aux) (void)hipStreamDestroy(s);
     c.aux.clear();
     SHARP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.main_stream = c.stream;
     {   // the second stream of the RP stage: its own priority class, hence its own hardware queue (see aux_stream)
         int lo = 0, hi = 0;
         SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
