@@ -338,7 +338,7 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
     for (uint32_t l = 0; l < cap[0] + cap[1]; ++l)       // (every lane of a sign's range holds at least one code)
         for (uint32_t q = 0; q < 4u; ++q) {
             uint16_t *sp = slot_ptr(l, q);
-            if (*sp == static_cast<uint16_t>(kCodePad)) *sp = pad_code(ncomp, l % gw);
+            if (*sp == static_cast<uint16_t>(kCodePad)) *sp = pad_code(ncomp, (l + static_cast<uint32_t>(g)) % gw);   // (rotated by the gene: see pad_code)
             if (l >= lane0[1]) *sp |= static_cast<uint16_t>(kCodeNeg);
         }
     if (cap[0] + cap[1] > gw) ent[g * span + span - 1] |= static_cast<uint16_t>(kCodeMore);
