@@ -57,7 +57,15 @@ struct SharpOut {
 namespace {
 
 // big per-call device buffers are kept between calls (hipMalloc/hipFree of multi-GB buffers costs up to tens of ms)
-struct DriverWs { DevBuf<double> E, Eb, viE_sh, viE_out; DevBuf<int> pos, posb; hipEvent_t mean_go = nullptr, mean_done = nullptr; hipStream_t mean_stream = nullptr; };     // (Eb / posb: the block prepared ahead of time)
+struct DriverWs {
+    DevBuf<double> E, Eb, viE_sh, viE_out;       // Eb / posb: the block prepared ahead of time
+    DevBuf<int> pos, posb;
+    hipEvent_t mean_go = nullptr, mean_done = nullptr;
+    hipStream_t mean_stream = nullptr;
+    DevBuf<double> Ebatch;                       // Ebatch / posbatch: all blocks of a batched SHARP_unlimited window
+    DevBuf<int> posbatch;
+    DevBuf<double> fold_means, block_means;      // grow-only: a hipFree in a block's tail would wait for every stream
+};
 DriverWs &dws() { static DriverWs w; return w; }
 
 // allrpinfo of the last SHARP_small run (R/SHARP.R:350-387,446): the colour index of every cell under every random projection; the
@@ -200,7 +208,7 @@ struct PendingFront { std::unique_ptr<LargeFront> f; hipStream_t stream = nullpt
 PendingFront &pending_front() { static PendingFront p; return p; }
 }  // namespace
 
-static void large_front(LargeFront &F, const SharpArgs &a, bool ahead) {
+static void large_front(LargeFront &F, const SharpArgs &a, bool ahead, double *E_into = nullptr, int *pos_into = nullptr) {
     const int n = F.n, m = F.m, K = F.K, p = F.p;
     F.shuffle = n < 100000;                                                     // :504-507
     std::vector<int> &pos = F.pos;
@@ -214,11 +222,16 @@ static void large_front(LargeFront &F, const SharpArgs &a, bool ahead) {
     F.T = static_cast<int>(F.fst.size()) - 1;
     { HostTimer ht("projector_build"); F.pr = projector_for(a, m, p, K); }       // :539-549
     F.ldE = static_cast<long long>(F.pr->K) * p;
-    DevBuf<double> &E = ahead ? dws().Eb : dws().E;
-    { HostTimer ht("alloc_E"); E.ensure(static_cast<size_t>(n) * F.ldE); }
-    DevBuf<int> &dpos = ahead ? dws().posb : dws().pos;
-    if (F.shuffle) { dpos.ensure(n); dpos.upload(pos.data(), n); }
-    F.E = E.p; F.dpos = F.shuffle ? dpos.p : nullptr;
+    if (E_into) {                                                               // (a block of a batch: rows of the batch's own buffers)
+        F.E = E_into; F.dpos = F.shuffle ? pos_into : nullptr;
+        if (F.shuffle) SHARP_HIP_CHECK(hipMemcpyAsync(pos_into, pos.data(), static_cast<size_t>(n) * sizeof(int), hipMemcpyHostToDevice, ctx().stream));
+    } else {
+        DevBuf<double> &E = ahead ? dws().Eb : dws().E;
+        { HostTimer ht("alloc_E"); E.ensure(static_cast<size_t>(n) * F.ldE); }
+        DevBuf<int> &dpos = ahead ? dws().posb : dws().pos;
+        if (F.shuffle) { dpos.ensure(n); dpos.upload(pos.data(), n); }
+        F.E = E.p; F.dpos = F.shuffle ? dpos.p : nullptr;
+    }
     // E rows are written straight into shuffled order, so fold t is the contiguous row range [fst[t], fst[t+1])
     project_dev(*F.pr, F.dX, m, n, F.ld, a.flag, F.E, F.ldE, F.dpos);             // :567-585 for every (k, t)
     if (a.fpart) {                                                              // newE1 = round(newE1, digits = 1)  (unlimited2 :410)
@@ -236,82 +249,15 @@ static void large_front(LargeFront &F, const SharpArgs &a, bool ahead) {
         }
 }
 
-void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, int ng, HcParams base, SharpOut &out) {
-    HostTimer ht_all("sharp_large_total");
-    last_small().valid = false;                                                 // E is about to be overwritten
-    HcParams bp = base; bp.N_cluster = a.indN;
-    if (a.fpart) bp.maxN = 40;                                                  // "for partition clustering" (unlimited2 :421)
-    // the front: prepared ahead of time by the previous block's call, or now
-    std::unique_ptr<LargeFront> Fp;
-    PendingFront &PF = pending_front();
-    if (PF.f) {
-        if (PF.f->matches(dX, m, n, ld, K, p, ng, a, bp)) {
-            Fp = std::move(PF.f);
-            std::swap(dws().E, dws().Eb);                                       // its buffers become the current block's
-            std::swap(dws().pos, dws().posb);
-        } else {
-            SHARP_HIP_CHECK(hipStreamSynchronize(PF.stream));                   // (a prepared block that is not the one asked for: dropped)
-            PF.f.reset();
-        }
-    }
-    if (!Fp) {
-        Fp.reset(new LargeFront);
-        Fp->dX = dX; Fp->m = m; Fp->n = n; Fp->ld = ld; Fp->K = K; Fp->p = p; Fp->ng = ng; Fp->flag = a.flag; Fp->projector = a.projector;
-        Fp->rN_seed = a.rN_seed; Fp->fpart = a.fpart; Fp->bp = bp;
-        large_front(*Fp, a, false);
-    }
-    LargeFront &F = *Fp;
+// Everything of SHARP_large behind the base clustering (R/SHARP.R:620-851): per-fold wMetaC, cross-fold sMetaC, un-shuffle, the
+// small-cluster merge and the relabel.  hr: the K*T results of the block's base tasks, task (k, t) at k*T + t.
+static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, const HcParams &base, const HcResult *hr, SharpOut &out) {
+    const int n = F.n, T = F.T;
     const bool shuffle = F.shuffle;
     const std::vector<int> &reind = F.reind, &fst = F.fst;
-    const int T = F.T;
     const long long ldE = F.ldE;
     struct { double *p; } E{F.E};
     struct { int *p; } dpos{F.dpos};
-    // The NEXT block's front on a side stream.  If this block's own front was prepared ahead, its agglomeration is enqueued first and
-    // the next front waits for it: it then runs under this block's statistics and host-bound tail instead of beside the HBM-bound
-    // agglomeration (which it only slowed down: 259 -> 246 ms for the ten blocks of cfg3 ungated).
-    hipEvent_t after_agglo = nullptr;
-    if (F.hc && a.next_dX.p && !getenv("SHARP_PREFETCH_UNGATED")) { HostTimer ht("base_clustering_total"); after_agglo = hc_prefetch_agglomerate(*F.hc); }
-    if (a.next_dX.p && a.projector && !getenv("SHARP_NO_BLOCK_PREFETCH")) {
-        const int nn = static_cast<int>(a.next_n);
-        const int Tn = (nn + ng - 1) / ng;
-        if (a.next_n >= 5000 && a.next_n < (1LL << 31) && static_cast<long long>(K) * Tn <= ctx().num_cu && Tn > 1) {
-            std::unique_ptr<LargeFront> N(new LargeFront);
-            N->dX = a.next_dX; N->m = m; N->n = nn; N->ld = a.next_ld; N->K = K; N->p = p; N->ng = ng; N->flag = a.flag;
-            N->projector = a.projector; N->rN_seed = a.rN_seed; N->fpart = a.fpart; N->bp = bp;
-            if (a.maxN <= 0 && !a.fpart) N->bp.maxN = std::max(40, (nn + 4999) / 5000);   // the next block's own default (R/SHARP.R:144-146)
-            if (!PF.stream) {
-                // lowest priority: the tail's small kernels (on the critical path) go first whenever they are ready; at equal priority the
-                // next block's distance GEMM kept every CU busy and they waited (the tail took 12 ms instead of 6.6)
-                int lo = 0, hi = 0;
-                SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-                SHARP_HIP_CHECK(hipStreamCreateWithPriority(&PF.stream, hipStreamNonBlocking, lo));
-            }
-            {
-                // (the main stream has nothing pending that the next block depends on; its buffers are its own)
-                // This block's own front ran on the main stream (first block of a call): the side stream must not start before it has
-                // finished -- the RP stage's chunk buffers (rp2.hip) are shared, and the next block's compaction would overwrite
-                // entries this block's apply kernels are still reading.  (A front prepared ahead ran on the side stream itself.)
-                if (!F.hc) {
-                    if (!PF.main_done) SHARP_HIP_CHECK(hipEventCreateWithFlags(&PF.main_done, hipEventDisableTiming));
-                    SHARP_HIP_CHECK(hipEventRecord(PF.main_done, ctx().stream));
-                    SHARP_HIP_CHECK(hipStreamWaitEvent(PF.stream, PF.main_done, 0));
-                }
-                StreamScope scope(PF.stream);
-                if (after_agglo) SHARP_HIP_CHECK(hipStreamWaitEvent(PF.stream, after_agglo, 0));
-                large_front(*N, a, true);
-                if (hc_prefetch_possible(N->tasks)) N->hc = hc_prefetch_begin(N->tasks, PF.parity ^= 1);
-            }
-            if (N->hc) PF.f = std::move(N);
-            else SHARP_HIP_CHECK(hipStreamSynchronize(PF.stream));              // (cannot be kept: finish it, the projection is simply redone)
-        }
-    }
-    std::vector<HcResult> hr;
-    {
-        HostTimer ht("base_clustering_total");
-        if (F.hc) hc_prefetch_finish(*F.hc, false, hr);
-        else get_opt_hclust_batch(F.tasks, false, hr);
-    }
     DevBuf<double> &viE_sh = dws().viE_sh;                                      // enE / K in shuffled order (:750,776)
     viE_sh.ensure(static_cast<size_t>(n) * p);
     // The ensemble mean streams all of E once (HBM-bound, 0.47 ms at cfg2) and is first needed by the final sMetaC: on the side stream
@@ -338,7 +284,7 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
     }
     // enrp per fold (:627-635); labels "<colour>p<t>" only need to be distinct per (k, t): the colour id does
     std::vector<std::vector<int>> enrp(T);
-    for (const HcResult &r : hr) out.rc |= r.rc;
+    for (int q = 0; q < K * T; ++q) out.rc |= hr[q].rc;
     host_parallel_for(T, 8, [&](int t) {
         const int nt = fst[t + 1] - fst[t];
         enrp[t].resize(static_cast<size_t>(nt) * K);
@@ -394,7 +340,8 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
         std::fill(Slab.begin(), Slab.end(), 1);
         stf.assign(nCu, 1);
     } else {
-        DevBuf<double> means(static_cast<size_t>(nCu) * p);
+        DevBuf<double> &means = dws().fold_means;                               // (kept: hipMalloc / hipFree synchronise the whole device, and in a
+        means.ensure(static_cast<size_t>(nCu) * p);                             // batched SHARP_unlimited later chunks' agglomeration is in flight)
         cluster_means_dev(viE_sh.p, p, n, p, uid, nCu, means.p);                // sMetaC :58-63 on E1 = enE/K
         HcParams sp = base; sp.N_cluster = a.N_cluster;
         SmResult sr;
@@ -433,6 +380,79 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
     if (a.N_cluster <= 0 && n > 10000) merge_small(out.pred);                   // :816-825
     out.n_pred = relabel_first(out.pred);                                       // :828-843
     stream_sync();
+}
+
+void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, int ng, HcParams base, SharpOut &out) {
+    HostTimer ht_all("sharp_large_total");
+    last_small().valid = false;                                                 // E is about to be overwritten
+    HcParams bp = base; bp.N_cluster = a.indN;
+    if (a.fpart) bp.maxN = 40;                                                  // "for partition clustering" (unlimited2 :421)
+    // the front: prepared ahead of time by the previous block's call, or now
+    std::unique_ptr<LargeFront> Fp;
+    PendingFront &PF = pending_front();
+    if (PF.f) {
+        if (PF.f->matches(dX, m, n, ld, K, p, ng, a, bp)) {
+            Fp = std::move(PF.f);
+            std::swap(dws().E, dws().Eb);                                       // its buffers become the current block's
+            std::swap(dws().pos, dws().posb);
+        } else {
+            SHARP_HIP_CHECK(hipStreamSynchronize(PF.stream));                   // (a prepared block that is not the one asked for: dropped)
+            PF.f.reset();
+        }
+    }
+    if (!Fp) {
+        Fp.reset(new LargeFront);
+        Fp->dX = dX; Fp->m = m; Fp->n = n; Fp->ld = ld; Fp->K = K; Fp->p = p; Fp->ng = ng; Fp->flag = a.flag; Fp->projector = a.projector;
+        Fp->rN_seed = a.rN_seed; Fp->fpart = a.fpart; Fp->bp = bp;
+        large_front(*Fp, a, false);
+    }
+    LargeFront &F = *Fp;
+    // The NEXT block's front on a side stream.  If this block's own front was prepared ahead, its agglomeration is enqueued first and
+    // the next front waits for it: it then runs under this block's statistics and host-bound tail instead of beside the HBM-bound
+    // agglomeration (which it only slowed down: 259 -> 246 ms for the ten blocks of cfg3 ungated).
+    hipEvent_t after_agglo = nullptr;
+    if (F.hc && a.next_dX.p && !getenv("SHARP_PREFETCH_UNGATED")) { HostTimer ht("base_clustering_total"); after_agglo = hc_prefetch_agglomerate(*F.hc); }
+    if (a.next_dX.p && a.projector && !getenv("SHARP_NO_BLOCK_PREFETCH")) {
+        const int nn = static_cast<int>(a.next_n);
+        const int Tn = (nn + ng - 1) / ng;
+        if (a.next_n >= 5000 && a.next_n < (1LL << 31) && static_cast<long long>(K) * Tn <= ctx().num_cu && Tn > 1) {
+            std::unique_ptr<LargeFront> N(new LargeFront);
+            N->dX = a.next_dX; N->m = m; N->n = nn; N->ld = a.next_ld; N->K = K; N->p = p; N->ng = ng; N->flag = a.flag;
+            N->projector = a.projector; N->rN_seed = a.rN_seed; N->fpart = a.fpart; N->bp = bp;
+            if (a.maxN <= 0 && !a.fpart) N->bp.maxN = std::max(40, (nn + 4999) / 5000);   // the next block's own default (R/SHARP.R:144-146)
+            if (!PF.stream) {
+                // lowest priority: the tail's small kernels (on the critical path) go first whenever they are ready; at equal priority the
+                // next block's distance GEMM kept every CU busy and they waited (the tail took 12 ms instead of 6.6)
+                int lo = 0, hi = 0;
+                SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                SHARP_HIP_CHECK(hipStreamCreateWithPriority(&PF.stream, hipStreamNonBlocking, lo));
+            }
+            {
+                // (the main stream has nothing pending that the next block depends on; its buffers are its own)
+                // This block's own front ran on the main stream (first block of a call): the side stream must not start before it has
+                // finished -- the RP stage's chunk buffers (rp2.hip) are shared, and the next block's compaction would overwrite
+                // entries this block's apply kernels are still reading.  (A front prepared ahead ran on the side stream itself.)
+                if (!F.hc) {
+                    if (!PF.main_done) SHARP_HIP_CHECK(hipEventCreateWithFlags(&PF.main_done, hipEventDisableTiming));
+                    SHARP_HIP_CHECK(hipEventRecord(PF.main_done, ctx().stream));
+                    SHARP_HIP_CHECK(hipStreamWaitEvent(PF.stream, PF.main_done, 0));
+                }
+                StreamScope scope(PF.stream);
+                if (after_agglo) SHARP_HIP_CHECK(hipStreamWaitEvent(PF.stream, after_agglo, 0));
+                large_front(*N, a, true);
+                if (hc_prefetch_possible(N->tasks)) N->hc = hc_prefetch_begin(N->tasks, PF.parity ^= 1);
+            }
+            if (N->hc) PF.f = std::move(N);
+            else SHARP_HIP_CHECK(hipStreamSynchronize(PF.stream));              // (cannot be kept: finish it, the projection is simply redone)
+        }
+    }
+    std::vector<HcResult> hr;
+    {
+        HostTimer ht("base_clustering_total");
+        if (F.hc) hc_prefetch_finish(*F.hc, false, hr);
+        else get_opt_hclust_batch(F.tasks, false, hr);
+    }
+    large_tail(F, a, K, p, base, hr.data(), out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -483,6 +503,8 @@ void sharp_front_dev(XRef dX, int m, long long n_, long long ld, SharpArgs a, Sh
 // ---------------------------------------------------------------------------------------------
 // one block: y[[i]] = SHARP(mat, reduced.ndim = p, prep = FALSE, logflag = FALSE, rM = rM, ensize.K, rN.seed)
 // (:135) and the colMeans of its viE per predicted cluster -- all sMetaC ever uses of E1 (:163, R/sMetaC.R:58-63)
+void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector<int> &pred, std::vector<double> &means,
+                             std::vector<long long> &counts, double *viE_host);
 void unlimited_block_dev(XRef dX, int m, long long nb, long long ld, int p, int projector, int K, double rN_seed,
                          std::vector<int> &pred, std::vector<double> &means, std::vector<long long> &counts, double *viE_host,
                          int flag = 1, const SharpArgs *fpart_args = nullptr, XRef next_dX = XRef(), long long next_n = 0,
@@ -494,16 +516,83 @@ void unlimited_block_dev(XRef dX, int m, long long nb, long long ld, int p, int 
     a.fpart = fpart_args != nullptr;
     SharpOut o;
     sharp_front_dev(dX, m, nb, ld, a, o);
+    unlimited_block_summary(o, nb, p, pred, means, counts, viE_host);
+}
+
+// labels, per-cluster means of viE and cluster sizes of one finished block (what the cross-block sMetaC needs, :153-163)
+void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector<int> &pred, std::vector<double> &means,
+                             std::vector<long long> &counts, double *viE_host) {
     pred = o.pred;
     const int G = o.n_pred;
     std::vector<int> uid(pred.size());
     counts.assign(G, 0);
     for (size_t i = 0; i < pred.size(); ++i) { uid[i] = pred[i] - 1; ++counts[pred[i] - 1]; }   // ids are first-appearance ordered
-    DevBuf<double> dm(static_cast<size_t>(G) * p);
+    DevBuf<double> &dm = dws().block_means;
+    dm.ensure(static_cast<size_t>(G) * p);
     cluster_means_dev(o.viE.p, p, static_cast<int>(nb), p, uid, G, dm.p);
     means.resize(static_cast<size_t>(G) * p);
     dm.download(means.data(), means.size());
     if (viE_host) o.viE.download(viE_host, static_cast<size_t>(nb) * p);        // E1 rows of this block (:153), viewflag only
+}
+
+// Blocks [b0, b1) of a SHARP_unlimited call whose base-clustering tasks run as ONE pipelined batch (get_opt_hclust_batch: chunks of
+// at most one task per CU, chunk j + 1's distance GEMM beside chunk j's agglomeration, chunk j's statistics beside chunk j + 1's
+// agglomeration) instead of block after block: the tasks of all blocks are independent, and a block's own tail -- per-fold wMetaC,
+// sMetaC, relabels: small kernels and host loops -- runs from the batch's progress callback while later chunks' agglomeration keeps
+// the HBM busy.  Every block is the same SHARP() call as in the block-by-block form (same shuffle, folds, parameters): same labels.
+// deliver(b, out): called once per block, in block order.
+static void unlimited_batch_window(const XRef *dX, const long long *ncb, const long long *ldb, int b0, int b1, int m, int p, int proj, int K,
+                                   double rN_seed, const std::function<void(int, const SharpOut &)> &deliver) {
+    PendingFront &PF = pending_front();
+    if (PF.f) { SHARP_HIP_CHECK(hipStreamSynchronize(PF.stream)); PF.f.reset(); }   // (no block-by-block front may be pending)
+    const int nbk = b1 - b0;
+    std::vector<std::unique_ptr<LargeFront>> F(nbk);
+    std::vector<SharpArgs> A(nbk);
+    std::vector<HcParams> base(nbk);
+    long long rows = 0;
+    for (int q = 0; q < nbk; ++q) rows += ncb[b0 + q];
+    const long long ldE = static_cast<long long>(get_projector(proj)->K) * p;
+    DriverWs &W = dws();
+    W.Ebatch.ensure(static_cast<size_t>(rows) * ldE);
+    W.posbatch.ensure(static_cast<size_t>(rows));
+    last_small().valid = false;
+    std::vector<HcTask> tasks;
+    std::vector<size_t> first(nbk + 1, 0);
+    long long r0 = 0;
+    for (int q = 0; q < nbk; ++q) {
+        const int n = static_cast<int>(ncb[b0 + q]);
+        SharpArgs &a = A[q];
+        a.K = K; a.reduced_ndim = p; a.flag = 1; a.projector = proj; a.rN_seed = rN_seed; a.want_viE = true;   // as unlimited_block_dev
+        HcParams &bs = base[q];                                                 // as sharp_front_dev for the large path
+        bs.hmethod = 1; bs.minN = 2; bs.maxN = std::max(40, (n + 4999) / 5000); bs.sil_thre = 0.35; bs.height_Ntimes = 2.0;
+        HcParams bp = bs; bp.N_cluster = a.indN;
+        F[q].reset(new LargeFront);
+        LargeFront &f = *F[q];
+        f.dX = dX[b0 + q]; f.m = m; f.n = n; f.ld = ldb[b0 + q]; f.K = K; f.p = p; f.ng = 2000; f.flag = a.flag; f.projector = proj;
+        f.rN_seed = rN_seed; f.fpart = false; f.bp = bp;
+        large_front(f, a, false, W.Ebatch.p + r0 * ldE, W.posbatch.p + r0);
+        tasks.insert(tasks.end(), f.tasks.begin(), f.tasks.end());
+        first[q + 1] = tasks.size();
+        r0 += n;
+    }
+    std::vector<HcResult> hr;
+    int next = 0;
+    const std::function<void(size_t)> progress = [&](size_t done) {
+        while (next < nbk && first[next + 1] <= done) {
+            SharpOut o;
+            o.path = 1;
+            large_tail(*F[next], A[next], K, p, base[next], hr.data() + first[next], o);
+            o.p = p; o.K = K;
+            deliver(b0 + next, o);
+            F[next].reset();
+            ++next;
+        }
+    };
+    {
+        HostTimer ht("base_clustering_total");
+        get_opt_hclust_batch(tasks, false, hr, &progress);
+    }
+    progress(tasks.size());
 }
 
 // cross-block sMetaC on the gathered centroids, small-cluster merge and size-ordered relabel (:163-183)
@@ -763,7 +852,39 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
     std::vector<int> first(nblocks + 1, 0);
     long long off = 0;
     try {
-        for (int b = 0; b < nblocks; ++b) {                                                                    // :125-149
+        auto take = [&](int b, std::vector<int> &pb, std::vector<double> &mb, std::vector<long long> &cb) {
+            std::copy(pb.begin(), pb.end(), pred + off);
+            means.insert(means.end(), mb.begin(), mb.end());
+            counts.insert(counts.end(), cb.begin(), cb.end());
+            first[b + 1] = first[b] + static_cast<int>(cb.size());
+            off += ncb[b];
+        };
+        int b = 0;
+        while (b < nblocks) {                                                                                  // :125-149
+            // Several large-path blocks whose base tasks outnumber the CUs: one pipelined batch (unlimited_batch_window), in windows of
+            // at most ~16 GB of projections.  SHARP_UNLIMITED_BATCH=0: block after block, each preparing the next under its tail.
+            int e = b;
+            long long rows = 0, ntasks = 0;
+            const char *ub = getenv("SHARP_UNLIMITED_BATCH");
+            if (!(ub && ub[0] == '0')) {
+                while (e < nblocks && ncb[e] >= 5000 && ncb[e] < (1LL << 31) &&
+                       (rows + ncb[e]) * static_cast<long long>(K) * p * 8 <= (16LL << 30)) {
+                    rows += ncb[e];
+                    ntasks += static_cast<long long>(K) * ((ncb[e] + 1999) / 2000);
+                    ++e;
+                }
+            }
+            if (e - b >= 2 && ntasks > 2LL * ctx().num_cu) {
+                unlimited_batch_window(dX_blocks, ncb, ldb, b, e, m, p, proj, K, rN_seed, [&](int bb, const SharpOut &o) {
+                    std::vector<int> pb;
+                    std::vector<double> mb;
+                    std::vector<long long> cb;
+                    unlimited_block_summary(o, ncb[bb], p, pb, mb, cb, viE ? viE + static_cast<size_t>(off) * p : nullptr);
+                    take(bb, pb, mb, cb);
+                });
+                b = e;
+                continue;
+            }
             std::vector<int> pb;
             std::vector<double> mb;
             std::vector<long long> cb;
@@ -771,11 +892,8 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
             unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb,
                                 viE ? viE + static_cast<size_t>(off) * p : nullptr, 1, nullptr, more ? dX_blocks[b + 1] : XRef(),
                                 more ? ncb[b + 1] : 0, more ? ldb[b + 1] : 0);
-            std::copy(pb.begin(), pb.end(), pred + off);
-            means.insert(means.end(), mb.begin(), mb.end());
-            counts.insert(counts.end(), cb.begin(), cb.end());
-            first[b + 1] = first[b] + static_cast<int>(cb.size());
-            off += ncb[b];
+            take(b, pb, mb, cb);
+            ++b;
         }
     } catch (...) { drop_projector(proj); throw; }
     drop_projector(proj);

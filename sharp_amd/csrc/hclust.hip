@@ -1474,8 +1474,9 @@ struct Workspace {
 };
 // Two sets of buffers so that consecutive chunks of tasks can be in flight together (run_chunks); the scratch of the agglomeration
 // itself (S0, S1, img, remaining) is only ever used by one chunk at a time and always comes from set 0.
-// (slots 2 and 3: batches whose distance matrices are built ahead of time for the NEXT block of a SHARP_unlimited run, hc_prefetch_*)
-Workspace &ws(int slot = 0) { static Workspace w[4]; return w[slot]; }
+// Slot 3: the third set of a batch of three chunks or more; slot 2: a batch started from another batch's progress callback;
+// slots 4 and 5: batches whose distance matrices are built ahead of time for the NEXT block of a SHARP_unlimited run (hc_prefetch_*).
+Workspace &ws(int slot = 0) { static Workspace w[6]; return w[slot]; }
 
 inline long long rup(long long v, long long a) { return (v + a - 1) / a * a; }
 
@@ -1540,6 +1541,8 @@ struct ChunkJob {
     bool seq_pending = false;                  // the sequential fallback kernel is still to be launched (with the statistics phase)
     bool has_next = false;                     // pipelined: another chunk follows (its distance GEMM is enqueued before this one's tail)
     bool one_range = false;                    // everything on the current stream (a batch prepared ahead of time, hc_prefetch_begin)
+    int scratch_slot = 0;                      // whose S0 / S1 / img / remaining the agglomeration uses (set 0 unless the batch is nested)
+    int prev_slot = 1, next_slot = 1;          // pipelined: the slots of the chunk before and after this one (two or three slots in rotation)
     hipEvent_t mid_event = nullptr;            // recorded behind round `mid_round` of the round-per-launch agglomeration (if it gets that far)
     int mid_round = 8;
     bool mid_recorded = false;
@@ -1548,14 +1551,14 @@ struct ChunkJob {
 };
 enum : int { PH_DIST = 1, PH_AGGLO = 2, PH_STATS = 4, PH_ALL = 7 };
 struct PipeEvents {
-    hipEvent_t in = nullptr, out[8] = {nullptr}, gemm[2] = {nullptr, nullptr}, hc[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    hipEvent_t in = nullptr, out[8] = {nullptr}, gemm[6] = {nullptr}, hc[6] = {nullptr}, done[6] = {nullptr};   // (per workspace slot)
 };
 PipeEvents &pipe_events() {
     static PipeEvents e;
     if (!e.in) {
         SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.in, hipEventDisableTiming));
         for (auto &x : e.out) SHARP_HIP_CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < 6; ++q) {
             SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.gemm[q], hipEventDisableTiming));
             SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.hc[q], hipEventDisableTiming));
             SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.done[q], hipEventDisableTiming));
@@ -1568,7 +1571,7 @@ PipeEvents &pipe_events() {
 void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
     Ctx &c = ctx();
     Workspace &W = ws(J.slot);
-    Workspace &W0 = ws(0);                     // agglomeration scratch: shared, one chunk's agglomeration runs at a time
+    Workspace &W0 = ws(J.scratch_slot);        // agglomeration scratch: shared, one chunk's agglomeration runs at a time
     PipeEvents &EV = pipe_events();
     const size_t i0 = J.i0;
     const int T = J.T = static_cast<int>(J.i1 - J.i0);
@@ -1737,7 +1740,7 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
 void enqueue_chunk(ChunkJob &J, int phases) {
     Ctx &c = ctx();
     Workspace &W = ws(J.slot);
-    Workspace &W0 = ws(0);
+    Workspace &W0 = ws(J.scratch_slot);
     PipeEvents &EV = pipe_events();
     const int NS = J.NS, max_n = J.max_n, max_p = J.max_p, max_nk = J.max_nk, max_kpad = J.max_kpad;
     hipStream_t main_stream = c.stream;
@@ -1784,7 +1787,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         if (NS > 1) SHARP_HIP_CHECK(hipStreamWaitEvent(st, ev_in, 0));
         // pipelined: this chunk's distance GEMM starts when the previous chunk's has finished, i.e. together with the previous
         // chunk's agglomeration, and fills the CUs that one leaves free (it holds a whole CU per task)
-        if (J.pipe && !J.first) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.slot ^ 1], 0));
+        if (J.pipe && !J.first) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.prev_slot], 0));
         // a3: rows -> centred/normalised (+ 1 - S for similarity input), then D = 1 - U U^T
         row_prep_batched(W.prep.p + R.t0, Ts, max_n, max_p);
         if (R.cnt[0]) gemm_tn_f64_batched(W.gemm.p + R.off[0], R.cnt[0], max_n, max_n, "corr_dist_gemm", true, true);
@@ -1796,7 +1799,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         }
         }
         if (phases & PH_AGGLO) {
-        if (J.pipe && !J.first) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.hc[J.slot ^ 1], 0));   // one agglomeration at a time (S0 / S1)
+        if (J.pipe && !J.first) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.hc[J.prev_slot], 0));   // one agglomeration at a time (S0 / S1)
         // a4: agglomeration.  Reducible methods go through the bulk-synchronous kernel (streams whole rows between two scratch
         // matrices, D stays pristine); whatever it abandons (exact ties, centroid/median, n > 4096) is done by the
         // sequential NN-list kernel, which skips the tasks whose status is 0 -- no host round trip in between.
@@ -1901,7 +1904,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         // pipelined: the next chunk's distance GEMM (already enqueued) is on the critical path -- its agglomeration cannot start
         // before it -- and this tail is not: it waits for that GEMM and then runs beside the next agglomeration, whose stream has
         // the higher priority or is served first, on the CUs that one leaves free
-        if (J.pipe && J.has_next) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.slot ^ 1], 0));
+        if (J.pipe && J.has_next) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.next_slot], 0));
         if (J.seq_pending) { launch_sequential(true); J.seq_pending = false; }
         // a5a: labels for every candidate k
         {
@@ -2062,10 +2065,26 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
 
 }  // namespace
 
-void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::vector<HcResult> &out) {
+namespace { int g_batch_depth = 0; }         // > 0 while a batch's progress callback runs: a batch started from there is nested
+
+void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::vector<HcResult> &out,
+                          const std::function<void(size_t)> *progress) {
     out.assign(tasks.size(), HcResult());
     if (tasks.empty()) return;
     ctx();
+    if (g_batch_depth > 0) {
+        // A batch started from another batch's progress callback (the per-fold wMetaC and the sMetaC of a finished block while later
+        // chunks of the outer batch are in flight): one chunk on the current stream, with the third set of buffers and its OWN
+        // agglomeration scratch -- the outer batch's chunks own sets 0 and 1 and share set 0's scratch.
+        SHARP_REQUIRE(!progress && tasks.size() <= static_cast<size_t>(ctx().num_cu) * 4, "get_opt_hclust: nested batch too large");
+        ChunkJob J;
+        J.i0 = 0; J.i1 = tasks.size();
+        J.slot = 2; J.scratch_slot = 2; J.one_range = true;
+        setup_chunk(tasks, J);
+        enqueue_chunk(J, PH_ALL);
+        finish_chunk(tasks, J, want_v, out);
+        return;
+    }
     size_t free_b = 0, total_b = 0;
     SHARP_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     const double budget = std::max(0.5 * static_cast<double>(free_b), 2.0e9);
@@ -2077,7 +2096,15 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
     {
         const size_t ncu = static_cast<size_t>(ctx().num_cu);
         if (const char *e = getenv("SHARP_HC_CHUNK")) max_tasks = std::max<size_t>(1, static_cast<size_t>(atoll(e)));
-        else if (tasks.size() > ncu) { const size_t nch = (tasks.size() + ncu - 1) / ncu; max_tasks = (tasks.size() + nch - 1) / nch; }
+        else if (tasks.size() > ncu) {
+            size_t nch = (tasks.size() + ncu - 1) / ncu;
+            // Many chunks (the blocks of a SHARP_unlimited call as one batch): what counts is the steady state, where chunk j + 1's distance
+            // GEMM has only the CUs chunk j's agglomeration leaves free -- with 250 tasks per chunk that is 6 CUs and the two run one after
+            // the other (36 ms per chunk); at most 3/4 of the CUs per chunk leaves the GEMM a quarter of the chip (18 ms per chunk of 179).
+            // Two chunks (cfg2, cfg4's share) are better off as large as they can be: an agglomeration of 137 tasks takes as long as one of 188.
+            if (nch >= 3) nch = (tasks.size() + ncu * 3 / 4 - 1) / (ncu * 3 / 4);
+            max_tasks = (tasks.size() + nch - 1) / nch;
+        }
     }
     std::vector<std::pair<size_t, size_t>> bounds;
     size_t i0 = 0;
@@ -2113,22 +2140,47 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
         return;
     }
     SHARP_HIP_CHECK(hipEventRecord(pipe_events().in, ctx().stream));        // the tasks' inputs are ready
-    // host order: dist(0) agglo(0) | dist(1) stats(0) agglo(1) | fetch(0) dist(2) stats(1) agglo(2) | fetch(1) ...
-    ChunkJob jobs[2];
+    // Two chunks: two sets of buffers, host order  dist(0) agglo(0) | dist(1) stats(0) agglo(1) | fetch(0) fetch(1).
+    // Three chunks or more: THREE sets in rotation (0, 1, 3), host order  ... | dist(j) stats(j-1) agglo(j) fetch(j-2) | ... : with two sets
+    // chunk j's distance GEMM could only be enqueued once chunk j - 2's statistics -- which run beside chunk j - 1's agglomeration -- had
+    // been fetched, i.e. when that agglomeration was over: GEMM and agglomeration then took turns (27.5 ms per chunk of 179 tasks).
+    auto call_progress = [&](size_t done) {
+        if (!progress) return;
+        ++g_batch_depth;
+        try { (*progress)(done); } catch (...) { --g_batch_depth; throw; }
+        --g_batch_depth;
+    };
     const size_t nb = bounds.size();
-    for (size_t j = 0; j < nb; ++j) {
-        ChunkJob &J = jobs[j & 1];
-        if (j >= 2) finish_chunk(tasks, J, want_v, out);                    // chunk j - 2 used this slot
+    const size_t R = nb >= 3 ? 3 : 2;
+    static const int slot_of[3] = {0, 1, 3};
+    ChunkJob jobs[3];
+    size_t fetched = 0;                                                     // chunks 0 .. fetched - 1 are finished
+    auto fetch_upto = [&](size_t upto) {                                    // finish chunks in order, report
+        for (; fetched < upto; ++fetched) finish_chunk(tasks, jobs[fetched % R], want_v, out);
+    };
+    auto start_chunk = [&](size_t j) {                                      // descriptors, uploads, rows and distance matrices of chunk j
+        ChunkJob &J = jobs[j % R];
+        J = ChunkJob();
         J.i0 = bounds[j].first; J.i1 = bounds[j].second;
-        J.slot = static_cast<int>(j & 1); J.pipe = true; J.first = j == 0; J.has_next = j + 1 < nb;
+        J.slot = slot_of[j % R]; J.prev_slot = slot_of[(j + R - 1) % R]; J.next_slot = slot_of[(j + 1) % R];
+        J.pipe = true; J.first = j == 0; J.has_next = j + 1 < nb;
         setup_chunk(tasks, J);
         enqueue_chunk(J, PH_DIST);
-        if (j >= 1) enqueue_chunk(jobs[(j - 1) & 1], PH_STATS);
-        enqueue_chunk(J, PH_AGGLO);
+    };
+    start_chunk(0);
+    for (size_t j = 0; j < nb; ++j) {
+        if (j >= 1) enqueue_chunk(jobs[(j - 1) % R], PH_STATS);
+        enqueue_chunk(jobs[j % R], PH_AGGLO);
+        // chunk j - 2's statistics ran beside chunk j - 1's agglomeration: fetched now, which also frees its set for chunk j + 1, whose
+        // distance matrices are enqueued at once (they wait, on the device, for chunk j's GEMM); then the caller's work on finished
+        // tasks, with chunk j's agglomeration and chunk j + 1's GEMM for the device to chew on
+        if (R == 3 && j >= 2) fetch_upto(j - 1);
+        if (j + 1 < nb) start_chunk(j + 1);
+        if (fetched > 0) call_progress(bounds[fetched - 1].second);
     }
-    enqueue_chunk(jobs[(nb - 1) & 1], PH_STATS);
-    if (nb >= 2) finish_chunk(tasks, jobs[(nb - 2) & 1], want_v, out);
-    finish_chunk(tasks, jobs[(nb - 1) & 1], want_v, out);
+    enqueue_chunk(jobs[(nb - 1) % R], PH_STATS);
+    if (nb >= 2) { fetch_upto(nb - 1); call_progress(bounds[nb - 2].second); }
+    fetch_upto(nb);
 }
 
 // ---- a batch whose distance matrices are built ahead of time (SHARP_unlimited: the next block's front under the current block's tail)
@@ -2156,7 +2208,7 @@ std::shared_ptr<HcPrefetch> hc_prefetch_begin(std::vector<HcTask> tasks, int slo
     auto P = std::make_shared<HcPrefetch>();
     P->tasks = std::move(tasks);
     P->J.i0 = 0; P->J.i1 = P->tasks.size();
-    P->J.slot = 2 + (slot & 1);
+    P->J.slot = 4 + (slot & 1);
     P->J.one_range = true;
     setup_chunk(P->tasks, P->J);
     enqueue_chunk(P->J, PH_DIST);                           // on the stream that is current here (the caller's prefetch stream)

@@ -2,6 +2,7 @@
 // agglomerative tree, cutree for every candidate k, median silhouette, CH index, model selection.
 #pragma once
 #include <memory>
+#include <functional>
 #include <vector>
 
 #include "common.hpp"
@@ -42,7 +43,11 @@ struct HcResult {
 constexpr int kHcLdsMaxN = 7168;
 constexpr int kHcMaxN = 16384;
 
-void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::vector<HcResult> &out);
+// progress (optional; only used when the batch runs as pipelined chunks): called with the number of leading tasks whose results in
+// `out` are final, at moments when the device has later chunks' agglomeration to work on; it may itself call get_opt_hclust_batch
+// (that nested batch gets buffers and agglomeration scratch of its own).
+void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::vector<HcResult> &out,
+                          const std::function<void(size_t)> *progress = nullptr);
 
 // The same batch in two halves, for a caller that overlaps the front of its NEXT block with the tail of the current one
 // (SHARP_unlimited with several blocks per GPU): hc_prefetch_begin uploads the descriptors and enqueues the row preparation and the

@@ -253,3 +253,37 @@ def test_unlimited_merge_beyond_7168_rows(env, oracle):
     fid, nf = dev.unlimited_merge(M, Cn, ncells)
     ref = oracle.unlimited_merge(M, Cn, ncells)
     assert nf == ref["n_final"] and np.array_equal(fid, ref["final_id"])
+
+
+def test_unlimited_batched_base_clustering_equals_block_by_block(env, monkeypatch):
+    """SHARP_unlimited on several large-path blocks runs the base-clustering tasks of ALL blocks as one pipelined batch (three buffer
+    sets in rotation, each block's wMetaC / sMetaC tail from the batch's progress callback as a nested batch); block after block
+    (SHARP_UNLIMITED_BATCH=0) must give the same labels, cluster count and ensemble projection."""
+    sa, dev, torch = env
+    lib = sa.lib()
+    B, nb, m, K = 8, 28000, 1500, 5                      # 8 blocks x 14 folds x 5 RPs = 560 tasks > 2 x 256 CUs
+    blocks = []
+    for b in range(B):
+        x = torch.empty((nb + 37 * b, m), dtype=torch.float32, device="cuda")       # ragged block sizes
+        dev.synth_fill(x, 20261003, b * 40000, 6, 200)
+        blocks.append(x)
+
+    def run():
+        ptrs = (C.c_void_p * B)(*[x.data_ptr() for x in blocks])
+        ncb = np.array([x.shape[0] for x in blocks], np.int64)
+        ldb = np.array([x.stride(0) for x in blocks], np.int64)
+        pred = np.zeros(int(ncb.sum()), np.int32)
+        npred, pu = C.c_int(), C.c_int()
+        rc = lib.sharp_SHARP_unlimited_dev(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), ldb.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                           B, m, K, 0, 0, 0, C.c_double(2103), pred.ctypes.data_as(C.POINTER(C.c_int)),
+                                           C.byref(npred), C.byref(pu))
+        assert rc in (0, 16, 32, 48), lib.sharp_last_error()
+        return pred, npred.value, pu.value
+
+    p1, n1, pu1 = run()
+    p1b, n1b, _ = run()                                   # (and the batched form is reproducible)
+    monkeypatch.setenv("SHARP_UNLIMITED_BATCH", "0")
+    p0, n0, pu0 = run()
+    monkeypatch.delenv("SHARP_UNLIMITED_BATCH")
+    assert pu1 == pu0 and n1 == n0 == n1b
+    assert np.array_equal(p1, p0) and np.array_equal(p1, p1b)
