@@ -75,6 +75,8 @@ struct Ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t main_stream = nullptr;   // `stream` outside every StreamScope
+    bool polite = false;                 // work enqueued now is a block prepared ahead of time under another block's tail (SHARP_unlimited):
+                                         // long launches go out in slices, nothing goes to the high-priority second stream
     hipStream_t stream2 = nullptr;   // side stream: producer kernels that overlap with consumers on `stream`
     std::vector<hipStream_t> aux;    // extra streams for pipelined task ranges (created on demand, see aux_stream())
     hipStream_t aux_stream(int i);

@@ -438,6 +438,7 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
                     SHARP_HIP_CHECK(hipStreamWaitEvent(PF.stream, PF.main_done, 0));
                 }
                 StreamScope scope(PF.stream);
+                struct Polite { Polite() { ctx().polite = true; } ~Polite() { ctx_unchecked().polite = false; } } polite;
                 if (after_agglo) SHARP_HIP_CHECK(hipStreamWaitEvent(PF.stream, after_agglo, 0));
                 large_front(*N, a, true);
                 if (hc_prefetch_possible(N->tasks)) N->hc = hc_prefetch_begin(N->tasks, PF.parity ^= 1);

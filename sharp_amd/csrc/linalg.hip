@@ -221,12 +221,12 @@ void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_
             const int ntm = (max_M + FT - 1) / FT, ntn = (max_N + FT - 1) / FT;
             const int tiles_max = symmetric ? ntn * (ntn + 1) / 2 : ntm * ntn;
             const long long blocks = static_cast<long long>((nz + 7) / 8) * 8 * tiles_max;
-            // On a side stream (the next block of SHARP_unlimited prepared under the current block's tail) the batch goes out in slices
+            // A block prepared ahead of time under another block's tail (Ctx::polite, SHARP_unlimited block after block): the batch goes out in slices
             // of a few rounds of workgroups: a freed half of a CU always fits the next 512-thread workgroup of this kernel, never the
             // 1024-thread workgroups of the tail's agglomeration kernels, which then waited -- whatever the stream priorities -- until
             // the whole batch had been dispatched (2.4 ms instead of 0.2 for the per-fold wMetaC trees).  Between slices the queue drains.
             long long slice = blocks;
-            if (c.stream != c.main_stream) {
+            if (c.polite) {
                 const char *e = getenv("SHARP_GEMM_SLICE");                // workgroups per CU in a slice (0: no slices)
                 const int per_cu = e ? atoi(e) : 8;
                 if (per_cu > 0) slice = static_cast<long long>(c.num_cu) * per_cu;

@@ -386,7 +386,7 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
     const char *ser = getenv("SHARP_RP_SERIAL");
     // (a block prepared ahead of time on a side stream, SHARP_unlimited: everything on that stream -- the second stream is a high-
     // priority one, and its compaction kernels would take the chip from the current block's tail)
-    const bool serial = ser ? ser[0] == '1' : (c.stream != c.main_stream || g.ncomp >= 4096);
+    const bool serial = ser ? ser[0] == '1' : (c.polite || g.ncomp >= 4096);
     hipStream_t s2 = serial ? c.stream : c.stream2;
     const int cap = (m + 3) / 4 * 4;                         // worst case: every gene non-zero
     // chunks of cells: two (genes, fix, counts) buffers of <= 2 GB each (sized for the worst case, every gene non-zero);
