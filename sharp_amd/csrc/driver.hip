@@ -867,9 +867,11 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
             int e = b;
             long long rows = 0, ntasks = 0;
             const char *ub = getenv("SHARP_UNLIMITED_BATCH");
+            long long window_bytes = 16LL << 30;
+            if (const char *wb = getenv("SHARP_UNLIMITED_WINDOW_MB")) window_bytes = std::max(1LL, atoll(wb)) << 20;   // (tests: several windows)
             if (!(ub && ub[0] == '0')) {
                 while (e < nblocks && ncb[e] >= 5000 && ncb[e] < (1LL << 31) &&
-                       (rows + ncb[e]) * static_cast<long long>(K) * p * 8 <= (16LL << 30)) {
+                       (rows + ncb[e]) * static_cast<long long>(K) * p * 8 <= window_bytes) {
                     rows += ncb[e];
                     ntasks += static_cast<long long>(K) * ((ncb[e] + 1999) / 2000);
                     ++e;

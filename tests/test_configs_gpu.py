@@ -261,7 +261,7 @@ def test_unlimited_batched_base_clustering_equals_block_by_block(env, monkeypatc
     (SHARP_UNLIMITED_BATCH=0) must give the same labels, cluster count and ensemble projection."""
     sa, dev, torch = env
     lib = sa.lib()
-    B, nb, m, K = 8, 28000, 1500, 5                      # 8 blocks x 14 folds x 5 RPs = 560 tasks > 2 x 256 CUs
+    B, nb, m, K = 12, 28000, 1500, 5                     # 12 blocks x 14 folds x 5 RPs = 840 tasks: five chunks, three buffer sets
     blocks = []
     for b in range(B):
         x = torch.empty((nb + 37 * b, m), dtype=torch.float32, device="cuda")       # ragged block sizes
@@ -287,3 +287,10 @@ def test_unlimited_batched_base_clustering_equals_block_by_block(env, monkeypatc
     monkeypatch.delenv("SHARP_UNLIMITED_BATCH")
     assert pu1 == pu0 and n1 == n0 == n1b
     assert np.array_equal(p1, p0) and np.array_equal(p1, p1b)
+    # windows (SHARP_UNLIMITED_WINDOW_MB; 0.51 GB of projections per block): 4200 MB = a batched window of eight blocks (560 tasks) and
+    # then four blocks one after the other (280 tasks are too few for a batch); 2100 MB = windows of four, i.e. all block after block
+    for mb in ("4200", "2100"):
+        monkeypatch.setenv("SHARP_UNLIMITED_WINDOW_MB", mb)
+        pw, nw, _ = run()
+        monkeypatch.delenv("SHARP_UNLIMITED_WINDOW_MB")
+        assert nw == n1 and np.array_equal(pw, p1)
