@@ -413,8 +413,11 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
         W.fixtab_scale = tab_key;
     }
     KernelTimer t("rp_stage");                                 // the whole stage, measured on the main stream
-    SHARP_HIP_CHECK(hipEventRecord(W.ev_start, c.stream));
-    SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_start, 0));
+    const bool two = s2 != c.stream;                           // (one stream: its order is all the synchronisation there is to do)
+    if (two) {
+        SHARP_HIP_CHECK(hipEventRecord(W.ev_start, c.stream));
+        SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_start, 0));
+    }
     W.counts.ensure(n);
     SHARP_HIP_CHECK(hipMemsetAsync(W.counts.p, 0, static_cast<size_t>(n) * 4, s2));
     const int nchunks = static_cast<int>((n + chunk - 1) / chunk);
@@ -423,7 +426,7 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
         const int q = ch & 1;
         const long long c0 = ch * chunk;
         const int nc = static_cast<int>(std::min<long long>(chunk, n - c0));
-        if (ch >= 2) SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_apply[q], 0));      // buffer q free again
+        if (two && ch >= 2) SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_apply[q], 0));      // buffer q free again
         const long long waves = static_cast<long long>(nc) * units;
         int cp_per_cu = 8;
         if (const char *e = getenv("SHARP_RP_CP_WGS")) cp_per_cu = std::max(1, atoi(e));   // tuning knob
@@ -438,15 +441,17 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
                                    cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p);
             launch_check("rp_compact_kernel");
         }
-        SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[q], s2));
-        SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, W.ev_compact[q], 0));
+        if (two) {
+            SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[q], s2));
+            SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, W.ev_compact[q], 0));
+        }
         {
             KernelTimer ta("rp_apply");
             if (g.gw == 16) launch_apply<16>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
             else if (g.gw == 8) launch_apply<8>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
             else launch_apply<4>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
         }
-        SHARP_HIP_CHECK(hipEventRecord(W.ev_apply[q], c.stream));
+        if (two) SHARP_HIP_CHECK(hipEventRecord(W.ev_apply[q], c.stream));
     }
 }
 
