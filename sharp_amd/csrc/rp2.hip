@@ -254,7 +254,10 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
             dst[u] = *reinterpret_cast<const uint2 *>(entb + (group_bcast<GW, u>(gofs) + static_cast<uint32_t>(8 * lg)));
         });
     };
+    long long row_next = 0;               // E row of the cell being set up (row_map is read here, a cell ahead: read in front of the
+                                          // epilogue it was a dependent load in every cell's critical path, 8 % of the kernel)
     auto begin_cell = [&](long long ci) {
+        row_next = row_map ? static_cast<long long>(row_map[cell0 + ci]) : cell0 + ci;
         nnz = static_cast<int>(counts[ci]);
         nb = (nnz + 63) >> 6;
         gsrc = genes + ci * cap;
@@ -323,10 +326,10 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
                 if (b + NW < nb) step(b + NW, cdn, cd);
             }
         }
+        const long long row = row_next;
         if (ci + gridDim.x < ncell) begin_cell(ci + gridDim.x);   // (its row lists travel under the barrier and the epilogue)
         __syncthreads();   // every wave's atomics for this cell have landed
-        const long long cell = cell0 + ci;
-        double *erow = E + (row_map ? static_cast<long long>(row_map[cell]) : cell) * ldE + comp0;
+        double *erow = E + row * ldE + comp0;
         for (int c = tid; c < ncomp; c += AP_THREADS) {
             const long long a = static_cast<long long>(atomicExch(&acc[c], 0ull));   // read and clear in one LDS operation (ds_wrxchg_rtn_b64)
             // streaming store: E is next read by another kernel, and kept out of the L2 it does not push row lists (and the compaction's
