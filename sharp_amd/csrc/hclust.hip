@@ -1543,6 +1543,7 @@ struct ChunkJob {
     bool one_range = false;                    // everything on the current stream (a batch prepared ahead of time, hc_prefetch_begin)
     int scratch_slot = 0;                      // whose S0 / S1 / img / remaining the agglomeration uses (set 0 unless the batch is nested)
     int prev_slot = 1, next_slot = 1;          // pipelined: the slots of the chunk before and after this one (two or three slots in rotation)
+    int next2_slot = -1;                       // three slots: the chunk after the next, whose distance GEMM the statistics also let pass
     hipEvent_t mid_event = nullptr;            // recorded behind round `mid_round` of the round-per-launch agglomeration (if it gets that far)
     int mid_round = 8;
     bool mid_recorded = false;
@@ -1789,7 +1790,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         // chunk's agglomeration, and fills the CUs that one leaves free (it holds a whole CU per task)
         if (J.pipe && !J.first) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.prev_slot], 0));
         // a3: rows -> centred/normalised (+ 1 - S for similarity input), then D = 1 - U U^T
-        row_prep_batched(W.prep.p + R.t0, Ts, max_n, max_p);
+        row_prep_batched(W.prep.p + R.t0, Ts, max_n, max_p, !R.any_sym);
         if (R.cnt[0]) gemm_tn_f64_batched(W.gemm.p + R.off[0], R.cnt[0], max_n, max_n, "corr_dist_gemm", true, true);
         if (J.pipe) SHARP_HIP_CHECK(hipEventRecord(EV.gemm[J.slot], st));
         if (R.any_sym) {
@@ -1905,6 +1906,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         // before it -- and this tail is not: it waits for that GEMM and then runs beside the next agglomeration, whose stream has
         // the higher priority or is served first, on the CUs that one leaves free
         if (J.pipe && J.has_next) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.next_slot], 0));
+        if (J.pipe && J.next2_slot >= 0) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.next2_slot], 0));
         if (J.seq_pending) { launch_sequential(true); J.seq_pending = false; }
         // a5a: labels for every candidate k
         {
@@ -2168,14 +2170,22 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
         enqueue_chunk(J, PH_DIST);
     };
     start_chunk(0);
+    const bool stats_last = R == 3 && !getenv("SHARP_HC_STATS_EARLY");
     for (size_t j = 0; j < nb; ++j) {
-        if (j >= 1) enqueue_chunk(jobs[(j - 1) % R], PH_STATS);
+        if (j >= 1 && !stats_last) enqueue_chunk(jobs[(j - 1) % R], PH_STATS);
         enqueue_chunk(jobs[j % R], PH_AGGLO);
         // chunk j - 2's statistics ran beside chunk j - 1's agglomeration: fetched now, which also frees its set for chunk j + 1, whose
         // distance matrices are enqueued at once (they wait, on the device, for chunk j's GEMM); then the caller's work on finished
         // tasks, with chunk j's agglomeration and chunk j + 1's GEMM for the device to chew on
         if (R == 3 && j >= 2) fetch_upto(j - 1);
         if (j + 1 < nb) start_chunk(j + 1);
+        // three sets: chunk j - 1's statistics go behind chunk j + 1's distance GEMM as well -- that GEMM decides when the next agglomeration
+        // can start, the statistics only when a finished block's tail can; beside one agglomeration both crawled
+        if (j >= 1 && stats_last) {
+            ChunkJob &P = jobs[(j - 1) % R];
+            P.next2_slot = j + 1 < nb ? jobs[(j + 1) % R].slot : -1;
+            enqueue_chunk(P, PH_STATS);
+        }
         if (fetched > 0) call_progress(bounds[fetched - 1].second);
     }
     enqueue_chunk(jobs[(nb - 1) % R], PH_STATS);

@@ -254,7 +254,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 // sum over the row held as RP_MAXV values per lane (entries beyond p are zero and masked by the caller)
 constexpr int RP_MAXV = 8;
 
-__global__ __launch_bounds__(256) void row_prep_kernel(const RowPrepTask *__restrict__ tasks) {
+// feature rows short enough to stay in registers: prepared AND transposed by row_prep_t_kernel
+__device__ __forceinline__ bool fused_rows(const RowPrepTask &t) { return t.mode == 0 && t.p <= 64 * RP_MAXV; }
+
+__global__ __launch_bounds__(256) void row_prep_kernel(const RowPrepTask *__restrict__ tasks, int skip_fused) {
     const RowPrepTask t = tasks[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(256) void row_prep_kernel(const RowPrepTask *__rest
     gcdp x = (gcdp)t.src + static_cast<long long>(row) * t.lds;
     gdp cr = (gdp)t.Cr + static_cast<long long>(row) * t.p;
     const int p = t.p;
+    if (fused_rows(t) && skip_fused) return;              // row_prep_t_kernel's
     if (t.mode == 0 && p <= 64 * RP_MAXV) {
         // feature rows of a base-clustering task (p = reduced dimension): the row is read once and kept in registers;
         // the arithmetic and its order are those of the general path below
@@ -325,8 +329,9 @@ __global__ __launch_bounds__(256) void row_prep_kernel(const RowPrepTask *__rest
 }
 
 // Cr (n x p) -> Ct (p x nld), 32x32 tiles through LDS
-__global__ __launch_bounds__(256) void transpose_kernel(const RowPrepTask *__restrict__ tasks) {
+__global__ __launch_bounds__(256) void transpose_kernel(const RowPrepTask *__restrict__ tasks, int skip_fused) {
     const RowPrepTask t = tasks[blockIdx.z];
+    if (fused_rows(t) && skip_fused) return;
     __shared__ double tile[32][33];
     const int r0 = blockIdx.y * 32, q0 = blockIdx.x * 32;
     if (r0 >= t.nld || q0 >= t.p_pad) return;
@@ -342,16 +347,82 @@ __global__ __launch_bounds__(256) void transpose_kernel(const RowPrepTask *__res
     }
 }
 
-void row_prep_batched(const RowPrepTask *d_tasks, int count, int max_n, int max_p) {
+// Row preparation and transposition in one pass for feature rows of at most 64 * RP_MAXV values (every base-clustering task): sixteen
+// rows per workgroup, a row per wave at a time with the register path's arithmetic (same operations in the same order as
+// row_prep_kernel), the normalised rows written to Cr and kept in LDS, from where Ct's columns go out as 128-byte runs.  One read of
+// the source instead of a write and a re-read of Cr in between -- beside an HBM-bound agglomeration (pipelined chunks) the separate
+// transpose crawled (8 ms for 0.55 ms of work).
+constexpr int RT_ROWS = 16;
+__global__ __launch_bounds__(256) void row_prep_t_kernel(const RowPrepTask *__restrict__ tasks) {
+    const RowPrepTask t = tasks[blockIdx.y];
+    const int r0 = blockIdx.x * RT_ROWS;
+    if (!fused_rows(t) || r0 >= t.nld) return;
+    extern __shared__ double rt_tile[];                   // [RT_ROWS][ldt]
+    const int p = t.p, ldt = t.p_pad + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < RT_ROWS; i += 4) {
+        const int row = r0 + i;
+        double *trow = rt_tile + i * ldt;
+        if (row >= t.n) {                                 // padding rows of Ct are zero
+            for (int q = lane; q < t.p_pad; q += 64) trow[q] = 0.0;
+            continue;
+        }
+        gcdp x = (gcdp)t.src + static_cast<long long>(row) * t.lds;
+        gdp cr = (gdp)t.Cr + static_cast<long long>(row) * t.p;
+        double xv[RP_MAXV];
+#pragma unroll
+        for (int u = 0; u < RP_MAXV; ++u) { const int q = lane + 64 * u; xv[u] = x[q < p ? q : 0]; }
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < RP_MAXV; ++u) if (lane + 64 * u < p) s += xv[u];
+        const double mean = wave_sum(s) / p;
+        double ss = 0.0;
+#pragma unroll
+        for (int u = 0; u < RP_MAXV; ++u) if (lane + 64 * u < p) { const double c = xv[u] - mean; ss += c * c; }
+        const double sd = sqrt(wave_sum(ss) / static_cast<double>(p - 1 > 1 ? p - 1 : 1));
+        double s2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < RP_MAXV; ++u) if (lane + 64 * u < p) { xv[u] = (xv[u] - mean) / sd; s2 += xv[u]; }
+        const double mean2 = wave_sum(s2) / p;
+        double n2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < RP_MAXV; ++u) if (lane + 64 * u < p) { xv[u] -= mean2; n2 += xv[u] * xv[u]; }
+        const double nr = sqrt(wave_sum(n2));
+#pragma unroll
+        for (int u = 0; u < RP_MAXV; ++u) {
+            const int q = lane + 64 * u;
+            if (q < p) { const double v = xv[u] / nr; cr[q] = v; trow[q] = v; }
+            else if (q < t.p_pad) trow[q] = 0.0;          // padding rows of Ct
+        }
+        if (lane == 0) ((gdp)t.nrm)[row] = 1.0;
+    }
+    __syncthreads();
+    const int i = threadIdx.x & (RT_ROWS - 1);
+    for (int q = threadIdx.x / RT_ROWS; q < t.p_pad; q += 256 / RT_ROWS)
+        ((gdp)t.Ct)[static_cast<long long>(q) * t.nld + r0 + i] = rt_tile[i * ldt + q];
+}
+
+// all_feature_rows: every task of the batch has feature rows of at most 64 * RP_MAXV values (the caller knows; the old pair of kernels is
+// then not launched at all)
+void row_prep_batched(const RowPrepTask *d_tasks, int count, int max_n, int max_p, bool all_feature_rows) {
     if (count <= 0 || max_n <= 0) return;
     Ctx &c = ctx();
     KernelTimer tm("row_prep");
+    const bool fused = max_p <= 64 * RP_MAXV && !getenv("SHARP_ROWPREP_SPLIT");
     for (int z0 = 0; z0 < count; z0 += 65535) {
         const int nz = std::min(65535, count - z0);
-        hipLaunchKernelGGL(row_prep_kernel, dim3((max_n + 3) / 4, nz), dim3(256), 0, c.stream, d_tasks + z0);
-        launch_check("row_prep_kernel");
         const int nld_max = (max_n + 127) / 128 * 128;
-        hipLaunchKernelGGL(transpose_kernel, dim3((max_p + 15 + 31) / 32, (nld_max + 31) / 32, nz), dim3(256), 0, c.stream, d_tasks + z0);
+        if (fused) {
+            const size_t lds = static_cast<size_t>(RT_ROWS) * ((max_p + 15) / 16 * 16 + 1) * sizeof(double);
+            SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_prep_t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                static_cast<int>(lds)));
+            hipLaunchKernelGGL(row_prep_t_kernel, dim3(nld_max / RT_ROWS, nz), dim3(256), lds, c.stream, d_tasks + z0);
+            launch_check("row_prep_t_kernel");
+            if (all_feature_rows) continue;
+        }
+        hipLaunchKernelGGL(row_prep_kernel, dim3((max_n + 3) / 4, nz), dim3(256), 0, c.stream, d_tasks + z0, fused ? 1 : 0);
+        launch_check("row_prep_kernel");
+        hipLaunchKernelGGL(transpose_kernel, dim3((max_p + 15 + 31) / 32, (nld_max + 31) / 32, nz), dim3(256), 0, c.stream, d_tasks + z0, fused ? 1 : 0);
         launch_check("transpose_kernel");
     }
 }

@@ -43,6 +43,6 @@ struct RowPrepTask {
     double *nrm;         // n
     double *D;           // nld x nld (mode 1 only)
 };
-void row_prep_batched(const RowPrepTask *d_tasks, int count, int max_n, int max_p);
+void row_prep_batched(const RowPrepTask *d_tasks, int count, int max_n, int max_p, bool all_feature_rows = false);
 
 }  // namespace sharp
