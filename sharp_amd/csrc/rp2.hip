@@ -1,17 +1,17 @@
 // rp2.hip -- the RP matmul (R/RPmat.R:32, R/SHARP.R:343-345,569-585) as a two-kernel
-// producer/consumer pipeline over chunks of cells, on two HIP streams:
-//   rp_compact_kernel (stream2): streams X once (the only HBM-bound part), compacts the non-zeros of every
-//       cell wave-locally (ballot prefix), evaluates fp64 log2(1+x) -> 44-bit fixed point for them and appends
-//       (gene, fix) to the cell's list in a chunk buffer.  No workgroup barriers: every wave is independent
-//       and keeps two 1024-gene units in flight behind the one it is compacting.
-//   rp_apply_kernel (stream): per cell, walks the list in 64-entry batches; each GW-lane group takes the entries held by its own
+// producer/consumer pipeline over chunks of cells:
+//   rp_compact_kernel: streams X once (the only HBM-bound part) and appends one entry per non-zero to its cell's list
+//       in a chunk buffer: (gene, count) for integer counts, else the gene and its 44-bit fixed-point fp64 log2(1+x).  Every wave
+//       is independent (no workgroup barrier) and keeps two 1024-gene units in flight behind the one it is writing out.
+//   rp_apply_kernel: per cell, walks the list in 64-entry batches; each GW-lane group takes the entries held by its own
 //       lanes: gene and term of entry u reach the group by DPP row broadcast, each lane fetches its 8 bytes of that gene's packed row
 //       list (L2 resident) and adds +-term into the per-cell accumulators in LDS with ds_add_u64: a code is its accumulator's LDS
 //       address after one AND (projector.hpp).  Four batches are in flight per wave (atomics, row lists, terms, entry words); the
 //       next cell's first batches are set up before the two barriers around the epilogue that scales by sqrt(s)/sqrt(p) and
 //       writes the K*p row of E.  The loop holds no LDS operation but the atomics and waits for no load it has just issued.
-// Chunk c+1 is compacted while chunk c is applied, so the HBM stream overlaps the L2 gather and the LDS
-// atomics; integer accumulation keeps E bit-reproducible whatever the interleaving.
+// The chunks go compact(0) apply(0) compact(1) ... on one stream (two chunk buffers; SHARP_RP_SERIAL=0: compaction on a second
+// stream, beside the previous chunk's apply -- no faster, see project_dev_split); integer accumulation keeps E bit-reproducible
+// whatever the interleaving.
 #include "projector.hpp"
 
 #include <cmath>
@@ -382,14 +382,11 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
                        int fix_bits, double *dE, long long ldE, const int *d_row_map) {
     Ctx &c = ctx();
     SplitWs &W = sws();
-    // Two streams (chunk c + 1 is compacted while chunk c is applied) or one.  With many output components (K = 15: 5865) the
-    // apply kernel holds most wave slots, the compaction beside it runs 3x slower (0.54 instead of 0.18 ms per launch) and the
-    // stage takes the same time either way (4.40 vs 4.45 ms): there the kernels run one after the other, each at its own best.
-    // With few components (K = 5) the overlap is worth 4 % of the stage.  SHARP_RP_SERIAL = 1 / 0 forces the choice.
+    // One stream by default: the two kernels do not overlap when they share the chip (each is limited by the memory requests a CU keeps
+    // in flight), so chunk c + 1 compacted beside chunk c's apply buys nothing and the cross-stream events between the
+    // launches cost 2 % (K = 5: 2.24 against 2.29 ms per stage; K = 15 the same either way).  SHARP_RP_SERIAL=0: two streams.
     const char *ser = getenv("SHARP_RP_SERIAL");
-    // (a block prepared ahead of time on a side stream, SHARP_unlimited: everything on that stream -- the second stream is a high-
-    // priority one, and its compaction kernels would take the chip from the current block's tail)
-    const bool serial = ser ? ser[0] == '1' : (c.polite || g.ncomp >= 4096);
+    const bool serial = !(ser && ser[0] == '0');
     hipStream_t s2 = serial ? c.stream : c.stream2;
     const int cap = (m + 3) / 4 * 4;                         // worst case: every gene non-zero
     // chunks of cells: two (genes, fix, counts) buffers of <= 2 GB each (sized for the worst case, every gene non-zero);
