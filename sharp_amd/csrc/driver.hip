@@ -737,9 +737,11 @@ int sharp_last_rpinfo(int *n, int *K, int *p, int *enrp, double *indE) {
 int sharp_trim(void) {
     SHARP_API_BEGIN
     ctx();
-    stream_sync();
+    SHARP_HIP_CHECK(hipDeviceSynchronize());
     host_block().release();
     upload_release_staging();
+    dws().Ebatch.release();                              // a batched SHARP_unlimited window's projections (up to 16 GB)
+    dws().posbatch.release();
     SHARP_API_END
 }
 
