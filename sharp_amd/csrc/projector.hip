@@ -284,8 +284,8 @@ __global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int
 // l lives in segment l / gw (the gene's own segment g, then its overflow segments from extra_base), slots 4 (l % gw) .. + 3, and its
 // slot q goes out with the lane group's q-th atomic instruction.  A 64-bit LDS atomic is served per 16 contiguous lanes over 16
 // eight-byte bank pairs (MI355X_MICROARCH.md, LDS: the ds_write_b64 row): one cycle plus one per extra code of the same class
-// (component mod 16) in the instruction.  So the codes are dealt to the four slot columns round-robin in class order (the codes of
-// a class land in different columns), within the room of their sign's lanes: SQ_LDS_BANK_CONFLICT -55 % against component order.
+// (component mod 16) in the instruction.  So the codes of a class are dealt to different slot columns, the most populous classes
+// first, within the room of their sign's lanes.
 // The lanes the gene does not use keep kCodePad in every slot; the unused slots of a lane that holds codes get the lane's pad_code
 // (projector.hpp); every slot of a negative lane carries the sign bit, the consumer reads it from slot 0.
 __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint32_t gw, int ncomp, size_t g, size_t extra_base, uint16_t *ent) {
@@ -301,44 +301,55 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
         const size_t seg = sgm == 0 ? g : extra_base + (sgm - 1);
         return ent + seg * span + 4u * (lane % gw) + q;
     };
-    // rank of every code in (class, arrival) order without sorting: per-class counts (16 x 16 bit), their prefix, one more pass
-    unsigned long long start[4] = {0ull, 0ull, 0ull, 0ull};
+    // codes per class (16 x 16 bit)
+    unsigned long long per[4] = {0ull, 0ull, 0ull, 0ull};
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t c = src[i] & 15u;
-        start[c >> 2] += 1ull << ((c & 3u) * 16u);
+        per[c >> 2] += 1ull << ((c & 3u) * 16u);
     }
-    uint32_t run = 0;
-    for (uint32_t c = 0; c < 16u; ++c) {
-        const uint32_t sh = (c & 3u) * 16u;
-        const uint32_t k = static_cast<uint32_t>(start[c >> 2] >> sh) & 0xffffu;
-        start[c >> 2] = (start[c >> 2] & ~(0xffffull << sh)) | (static_cast<unsigned long long>(run) << sh);
-        run += k;
-    }
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t c = src[i] & 15u, sh = (c & 3u) * 16u;
-        const uint32_t rank = static_cast<uint32_t>(start[c >> 2] >> sh) & 0xffffu;
-        start[c >> 2] += 1ull << sh;
-        const uint32_t s = (src[i] & 0x8000u) ? 1u : 0u;
-        // the codes of a class have consecutive ranks, hence different first-choice columns; a column that is full for the code's
-        // sign, or holds the class already, passes it on (4 cap[s] >= the sign's codes: there is room somewhere)
-        const unsigned long long cs = s ? cnt[1] : cnt[0];
-        uint32_t q = 4u;
-        for (uint32_t t = 0; t < 4u && q == 4u; ++t) {   // first choice: room for the sign and the class not in the column yet
-            const uint32_t qq = (rank + t) & 3u;
-            if ((static_cast<uint32_t>(cs >> (16u * qq)) & 0xffffu) < cap[s] && !((colmask >> (16u * qq + c)) & 1ull)) q = qq;
+    auto class_count = [&](uint32_t c) { return static_cast<uint32_t>(per[c >> 2] >> ((c & 3u) * 16u)) & 0xffffu; };
+    // Most constrained first: the classes in order of decreasing population (a class of four codes needs all four columns; the singles
+    // fit anywhere), each code to the column that has the most room left for its sign among those that do not hold its class yet.
+    // Only a class of more than four codes, or a sign whose columns are full, forces two codes of a class into one column.
+    uint32_t done_classes = 0u;
+    for (uint32_t round = 0; round < 16u; ++round) {
+        uint32_t c = 16u, best = 0u;
+        for (uint32_t cc = 0; cc < 16u; ++cc)
+            if (!((done_classes >> cc) & 1u) && (c == 16u || class_count(cc) > best)) { c = cc; best = class_count(cc); }
+        done_classes |= 1u << c;
+        if (best == 0u) break;
+        for (uint32_t i = 0; i < n; ++i) {
+            if ((src[i] & 15u) != c) continue;
+            const uint32_t s = (src[i] & 0x8000u) ? 1u : 0u;
+            const unsigned long long cs = s ? cnt[1] : cnt[0];
+            uint32_t q = 4u, room = 0u;
+            for (uint32_t qq = 0; qq < 4u; ++qq) {        // room for the sign and the class not in the column yet: the emptiest
+                const uint32_t used = static_cast<uint32_t>(cs >> (16u * qq)) & 0xffffu;
+                if (used < cap[s] && !((colmask >> (16u * qq + c)) & 1ull) && (q == 4u || cap[s] - used > room)) { q = qq; room = cap[s] - used; }
+            }
+            if (q == 4u)
+                for (uint32_t qq = 0; qq < 4u; ++qq) {    // a conflict cannot be avoided: the emptiest column with room (4 cap[s] >= the sign's codes)
+                    const uint32_t used = static_cast<uint32_t>(cs >> (16u * qq)) & 0xffffu;
+                    if (used < cap[s] && (q == 4u || cap[s] - used > room)) { q = qq; room = cap[s] - used; }
+                }
+            colmask |= 1ull << (16u * q + c);
+            *slot_ptr(lane0[s] + (static_cast<uint32_t>(cs >> (16u * q)) & 0xffffu), q) = static_cast<uint16_t>((src[i] & 0x7fffu) << 3);
+            if (s) cnt[1] += 1ull << (16u * q); else cnt[0] += 1ull << (16u * q);
         }
-        for (uint32_t t = 0; t < 4u && q == 4u; ++t) {
-            const uint32_t qq = (rank + t) & 3u;
-            if ((static_cast<uint32_t>(cs >> (16u * qq)) & 0xffffu) < cap[s]) q = qq;
-        }
-        colmask |= 1ull << (16u * q + c);
-        *slot_ptr(lane0[s] + (static_cast<uint32_t>(cs >> (16u * q)) & 0xffffu), q) = static_cast<uint16_t>((src[i] & 0x7fffu) << 3);
-        if (s) cnt[1] += 1ull << (16u * q); else cnt[0] += 1ull << (16u * q);
     }
+    // the unused slots of the lanes that hold codes: a dump accumulator whose class the slot's column does not hold yet (and no other
+    // pad of the column has taken), so that the padding costs its instruction no LDS cycle either
     for (uint32_t l = 0; l < cap[0] + cap[1]; ++l)       // (every lane of a sign's range holds at least one code)
         for (uint32_t q = 0; q < 4u; ++q) {
             uint16_t *sp = slot_ptr(l, q);
-            if (*sp == static_cast<uint16_t>(kCodePad)) *sp = pad_code(ncomp, (l + static_cast<uint32_t>(g)) % gw);   // (rotated by the gene: see pad_code)
+            if (*sp == static_cast<uint16_t>(kCodePad)) {
+                uint32_t d = (l + static_cast<uint32_t>(g)) % gw;                       // (start rotated by the gene: genes that share an instruction
+                for (uint32_t t = 0; t < 16u; ++t) {                                    //  then rarely pick the same dump accumulator)
+                    const uint32_t dd = (d + t) % 16u, cls = (static_cast<uint32_t>(ncomp) + dd) & 15u;
+                    if (!((colmask >> (16u * q + cls)) & 1ull)) { d = dd; colmask |= 1ull << (16u * q + cls); break; }
+                }
+                *sp = pad_code(ncomp, d);
+            }
             if (l >= lane0[1]) *sp |= static_cast<uint16_t>(kCodeNeg);
         }
     if (cap[0] + cap[1] > gw) ent[g * span + span - 1] |= static_cast<uint16_t>(kCodeMore);

@@ -334,6 +334,9 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
             const long long a = static_cast<long long>(atomicExch(&acc[c], 0ull));   // read and clear in one LDS operation (ds_wrxchg_rtn_b64)
             // streaming store: E is next read by another kernel, and kept out of the L2 it does not push row lists (and the compaction's
             // entries) out -- apply 344 -> 331 us, the compaction beside it 175 -> 159 us per launch
+#ifdef SHARP_ABLATE_ESTORE          // (diagnostic: what the E write costs -- only every 64th component is stored)
+            if ((c & 63) == 0)
+#endif
             __builtin_nontemporal_store(out_scale * (val * (static_cast<double>(a) * inv_fix)), &erow[c]);
         }
         __syncthreads();
