@@ -288,7 +288,9 @@ __global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int
 // first, within the room of their sign's lanes.
 // The lanes the gene does not use keep kCodePad in every slot; the unused slots of a lane that holds codes get the lane's pad_code
 // (projector.hpp); every slot of a negative lane carries the sign bit, the consumer reads it from slot 0.
-__host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint32_t gw, int ncomp, size_t g, size_t extra_base, uint16_t *ent) {
+constexpr uint32_t kPlacePerm = 64;   // codes of a gene whose class order fits the caller's scratch (longer lists take the slow loop)
+__host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint32_t gw, int ncomp, size_t g, size_t extra_base, uint16_t *ent,
+                                           unsigned char *perm /* kPlacePerm bytes of scratch */) {
     const uint32_t span = 4u * gw;
     uint32_t np = 0;
     for (uint32_t i = 0; i < n; ++i) np += (src[i] & 0x8000u) ? 0u : 1u;
@@ -311,30 +313,54 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
     // Most constrained first: the classes in order of decreasing population (a class of four codes needs all four columns; the singles
     // fit anywhere), each code to the column that has the most room left for its sign among those that do not hold its class yet.
     // Only a class of more than four codes, or a sign whose columns are full, forces two codes of a class into one column.
-    uint32_t done_classes = 0u;
-    for (uint32_t round = 0; round < 16u; ++round) {
-        uint32_t c = 16u, best = 0u;
-        for (uint32_t cc = 0; cc < 16u; ++cc)
-            if (!((done_classes >> cc) & 1u) && (c == 16u || class_count(cc) > best)) { c = cc; best = class_count(cc); }
-        done_classes |= 1u << c;
-        if (best == 0u) break;
-        for (uint32_t i = 0; i < n; ++i) {
-            if ((src[i] & 15u) != c) continue;
-            const uint32_t s = (src[i] & 0x8000u) ? 1u : 0u;
-            const unsigned long long cs = s ? cnt[1] : cnt[0];
-            uint32_t q = 4u, room = 0u;
-            for (uint32_t qq = 0; qq < 4u; ++qq) {        // room for the sign and the class not in the column yet: the emptiest
+    auto place = [&](uint32_t i) {
+        const uint32_t c = src[i] & 15u;
+        const uint32_t s = (src[i] & 0x8000u) ? 1u : 0u;
+        const unsigned long long cs = s ? cnt[1] : cnt[0];
+        uint32_t q = 4u, room = 0u;
+        for (uint32_t qq = 0; qq < 4u; ++qq) {            // room for the sign and the class not in the column yet: the emptiest
+            const uint32_t used = static_cast<uint32_t>(cs >> (16u * qq)) & 0xffffu;
+            if (used < cap[s] && !((colmask >> (16u * qq + c)) & 1ull) && (q == 4u || cap[s] - used > room)) { q = qq; room = cap[s] - used; }
+        }
+        if (q == 4u)
+            for (uint32_t qq = 0; qq < 4u; ++qq) {        // a conflict cannot be avoided: the emptiest column with room (4 cap[s] >= the sign's codes)
                 const uint32_t used = static_cast<uint32_t>(cs >> (16u * qq)) & 0xffffu;
-                if (used < cap[s] && !((colmask >> (16u * qq + c)) & 1ull) && (q == 4u || cap[s] - used > room)) { q = qq; room = cap[s] - used; }
+                if (used < cap[s] && (q == 4u || cap[s] - used > room)) { q = qq; room = cap[s] - used; }
             }
-            if (q == 4u)
-                for (uint32_t qq = 0; qq < 4u; ++qq) {    // a conflict cannot be avoided: the emptiest column with room (4 cap[s] >= the sign's codes)
-                    const uint32_t used = static_cast<uint32_t>(cs >> (16u * qq)) & 0xffffu;
-                    if (used < cap[s] && (q == 4u || cap[s] - used > room)) { q = qq; room = cap[s] - used; }
-                }
-            colmask |= 1ull << (16u * q + c);
-            *slot_ptr(lane0[s] + (static_cast<uint32_t>(cs >> (16u * q)) & 0xffffu), q) = static_cast<uint16_t>((src[i] & 0x7fffu) << 3);
-            if (s) cnt[1] += 1ull << (16u * q); else cnt[0] += 1ull << (16u * q);
+        colmask |= 1ull << (16u * q + c);
+        *slot_ptr(lane0[s] + (static_cast<uint32_t>(cs >> (16u * q)) & 0xffffu), q) = static_cast<uint16_t>((src[i] & 0x7fffu) << 3);
+        if (s) cnt[1] += 1ull << (16u * q); else cnt[0] += 1ull << (16u * q);
+    };
+    // the classes in order of decreasing population; within a class the codes keep their order
+    unsigned char order[16];
+    {
+        uint32_t done_classes = 0u;
+        for (uint32_t round = 0; round < 16u; ++round) {
+            uint32_t c = 16u, best = 0u;
+            for (uint32_t cc = 0; cc < 16u; ++cc)
+                if (!((done_classes >> cc) & 1u) && (c == 16u || class_count(cc) > best)) { c = cc; best = class_count(cc); }
+            done_classes |= 1u << c;
+            order[round] = static_cast<unsigned char>(c);
+        }
+    }
+    if (n <= kPlacePerm) {                               // one counting sort by class rank, then one pass
+        unsigned long long off[4] = {0ull, 0ull, 0ull, 0ull};   // first position of every class, 16 x 16 bit
+        uint32_t run = 0u;
+        for (uint32_t r = 0; r < 16u; ++r) {
+            const uint32_t c = order[r];
+            off[c >> 2] |= static_cast<unsigned long long>(run) << ((c & 3u) * 16u);
+            run += class_count(c);
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t c = src[i] & 15u, sh = (c & 3u) * 16u;
+            perm[static_cast<uint32_t>(off[c >> 2] >> sh) & 0xffffu] = static_cast<unsigned char>(i);
+            off[c >> 2] += 1ull << sh;
+        }
+        for (uint32_t j = 0; j < n; ++j) place(perm[j]);
+    } else {
+        for (uint32_t r = 0; r < 16u; ++r) {
+            if (class_count(order[r]) == 0u) break;
+            for (uint32_t i = 0; i < n; ++i) if ((src[i] & 15u) == order[r]) place(i);
         }
     }
     // the unused slots of the lanes that hold codes: a dump accumulator whose class the slot's column does not hold yet (and no other
@@ -372,7 +398,8 @@ __global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, u
     }
     size_t extra_base = 0;
     if (novf > 0) extra_base = ovf_slot[g].x;
-    place_gene(src, len, static_cast<uint32_t>(gw), ncomp, static_cast<size_t>(g), extra_base, ent);
+    __shared__ unsigned char sperm[64][kPlacePerm];       // (blockDim.x = 64)
+    place_gene(src, len, static_cast<uint32_t>(gw), ncomp, static_cast<size_t>(g), extra_base, ent, sperm[threadIdx.x]);
 }
 __global__ void proj_fill_u16_kernel(uint16_t *p, size_t n, uint16_t v) {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) p[i] = v;
@@ -461,7 +488,8 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
             const uint16_t *src = flat.data() + rowptr[g];
             size_t extra_base = 0;
             if (lanes[g] > grp.gw) extra_base = ovf_info[ov++].x;
-            place_gene(src, len, static_cast<uint32_t>(grp.gw), grp.ncomp, static_cast<size_t>(g), extra_base, ent.data());
+            unsigned char perm[kPlacePerm];
+            place_gene(src, len, static_cast<uint32_t>(grp.gw), grp.ncomp, static_cast<size_t>(g), extra_base, ent.data(), perm);
         }
         grp.ent.alloc(ent.size());
         grp.ent.upload(ent.data(), ent.size());
@@ -594,7 +622,8 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         hipLaunchKernelGGL(proj_fill_u16_kernel, dim3(256), dim3(256), 0, c.stream, grp.ent.p, nent, static_cast<uint16_t>(kCodePad));
         hipLaunchKernelGGL(proj_fill_kernel, dim3(16, grp.kcount, S), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
                            static_cast<uint32_t>(p), d_rowptr.p, d_fill.p, d_flat.p);
-        hipLaunchKernelGGL(proj_layout_kernel, dim3((m + 255) / 256), dim3(256), 0, c.stream, m, d_rowptr.p, d_flat.p, grp.gw, grp.ncomp,
+        hipLaunchKernelGGL(proj_layout_kernel, dim3((m + 63) / 64), dim3(64), 0, c.stream,      // (one thread per gene, a wave per workgroup: every CU gets some)
+                           m, d_rowptr.p, d_flat.p, grp.gw, grp.ncomp,
                            grp.ovf_slot.p, grp.ovf_info.p, grp.novf, grp.ent.p);
         launch_check("proj_layout_kernel");
         stream_sync();                                   // the temporaries above are released on scope exit
