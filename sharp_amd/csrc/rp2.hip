@@ -99,11 +99,7 @@ __global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 4 : 2) void rp_compact
 #ifdef SHARP_ABLATE_XSTREAM     // (diagnostic: every cell read from one of 64 columns, i.e. no HBM stream)
         const CpVals<T> r = cp_load_unit<T>(X + ((cell0 + (in ? fc : ncell - 1)) & 63) * ld, in ? fu : units - 1, ld, lane);
 #else
-#ifdef SHARP_ABLATE_XSTREAM     // (diagnostic: every cell read from one of 64 columns, i.e. no HBM stream)
-        const CpVals<T> r = cp_load_unit<T>(X + ((cell0 + (in ? fc : ncell - 1)) & 63) * ld, in ? fu : units - 1, ld, lane);
-#else
         const CpVals<T> r = cp_load_unit<T>(X + (cell0 + (in ? fc : ncell - 1)) * ld, in ? fu : units - 1, ld, lane);
-#endif
 #endif
         advance(fc, fu);
         return r;
