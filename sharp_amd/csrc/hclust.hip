@@ -2169,8 +2169,9 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
         setup_chunk(tasks, J);
         enqueue_chunk(J, PH_DIST);
     };
-    start_chunk(0);
     const bool stats_last = R == 3 && !getenv("SHARP_HC_STATS_EARLY");
+    try {
+    start_chunk(0);
     for (size_t j = 0; j < nb; ++j) {
         if (j >= 1 && !stats_last) enqueue_chunk(jobs[(j - 1) % R], PH_STATS);
         enqueue_chunk(jobs[j % R], PH_AGGLO);
@@ -2191,6 +2192,10 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
     enqueue_chunk(jobs[(nb - 1) % R], PH_STATS);
     if (nb >= 2) { fetch_upto(nb - 1); call_progress(bounds[nb - 2].second); }
     fetch_upto(nb);
+    } catch (...) {
+        (void)hipDeviceSynchronize();                                       // chunks are in flight on their own streams: nothing of this batch
+        throw;                                                              // may still be running when the caller sees the error
+    }
 }
 
 // ---- a batch whose distance matrices are built ahead of time (SHARP_unlimited: the next block's front under the current block's tail)
