@@ -210,7 +210,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     int ncell, long long cell0, int cap, const unsigned int *__restrict__ counts, const uint32_t *__restrict__ genes,
     const long long *__restrict__ fixes, const long long *__restrict__ fixtab, const uint16_t *__restrict__ ent, unsigned int dummy_seg,
     const uint2 *__restrict__ ovf_slot, const uint2 *__restrict__ ovf_info, int novf, int ncomp, double inv_fix, double val,
-    double out_scale, double *__restrict__ E, long long ldE, int comp0, const int *__restrict__ row_map) {
+    double out_scale, double *__restrict__ E, long long ldE, int comp0, const int *__restrict__ row_map, unsigned int *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = AP_THREADS / 64, SPAN = 4 * GW, U = GW;   // a batch = 64 entries = U per group
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
@@ -314,8 +314,17 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
         gC = gN;
         fC = fN;
     };
-    if (static_cast<long long>(blockIdx.x) < ncell) begin_cell(blockIdx.x);
-    for (long long ci = blockIdx.x; ci < ncell; ci += gridDim.x) {
+    // Cells are handed out by a counter: workgroup w starts with cell w, every further cell is the next one nobody has taken (cells differ
+    // in their number of non-zeros, and ncell / gridDim.x is no integer: 16.3 cells per workgroup statically meant 17 for some).  The
+    // index after next is fetched by thread 0 under the epilogue and passed on through LDS at the epilogue's closing barrier.
+    unsigned int *qslot = reinterpret_cast<unsigned int *>(acc + ncomp + kDumpSlots);
+    long long ci = blockIdx.x, cnext = ncell;
+    if (tid == 0) *qslot = gridDim.x + atomicAdd(queue, 1u);
+    __syncthreads();
+    cnext = *qslot;
+    __syncthreads();
+    if (ci < ncell) begin_cell(ci);
+    for (; ci < ncell; ci = cnext, cnext = *qslot) {
         if (wave < nb) {
             for (int b = wave; b < nb; b += 2 * NW) {          // two steps per trip: the two row-list sets swap roles, nothing is copied
                 step(b, cd, cdn);
@@ -323,8 +332,9 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
             }
         }
         const long long row = row_next;
-        if (ci + gridDim.x < ncell) begin_cell(ci + gridDim.x);   // (its row lists travel under the barrier and the epilogue)
-        __syncthreads();   // every wave's atomics for this cell have landed
+        if (cnext < ncell) begin_cell(cnext);                     // (its row lists travel under the barrier and the epilogue)
+        __syncthreads();   // every wave's atomics for this cell have landed (and everybody has read the queue slot)
+        if (tid == 0) *qslot = gridDim.x + atomicAdd(queue, 1u);
         double *erow = E + row * ldE + comp0;
         for (int c = tid; c < ncomp; c += AP_THREADS) {
             const long long a = static_cast<long long>(atomicExch(&acc[c], 0ull));   // read and clear in one LDS operation (ds_wrxchg_rtn_b64)
@@ -354,9 +364,9 @@ SplitWs &sws() { static SplitWs w; return w; }
 template <int GW>
 static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell, long long cell0, int cap, const unsigned int *counts,
                          const uint32_t *genes, const long long *fixes, double inv_fix, double *dE, long long ldE, const int *row_map,
-                         hipStream_t st) {
+                         unsigned int *queue, hipStream_t st) {
     Ctx &c = ctx();
-    const size_t lds = static_cast<size_t>(g.ncomp + kDumpSlots) * 8;
+    const size_t lds = static_cast<size_t>(g.ncomp + kDumpSlots) * 8 + 8;     // accumulators, dump accumulators, the cell queue's slot
     auto kern = rp_apply_kernel<GW>;
     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     {   // scatter_codes<0>: the accumulators sit at LDS address 0, i.e. the kernel must not have static LDS in front of the dynamic block
@@ -372,7 +382,7 @@ static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(AP_THREADS), lds, st, ncell, cell0, cap, counts, genes, fixes,
                        static_cast<const long long *>(sws().fixtab.p),
                        g.ent.p, static_cast<unsigned int>(g.nseg), g.ovf_slot.p, g.ovf_info.p, g.novf, g.ncomp, inv_fix, pr.val,
-                       1.0 / std::sqrt(static_cast<double>(pr.p)), dE, ldE, g.k0 * pr.p, row_map);
+                       1.0 / std::sqrt(static_cast<double>(pr.p)), dE, ldE, g.k0 * pr.p, row_map, queue);
     launch_check("rp_apply_kernel");
 }
 
@@ -417,8 +427,9 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
         SHARP_HIP_CHECK(hipEventRecord(W.ev_start, c.stream));
         SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_start, 0));
     }
-    W.counts.ensure(n);
-    SHARP_HIP_CHECK(hipMemsetAsync(W.counts.p, 0, static_cast<size_t>(n) * 4, s2));
+    const int nchunks_all = static_cast<int>((n + chunk - 1) / chunk);
+    W.counts.ensure(static_cast<size_t>(n) + nchunks_all);      // entries per cell, then one cell-queue counter per chunk (apply kernel)
+    SHARP_HIP_CHECK(hipMemsetAsync(W.counts.p, 0, (static_cast<size_t>(n) + nchunks_all) * 4, s2));
     const int nchunks = static_cast<int>((n + chunk - 1) / chunk);
     const int units = (m + CP_UNIT - 1) / CP_UNIT;
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -446,9 +457,9 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
         }
         {
             KernelTimer ta("rp_apply");
-            if (g.gw == 16) launch_apply<16>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
-            else if (g.gw == 8) launch_apply<8>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
-            else launch_apply<4>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, c.stream);
+            if (g.gw == 16) launch_apply<16>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, W.counts.p + n + ch, c.stream);
+            else if (g.gw == 8) launch_apply<8>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, W.counts.p + n + ch, c.stream);
+            else launch_apply<4>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, W.counts.p + n + ch, c.stream);
         }
         if (two) SHARP_HIP_CHECK(hipEventRecord(W.ev_apply[q], c.stream));
     }
