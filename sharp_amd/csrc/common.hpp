@@ -65,6 +65,16 @@ struct XRef {
     const double *d64() const { return static_cast<const double *>(p); }
 };
 
+// Tuning switches, read from the environment ONCE (the first sharp_init) and kept: the kernels' hosts never call getenv per launch.
+struct Knobs {
+    bool rp_dual = true;        // SHARP_RP_DUAL=0: signed row-list codes even where two accumulator arrays would fit
+    bool rp_two_streams = false;   // SHARP_RP_SERIAL=0: the compaction of chunk c + 1 on a second stream beside the apply of chunk c
+    int rp_chunk = 0;           // SHARP_RP_CHUNK: cells per chunk of the RP stage (0: sized by the library)
+    int rp_cp_wgs = 8;          // SHARP_RP_CP_WGS / SHARP_RP_AP_WGS: workgroups per CU of the two RP kernels (upper bounds)
+    int rp_ap_wgs = 4;
+};
+const Knobs &knobs();
+
 struct KernelStat {
     double ms = 0;
     long long launches = 0;

@@ -289,11 +289,13 @@ __global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int
 // The lanes the gene does not use keep kCodePad in every slot; the unused slots of a lane that holds codes get the lane's pad_code
 // (projector.hpp); every slot of a negative lane carries the sign bit, the consumer reads it from slot 0.
 constexpr uint32_t kPlacePerm = 64;   // codes of a gene whose class order fits the caller's scratch (longer lists take the slow loop)
-__host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint32_t gw, int ncomp, size_t g, size_t extra_base, uint16_t *ent,
-                                           unsigned char *perm /* kPlacePerm bytes of scratch */) {
+__host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint32_t gw, int ncomp, int neg_base, size_t g, size_t extra_base,
+                                           uint16_t *ent, unsigned char *perm /* kPlacePerm bytes of scratch */) {
     const uint32_t span = 4u * gw;
+    const bool dual = neg_base > 0;                      // negative entries go to a second accumulator array: no signs, dense lanes
+    const int dump_base = dual ? 2 * neg_base : ncomp;   // the dump accumulators sit behind every real one
     uint32_t np = 0;
-    for (uint32_t i = 0; i < n; ++i) np += (src[i] & 0x8000u) ? 0u : 1u;
+    for (uint32_t i = 0; i < n; ++i) np += (!dual && (src[i] & 0x8000u)) ? 0u : 1u;
     const uint32_t cap[2] = {(np + 3u) / 4u, (n - np + 3u) / 4u};   // lanes per sign
     const uint32_t lane0[2] = {0u, cap[0]};
     unsigned long long cnt[2] = {0ull, 0ull};            // codes per (sign, column), 4 x 16 bit
@@ -314,8 +316,8 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
     // fit anywhere), each code to the column that has the most room left for its sign among those that do not hold its class yet.
     // Only a class of more than four codes, or a sign whose columns are full, forces two codes of a class into one column.
     auto place = [&](uint32_t i) {
-        const uint32_t c = src[i] & 15u;
-        const uint32_t s = (src[i] & 0x8000u) ? 1u : 0u;
+        const uint32_t c = src[i] & 15u;                // (neg_base % 16 == 0: both accumulators of a component are of one class)
+        const uint32_t s = (!dual && (src[i] & 0x8000u)) ? 1u : 0u;
         const unsigned long long cs = s ? cnt[1] : cnt[0];
         uint32_t q = 4u, room = 0u;
         for (uint32_t qq = 0; qq < 4u; ++qq) {            // room for the sign and the class not in the column yet: the emptiest
@@ -328,7 +330,8 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
                 if (used < cap[s] && (q == 4u || cap[s] - used > room)) { q = qq; room = cap[s] - used; }
             }
         colmask |= 1ull << (16u * q + c);
-        *slot_ptr(lane0[s] + (static_cast<uint32_t>(cs >> (16u * q)) & 0xffffu), q) = static_cast<uint16_t>((src[i] & 0x7fffu) << 3);
+        const uint32_t comp = (src[i] & 0x7fffu) + ((dual && (src[i] & 0x8000u)) ? static_cast<uint32_t>(neg_base) : 0u);
+        *slot_ptr(lane0[s] + (static_cast<uint32_t>(cs >> (16u * q)) & 0xffffu), q) = static_cast<uint16_t>(comp << 3);
         if (s) cnt[1] += 1ull << (16u * q); else cnt[0] += 1ull << (16u * q);
     };
     // the classes in order of decreasing population; within a class the codes keep their order
@@ -371,19 +374,19 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
             if (*sp == static_cast<uint16_t>(kCodePad)) {
                 uint32_t d = (l + static_cast<uint32_t>(g)) % gw;                       // (start rotated by the gene: genes that share an instruction
                 for (uint32_t t = 0; t < 16u; ++t) {                                    //  then rarely pick the same dump accumulator)
-                    const uint32_t dd = (d + t) % 16u, cls = (static_cast<uint32_t>(ncomp) + dd) & 15u;
+                    const uint32_t dd = (d + t) % 16u, cls = (static_cast<uint32_t>(dump_base) + dd) & 15u;
                     if (!((colmask >> (16u * q + cls)) & 1ull)) { d = dd; colmask |= 1ull << (16u * q + cls); break; }
                 }
-                *sp = pad_code(ncomp, d);
+                *sp = pad_code(dump_base, d);
             }
             if (l >= lane0[1]) *sp |= static_cast<uint16_t>(kCodeNeg);
         }
-    if (cap[0] + cap[1] > gw) ent[g * span + span - 1] |= static_cast<uint16_t>(kCodeMore);
+    if (cap[0] + cap[1] > gw) ent[g * span] |= static_cast<uint16_t>(kCodeMore);   // (slot 0 of lane 0: the one slot every consumer masks anyway)
 }
 
 // one thread per gene: order the gene's codes by component (the order of the host build: projector, then column) and
 // write them into the fixed-stride lane-major segments (+ overflow segments)
-__global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, uint16_t *__restrict__ flat, int gw, int ncomp,
+__global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, uint16_t *__restrict__ flat, int gw, int ncomp, int neg_base,
                                    const uint2 *__restrict__ ovf_slot, const uint2 *__restrict__ ovf_info, int novf,
                                    uint16_t *__restrict__ ent) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -399,7 +402,7 @@ __global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, u
     size_t extra_base = 0;
     if (novf > 0) extra_base = ovf_slot[g].x;
     __shared__ unsigned char sperm[64][kPlacePerm];       // (blockDim.x = 64)
-    place_gene(src, len, static_cast<uint32_t>(gw), ncomp, static_cast<size_t>(g), extra_base, ent, sperm[threadIdx.x]);
+    place_gene(src, len, static_cast<uint32_t>(gw), ncomp, neg_base, static_cast<size_t>(g), extra_base, ent, sperm[threadIdx.x]);
 }
 __global__ void proj_fill_u16_kernel(uint16_t *p, size_t n, uint16_t v) {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) p[i] = v;
@@ -410,6 +413,13 @@ std::map<int, std::shared_ptr<Projector>> g_table;
 int g_next = 1;
 
 }  // namespace
+
+int dual_neg_base(int ncomp) {
+    if (!knobs().rp_dual) return 0;
+    const int base = (ncomp + 15) / 16 * 16;             // (a multiple of 16: a component's two accumulators are of one LDS bank class)
+    // both arrays inside the 13-bit component field of a code, and in at most 64 KB of LDS (two workgroups per CU)
+    return (2 * base <= kMaxCompPerGroup && 2 * base * 8 <= 65536) ? base : 0;
+}
 
 static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, const double *seeds) {
     SHARP_REQUIRE(m >= 2 && p >= 1 && K >= 1, "projector: need m >= 2, p >= 1, K >= 1");
@@ -437,6 +447,7 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
         grp.k0 = k0;
         grp.kcount = std::min(per_group, K - k0);
         grp.ncomp = grp.kcount * p;
+        grp.neg_base = dual_neg_base(grp.ncomp);
         // gather the group's entries gene-major
         std::vector<uint32_t> rowptr(static_cast<size_t>(m) + 1, 0);
         std::vector<uint16_t> flat;
@@ -471,7 +482,7 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
         for (int g = 0; g < m; ++g) {
             int np = 0, nn = 0;
             for (uint32_t q = rowptr[g]; q < rowptr[g + 1]; ++q) { if (flat[q] & 0x8000u) ++nn; else ++np; }
-            lanes[g] = static_cast<uint16_t>(code_lanes(np, nn));
+            lanes[g] = static_cast<uint16_t>(grp.neg_base ? code_lanes(np + nn, 0) : code_lanes(np, nn));
             if (lanes[g] > grp.gw) {
                 const uint32_t extra = (lanes[g] - grp.gw + grp.gw - 1) / grp.gw;
                 ovf_gene.push_back(static_cast<uint32_t>(g));
@@ -489,7 +500,7 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
             size_t extra_base = 0;
             if (lanes[g] > grp.gw) extra_base = ovf_info[ov++].x;
             unsigned char perm[kPlacePerm];
-            place_gene(src, len, static_cast<uint32_t>(grp.gw), grp.ncomp, static_cast<size_t>(g), extra_base, ent.data(), perm);
+            place_gene(src, len, static_cast<uint32_t>(grp.gw), grp.ncomp, grp.neg_base, static_cast<size_t>(g), extra_base, ent.data(), perm);
         }
         grp.ent.alloc(ent.size());
         grp.ent.upload(ent.data(), ent.size());
@@ -558,6 +569,8 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         grp.k0 = k0;
         grp.kcount = std::min(per_group, K - k0);
         grp.ncomp = grp.kcount * p;
+        grp.neg_base = dual_neg_base(grp.ncomp);
+        const int neg_base = grp.neg_base;
         DevBuf<unsigned int> d_len(static_cast<size_t>(m) + 1), d_fill(static_cast<size_t>(m) + 1);
         d_len.zero(); d_fill.zero();
         hipLaunchKernelGGL(proj_count_kernel, dim3(16, grp.kcount, S), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
@@ -577,7 +590,7 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         std::vector<uint16_t> lanes(static_cast<size_t>(m));   // lanes of four same-sign codes the gene occupies
         for (int g = 0; g < m; ++g) {
             const int np = static_cast<int>(len[g] & 0xffffu), nn = static_cast<int>(len[g] >> 16);
-            lanes[g] = static_cast<uint16_t>(code_lanes(np, nn));
+            lanes[g] = static_cast<uint16_t>(neg_base ? code_lanes(np + nn, 0) : code_lanes(np, nn));
             len[g] = static_cast<unsigned int>(np + nn);
             rowptr[g + 1] = rowptr[g] + len[g];
             max_len = std::max<int>(max_len, static_cast<int>(len[g]));
@@ -623,7 +636,7 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         hipLaunchKernelGGL(proj_fill_kernel, dim3(16, grp.kcount, S), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
                            static_cast<uint32_t>(p), d_rowptr.p, d_fill.p, d_flat.p);
         hipLaunchKernelGGL(proj_layout_kernel, dim3((m + 63) / 64), dim3(64), 0, c.stream,      // (one thread per gene, a wave per workgroup: every CU gets some)
-                           m, d_rowptr.p, d_flat.p, grp.gw, grp.ncomp,
+                           m, d_rowptr.p, d_flat.p, grp.gw, grp.ncomp, grp.neg_base,
                            grp.ovf_slot.p, grp.ovf_info.p, grp.novf, grp.ent.p);
         launch_check("proj_layout_kernel");
         stream_sync();                                   // the temporaries above are released on scope exit

@@ -74,7 +74,7 @@ template <int GW, bool VEC>
 __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
     const float *__restrict__ X, int m, int n, long long ld, int log_flag, double fix_scale, double inv_fix,
     double val, double out_scale, const uint16_t *__restrict__ ent, const uint2 *__restrict__ ovf_slot,
-    const uint2 *__restrict__ ovf_info, int novf, int ncomp, double *__restrict__ E, long long ldE, int comp0,
+    const uint2 *__restrict__ ovf_info, int novf, int ncomp, int neg_base, double *__restrict__ E, long long ldE, int comp0,
     int nsteps, int step_len, int ablate, const int *__restrict__ row_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVE = RP_THREADS / 64;
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
     const int lane = tid & 63;
     const int grp = lane / GW, lg = lane % GW;
     NzSlot *list = reinterpret_cast<NzSlot *>(smem) + (tid >> 6) * WCAP;               // this wave's slots
-    for (int c = tid; c < ncomp; c += RP_THREADS) acc[c] = 0ull;
+    const int nacc = neg_base > 0 ? 2 * neg_base : ncomp;   // (dual accumulators: projector.hpp; the codes then carry no sign bit)
+    for (int c = tid; c < nacc; c += RP_THREADS) acc[c] = 0ull;
     __syncthreads();
 
     long long cell = blockIdx.x;
@@ -164,8 +165,8 @@ __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
                                 if (ablate < 1) scatter_codes<RP_CAP * sizeof(NzSlot)>(cd[u], fix);
                                 else if (cd[u].x == 0xdeadbeefu) acc[0] = 1;
                                 // rare: a full segment may continue in overflow segments
-                                const uint32_t lastcode = __shfl(cd[u].y >> 16, lane | (GW - 1));
-                                if ((lastcode & kCodeMore) != 0u && novf > 0) {
+                                const uint32_t firstcode = __shfl(cd[u].x, lane & ~(GW - 1));
+                                if ((firstcode & kCodeMore) != 0u && novf > 0) {
                                     const uint32_t g = list[e].gene;
                                     const uint2 oi = ovf_slot[g];
                                     {
@@ -187,8 +188,9 @@ __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
         // ---- epilogue: E[cell, comp0 + c] = (1/sqrt(p)) * (sqrt(s) * sum), clear accumulators
         double *erow = E + (row_map ? static_cast<long long>(row_map[cell]) : cell) * ldE + comp0;
         for (int c = tid; c < ncomp; c += RP_THREADS) {
-            const long long a = static_cast<long long>(acc[c]);
+            long long a = static_cast<long long>(acc[c]);
             acc[c] = 0ull;
+            if (neg_base > 0) { a -= static_cast<long long>(acc[neg_base + c]); acc[neg_base + c] = 0ull; }
             erow[c] = out_scale * (val * (static_cast<double>(a) * inv_fix));
         }
         __syncthreads();
@@ -223,7 +225,7 @@ template <int GW, bool VEC>
 static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float *dX, int m, int n, long long ld,
                       int log_flag, int fix_bits, double *dE, long long ldE, const int *row_map) {
     Ctx &c = ctx();
-    const size_t lds = RP_CAP * sizeof(NzSlot) + static_cast<size_t>(g.ncomp + kDumpSlots) * 8;   // + the pad codes' dump accumulators
+    const size_t lds = RP_CAP * sizeof(NzSlot) + static_cast<size_t>(g.acc_slots() + kDumpSlots) * 8;   // + the pad codes' dump accumulators
     const int nsteps = (m + RP_STEP - 1) / RP_STEP;
     const int step_len = ((m + nsteps - 1) / nsteps + 3) / 4 * 4;
     auto kern = rp_scatter_kernel<GW, VEC>;
@@ -244,7 +246,7 @@ static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float 
     const int ablate = abl ? atoi(abl) : 0;
     KernelTimer t("rp_stage");
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(RP_THREADS), lds, c.stream, dX, m, n, ld, log_flag,
-                       fix_scale, inv_fix, pr.val, out_scale, g.ent.p, g.ovf_slot.p, g.ovf_info.p, g.novf, g.ncomp, dE, ldE, g.k0 * pr.p,
+                       fix_scale, inv_fix, pr.val, out_scale, g.ent.p, g.ovf_slot.p, g.ovf_info.p, g.novf, g.ncomp, g.neg_base, dE, ldE, g.k0 * pr.p,
                        nsteps, step_len, ablate, row_map);
     launch_check("rp_scatter_kernel");
 }

@@ -187,36 +187,41 @@ __device__ __forceinline__ void static_for(F &&body) {
 template <int GW, int U_>
 __device__ __forceinline__ uint32_t group_bcast(uint32_t x) {
     static_assert(GW == 16 || GW == 8 || GW == 4, "a lane group is 4, 8 or 16 lanes");
-    uint32_t v = 0u;
-    if constexpr (GW == 16) {
-        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + U_, 0xf, 0xf, true));
-    } else if constexpr (GW == 8) {
-        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + U_, 0xf, 0x3, true));
-        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(x), 0x150 + 8 + U_, 0xf, 0xc, true));
-    } else {
-        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + U_, 0xf, 0x1, true));
-        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(x), 0x150 + 4 + U_, 0xf, 0x2, true));
-        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(x), 0x150 + 8 + U_, 0xf, 0x4, true));
-        v = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(x), 0x150 + 12 + U_, 0xf, 0x8, true));
+    // (the first move leaves the lanes outside its bank mask undefined -- no zero-initialised destination register -- and the
+    // following moves complete them: together the bank masks cover the row)
+    int v = __builtin_amdgcn_mov_dpp(static_cast<int>(x), 0x150 + U_, 0xf, GW == 16 ? 0xf : (GW == 8 ? 0x3 : 0x1), true);
+    if constexpr (GW == 8) {
+        v = __builtin_amdgcn_update_dpp(v, static_cast<int>(x), 0x150 + 8 + U_, 0xf, 0xc, true);
+    } else if constexpr (GW == 4) {
+        v = __builtin_amdgcn_update_dpp(v, static_cast<int>(x), 0x150 + 4 + U_, 0xf, 0x2, true);
+        v = __builtin_amdgcn_update_dpp(v, static_cast<int>(x), 0x150 + 8 + U_, 0xf, 0x4, true);
+        v = __builtin_amdgcn_update_dpp(v, static_cast<int>(x), 0x150 + 12 + U_, 0xf, 0x8, true);
     }
-    return v;
+    return static_cast<uint32_t>(v);
 }
 
 // A batch = 64 list entries, one per lane; lane group `grp` (GW lanes) works through ITS OWN lanes' entries (u = 0 .. GW-1): gene and
 // term of entry u reach the group's lanes by DPP row broadcast (no LDS scratch: the LDS pipe does the atomics and nothing else),
 // each lane fetches its 8 bytes of that gene's row list and adds the +-term at its four codes.
-template <int GW>
+// DUAL (ProjectorGroup::neg_base > 0): the group's negative entries have accumulators of their own, neg_base behind the positive ones; the
+// codes carry no sign, every lane adds the term as it is, and the epilogue takes the difference of the two arrays.  Measured per
+// instruction on gfx950 (tools/micro/valu_rate.hip): a DPP move, a compare, a conditional move or a three-operand instruction holds its
+// SIMD for 4.3 cycles, a plain two-operand one for 2.5, and the signed form spends 22 vector instructions per gene batch slot where
+// this one spends 11 -- the stage was bound by the vector ALU's issue rate in BOTH its kernels (82 % and 53 % busy), which is why they
+// never overlapped.
+template <int GW, bool DUAL>
 __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     int ncell, long long cell0, int cap, const unsigned int *__restrict__ counts, const uint32_t *__restrict__ genes,
     const long long *__restrict__ fixes, const long long *__restrict__ fixtab, const uint16_t *__restrict__ ent, unsigned int dummy_seg,
-    const uint2 *__restrict__ ovf_slot, const uint2 *__restrict__ ovf_info, int novf, int ncomp, double inv_fix, double val,
+    const uint2 *__restrict__ ovf_slot, const uint2 *__restrict__ ovf_info, int novf, int ncomp, int neg_base, double inv_fix, double val,
     double out_scale, double *__restrict__ E, long long ldE, int comp0, const int *__restrict__ row_map, unsigned int *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = AP_THREADS / 64, SPAN = 4 * GW, U = GW;   // a batch = 64 entries = U per group
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lg = lane % GW;
-    for (int c = tid; c < ncomp; c += AP_THREADS) acc[c] = 0ull;
+    const int nacc = DUAL ? 2 * neg_base : ncomp;             // accumulators in front of the dump slots
+    for (int c = tid; c < nacc; c += AP_THREADS) acc[c] = 0ull;
     __syncthreads();
 
     // Per-cell state of this wave: a four-stage pipeline over the cell's batches.  While the atomics of batch b run, the row lists of
@@ -275,38 +280,43 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
         asm volatile("" : "+v"(gL));      // the old entry words are dead before the new ones are asked for (else the loop ends on a copy
         wR = load_word(b + 3 * NW);       // of the word just requested, i.e. on its whole round trip)
         const uint32_t plo = static_cast<uint32_t>(fC), phi = static_cast<uint32_t>(static_cast<unsigned long long>(fC) >> 32);
-        const long long fneg = -fC;
-        const uint32_t nlo = static_cast<uint32_t>(fneg), nhi = static_cast<uint32_t>(static_cast<unsigned long long>(fneg) >> 32);
         uint32_t more = 0u;
-        static_for<U>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            const bool neg = (cur[u].x & kCodeNeg) != 0u;     // a lane's four codes share their sign
-            // (all four broadcasts with every lane enabled: a DPP read of a disabled lane returns nothing)
-            const uint32_t bpl = group_bcast<GW, u>(plo), bph = group_bcast<GW, u>(phi);
-            const uint32_t bnl = group_bcast<GW, u>(nlo), bnh = group_bcast<GW, u>(nhi);
-#ifdef SHARP_ABLATE_SELECT
-            const uint32_t lo = plo + (neg ? 1u : 0u), hi = phi;
-#else
-            const uint32_t lo = neg ? bnl : bpl, hi = neg ? bnh : bph;
-#endif
-            scatter_codes_signed<0>(cur[u], (static_cast<unsigned long long>(hi) << 32) | lo);
-            more |= cur[u].y;
-        });
-        // rare: a gene may continue in overflow segments (flag in the last slot of its segment: the group's last lane sees it).  One
-        // scalar test per batch.  (Broadcasts again, not LDS shuffles: a returning LDS operation anywhere in the loop makes every
-        // iteration wait for its atomics.)
-        if (__ballot((more & (kCodeMore << 16)) != 0u) != 0ull) {
+        if constexpr (DUAL) {
             static_for<U>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                const unsigned long long full = __ballot((cur[u].y & (kCodeMore << 16)) != 0u);
+                // (the broadcasts with every lane enabled: a DPP read of a disabled lane returns nothing)
+                const uint32_t lo = group_bcast<GW, u>(plo), hi = group_bcast<GW, u>(phi);
+                scatter_codes_plain<0>(cur[u], (static_cast<unsigned long long>(hi) << 32) | lo);
+                more |= cur[u].x;
+            });
+        } else {
+            const long long fneg = -fC;
+            const uint32_t nlo = static_cast<uint32_t>(fneg), nhi = static_cast<uint32_t>(static_cast<unsigned long long>(fneg) >> 32);
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const bool neg = (cur[u].x & kCodeNeg) != 0u;     // a lane's four codes share their sign
+                const uint32_t bpl = group_bcast<GW, u>(plo), bph = group_bcast<GW, u>(phi);
+                const uint32_t bnl = group_bcast<GW, u>(nlo), bnh = group_bcast<GW, u>(nhi);
+                const uint32_t lo = neg ? bnl : bpl, hi = neg ? bnh : bph;
+                scatter_codes_signed<0>(cur[u], (static_cast<unsigned long long>(hi) << 32) | lo);
+                more |= cur[u].x;
+            });
+        }
+        // rare: a gene may continue in overflow segments (flag in slot 0 of its first lane).  One scalar test per batch.  (Broadcasts
+        // again, not LDS shuffles: a returning LDS operation anywhere in the loop makes every iteration wait for its atomics.)
+        if (__ballot((more & kCodeMore) != 0u) != 0ull) {
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const unsigned long long full = __ballot((cur[u].x & kCodeMore) != 0u);
                 const uint32_t g = group_bcast<GW, u>(gC);
                 const uint32_t bpl = group_bcast<GW, u>(plo), bph = group_bcast<GW, u>(phi);
-                if ((full >> (lane | (GW - 1))) & 1ull) {
+                if ((full >> (lane & ~(GW - 1))) & 1ull) {
                     const long long f = static_cast<long long>((static_cast<unsigned long long>(bph) << 32) | bpl);
                     const uint2 oi = ovf_slot[g];
                     for (uint32_t sg = 0; sg < oi.y; ++sg) {
                         const uint2 c2 = *reinterpret_cast<const uint2 *>(ent + (static_cast<size_t>(oi.x) + sg) * SPAN + 4 * lg);
-                        scatter_codes_signed<0>(c2, static_cast<unsigned long long>((c2.x & kCodeNeg) ? -f : f));
+                        if constexpr (DUAL) scatter_codes_plain<0>(c2, static_cast<unsigned long long>(f));
+                        else scatter_codes_signed<0>(c2, static_cast<unsigned long long>((c2.x & kCodeNeg) ? -f : f));
                     }
                 }
             });
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     // Cells are handed out by a counter: workgroup w starts with cell w, every further cell is the next one nobody has taken (cells differ
     // in their number of non-zeros, and ncell / gridDim.x is no integer: 16.3 cells per workgroup statically meant 17 for some).  The
     // index after next is fetched by thread 0 under the epilogue and passed on through LDS at the epilogue's closing barrier.
-    unsigned int *qslot = reinterpret_cast<unsigned int *>(acc + ncomp + kDumpSlots);
+    unsigned int *qslot = reinterpret_cast<unsigned int *>(acc + nacc + kDumpSlots);
     long long ci = blockIdx.x, cnext = ncell;
     if (tid == 0) *qslot = gridDim.x + atomicAdd(queue, 1u);
     __syncthreads();
@@ -337,12 +347,10 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
         if (tid == 0) *qslot = gridDim.x + atomicAdd(queue, 1u);
         double *erow = E + row * ldE + comp0;
         for (int c = tid; c < ncomp; c += AP_THREADS) {
-            const long long a = static_cast<long long>(atomicExch(&acc[c], 0ull));   // read and clear in one LDS operation (ds_wrxchg_rtn_b64)
+            long long a = static_cast<long long>(atomicExch(&acc[c], 0ull));   // read and clear in one LDS operation (ds_wrxchg_rtn_b64)
+            if constexpr (DUAL) a -= static_cast<long long>(atomicExch(&acc[neg_base + c], 0ull));
             // streaming store: E is next read by another kernel, and kept out of the L2 it does not push row lists (and the compaction's
             // entries) out -- apply 344 -> 331 us, the compaction beside it 175 -> 159 us per launch
-#ifdef SHARP_ABLATE_ESTORE          // (diagnostic: what the E write costs -- only every 64th component is stored)
-            if ((c & 63) == 0)
-#endif
             __builtin_nontemporal_store(out_scale * (val * (static_cast<double>(a) * inv_fix)), &erow[c]);
         }
         __syncthreads();
@@ -361,13 +369,13 @@ struct SplitWs {
 SplitWs &sws() { static SplitWs w; return w; }
 }  // namespace
 
-template <int GW>
+template <int GW, bool DUAL>
 static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell, long long cell0, int cap, const unsigned int *counts,
                          const uint32_t *genes, const long long *fixes, double inv_fix, double *dE, long long ldE, const int *row_map,
                          unsigned int *queue, hipStream_t st) {
     Ctx &c = ctx();
-    const size_t lds = static_cast<size_t>(g.ncomp + kDumpSlots) * 8 + 8;     // accumulators, dump accumulators, the cell queue's slot
-    auto kern = rp_apply_kernel<GW>;
+    const size_t lds = static_cast<size_t>(g.acc_slots() + kDumpSlots) * 8 + 8;     // accumulators, dump accumulators, the cell queue's slot
+    auto kern = rp_apply_kernel<GW, DUAL>;
     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     {   // scatter_codes<0>: the accumulators sit at LDS address 0, i.e. the kernel must not have static LDS in front of the dynamic block
         hipFuncAttributes fa;
@@ -377,11 +385,11 @@ static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell
     int per_cu = 1;
     SHARP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), AP_THREADS, lds));
     per_cu = std::max(1, std::min(per_cu, 4));
-    if (const char *e = getenv("SHARP_RP_AP_WGS")) per_cu = std::max(1, std::min(per_cu, atoi(e)));   // tuning knob
+    per_cu = std::min(per_cu, knobs().rp_ap_wgs);
     const long long blocks = std::min<long long>(ncell, static_cast<long long>(c.num_cu) * per_cu);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(AP_THREADS), lds, st, ncell, cell0, cap, counts, genes, fixes,
                        static_cast<const long long *>(sws().fixtab.p),
-                       g.ent.p, static_cast<unsigned int>(g.nseg), g.ovf_slot.p, g.ovf_info.p, g.novf, g.ncomp, inv_fix, pr.val,
+                       g.ent.p, static_cast<unsigned int>(g.nseg), g.ovf_slot.p, g.ovf_info.p, g.novf, g.ncomp, g.neg_base, inv_fix, pr.val,
                        1.0 / std::sqrt(static_cast<double>(pr.p)), dE, ldE, g.k0 * pr.p, row_map, queue);
     launch_check("rp_apply_kernel");
 }
@@ -394,15 +402,13 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
     // One stream by default: the two kernels do not overlap when they share the chip (each is limited by the memory requests a CU keeps
     // in flight), so chunk c + 1 compacted beside chunk c's apply buys nothing and the cross-stream events between the
     // launches cost 2 % (K = 5: 2.24 against 2.29 ms per stage; K = 15 the same either way).  SHARP_RP_SERIAL=0: two streams.
-    const char *ser = getenv("SHARP_RP_SERIAL");
-    const bool serial = !(ser && ser[0] == '0');
-    hipStream_t s2 = serial ? c.stream : c.stream2;
+    hipStream_t s2 = knobs().rp_two_streams ? c.stream2 : c.stream;
     const int cap = (m + 3) / 4 * 4;                         // worst case: every gene non-zero
     // chunks of cells: two (genes, fix, counts) buffers of <= 2 GB each (sized for the worst case, every gene non-zero);
     // few, equal chunks: each launch pays a tail, and a chunk must give every workgroup several cells
     long long chunk = std::max<long long>(512, (2048LL << 20) / (static_cast<long long>(cap) * 12));
     chunk = std::min<long long>(chunk, 16384);
-    if (const char *ce = getenv("SHARP_RP_CHUNK")) chunk = std::max(64, atoi(ce));   // tuning knob
+    if (knobs().rp_chunk > 0) chunk = std::max(64, knobs().rp_chunk);
     chunk = std::min<long long>(chunk, n);
     {
         const long long nch = (n + chunk - 1) / chunk;
@@ -438,8 +444,7 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
         const int nc = static_cast<int>(std::min<long long>(chunk, n - c0));
         if (two && ch >= 2) SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_apply[q], 0));      // buffer q free again
         const long long waves = static_cast<long long>(nc) * units;
-        int cp_per_cu = 8;
-        if (const char *e = getenv("SHARP_RP_CP_WGS")) cp_per_cu = std::max(1, atoi(e));   // tuning knob
+        const int cp_per_cu = knobs().rp_cp_wgs;
         const int blocks = static_cast<int>(std::min<long long>((waves + 3) / 4, static_cast<long long>(c.num_cu) * cp_per_cu));
         {
             KernelTimer tc("rp_compact", s2);
@@ -457,9 +462,12 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
         }
         {
             KernelTimer ta("rp_apply");
-            if (g.gw == 16) launch_apply<16>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, W.counts.p + n + ch, c.stream);
-            else if (g.gw == 8) launch_apply<8>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, W.counts.p + n + ch, c.stream);
-            else launch_apply<4>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, W.counts.p + n + ch, c.stream);
+#define SHARP_AP(GWV, DU) launch_apply<GWV, DU>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, W.counts.p + n + ch, c.stream)
+            const bool dual = g.neg_base > 0;
+            if (g.gw == 16) { if (dual) SHARP_AP(16, true); else SHARP_AP(16, false); }
+            else if (g.gw == 8) { if (dual) SHARP_AP(8, true); else SHARP_AP(8, false); }
+            else { if (dual) SHARP_AP(4, true); else SHARP_AP(4, false); }
+#undef SHARP_AP
         }
         if (two) SHARP_HIP_CHECK(hipEventRecord(W.ev_apply[q], c.stream));
     }

@@ -20,7 +20,7 @@ namespace {
 
 // one thread per (gene, slot of its first segment or of one of its overflow segments)
 __global__ void rp_densify_kernel(const uint16_t *__restrict__ ent, const uint2 *__restrict__ ovf_slot, int novf, int m, int span, int ncomp,
-                                  int max_extra, double *__restrict__ Rd) {
+                                  int neg_base, int max_extra, double *__restrict__ Rd) {
     const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int per_gene = span * (1 + max_extra);
     const long long g = idx / per_gene;
@@ -40,7 +40,10 @@ __global__ void rp_densify_kernel(const uint16_t *__restrict__ ent, const uint2 
     if (!lane_live(pair01)) return;
     const uint32_t code = s[i];
     const int comp = static_cast<int>(code >> 3);
-    if (comp < ncomp) Rd[g * ncomp + comp] = (code & kCodeNeg) ? -1.0 : 1.0;      // (>= ncomp: an unused slot of a live lane)
+    if (neg_base > 0) {                                   // dual accumulators: the sign is the array the code points into
+        if (comp < ncomp) Rd[g * ncomp + comp] = 1.0;
+        else if (comp >= neg_base && comp - neg_base < ncomp) Rd[g * ncomp + comp - neg_base] = -1.0;
+    } else if (comp < ncomp) Rd[g * ncomp + comp] = (code & kCodeNeg) ? -1.0 : 1.0;      // (>= ncomp: an unused slot of a live lane)
 }
 
 // L[g][i] = f(X[cell0 + i][g]) for a 64 x 64 tile per workgroup (X: cell-major, L: gene-major)
@@ -104,7 +107,7 @@ void project_dev_dense(const Projector &pr, XRef X, int m, int n, long long ld, 
             }
             const long long threads = static_cast<long long>(m) * span * (1 + max_extra);
             hipLaunchKernelGGL(rp_densify_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, c.stream, g.ent.p, g.ovf_slot.p,
-                               g.novf, m, span, g.ncomp, max_extra, Rd.p);
+                               g.novf, m, span, g.ncomp, g.neg_base, max_extra, Rd.p);
             launch_check("rp_densify_kernel");
         }
         for (long long c0 = 0; c0 < n; c0 += chunk) {

@@ -199,6 +199,22 @@ HostTimer::~HostTimer() {
 
 }  // namespace sharp
 
+namespace sharp {
+const Knobs &knobs() {
+    static const Knobs k = [] {
+        Knobs v;
+        auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; };
+        v.rp_dual = num("SHARP_RP_DUAL", 1) != 0;
+        v.rp_two_streams = num("SHARP_RP_SERIAL", 1) == 0;
+        v.rp_chunk = num("SHARP_RP_CHUNK", 0);
+        v.rp_cp_wgs = std::max(1, num("SHARP_RP_CP_WGS", 8));
+        v.rp_ap_wgs = std::max(1, num("SHARP_RP_AP_WGS", 4));
+        return v;
+    }();
+    return k;
+}
+}  // namespace sharp
+
 using namespace sharp;
 
 extern "C" {
