@@ -37,16 +37,20 @@ template <> struct CpLayout<double> {
     __device__ static __forceinline__ int gene_of(int lane, int q) { return 2 * lane + 128 * (q >> 1) + (q & 1); }
 };
 
-template <typename T>
-__device__ __forceinline__ CpVals<T> cp_load_unit(const T *col, int u, long long ld, int lane) {
+// `unit` points at the unit's first gene.  CLAMP (only a cell's last, ragged unit): a load that would run past the column's `lim`
+// values (the leading dimension, a multiple of VEC) reads the unit's first values instead -- every load is unconditional -- and the
+// caller zeroes what lies beyond the last gene.  The other units need no address arithmetic at all: one lane offset, the load's
+// immediate offset, a scalar base.
+template <typename T, bool CLAMP>
+__device__ __forceinline__ CpVals<T> cp_load_unit(const T *unit, int lim, int lane) {
     typedef T tv __attribute__((ext_vector_type(CpLayout<T>::VEC)));
     constexpr int V = CpLayout<T>::VEC;
     CpVals<T> r;
 #pragma unroll
     for (int j = 0; j < CpLayout<T>::LOADS; ++j) {
-        const int g = u * CP_UNIT + V * (lane + 64 * j);
-        const int gc = g + V - 1 < ld ? g : 0;      // unconditional, clamped into the column (ld % V == 0, ld >= m)
-        const tv t = __builtin_nontemporal_load(reinterpret_cast<const tv *>(col + gc));
+        int g = V * (lane + 64 * j);
+        if (CLAMP) g = g + V - 1 < lim ? g : 0;
+        const tv t = __builtin_nontemporal_load(reinterpret_cast<const tv *>(unit + g));
 #pragma unroll
         for (int e = 0; e < V; ++e) r.v[V * j + e] = t[e];
     }
@@ -64,20 +68,30 @@ __global__ void rp_fixtab_kernel(double fix_scale, int log10_mode, long long *__
     if (x < CP_TAB) tab[x] = __double2ll_rn((log10_mode ? log10(1.0 + static_cast<double>(x)) : log2(1.0 + static_cast<double>(x))) * fix_scale);
 }
 
-// One wave per (cell, unit); units of a chunk are dealt round-robin to the waves of a persistent grid.
-// Compaction is lane-major: a lane counts its own non-zeros (16 candidates), one wave prefix scan places them, the
-// lane appends (gene, x) to the wave's LDS window; then one lane per non-zero turns x into the fixed-point term
-// (table for integer counts, fp64 log2 otherwise -- same bits either way) and the list goes out coalesced.
+// One wave per (cell, unit); units of a chunk are dealt round-robin to the waves of a persistent grid.  Both RP kernels were bound by
+// the vector ALU's issue rate, not by memory (tools/micro/valu_rate.hip: a compare, a conditional move, a DPP or a three-operand
+// instruction holds its SIMD for 4.3 cycles; this kernel ran 53 % and rp_apply 82 % VALU-busy, so they could not overlap either), hence
+// the form with the fewest vector instructions per candidate:
+//   * candidate q of every lane (16 per unit) is tested by ONE compare whose ballot is also its compaction: the non-zeros of the
+//     ballot write (gene, x) into the wave's LDS window at run + mbcnt(ballot) -- no per-lane counts, no prefix scan, no conditional
+//     moves; the scalar unit keeps the running offset and the unit's total;
+//   * the cell-list slot of unit i + 1 is reserved (one returning atomic per unit) while unit i is written out, so its round trip
+//     is never waited for;
+//   * one lane per NON-ZERO (11 % of the candidates) turns x into the entry: (gene, count) for integer counts below 256, else the
+//     gene and the 44-bit fixed-point fp64 log2(1 + x) beside it -- same bits either way -- and the list goes out coalesced.
 // The order of a cell's list is irrelevant: the consumer adds integers.
 // T = the storage type of the block: float (counts, fp32-exact data) or double (TPM-like values: the term is log2(1 + x) of the
 // double itself, as the reference computes it).
+template <typename T> struct CpSlot;
+template <> struct __attribute__((aligned(8))) CpSlot<float> { uint32_t gene; float x; };
+template <> struct __attribute__((aligned(16))) CpSlot<double> { double x; uint32_t gene; uint32_t pad; };
+
 template <typename T>
-__global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 4 : 2) void rp_compact_kernel(const T *__restrict__ X, int m, long long ld, long long cell0,
+__global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 6 : 3) void rp_compact_kernel(const T *__restrict__ X, int m, long long ld, long long cell0,
                                                                 int ncell, int log_flag, double fix_scale, int cap,
                                                                 unsigned int *__restrict__ counts, uint32_t *__restrict__ genes,
                                                                 long long *__restrict__ fixes) {
-    __shared__ uint32_t sg[CP_THREADS / 64][CP_UNIT];
-    __shared__ T sx[CP_THREADS / 64][CP_UNIT];
+    __shared__ CpSlot<T> win[CP_THREADS / 64][CP_UNIT / 2];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the unit bookkeeping runs on the SALU)
     const int units = (m + CP_UNIT - 1) / CP_UNIT;
     const long long total = static_cast<long long>(ncell) * units;
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 4 : 2) void rp_compact
     const long long it0 = static_cast<long long>(blockIdx.x) * (CP_THREADS / 64) + w;
     if (it0 >= total) return;
     // (cell, unit) of the unit being worked on and of the unit being fetched (two strides ahead), advanced by (stride / units,
-    // stride % units) with a carry: the two 64-bit divisions per unit this replaces were a quarter of the kernel's vector instructions
+    // stride % units) with a carry
     const int sdiv = static_cast<int>(stride / units), smod = static_cast<int>(stride % units);
     int c = static_cast<int>(it0 / units), u = static_cast<int>(it0 % units);
     int fc = c, fu = u;
@@ -96,79 +110,123 @@ __global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 4 : 2) void rp_compact
     };
     auto fetch = [&]() -> CpVals<T> {                     // the unit at (fc, fu), clamped to the chunk's last one; then one stride on
         const bool in = fc < ncell;
-#ifdef SHARP_ABLATE_XSTREAM     // (diagnostic: every cell read from one of 64 columns, i.e. no HBM stream)
-        const CpVals<T> r = cp_load_unit<T>(X + ((cell0 + (in ? fc : ncell - 1)) & 63) * ld, in ? fu : units - 1, ld, lane);
-#else
-        const CpVals<T> r = cp_load_unit<T>(X + (cell0 + (in ? fc : ncell - 1)) * ld, in ? fu : units - 1, ld, lane);
-#endif
+        const int uu = in ? fu : units - 1;
+        const T *unit = X + (cell0 + (in ? fc : ncell - 1)) * ld + static_cast<long long>(uu) * CP_UNIT;
+        CpVals<T> r;
+        if (uu * CP_UNIT + CP_UNIT <= m) {                 // wave-uniform: only the last unit of a cell is ragged
+            r = cp_load_unit<T, false>(unit, 0, lane);
+        } else {                                           // its candidates beyond the last gene become zeros: nothing below tests a bound
+            r = cp_load_unit<T, true>(unit, static_cast<int>(ld - static_cast<long long>(uu) * CP_UNIT), lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (uu * CP_UNIT + CpLayout<T>::gene_of(lane, q) >= m) r.v[q] = T(0);
+        }
         advance(fc, fu);
         return r;
     };
-    CpVals<T> b1 = fetch(), b2 = fetch();
+    // the non-zeros of a unit: a scalar
+    auto count_unit = [&](const CpVals<T> &b) -> int {
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) n += __popcll(__ballot(b.v[q] != T(0)));
+        return n;
+    };
+    // The reservation of a unit's slot in its cell's list is lane 0's returning atomic, ISSUED here and waited for an iteration later
+    // (reserved()): written with the builtin, the compiler waits for the result on the spot -- a full memory round trip per unit, with
+    // the unit fetched just before it -- so both halves are inline assembly, and the order of the vector-memory operations between them
+    // is part of the contract: reserve(), then the CpLayout<T>::LOADS loads of ONE fetch(), then reserved() -- `s_waitcnt vmcnt(LOADS)`
+    // waits for everything older than those loads (vmcnt counts loads, stores and atomics in issue order), i.e. for the atomic, and
+    // leaves the fetch in flight.
+    auto reserve = [&](int cc, int n) -> unsigned int {
+        unsigned int ret = 0u;
+#if defined(SHARP_LAB_CP) && (SHARP_LAB_CP == 2 || SHARP_LAB_CP == 4)   // (lab build: no reservation)
+        if (false) {
+#else
+        if (lane == 0 && cc < ncell) {
+#endif
+            unsigned int *cp = counts + cc;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ret) : "v"(cp), "v"(static_cast<unsigned int>(n)) : "memory");
+        }
+        return ret;
+    };
+    auto reserved = [&](unsigned int ret) -> unsigned int {
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ret) : "n"(CpLayout<T>::LOADS) : "memory");
+        return static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(ret)));
+    };
+    // Two units per wave: b1 is being written out, b2 is in flight behind it (waited for, by the compiler's own count, where it is
+    // copied into b1 at the end of the iteration).
+    CpVals<T> b1 = fetch();
+    int cnt1 = count_unit(b1);
+    unsigned int res1 = reserve(c, cnt1);
+    CpVals<T> b2 = fetch();
+    int cn = c, un = u;                                    // (cell, unit) of b2
+    advance(cn, un);
     for (; c < ncell; advance(c, u)) {
-        const CpVals<T> b0 = b1;
-        b1 = b2;
-        b2 = fetch();
-        const T *vals = b0.v;
-        const int ubase = u * CP_UNIT;                     // gene of candidate q: ubase + CpLayout<T>::gene_of(lane, q)
-        unsigned nzm = 0;
-        if (u * CP_UNIT + CP_UNIT <= m) {                  // wave-uniform: only the last unit of a cell is ragged
+        unsigned int base = reserved(res1);                // (first: nothing may be issued between the fetch and this wait)
+        const int ubase = u * CP_UNIT;
+        CpSlot<T> *wp = win[w];
+        uint32_t *gout = genes + static_cast<long long>(c) * cap;
+        long long *fout = fixes + static_cast<long long>(c) * cap;
+        // a unit goes out in two halves of eight candidates per lane: a half has at most CP_UNIT / 2 non-zeros, the window's size
+#if defined(SHARP_LAB_CP) && (SHARP_LAB_CP == 2 || SHARP_LAB_CP == 4)
+        base = static_cast<unsigned int>(u) * 128u;
+#endif
+#if defined(SHARP_LAB_CP) && SHARP_LAB_CP >= 3                              // (lab build: count only)
+        if (cnt1 == 0x7fffffff)
+#endif
 #pragma unroll
-            for (int q = 0; q < 16; ++q) nzm |= vals[q] != T(0) ? (1u << q) : 0u;
-        } else {
+        for (int h = 0; h < 2; ++h) {
+            int run = 0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) nzm |= (ubase + CpLayout<T>::gene_of(lane, q) < m && vals[q] != T(0)) ? (1u << q) : 0u;
-        }
-        const int mine = __popc(nzm);
-        // inclusive prefix sum over the wave: four shifts inside the rows of 16 lanes, then row 0 -> 1 and 2 -> 3, then rows 0-1 -> 2-3
-        // (DPP: no LDS shuffles)
-        int incl = mine;
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);   // row_shr:1
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);   // row_shr:2
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);   // row_shr:4
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);   // row_shr:8
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-        const int cntw = __builtin_amdgcn_readlane(incl, 63);
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(&counts[c], static_cast<unsigned int>(cntw));
-        int pos = incl - mine;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            if ((nzm >> q) & 1u) {
-                sg[w][pos] = static_cast<uint32_t>(ubase + CpLayout<T>::gene_of(lane, q));
-                sx[w][pos] = vals[q];
-                ++pos;
-            }
-        }
-        base = __builtin_amdgcn_readfirstlane(base);
-        __builtin_amdgcn_wave_barrier();
-        uint32_t *gout = genes + static_cast<long long>(c) * cap + base;
-        long long *fout = fixes + static_cast<long long>(c) * cap + base;
-        for (int e0 = 0; e0 < cntw; e0 += 64) {            // one lane per non-zero
-            const int e = e0 + lane;
-            const bool live = e < cntw;
-            const T x = sx[w][live ? e : 0];
-            const uint32_t gg = sg[w][live ? e : 0];
-            // Integer counts below CP_TAB (scRNA counts, the synthetic data) travel as (gene, count) in ONE 32-bit word: the
-            // consumer takes their term from the same 256-entry table; everything else (non-integer or large values, raw mode)
-            // sets kEntryFull and stores its 64-bit term beside the word -- 4 instead of 12 bytes per non-zero written and read.
-            uint32_t entry = gg | kEntryFull;
-            long long fx = 0ll;
-            bool full = true;
-            if (log_flag) {
-                const unsigned xi = (x >= T(0) && x < T(CP_TAB)) ? static_cast<unsigned>(x) : 0u;
-                const bool tab = static_cast<T>(xi) == x && x < T(CP_TAB);
-                if (tab) { entry = gg | (xi << kEntryCountShift); full = false; }
-                if (__ballot(live && !tab) != 0ull) {      // the general path
-                    if (!tab) fx = __double2ll_rn((log_flag == 2 ? log10(1.0 + static_cast<double>(x)) : log2(1.0 + static_cast<double>(x))) * fix_scale);
+            for (int q = 8 * h; q < 8 * h + 8; ++q) {
+                const bool nz = b1.v[q] != T(0);
+                const unsigned long long mk = __ballot(nz);
+                if (nz) {
+                    const int pos = run + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mk >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mk), 0u)));
+                    CpSlot<T> sl;
+                    sl.gene = static_cast<uint32_t>(ubase + CpLayout<T>::gene_of(lane, q));
+                    sl.x = b1.v[q];
+                    wp[pos] = sl;
                 }
-            } else {
-                fx = __double2ll_rn(static_cast<double>(x) * fix_scale);
+                run += __popcll(mk);
             }
-            if (live) { gout[e] = entry; if (full) fout[e] = fx; }
+            __builtin_amdgcn_wave_barrier();
+            for (int e0 = 0; e0 < run; e0 += 64) {         // one lane per non-zero
+                const int e = e0 + lane;
+                const bool live = e < run;
+                const CpSlot<T> sl = wp[live ? e : 0];
+                const T x = sl.x;
+                const uint32_t gg = sl.gene;
+                // Integer counts below CP_TAB (scRNA counts, the synthetic data) travel as (gene, count) in ONE 32-bit word: the
+                // consumer takes their term from the same 256-entry table; everything else (non-integer or large values, raw mode)
+                // sets kEntryFull and stores its 64-bit term beside the word -- 4 instead of 12 bytes per non-zero written and read.
+                uint32_t entry = gg | kEntryFull;
+                long long fx = 0ll;
+                bool full = true;
+                if (log_flag) {
+                    const unsigned xi = (x >= T(0) && x < T(CP_TAB)) ? static_cast<unsigned>(x) : 0u;
+                    const bool tab = static_cast<T>(xi) == x && x < T(CP_TAB);
+                    if (tab) { entry = gg | (xi << kEntryCountShift); full = false; }
+                    if (__ballot(live && !tab) != 0ull) {      // the general path
+                        if (!tab) fx = __double2ll_rn((log_flag == 2 ? log10(1.0 + static_cast<double>(x)) : log2(1.0 + static_cast<double>(x))) * fix_scale);
+                    }
+                } else {
+                    fx = __double2ll_rn(static_cast<double>(x) * fix_scale);
+                }
+#if defined(SHARP_LAB_CP) && SHARP_LAB_CP == 1                              // (lab build: no list stores)
+                if (live && entry == 0x12345u) { gout[base + e] = entry; if (full) fout[base + e] = fx; }
+#else
+                if (live) { gout[base + e] = entry; if (full) fout[base + e] = fx; }
+#endif
+            }
+            __builtin_amdgcn_wave_barrier();
+            base += static_cast<unsigned int>(run);
         }
-        __builtin_amdgcn_wave_barrier();
+        b1 = b2;                                           // (the compiler's wait for the unit in flight)
+        cnt1 = count_unit(b1);                             // the next unit's slot is asked for an iteration before it is used
+        res1 = reserve(cn, cnt1);
+        advance(cn, un);
+        b2 = fetch();
     }
 }
 
@@ -249,7 +307,11 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     };
     const unsigned char *entb = reinterpret_cast<const unsigned char *>(ent);
     auto load_lists = [&](uint32_t g, uint2 (&dst)[U]) {
+#ifdef SHARP_LAB_AP_L1        // (lab build: every row list from one of 64 segments, i.e. from the CU's L1 -- what the L2 gathers cost)
+        const uint32_t gofs = (g & 63u) * static_cast<uint32_t>(SPAN * 2);
+#else
         const uint32_t gofs = g * static_cast<uint32_t>(SPAN * 2);    // byte offset of the lane's own entry's segment (32 bits: < 2^21 segments)
+#endif
         static_for<U>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             dst[u] = *reinterpret_cast<const uint2 *>(entb + (group_bcast<GW, u>(gofs) + static_cast<uint32_t>(8 * lg)));
@@ -444,7 +506,15 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
         const int nc = static_cast<int>(std::min<long long>(chunk, n - c0));
         if (two && ch >= 2) SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_apply[q], 0));      // buffer q free again
         const long long waves = static_cast<long long>(nc) * units;
-        const int cp_per_cu = knobs().rp_cp_wgs;
+        // a persistent grid of exactly the workgroups that are resident together (the units are dealt to the waves statically)
+        static int cp_occ[2] = {0, 0};
+        int &occ = cp_occ[dX.f64 ? 1 : 0];
+        if (occ == 0) {
+            const void *kf = dX.f64 ? reinterpret_cast<const void *>(rp_compact_kernel<double>) : reinterpret_cast<const void *>(rp_compact_kernel<float>);
+            SHARP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, CP_THREADS, 0));
+            occ = std::max(1, occ);
+        }
+        const int cp_per_cu = std::min(occ, knobs().rp_cp_wgs);
         const int blocks = static_cast<int>(std::min<long long>((waves + 3) / 4, static_cast<long long>(c.num_cu) * cp_per_cu));
         {
             KernelTimer tc("rp_compact", s2);
@@ -460,6 +530,7 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
             SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[q], s2));
             SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, W.ev_compact[q], 0));
         }
+#ifndef SHARP_LAB_CP          // (a lab build of the compaction leaves no valid lists behind: the apply kernel is not launched)
         {
             KernelTimer ta("rp_apply");
 #define SHARP_AP(GWV, DU) launch_apply<GWV, DU>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, W.counts.p + n + ch, c.stream)
@@ -469,6 +540,7 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
             else { if (dual) SHARP_AP(4, true); else SHARP_AP(4, false); }
 #undef SHARP_AP
         }
+#endif
         if (two) SHARP_HIP_CHECK(hipEventRecord(W.ev_apply[q], c.stream));
     }
 }
