@@ -51,6 +51,9 @@ int sharp_device_count(int *count);
 int sharp_init(int device);
 int sharp_shutdown(void);
 int sharp_synchronize(void);
+/* The library reads its tuning switches (SHARP_* environment variables: kernel forms, chunk sizes, pipeline depths -- none changes a
+ * result) ONCE, at its first use; this re-reads them, for a host that changes its environment afterwards (the tests do). */
+int sharp_reload_options(void);
 /* Per-kernel HIP-event timing on the library's stream (used by bench.py's roofline). */
 int sharp_profile_enable(int on);
 int sharp_profile_reset(void);

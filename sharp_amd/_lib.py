@@ -60,3 +60,8 @@ def init(device=None):
 def ensure_init():
     if _initialised_device is None:
         init()
+
+
+def reload_options():
+    """Ask the library to read its SHARP_* environment switches again (it reads them once, at first use)."""
+    check(lib().sharp_reload_options())

@@ -72,8 +72,11 @@ struct Knobs {
     int rp_chunk = 0;           // SHARP_RP_CHUNK: cells per chunk of the RP stage (0: sized by the library)
     int rp_cp_wgs = 8;          // SHARP_RP_CP_WGS / SHARP_RP_AP_WGS: workgroups per CU of the two RP kernels (upper bounds)
     int rp_ap_wgs = 4;
+    int rp_kernel = 0;          // SHARP_RP_KERNEL: "fused" (1) the single-kernel RP form, "dense" (2) the MFMA form, "sparse" (3) never the dense form
+    int rp_shape = 0;           // SHARP_RP_SHAPE=1: 8 lanes x 4 slots per gene where the default is 16 x 2 (A/B runs)
 };
 const Knobs &knobs();
+void reload_knobs();
 
 struct KernelStat {
     double ms = 0;

@@ -289,21 +289,21 @@ __global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int
 // The lanes the gene does not use keep kCodePad in every slot; the unused slots of a lane that holds codes get the lane's pad_code
 // (projector.hpp); every slot of a negative lane carries the sign bit, the consumer reads it from slot 0.
 constexpr uint32_t kPlacePerm = 64;   // codes of a gene whose class order fits the caller's scratch (longer lists take the slow loop)
-__host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint32_t gw, int ncomp, int neg_base, size_t g, size_t extra_base,
-                                           uint16_t *ent, unsigned char *perm /* kPlacePerm bytes of scratch */) {
-    const uint32_t span = 4u * gw;
+__host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint32_t gw, uint32_t S /* slots per lane: 2 or 4 */, int ncomp, int neg_base,
+                                           size_t g, size_t extra_base, uint16_t *ent, unsigned char *perm /* kPlacePerm bytes of scratch */) {
+    const uint32_t span = S * gw;
     const bool dual = neg_base > 0;                      // negative entries go to a second accumulator array: no signs, dense lanes
     const int dump_base = dual ? 2 * neg_base : ncomp;   // the dump accumulators sit behind every real one
     uint32_t np = 0;
     for (uint32_t i = 0; i < n; ++i) np += (!dual && (src[i] & 0x8000u)) ? 0u : 1u;
-    const uint32_t cap[2] = {(np + 3u) / 4u, (n - np + 3u) / 4u};   // lanes per sign
+    const uint32_t cap[2] = {(np + S - 1u) / S, (n - np + S - 1u) / S};   // lanes per sign
     const uint32_t lane0[2] = {0u, cap[0]};
     unsigned long long cnt[2] = {0ull, 0ull};            // codes per (sign, column), 4 x 16 bit
     unsigned long long colmask = 0ull;                   // classes present per column, 4 x 16 bit
     auto slot_ptr = [&](uint32_t lane, uint32_t q) -> uint16_t * {
         const uint32_t sgm = lane / gw;
         const size_t seg = sgm == 0 ? g : extra_base + (sgm - 1);
-        return ent + seg * span + 4u * (lane % gw) + q;
+        return ent + seg * span + S * (lane % gw) + q;
     };
     // codes per class (16 x 16 bit)
     unsigned long long per[4] = {0ull, 0ull, 0ull, 0ull};
@@ -320,12 +320,12 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
         const uint32_t s = (!dual && (src[i] & 0x8000u)) ? 1u : 0u;
         const unsigned long long cs = s ? cnt[1] : cnt[0];
         uint32_t q = 4u, room = 0u;
-        for (uint32_t qq = 0; qq < 4u; ++qq) {            // room for the sign and the class not in the column yet: the emptiest
+        for (uint32_t qq = 0; qq < S; ++qq) {             // room for the sign and the class not in the column yet: the emptiest
             const uint32_t used = static_cast<uint32_t>(cs >> (16u * qq)) & 0xffffu;
             if (used < cap[s] && !((colmask >> (16u * qq + c)) & 1ull) && (q == 4u || cap[s] - used > room)) { q = qq; room = cap[s] - used; }
         }
         if (q == 4u)
-            for (uint32_t qq = 0; qq < 4u; ++qq) {        // a conflict cannot be avoided: the emptiest column with room (4 cap[s] >= the sign's codes)
+            for (uint32_t qq = 0; qq < S; ++qq) {         // a conflict cannot be avoided: the emptiest column with room (S cap[s] >= the sign's codes)
                 const uint32_t used = static_cast<uint32_t>(cs >> (16u * qq)) & 0xffffu;
                 if (used < cap[s] && (q == 4u || cap[s] - used > room)) { q = qq; room = cap[s] - used; }
             }
@@ -369,7 +369,7 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
     // the unused slots of the lanes that hold codes: a dump accumulator whose class the slot's column does not hold yet (and no other
     // pad of the column has taken), so that the padding costs its instruction no LDS cycle either
     for (uint32_t l = 0; l < cap[0] + cap[1]; ++l)       // (every lane of a sign's range holds at least one code)
-        for (uint32_t q = 0; q < 4u; ++q) {
+        for (uint32_t q = 0; q < S; ++q) {
             uint16_t *sp = slot_ptr(l, q);
             if (*sp == static_cast<uint16_t>(kCodePad)) {
                 uint32_t d = (l + static_cast<uint32_t>(g)) % gw;                       // (start rotated by the gene: genes that share an instruction
@@ -386,7 +386,7 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
 
 // one thread per gene: order the gene's codes by component (the order of the host build: projector, then column) and
 // write them into the fixed-stride lane-major segments (+ overflow segments)
-__global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, uint16_t *__restrict__ flat, int gw, int ncomp, int neg_base,
+__global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, uint16_t *__restrict__ flat, int gw, int slots, int ncomp, int neg_base,
                                    const uint2 *__restrict__ ovf_slot, const uint2 *__restrict__ ovf_info, int novf,
                                    uint16_t *__restrict__ ent) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -402,7 +402,7 @@ __global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, u
     size_t extra_base = 0;
     if (novf > 0) extra_base = ovf_slot[g].x;
     __shared__ unsigned char sperm[64][kPlacePerm];       // (blockDim.x = 64)
-    place_gene(src, len, static_cast<uint32_t>(gw), ncomp, neg_base, static_cast<size_t>(g), extra_base, ent, sperm[threadIdx.x]);
+    place_gene(src, len, static_cast<uint32_t>(gw), static_cast<uint32_t>(slots), ncomp, neg_base, static_cast<size_t>(g), extra_base, ent, sperm[threadIdx.x]);
 }
 __global__ void proj_fill_u16_kernel(uint16_t *p, size_t n, uint16_t v) {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) p[i] = v;
@@ -413,6 +413,19 @@ std::map<int, std::shared_ptr<Projector>> g_table;
 int g_next = 1;
 
 }  // namespace
+
+// The shape of a group's row-list segments: gw lanes per gene, `slots` codes per lane.  `cover` = mean + 3 sd codes per gene.  A 64-bit
+// LDS atomic is served per 16 contiguous lanes, one cycle when their bank classes differ: with ONE gene per 16-lane group the packer
+// controls every class an instruction touches (place_gene), with two genes in a group (8 lanes each) their classes collide at random --
+// the apply kernel at K = 5, 8 lanes x 4 slots, spent 3.3 of its 7.3 LDS cycles per atomic instruction on such conflicts, and the LDS
+// is what bounds that kernel (row lists served from the CU's L1 instead of L2 leave its time unchanged).  Hence 16 lanes x 2 slots
+// from 17 codes per gene on; only short lists (K = 1, 2) keep 4-lane groups: there the vector instructions per gene weigh more.
+static void choose_shape(ProjectorGroup &grp, double cover) {
+    if (cover <= 16) { grp.gw = 4; grp.slots = 4; }
+    else if (cover <= 32) { grp.gw = 16; grp.slots = 2; }
+    else { grp.gw = 16; grp.slots = 4; }
+    if (knobs().rp_shape == 1 && cover > 16 && cover <= 32) { grp.gw = 8; grp.slots = 4; }   // SHARP_RP_SHAPE=1: the 8 x 4 form (A/B runs)
+}
 
 int dual_neg_base(int ncomp) {
     if (!knobs().rp_dual) return 0;
@@ -473,8 +486,8 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
         grp.max_len = max_len;
         // lanes per gene: the smallest width whose 4*gw-entry segment covers mean + ~3 sd
         const double cover = grp.mean_len + 3.0 * std::sqrt(grp.mean_len) + 1.0;
-        grp.gw = cover <= 16 ? 4 : (cover <= 32 ? 8 : 16);
-        const int span = 4 * grp.gw;
+        choose_shape(grp, cover);
+        const int span = grp.slots * grp.gw;
         std::vector<uint32_t> ovf_gene;
         std::vector<uint2> ovf_info;
         long long nseg = m;
@@ -482,7 +495,7 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
         for (int g = 0; g < m; ++g) {
             int np = 0, nn = 0;
             for (uint32_t q = rowptr[g]; q < rowptr[g + 1]; ++q) { if (flat[q] & 0x8000u) ++nn; else ++np; }
-            lanes[g] = static_cast<uint16_t>(grp.neg_base ? code_lanes(np + nn, 0) : code_lanes(np, nn));
+            lanes[g] = static_cast<uint16_t>(grp.neg_base ? code_lanes(np + nn, 0, grp.slots) : code_lanes(np, nn, grp.slots));
             if (lanes[g] > grp.gw) {
                 const uint32_t extra = (lanes[g] - grp.gw + grp.gw - 1) / grp.gw;
                 ovf_gene.push_back(static_cast<uint32_t>(g));
@@ -500,7 +513,7 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
             size_t extra_base = 0;
             if (lanes[g] > grp.gw) extra_base = ovf_info[ov++].x;
             unsigned char perm[kPlacePerm];
-            place_gene(src, len, static_cast<uint32_t>(grp.gw), grp.ncomp, grp.neg_base, static_cast<size_t>(g), extra_base, ent.data(), perm);
+            place_gene(src, len, static_cast<uint32_t>(grp.gw), static_cast<uint32_t>(grp.slots), grp.ncomp, grp.neg_base, static_cast<size_t>(g), extra_base, ent.data(), perm);
         }
         grp.ent.alloc(ent.size());
         grp.ent.upload(ent.data(), ent.size());
@@ -590,7 +603,7 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         std::vector<uint16_t> lanes(static_cast<size_t>(m));   // lanes of four same-sign codes the gene occupies
         for (int g = 0; g < m; ++g) {
             const int np = static_cast<int>(len[g] & 0xffffu), nn = static_cast<int>(len[g] >> 16);
-            lanes[g] = static_cast<uint16_t>(neg_base ? code_lanes(np + nn, 0) : code_lanes(np, nn));
+            lanes[g] = static_cast<uint16_t>(np);           // (positive codes for now: the lanes are sized below, once the group's shape is known)
             len[g] = static_cast<unsigned int>(np + nn);
             rowptr[g + 1] = rowptr[g] + len[g];
             max_len = std::max<int>(max_len, static_cast<int>(len[g]));
@@ -599,12 +612,14 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         grp.mean_len = static_cast<double>(grp.nnz) / m;
         grp.max_len = max_len;
         const double cover = grp.mean_len + 3.0 * std::sqrt(grp.mean_len) + 1.0;
-        grp.gw = cover <= 16 ? 4 : (cover <= 32 ? 8 : 16);
-        const int span = 4 * grp.gw;
+        choose_shape(grp, cover);
+        const int span = grp.slots * grp.gw;
         std::vector<uint32_t> ovf_gene;
         std::vector<uint2> ovf_info;
         long long nseg = m;
         for (int g = 0; g < m; ++g) {
+            const int np = lanes[g], nn = static_cast<int>(len[g]) - np;
+            lanes[g] = static_cast<uint16_t>(neg_base ? code_lanes(np + nn, 0, grp.slots) : code_lanes(np, nn, grp.slots));
             if (lanes[g] > grp.gw) {
                 const uint32_t extra = (lanes[g] - grp.gw + grp.gw - 1) / grp.gw;
                 ovf_gene.push_back(static_cast<uint32_t>(g));
@@ -636,7 +651,7 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         hipLaunchKernelGGL(proj_fill_kernel, dim3(16, grp.kcount, S), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
                            static_cast<uint32_t>(p), d_rowptr.p, d_fill.p, d_flat.p);
         hipLaunchKernelGGL(proj_layout_kernel, dim3((m + 63) / 64), dim3(64), 0, c.stream,      // (one thread per gene, a wave per workgroup: every CU gets some)
-                           m, d_rowptr.p, d_flat.p, grp.gw, grp.ncomp, grp.neg_base,
+                           m, d_rowptr.p, d_flat.p, grp.gw, grp.slots, grp.ncomp, grp.neg_base,
                            grp.ovf_slot.p, grp.ovf_info.p, grp.novf, grp.ent.p);
         launch_check("proj_layout_kernel");
         stream_sync();                                   // the temporaries above are released on scope exit

@@ -70,16 +70,17 @@ __device__ __forceinline__ RpStepVals rp_load_step(const float *col, int s, int 
 // epilogue.  Per step a wave has ONE dependent L2 round trip: the row-list loads of all its non-zero
 // genes are issued together right after compaction (fixed-stride segments need no pointer lookup) and
 // the fp64 log2 pass runs while they are in flight.
-template <int GW, bool VEC>
+template <int GW, int SLOTS, bool VEC>
 __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
     const float *__restrict__ X, int m, int n, long long ld, int log_flag, double fix_scale, double inv_fix,
     double val, double out_scale, const uint16_t *__restrict__ ent, const uint2 *__restrict__ ovf_slot,
     const uint2 *__restrict__ ovf_info, int novf, int ncomp, int neg_base, double *__restrict__ E, long long ldE, int comp0,
-    int nsteps, int step_len, int ablate, const int *__restrict__ row_map) {
+    int nsteps, int step_len, const int *__restrict__ row_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVE = RP_THREADS / 64;
     constexpr int WCAP = RP_CAP / NWAVE;                                               // slots per wave
-    constexpr int NG = 64 / GW, SPAN = 4 * GW;
+    constexpr int NG = 64 / GW, SPAN = SLOTS * GW;
+    constexpr uint32_t ACC0 = RP_CAP * sizeof(NzSlot);                                 // LDS address of accumulator 0
     constexpr int U = 16;                                                              // row lists in flight per group
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem + RP_CAP * sizeof(NzSlot));
 
@@ -138,32 +139,31 @@ __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
                 __builtin_amdgcn_wave_barrier();
                 for (int e0 = 0; e0 < nnz; e0 += U * NG) {
                     // ---- pass 3a: issue the row-list loads of up to U genes per group (8 bytes per lane each)
-                    uint2 cd[U];
-                    if (ablate < 2) {
+                    RowWord<SLOTS> cd[U];
+                    {
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             const int e = e0 + grp + u * NG;
-                            cd[u] = make_uint2(0xffffffffu, 0xffffffffu);
-                            if (e < nnz)
-                                cd[u] = *reinterpret_cast<const uint2 *>(ent + static_cast<size_t>(list[e].gene) * SPAN + 4 * lg);
+                            cd[u].x = 0xffffffffu;
+                            if (e < nnz) cd[u] = load_row_word<SLOTS>(ent + static_cast<size_t>(list[e].gene) * SPAN + SLOTS * lg);
                         }
                     }
                     // ---- pass 2 (under the loads): one lane per non-zero, fixed-point log2(1+x) in fp64
-                    if (ablate < 3) for (int e = e0 + lane; e < nnz && e < e0 + U * NG; e += 64) {
+                    for (int e = e0 + lane; e < nnz && e < e0 + U * NG; e += 64) {
                         const float x = __uint_as_float(list[e].xbits);
                         const double L = log_flag == 2 ? log10(1.0 + static_cast<double>(x)) : (log_flag ? log2(1.0 + static_cast<double>(x)) : static_cast<double>(x));   // 2: SHARP_unlimited2's log10
                         list[e].fix = __double2ll_rn(L * fix_scale);
                     }
                     __builtin_amdgcn_wave_barrier();
                     // ---- pass 3b: LDS atomics
-                    if (ablate < 2) {
+                    {
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             const int e = e0 + grp + u * NG;
                             if (e < nnz) {
                                 const long long fix = list[e].fix;
-                                if (ablate < 1) scatter_codes<RP_CAP * sizeof(NzSlot)>(cd[u], fix);
-                                else if (cd[u].x == 0xdeadbeefu) acc[0] = 1;
+                                const bool sgn = neg_base == 0;     // signed codes: bit 0 of every slot of a negative lane
+                                scatter_row_word<ACC0, SLOTS, true>(cd[u], static_cast<unsigned long long>((sgn && (cd[u].x & kCodeNeg)) ? -fix : fix));
                                 // rare: a full segment may continue in overflow segments
                                 const uint32_t firstcode = __shfl(cd[u].x, lane & ~(GW - 1));
                                 if ((firstcode & kCodeMore) != 0u && novf > 0) {
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(RP_THREADS, 4) void rp_scatter_kernel(
                                     const uint2 oi = ovf_slot[g];
                                     {
                                         for (uint32_t sg = 0; sg < oi.y; ++sg) {
-                                            const uint2 c = *reinterpret_cast<const uint2 *>(ent + (static_cast<size_t>(oi.x) + sg) * SPAN + 4 * lg);
-                                            scatter_codes<RP_CAP * sizeof(NzSlot)>(c, fix);
+                                            const RowWord<SLOTS> c = load_row_word<SLOTS>(ent + (static_cast<size_t>(oi.x) + sg) * SPAN + SLOTS * lg);
+                                            scatter_row_word<ACC0, SLOTS, true>(c, static_cast<unsigned long long>((sgn && (c.x & kCodeNeg)) ? -fix : fix));
                                         }
                                     }
                                 }
@@ -221,15 +221,15 @@ __global__ void absmax_kernel(const T *__restrict__ X, int m, int n, long long l
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));  // non-negative floats order as uints
 }
 
-template <int GW, bool VEC>
+template <int GW, int SLOTS, bool VEC>
 static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float *dX, int m, int n, long long ld,
                       int log_flag, int fix_bits, double *dE, long long ldE, const int *row_map) {
     Ctx &c = ctx();
     const size_t lds = RP_CAP * sizeof(NzSlot) + static_cast<size_t>(g.acc_slots() + kDumpSlots) * 8;   // + the pad codes' dump accumulators
     const int nsteps = (m + RP_STEP - 1) / RP_STEP;
     const int step_len = ((m + nsteps - 1) / nsteps + 3) / 4 * 4;
-    auto kern = rp_scatter_kernel<GW, VEC>;
-    {   // scatter_codes<RP_CAP * sizeof(NzSlot)>: the dynamic LDS block must start at LDS address 0 (no static LDS in the kernel)
+    auto kern = rp_scatter_kernel<GW, SLOTS, VEC>;
+    {   // scatter_row_word<ACC0, ...>: the dynamic LDS block must start at LDS address 0 (no static LDS in the kernel)
         hipFuncAttributes fa;
         SHARP_HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
         SHARP_REQUIRE(fa.sharedSizeBytes == 0, "rp_scatter_kernel: static LDS in front of the dynamic block");
@@ -242,12 +242,10 @@ static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float 
     long long blocks = std::min<long long>(n, static_cast<long long>(c.num_cu) * per_cu);
     const double fix_scale = std::ldexp(1.0, fix_bits), inv_fix = std::ldexp(1.0, -fix_bits);
     const double out_scale = 1.0 / std::sqrt(static_cast<double>(pr.p));
-    const char *abl = getenv("SHARP_RP_ABLATE");   // debug: 1 no atomics, 2 no scatter pass, 3 no log2 pass either
-    const int ablate = abl ? atoi(abl) : 0;
     KernelTimer t("rp_stage");
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(RP_THREADS), lds, c.stream, dX, m, n, ld, log_flag,
                        fix_scale, inv_fix, pr.val, out_scale, g.ent.p, g.ovf_slot.p, g.ovf_info.p, g.novf, g.ncomp, g.neg_base, dE, ldE, g.k0 * pr.p,
-                       nsteps, step_len, ablate, row_map);
+                       nsteps, step_len, row_map);
     launch_check("rp_scatter_kernel");
 }
 
@@ -264,8 +262,7 @@ void project_dev(const Projector &pr, XRef X, int m, int n, long long ld, int lo
     Ctx &c = ctx();
     {
         // a projector of density 1/sqrt(m) >= 1/4 is not sparse: the dense form on the MFMA (also SHARP_RP_KERNEL=dense, for cross-checks)
-        const char *kv = getenv("SHARP_RP_KERNEL");
-        if (kv ? std::string(kv) == "dense" : m <= 16) {
+        if (knobs().rp_kernel == 2 || (knobs().rp_kernel == 0 && m <= 16)) {
             project_dev_dense(pr, X, m, n, ld, log_flag, dE, ldE, d_row_map);
             return;
         }
@@ -293,17 +290,18 @@ void project_dev(const Projector &pr, XRef X, int m, int n, long long ld, int lo
     SHARP_REQUIRE(!X.f64 || (vec && m >= 8 && m <= (1 << 20)), "project: an fp64 block must be 16-byte aligned with an even leading dimension");
     for (const auto &g : pr.groups) {
         const int gw = g.gw;
-#define SHARP_RP_CASE(GWV)                                                                          \
-    if (vec) launch_rp<GWV, true>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);      \
-    else launch_rp<GWV, false>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map)
-        const char *kv = getenv("SHARP_RP_KERNEL");   // "fused": the single-kernel form (always used for unaligned X)
-        if (vec && m >= 8 && m <= (1 << 20) && (X.f64 || !(kv && std::string(kv) == "fused"))) {   // (20-bit gene index in the compacted entries)
+#define SHARP_RP_CASE(GWV, SL)                                                                          \
+    if (vec) launch_rp<GWV, SL, true>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);      \
+    else launch_rp<GWV, SL, false>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map)
+        const bool fused = knobs().rp_kernel == 1;   // SHARP_RP_KERNEL=fused: the single-kernel form (always used for unaligned X)
+        if (vec && m >= 8 && m <= (1 << 20) && (X.f64 || !fused)) {   // (20-bit gene index in the compacted entries)
             project_dev_split(pr, g, X, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);
             continue;
         }
-        if (gw == 16) { SHARP_RP_CASE(16); }
-        else if (gw == 8) { SHARP_RP_CASE(8); }
-        else { SHARP_RP_CASE(4); }
+        if (gw == 16 && g.slots == 4) { SHARP_RP_CASE(16, 4); }
+        else if (gw == 16) { SHARP_RP_CASE(16, 2); }
+        else if (gw == 8) { SHARP_RP_CASE(8, 4); }
+        else { SHARP_RP_CASE(4, 4); }
 #undef SHARP_RP_CASE
     }
 }

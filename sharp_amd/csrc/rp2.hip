@@ -267,14 +267,15 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t x) {
 // SIMD for 4.3 cycles, a plain two-operand one for 2.5, and the signed form spends 22 vector instructions per gene batch slot where
 // this one spends 11 -- the stage was bound by the vector ALU's issue rate in BOTH its kernels (82 % and 53 % busy), which is why they
 // never overlapped.
-template <int GW, bool DUAL>
+template <int GW, int SLOTS, bool DUAL>
 __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     int ncell, long long cell0, int cap, const unsigned int *__restrict__ counts, const uint32_t *__restrict__ genes,
     const long long *__restrict__ fixes, const long long *__restrict__ fixtab, const uint16_t *__restrict__ ent, unsigned int dummy_seg,
     const uint2 *__restrict__ ovf_slot, const uint2 *__restrict__ ovf_info, int novf, int ncomp, int neg_base, double inv_fix, double val,
     double out_scale, double *__restrict__ E, long long ldE, int comp0, const int *__restrict__ row_map, unsigned int *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NW = AP_THREADS / 64, SPAN = 4 * GW, U = GW;   // a batch = 64 entries = U per group
+    constexpr int NW = AP_THREADS / 64, SPAN = SLOTS * GW, U = GW;   // a batch = 64 entries = U per group
+    typedef RowWord<SLOTS> Row;                                // a lane's SLOTS codes of one gene: one 4- or 8-byte load
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lg = lane % GW;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
     const long long *fsrc = fixes;
     uint32_t gC = 0u, gL = 0u, wR = 0u;   // genes of the batch being added / of the batch after the next; entry words of the one after that
     long long fC = 0ll, fL = 0ll;         // their terms
-    uint2 cd[U], cdn[U];
+    Row cd[U], cdn[U];
     auto load_word = [&](int b) -> uint32_t {                  // lane = entry of batch b; unconditional, clamped
         const int e = (b << 6) + lane;
         return gsrc[e < nnz ? e : 0];
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
         f = e < nnz ? ff : 0ll;
     };
     const unsigned char *entb = reinterpret_cast<const unsigned char *>(ent);
-    auto load_lists = [&](uint32_t g, uint2 (&dst)[U]) {
+    auto load_lists = [&](uint32_t g, Row (&dst)[U]) {
 #ifdef SHARP_LAB_AP_L1        // (lab build: every row list from one of 64 segments, i.e. from the CU's L1 -- what the L2 gathers cost)
         const uint32_t gofs = (g & 63u) * static_cast<uint32_t>(SPAN * 2);
 #else
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
 #endif
         static_for<U>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
-            dst[u] = *reinterpret_cast<const uint2 *>(entb + (group_bcast<GW, u>(gofs) + static_cast<uint32_t>(8 * lg)));
+            dst[u] = load_row_word<SLOTS>(entb + (group_bcast<GW, u>(gofs) + static_cast<uint32_t>(2 * SLOTS * lg)));
         });
     };
     long long row_next = 0;               // E row of the cell being set up (row_map is read here, a cell ahead: read in front of the
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
         }
     };
     // one pipeline step: the atomics of batch b from the row lists in `cur`, the row lists of batch b+NW into `nxt`
-    auto step = [&](int b, uint2 (&cur)[U], uint2 (&nxt)[U]) {
+    auto step = [&](int b, Row (&cur)[U], Row (&nxt)[U]) {
         const uint32_t gN = gL;
         const long long fN = fL;
         load_lists(gN, nxt);
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
                 constexpr int u = decltype(uc)::value;
                 // (the broadcasts with every lane enabled: a DPP read of a disabled lane returns nothing)
                 const uint32_t lo = group_bcast<GW, u>(plo), hi = group_bcast<GW, u>(phi);
-                scatter_codes_plain<0>(cur[u], (static_cast<unsigned long long>(hi) << 32) | lo);
+                scatter_row_word<0, SLOTS, false>(cur[u], (static_cast<unsigned long long>(hi) << 32) | lo);
                 more |= cur[u].x;
             });
         } else {
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
                 const uint32_t bpl = group_bcast<GW, u>(plo), bph = group_bcast<GW, u>(phi);
                 const uint32_t bnl = group_bcast<GW, u>(nlo), bnh = group_bcast<GW, u>(nhi);
                 const uint32_t lo = neg ? bnl : bpl, hi = neg ? bnh : bph;
-                scatter_codes_signed<0>(cur[u], (static_cast<unsigned long long>(hi) << 32) | lo);
+                scatter_row_word<0, SLOTS, true>(cur[u], (static_cast<unsigned long long>(hi) << 32) | lo);
                 more |= cur[u].x;
             });
         }
@@ -376,9 +377,9 @@ __global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
                     const long long f = static_cast<long long>((static_cast<unsigned long long>(bph) << 32) | bpl);
                     const uint2 oi = ovf_slot[g];
                     for (uint32_t sg = 0; sg < oi.y; ++sg) {
-                        const uint2 c2 = *reinterpret_cast<const uint2 *>(ent + (static_cast<size_t>(oi.x) + sg) * SPAN + 4 * lg);
-                        if constexpr (DUAL) scatter_codes_plain<0>(c2, static_cast<unsigned long long>(f));
-                        else scatter_codes_signed<0>(c2, static_cast<unsigned long long>((c2.x & kCodeNeg) ? -f : f));
+                        const Row c2 = load_row_word<SLOTS>(ent + (static_cast<size_t>(oi.x) + sg) * SPAN + SLOTS * lg);
+                        if constexpr (DUAL) scatter_row_word<0, SLOTS, false>(c2, static_cast<unsigned long long>(f));
+                        else scatter_row_word<0, SLOTS, true>(c2, static_cast<unsigned long long>((c2.x & kCodeNeg) ? -f : f));
                     }
                 }
             });
@@ -431,15 +432,15 @@ struct SplitWs {
 SplitWs &sws() { static SplitWs w; return w; }
 }  // namespace
 
-template <int GW, bool DUAL>
+template <int GW, int SLOTS, bool DUAL>
 static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell, long long cell0, int cap, const unsigned int *counts,
                          const uint32_t *genes, const long long *fixes, double inv_fix, double *dE, long long ldE, const int *row_map,
                          unsigned int *queue, hipStream_t st) {
     Ctx &c = ctx();
     const size_t lds = static_cast<size_t>(g.acc_slots() + kDumpSlots) * 8 + 8;     // accumulators, dump accumulators, the cell queue's slot
-    auto kern = rp_apply_kernel<GW, DUAL>;
+    auto kern = rp_apply_kernel<GW, SLOTS, DUAL>;
     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    {   // scatter_codes<0>: the accumulators sit at LDS address 0, i.e. the kernel must not have static LDS in front of the dynamic block
+    {   // scatter_row_word<0, ...>: the accumulators sit at LDS address 0, i.e. the kernel must not have static LDS in front of the dynamic block
         hipFuncAttributes fa;
         SHARP_HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
         SHARP_REQUIRE(fa.sharedSizeBytes == 0, "rp_apply_kernel: static LDS in front of the accumulators");
@@ -533,11 +534,12 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
 #ifndef SHARP_LAB_CP          // (a lab build of the compaction leaves no valid lists behind: the apply kernel is not launched)
         {
             KernelTimer ta("rp_apply");
-#define SHARP_AP(GWV, DU) launch_apply<GWV, DU>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, W.counts.p + n + ch, c.stream)
+#define SHARP_AP(GWV, SL, DU) launch_apply<GWV, SL, DU>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, W.counts.p + n + ch, c.stream)
             const bool dual = g.neg_base > 0;
-            if (g.gw == 16) { if (dual) SHARP_AP(16, true); else SHARP_AP(16, false); }
-            else if (g.gw == 8) { if (dual) SHARP_AP(8, true); else SHARP_AP(8, false); }
-            else { if (dual) SHARP_AP(4, true); else SHARP_AP(4, false); }
+            if (g.gw == 16 && g.slots == 4) { if (dual) SHARP_AP(16, 4, true); else SHARP_AP(16, 4, false); }
+            else if (g.gw == 16) { if (dual) SHARP_AP(16, 2, true); else SHARP_AP(16, 2, false); }
+            else if (g.gw == 8) { if (dual) SHARP_AP(8, 4, true); else SHARP_AP(8, 4, false); }
+            else { if (dual) SHARP_AP(4, 4, true); else SHARP_AP(4, 4, false); }
 #undef SHARP_AP
         }
 #endif

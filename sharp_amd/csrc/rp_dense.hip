@@ -19,7 +19,7 @@ namespace sharp {
 namespace {
 
 // one thread per (gene, slot of its first segment or of one of its overflow segments)
-__global__ void rp_densify_kernel(const uint16_t *__restrict__ ent, const uint2 *__restrict__ ovf_slot, int novf, int m, int span, int ncomp,
+__global__ void rp_densify_kernel(const uint16_t *__restrict__ ent, const uint2 *__restrict__ ovf_slot, int novf, int m, int span, int slots, int ncomp,
                                   int neg_base, int max_extra, double *__restrict__ Rd) {
     const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int per_gene = span * (1 + max_extra);
@@ -35,8 +35,8 @@ __global__ void rp_densify_kernel(const uint16_t *__restrict__ ent, const uint2 
         seg = static_cast<size_t>(oi.x) + (sgm - 1);
     }
     const uint16_t *s = ent + seg * span;
-    const int lane = i >> 2;
-    const uint32_t pair01 = static_cast<uint32_t>(s[4 * lane]) | (static_cast<uint32_t>(s[4 * lane + 1]) << 16);
+    const int lane = i / slots;
+    const uint32_t pair01 = static_cast<uint32_t>(s[slots * lane]) | (static_cast<uint32_t>(s[slots * lane + 1]) << 16);
     if (!lane_live(pair01)) return;
     const uint32_t code = s[i];
     const int comp = static_cast<int>(code >> 3);
@@ -93,7 +93,7 @@ void project_dev_dense(const Projector &pr, XRef X, int m, int n, long long ld, 
     chunk = std::min<long long>(chunk, (n + 63) / 64 * 64);
     DevBuf<double> L(static_cast<size_t>(m) * chunk);
     for (const auto &g : pr.groups) {
-        const int span = 4 * g.gw;
+        const int span = g.span();
         DevBuf<double> Rd(static_cast<size_t>(m) * g.ncomp), Ec(static_cast<size_t>(chunk) * g.ncomp);
         DevBuf<GemmTask> dt(1);
         Rd.zero();
@@ -107,7 +107,7 @@ void project_dev_dense(const Projector &pr, XRef X, int m, int n, long long ld, 
             }
             const long long threads = static_cast<long long>(m) * span * (1 + max_extra);
             hipLaunchKernelGGL(rp_densify_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, c.stream, g.ent.p, g.ovf_slot.p,
-                               g.novf, m, span, g.ncomp, g.neg_base, max_extra, Rd.p);
+                               g.novf, m, span, g.slots, g.ncomp, g.neg_base, max_extra, Rd.p);
             launch_check("rp_densify_kernel");
         }
         for (long long c0 = 0; c0 < n; c0 += chunk) {

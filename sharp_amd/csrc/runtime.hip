@@ -200,19 +200,22 @@ HostTimer::~HostTimer() {
 }  // namespace sharp
 
 namespace sharp {
-const Knobs &knobs() {
-    static const Knobs k = [] {
-        Knobs v;
-        auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; };
-        v.rp_dual = num("SHARP_RP_DUAL", 1) != 0;
-        v.rp_two_streams = num("SHARP_RP_SERIAL", 1) == 0;
-        v.rp_chunk = num("SHARP_RP_CHUNK", 0);
-        v.rp_cp_wgs = std::max(1, num("SHARP_RP_CP_WGS", 8));
-        v.rp_ap_wgs = std::max(1, num("SHARP_RP_AP_WGS", 4));
-        return v;
-    }();
-    return k;
+// The one place the library reads its environment: at the first use (sharp_init) and again only when sharp_reload_options() asks for it.
+static Knobs read_knobs() {
+    Knobs v;
+    auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; };
+    v.rp_dual = num("SHARP_RP_DUAL", 1) != 0;
+    v.rp_two_streams = num("SHARP_RP_SERIAL", 1) == 0;
+    v.rp_chunk = num("SHARP_RP_CHUNK", 0);
+    v.rp_cp_wgs = std::max(1, num("SHARP_RP_CP_WGS", 8));
+    v.rp_ap_wgs = std::max(1, num("SHARP_RP_AP_WGS", 4));
+    v.rp_shape = num("SHARP_RP_SHAPE", 0);
+    if (const char *kv = getenv("SHARP_RP_KERNEL")) v.rp_kernel = !strcmp(kv, "fused") ? 1 : !strcmp(kv, "dense") ? 2 : !strcmp(kv, "sparse") ? 3 : 0;
+    return v;
 }
+static Knobs &knobs_storage() { static Knobs k = read_knobs(); return k; }
+const Knobs &knobs() { return knobs_storage(); }
+void reload_knobs() { knobs_storage() = read_knobs(); }
 }  // namespace sharp
 
 using namespace sharp;
@@ -288,6 +291,12 @@ int sharp_shutdown(void) {
         c.aux.clear();
         c.ready = false;
     }
+    SHARP_API_END
+}
+
+int sharp_reload_options(void) {
+    SHARP_API_BEGIN
+    reload_knobs();
     SHARP_API_END
 }
 
