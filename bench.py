@@ -11,10 +11,12 @@ A "step" is one pass of the hot path over one batch of synthetic input already r
           ensize.K = 15 (SHARP_large: projectors, RP matmul, 375 base-clustering tasks, 25 wMetaC, sMetaC).
   N = 1, --config cfg3: BASELINE.json configs[2]: SHARP_unlimited on 500 000 cells x 20 000 genes as 10 blocks, K = 5.
           (The default run also times cfg3 once, after the timed region, and reports it under "other_configs".)
-  N > 1 : BASELINE.json configs[3]: SHARP_unlimited on 1.3 M cells x 27 000 genes, ensize.K = 5, as its EIGHT blocks of
-          162 500 cells whatever N is, block b on GPU b mod N (one per GPU at N = 8), p = 508 from the global count: the
-          total problem and its labels are the same for every N ("scaling": "strong").  The only data-path collective is the all-gather of the per-block centroid table
-          before the final sMetaC (sharp_amd/dist.py).
+  N > 1, and N = 1 with --config cfg4: BASELINE.json configs[3]: SHARP_unlimited on 1.3 M cells x 27 000 genes, ensize.K = 5, as
+          its EIGHT blocks of 162 500 cells whatever N is, block b on GPU b mod N (one per GPU at N = 8; all eight one after the other
+          on the one GPU at N = 1: 140 GB of X), p = 508 from the global count: the total problem and its labels are the same for
+          every N ("scaling": "strong"), so `--gpus 1 --config cfg4` is the N = 1 point of the curve the N > 1 runs draw (the default
+          run reports it under "other_configs.cfg4_one_gpu").  The only data-path collective is the all-gather of the per-block
+          centroid table before the final sMetaC (sharp_amd/dist.py).
 The JSON carries `roofline` for the RP matmul stage (rp_compact_kernel + rp_apply_kernel; HBM-bound: X is read once for
 all K projectors) from HIP events on the library's streams inside the timed region, the same stage at the
 K = 5 shapes of cfg3 and of cfg4's per-GPU share (`roofline.by_config`), and `cpu_baseline`: the fp64 CPU oracle (a
@@ -68,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["cfg2", "cfg3"], default="cfg2", help="N = 1 workload (N > 1 always runs cfg4)")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4"], default="cfg2", help="N = 1 workload (N > 1 always runs cfg4)")
     ap.add_argument("--cells", type=int, default=0, help="override the TOTAL number of cells of the workload (tests)")
     ap.add_argument("--genes", type=int, default=0, help="override the number of genes (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,16 +137,17 @@ def main():
 
     # ---- workload of this run: synthetic blocks generated on the device (counter-based: identical on CPU and GPU)
     state = {}
-    if world > 1:
+    if world > 1 or args.config == "cfg4":
         cfg, tag = dict(CFG4), "cfg4"
     else:
         cfg, tag = (dict(CFG2), "cfg2") if args.config == "cfg2" else (dict(CFG3), "cfg3")
+    sharded = tag == "cfg4"                                  # blocks dealt to the ranks (all of them to the one rank at N = 1)
     if args.cells:
         cfg["cells"] = args.cells
     if args.genes:
         cfg["genes"] = args.genes
     n_total, m, K = cfg["cells"], cfg["genes"], cfg["K"]
-    if world > 1:
+    if sharded:
         # The data set is cut into the EIGHT blocks of configs[3] whatever N is (one block per GPU at N = 8; at N = 2 / 4 a rank runs 4 / 2
         # blocks one after the other, block b on rank b mod N), so every N clusters the same blocks and finds the same labels: strong
         # scaling of one fixed problem.  (Tests shrink the data set: blocks below 5000 cells would leave the SHARP_large path, so then one per rank.)
@@ -263,12 +266,12 @@ def main():
         result = {
             "metric": METRIC,
             "value": round(cells_per_s, 1), "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "baseline_config": {"cfg2": "configs[1]", "cfg3": "configs[2]", "cfg4": "configs[3]"}[tag],
-                       "cells_total": n_total, "cells_per_gpu": (sum(int(b.shape[0]) for b in blocks) if world > 1 else int(dX.shape[0])) if tag != "cfg3" else n_total, "cells_per_block": n_local, "genes": m, "n_RP": K,
+                       "cells_total": n_total, "cells_per_gpu": (sum(int(b.shape[0]) for b in blocks) if sharded else int(dX.shape[0])) if tag != "cfg3" else n_total, "cells_per_block": n_local, "genes": m, "n_RP": K,
                        "reduced_dim": p, "x_storage": "fp32 in HBM (synthetic counts are fp32-exact)",
-                       "parallelism": ("%d blocks, block b on GPU b mod %d; one all-gather of the per-block centroid tables" % (len(ncb), world)) if world > 1 else "single GPU"},
+                       "parallelism": ("%d blocks, block b on GPU b mod %d; one all-gather of the per-block centroid tables" % (len(ncb), world)) if sharded else "single GPU"},
             "roofline": roof,
             "other_kernels": others,
             "kernel_ms_per_step": stages,
@@ -366,7 +369,35 @@ def extra_configs(np, torch, sharp_amd, dev, lib, synth_block, unlimited_call, A
                          "value": round(nb / dt, 1), "unit": "cells/s", "seconds_per_call": round(dt, 4), "calls_timed": reps,
                          "clusters_found": int(mn.shape[0])}
     by_cfg["cfg4_share"] = rp_stage_alone(torch, sharp_amd, dev, lib, x, K, p)
-    del x
+    # ---- cfg4 whole on ONE GPU: the same eight 162 500-cell blocks the N > 1 runs deal out, one after the other here (140 GB of X
+    # resident): the N = 1 point of the strong-scaling curve (`--gpus 1 --config cfg4` times it as the headline value)
+    from sharp_amd import dist as sdist
+
+    B = CFG4["blocks"]
+    blocks = [x] + [synth_block(b * nb, nb, m) for b in range(1, B)]
+    truth = np.concatenate([dev.synth_labels(DATA_SEED, b * nb, nb, G_TRUE) for b in range(B)])
+    torch.cuda.synchronize()
+
+    def cfg4_step():
+        pg = sdist.global_reduced_dim(nb * B)
+        pj = sharp_amd.Projector(m, pg, [50 + RN_SEED + k for k in range(1, K + 1)])
+        res, nfin, _ = sdist.unlimited_sharded(blocks, list(range(B)), [nb] * B,
+                                               lambda blk, p_, nxt: dev.unlimited_block_dev(blk, p_, pj.handle, K, RN_SEED, next_block=nxt),
+                                               dev.unlimited_merge, device="cuda")
+        pj.close()
+        return np.concatenate([res[b] for b in range(B)]), nfin, pg
+    cfg4_step()                                                          # warm-up
+    lib.sharp_synchronize()
+    t0 = time.perf_counter()
+    pred, nfin, pg = cfg4_step()
+    lib.sharp_synchronize()
+    dt = time.perf_counter() - t0
+    out["cfg4_one_gpu"] = {"workload": "SHARP_unlimited on synthetic %d cells x %d genes as %d blocks of %d cells, block b on GPU b mod 1, ensize.K=%d, "
+                                       "rN.seed=%d (BASELINE.json configs[3] on one GPU: the N = 1 point of the curve `--gpus N` draws)"
+                                       % (nb * B, m, B, nb, K, RN_SEED),
+                           "value": round(nb * B / dt, 1), "unit": "cells/s", "seconds_per_call": round(dt, 4), "calls_timed": 1, "scaling": "strong",
+                           "reduced_dim": pg, "clusters_found": int(nfin), "ari_vs_planted_truth": round(float(ARI(truth, pred)["HA"]), 4)}
+    del x, blocks
     torch.cuda.empty_cache()
     return out, by_cfg
 
@@ -379,18 +410,25 @@ def cpu_baseline(np, dX, m, K):
     from sharp_amd.api import ARI
 
     orc.build()
-    cores = os.cpu_count() or 1
-    ns = 4000                                          # 2 folds x 15 projections = 30 base-clustering tasks
-    cores = min(cores, 2 * K)                          # the oracle parallelises over the K*T task grid only
+    present = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))           # the cores this process may run on (a GPU box hands out a share of the host)
+    except AttributeError:
+        avail = present
+    # a sample with at least as many base-clustering tasks as cores (the oracle parallelises over the K*T task grid, one task
+    # per thread): 2000-cell folds x K projections, between 4 000 and 16 000 cells
+    folds = max(2, min(8, -(-avail // K)))
+    ns = 2000 * folds
+    cores = min(avail, folds * K)
     Xs = dX[:ns].cpu().numpy().T.astype(np.float64)    # (genes, cells)
     t0 = time.perf_counter()
     ref = orc.SHARP(Xs, K=K, base_ncells=1, rN_seed=RN_SEED, nthreads=cores, want_view=False)
     t = time.perf_counter() - t0
     pred, _ = dev.SHARP_dev(dX[:ns], ensize_K=K, base_ncells=1, rN_seed=RN_SEED)
     ari = float(ARI(ref["pred_clusters"], pred)["HA"])
-    base = {"value": round(ns / t, 2), "unit": "cells/s", "cores": cores, "kind": "port",
-            "sample": "oracle SHARP_large on the first %d cells x %d genes of the same data (2 folds x %d RPs, OpenMP over "
-                      "the K*T task grid), %.1f s" % (ns, m, K, t)}
+    base = {"value": round(ns / t, 2), "unit": "cells/s", "cores": cores, "cores_available": avail, "cores_present": present, "kind": "port",
+            "sample": "oracle SHARP_large on the first %d cells x %d genes of the same data (%d folds x %d RPs = %d tasks, OpenMP over "
+                      "the K*T task grid on %d of the %d cores this process may use), %.1f s" % (ns, m, folds, K, folds * K, cores, avail, t)}
     return base, {"ari_gpu_vs_oracle_on_sample": round(ari, 4), "sample_cells": ns,
                   "full_size": "tests/test_configs_gpu.py::test_full_size_block_matches_oracle: a whole 50 000 x 20 000 block, labels identical"}
 

@@ -228,6 +228,28 @@ def SHARP(X, K=0, reduced_ndim=0, base_ncells=0, partition_ncells=0, hmethod="wa
     return dict(rc=rc, pred_clusters=pred, viE=viE, p=po.value, K=ko.value)
 
 
+def SHARP_large(X, K=5, p=None, ng=2000, hmethod="ward.D", N_cluster=0, enpN=0, indN=0, minN=2, maxN=0, sil_thre=0.35,
+                height_Ntimes=2.0, flag=True, rN_seed=2103, nthreads=1):
+    """R/SHARP.R:478-851 with its whole return contract: pred_clusters, viE and the soft cluster matrix x0 (:717-731,761-779)."""
+    m, n = X.shape
+    Xf = np.asfortranarray(X, dtype=np.float64)
+    if p is None:
+        p = int(np.ceil(np.log2(n) / 0.04))
+    if maxN <= 0:
+        maxN = max(40, -(-n // 5000))
+    pred = np.zeros(n, np.int32)
+    viE = np.zeros((n, p))
+    cap = max(maxN, 40) + 2
+    T = -(-n // ng)
+    cap = max(cap, T * K * max(maxN, 40) + 2) if T == 1 else cap + T * 2
+    x0 = np.zeros(n * cap)
+    ncol = C.c_int()
+    rc = lib().oracle_SHARP_large_x0(_dp(Xf), m, n, K, p, ng, HMETHODS[hmethod], int(N_cluster or 0), int(enpN or 0), int(indN or 0),
+                                     minN, maxN, C.c_double(sil_thre), C.c_double(height_Ntimes), int(bool(flag)), None,
+                                     C.c_double(rN_seed), nthreads, _ip(pred), _dp(viE), _dp(x0), cap, C.byref(ncol))
+    return dict(rc=rc, pred_clusters=pred, viE=viE, x0=x0[: n * ncol.value].reshape(ncol.value, n).T.copy())
+
+
 def SHARP_unlimited(blocks, K=0, N_cluster=0, minN=0, maxN=0, rN_seed=2103, nthreads=1, want_view=False):
     m = blocks[0].shape[0]
     ncb = np.array([b.shape[1] for b in blocks], np.int32)

@@ -947,7 +947,9 @@ double oracle_round1(double x) {
 static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng, int hmethod,
                             int N_cluster, int enpN, int indN, int minN, int maxN, double sil_thre,
                             double height_Ntimes, int flag, const int8_t *tern_in, double rN_seed,
-                            int nthreads, int *pred, double *viE_out, int fpart) {
+                            int nthreads, int *pred, double *viE_out, int fpart, double *x0_out, int x0_cap, int *x0_ncol) {
+    /* x0_out (n x x0_cap doubles, column-major; NULL: not wanted): the soft cluster matrix of :717-731 (block-diagonal over the folds'   */
+    /* wMetaC x0), its columns summed per final cluster (:763-773) and its rows put back in the original cell order (:779).                 */
     int rc = OR_OK;
     (void)nthreads;
     int *reind = (int *)xmalloc(sizeof(int) * (size_t)n);
@@ -996,13 +998,18 @@ static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng,
     free(Eall);
     /* per-fold wMetaC (:692-709); label "<id>en<t>" -> (t, id) packed */
     int *fColor = (int *)xmalloc(sizeof(int) * (size_t)n);
+    double **fx0 = (double **)xcalloc((size_t)T + 1, sizeof(double *));      /* per fold: wres$x0 (nt x nwC, column-major), wres$nwC (:703-707) */
+    int *fncl = (int *)xcalloc((size_t)T + 1, sizeof(int));
     #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
     for (int t = 1; t <= T; t++) {
         int c0 = fstart[t], nt = fstart[t + 1] - fstart[t];
         int *sub = (int *)xmalloc(sizeof(int) * (size_t)nt * (size_t)K);
         for (int k = 0; k < K; k++) memcpy(sub + (size_t)k * nt, enrp + (size_t)k * n + c0, sizeof(int) * (size_t)nt);
         int *fc = (int *)xmalloc(sizeof(int) * (size_t)nt); int ncl;
-        int r = oracle_wMetaC(sub, nt, K, hmethod, enpN, minN, maxN, sil_thre, height_Ntimes, fc, NULL, &ncl, NULL, NULL, NULL, NULL);
+        int capc = K * (maxN > 40 ? maxN : 40) + 2;        /* (the meta-clusters of a fold cannot outnumber its K * maxN base clusters) */
+        if (x0_out && !fpart) fx0[t] = (double *)xmalloc(sizeof(double) * (size_t)nt * (size_t)capc);
+        int r = oracle_wMetaC(sub, nt, K, hmethod, enpN, minN, maxN, sil_thre, height_Ntimes, fc, fx0[t], &ncl, NULL, NULL, NULL, NULL);
+        fncl[t] = ncl;
         if (r) {
             #pragma omp atomic
             rc |= r;
@@ -1019,17 +1026,46 @@ static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng,
             pred[dst] = fColor[i];
             if (viE_out) memcpy(viE_out + (size_t)dst * p, E1 + (size_t)i * p, sizeof(double) * (size_t)p);
         }
-        free(reind); free(folds); free(tern); free(fstart); free(enrp); free(enE); free(fColor); free(S); free(E1);
+        free(reind); free(folds); free(tern); free(fstart); free(enrp); free(enE); free(fColor); free(S); free(E1); free(fx0); free(fncl);
         return rc;
     }
+    /* column of sx0 (:717-731) of fold t's j-th cluster (uC = unique(fColor), :714: fold after fold, first appearance inside a fold -- */
+    /* the column order of the fold's own x0, R/wMetaC.R:180-208)                                                                        */
+    int *coff = (int *)xcalloc((size_t)T + 2, sizeof(int));
+    for (int t = 1; t <= T; t++) coff[t + 1] = coff[t] + fncl[t];
+    int lenuC = coff[T + 1], ncol = 0;
+    int *colmap = (int *)xmalloc(sizeof(int) * (size_t)(lenuC > 0 ? lenuC : 1));   /* sx0 column -> x0 column */
     if (T == 1) {
         /* :738-746 then :828: as.numeric("<id>en1") is NA for every cell -> one cluster */
         for (int i = 0; i < n; i++) S[i] = 1;
+        for (int q = 0; q < lenuC; q++) colmap[q] = q;     /* x0 = sx0 (:746) */
+        ncol = lenuC;
     } else {
         int *tf = (int *)xmalloc(sizeof(int) * (size_t)n); int nCu;
         rc |= oracle_sMetaC(fColor, E1, n, p, hmethod, N_cluster, minN, maxN, sil_thre, height_Ntimes, S, tf, &nCu);  /* :754 */
+        /* :761-773: sn = length(unique(stf)); x0[, i] = rowSums(sx0[, which(stf == i)]).  (nCu == lenuC: both count unique(fColor).) */
+        for (int q = 0; q < lenuC && q < nCu; q++) { colmap[q] = tf[q] - 1; if (tf[q] > ncol) ncol = tf[q]; }
         free(tf);
     }
+    if (x0_out) {
+        if (ncol > x0_cap) rc |= OR_ERR_ARG;
+        else {
+            for (size_t q = 0; q < (size_t)n * (size_t)ncol; q++) x0_out[q] = 0.0;
+            for (int t = 1; t <= T; t++) {
+                int c0 = fstart[t], nt = fstart[t + 1] - fstart[t];
+                for (int j = 0; j < fncl[t]; j++) {
+                    double *dstc = x0_out + (size_t)colmap[coff[t] + j] * n;
+                    for (int i = 0; i < nt; i++) {
+                        int dst = shuffle ? reind[c0 + i] - 1 : c0 + i;          /* x0[reind, ] = x0 (:779) */
+                        dstc[dst] += fx0[t][(size_t)j * nt + i];
+                    }
+                }
+            }
+        }
+        if (x0_ncol) *x0_ncol = ncol;
+    }
+    for (int t = 1; t <= T; t++) free(fx0[t]);
+    free(fx0); free(fncl); free(coff); free(colmap);
     for (int i = 0; i < n; i++) {                                            /* :775-783 */
         int dst = shuffle ? reind[i] - 1 : i;
         pred[dst] = S[i];
@@ -1046,7 +1082,15 @@ int oracle_SHARP_large(const double *X, int m, int n, int K, int p, int ng, int 
                        double height_Ntimes, int flag, const int8_t *tern_in, double rN_seed,
                        int nthreads, int *pred, double *viE_out) {
     return sharp_large_core(X, m, n, K, p, ng, hmethod, N_cluster, enpN, indN, minN, maxN, sil_thre, height_Ntimes, flag, tern_in,
-                            rN_seed, nthreads, pred, viE_out, 0);
+                            rN_seed, nthreads, pred, viE_out, 0, NULL, 0, NULL);
+}
+/* the same with enresults$x0 (R/SHARP.R:717-731,761-779): x0 is n x x0_cap doubles, column-major; *x0_ncol columns are filled */
+int oracle_SHARP_large_x0(const double *X, int m, int n, int K, int p, int ng, int hmethod,
+                          int N_cluster, int enpN, int indN, int minN, int maxN, double sil_thre,
+                          double height_Ntimes, int flag, const int8_t *tern_in, double rN_seed,
+                          int nthreads, int *pred, double *viE_out, double *x0, int x0_cap, int *x0_ncol) {
+    return sharp_large_core(X, m, n, K, p, ng, hmethod, N_cluster, enpN, indN, minN, maxN, sil_thre, height_Ntimes, flag, tern_in,
+                            rN_seed, nthreads, pred, viE_out, 0, x0, x0_cap, x0_ncol);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1216,7 +1260,7 @@ int oracle_SHARP_unlimited2(const double *Xcat, int m, int nb, const int *ncb, i
     for (int b = 0; b < nb; b++) {                                           /* :146-163 */
         int nbk = ncb[b];
         rc |= sharp_large_core(Xcat + off * (size_t)m, m, nbk, K, p, ng, hmethod, 0, enpN, indN, minN, maxN, sil_thre,
-                               height_Ntimes, flag ? 2 : 0, tern, rN_seed, nthreads, lab + off, E1 + off * (size_t)p, 1);
+                               height_Ntimes, flag ? 2 : 0, tern, rN_seed, nthreads, lab + off, E1 + off * (size_t)p, 1, NULL, 0, NULL);
         for (int j = 0; j < nbk; j++) { keys[off + j][0] = b; keys[off + j][1] = lab[off + j]; keys[off + j][2] = (int)(off + j); }
         off += (size_t)nbk;
     }

@@ -27,6 +27,10 @@ sharp_hip_load <- function(libdir = ".", device = 0L) {
     if (!h %in% names(.sharp_hmethods)) stop("invalid clustering method '", h, "'")
     .sharp_hmethods[[h]]
 }
+# a numeric matrix in DOUBLE storage: an integer count matrix (common with prep = FALSE) is INTSXP, and the .Call glue takes REAL()
+# of what it is handed -- the .C route coerces with as.double, so both bindings accept the same inputs
+.sharp_dmat <- function(x) { x <- data.matrix(x); storage.mode(x) <- "double"; x }
+
 .sharp_int <- function(x) if (missing(x) || is.null(x)) 0L else as.integer(x)
 
 # status -> R condition: 0 ok; 16 / 32 warning bits (reference quirks 8 and 11, DESIGN.md 9); anything else stop()
@@ -158,7 +162,7 @@ sMetaC <- function(rerowColor, sE1, folds, hmethod, finalN.cluster, minN.cluster
     sparse <- methods::is(scExp, "dgCMatrix")
     if (.sharp_has_glue()) {
         r <- if (sparse) .Call("R_sharp_SHARP_csc", scExp@p, scExp@i, scExp@x, dim(scExp), ipar, dpar, as.logical(forview))
-             else .Call("R_sharp_SHARP", data.matrix(scExp), ipar, dpar, as.logical(forview))
+             else .Call("R_sharp_SHARP", .sharp_dmat(scExp), ipar, dpar, as.logical(forview))
     } else {
         want <- if (forview) 3L else 0L
         args <- list(ipar[1], ipar[2], ipar[3], ipar[4], ipar[5], ipar[6], ipar[7], ipar[8], ipar[9], ipar[10], dpar[1], dpar[2],
@@ -206,7 +210,7 @@ sMetaC <- function(rerowColor, sE1, folds, hmethod, finalN.cluster, minN.cluster
     ncells <- sum(ncb)
     p <- ceiling(log2(ncells)/(0.2^2))
     if (.sharp_has_glue()) {
-        r <- .Call("R_sharp_unlimited", lapply(scExp, data.matrix), c(.sharp_int(ensize.K), .sharp_int(N.cluster), .sharp_int(minN.cluster),
+        r <- .Call("R_sharp_unlimited", lapply(scExp, .sharp_dmat), c(.sharp_int(ensize.K), .sharp_int(N.cluster), .sharp_int(minN.cluster),
                                                                        .sharp_int(maxN.cluster)), as.double(rN.seed), as.logical(viewflag))
     } else {
         r <- .C("sharp_C_SHARP_unlimited", unlist(lapply(scExp, function(b) as.double(data.matrix(b)))), nb, as.double(ncb), m,

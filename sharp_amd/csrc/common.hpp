@@ -68,11 +68,23 @@ struct XRef {
 // Tuning switches, read from the environment ONCE (the first sharp_init) and kept: the kernels' hosts never call getenv per launch.
 struct Knobs {
     bool rp_dual = true;        // SHARP_RP_DUAL=0: signed row-list codes even where two accumulator arrays would fit
-    bool rp_two_streams = false;   // SHARP_RP_SERIAL=0: the compaction of chunk c + 1 on a second stream beside the apply of chunk c
+    int rp_two_streams = -1;    // SHARP_RP_SERIAL=0 / 1: the compaction of chunk c + 1 on a second stream beside the apply of chunk c: always / never (default: by kernel form)
     int rp_chunk = 0;           // SHARP_RP_CHUNK: cells per chunk of the RP stage (0: sized by the library)
     int rp_cp_wgs = 8;          // SHARP_RP_CP_WGS / SHARP_RP_AP_WGS: workgroups per CU of the two RP kernels (upper bounds)
     int rp_ap_wgs = 4;
     int rp_kernel = 0;          // SHARP_RP_KERNEL: "fused" (1) the single-kernel RP form, "dense" (2) the MFMA form, "sparse" (3) never the dense form
+    int x_storage = 0;          // SHARP_X_STORAGE=fp32 / fp64: force the storage of uploaded blocks (0: fp32 when exact, else fp64)
+    bool block_prefetch = true; // SHARP_NO_BLOCK_PREFETCH=1: a block's front is not prepared under the previous block's tail
+    bool unlimited_batch = true;   // SHARP_UNLIMITED_BATCH=0: SHARP_unlimited block after block instead of one pipelined batch per window
+    int unlimited_window_mb = 0;   // SHARP_UNLIMITED_WINDOW_MB: projections per window of that batch (0: 16 GB)
+    int ml_min_levels = 0;      // SHARP_ML_MIN_LEVELS: candidate levels from which the incremental statistics take over (0: 256)
+    bool hc_mono = false, hc_seq = false;   // SHARP_HC_MONO=1 / SHARP_HC_SEQ=1 (cross-checks): one-launch agglomeration / sequential kernel only
+    int hc_split = -1;          // SHARP_HC_SPLIT=1 / 0: round-per-launch agglomeration forced on / off (-1: by task count)
+    int hc_ranges = 0, hc_wpt = 0, hc_finish_at = 15, hc_chunk = 0;   // SHARP_HC_RANGES / _WPT / _FINISH_AT / _CHUNK: ranges per chunk, workgroups per task, finishing round, tasks per chunk
+    bool hc_pipe = true;        // SHARP_HC_PIPE=0: one chunk of base-clustering tasks at a time
+    int gemm_slice = 8;         // SHARP_GEMM_SLICE: workgroups per CU per slice of a distance GEMM prepared under another block's tail
+    bool proj_host = false;     // SHARP_PROJ_HOST=1 (cross-check): the host build of the projectors
+    int upload_threads = 0;     // SHARP_UPLOAD_THREADS: host threads narrowing / copying an uploaded block (0: up to 32)
     int rp_shape = 0;           // SHARP_RP_SHAPE=1: 8 lanes x 4 slots per gene where the default is 16 x 2 (A/B runs)
 };
 const Knobs &knobs();
@@ -165,6 +177,10 @@ struct StreamScope {
     StreamScope(const StreamScope &) = delete;
     StreamScope &operator=(const StreamScope &) = delete;
 };
+
+// driver.hip: the side streams of the block pipeline (next block's front, ensemble mean) and the front prepared for the next call
+void drain_side_streams();
+void drop_pending_front();
 
 inline void stream_sync() { SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream)); }
 

@@ -143,6 +143,7 @@ __global__ void gather_rows_kernel(const double *__restrict__ src, const int *__
 // SHARP_small (R/SHARP.R:339-454)
 // ---------------------------------------------------------------------------------------------
 void sharp_small_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, HcParams base, SharpOut &out) {
+    last_small().valid = false;                          // E is about to be reallocated / overwritten: valid again only once this call has completed
     auto pr = projector_for(a, m, p, K);
     const long long ldE = static_cast<long long>(pr->K) * p;
     DevBuf<double> &E = dws().E;
@@ -155,7 +156,7 @@ void sharp_small_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
     get_opt_hclust_batch(tasks, false, hr);                                     // :366 getrowColor
     std::vector<int> enrp(static_cast<size_t>(n) * K);
     for (int k = 0; k < K; ++k) { out.rc |= hr[k].rc; for (int i = 0; i < n; ++i) enrp[static_cast<size_t>(k) * n + i] = colour_of(hr[k].f[i]); }
-    { LastSmall &L = last_small(); L.valid = true; L.n = n; L.K = K; L.p = p; L.ldE = ldE; L.enrp = enrp; }
+    { LastSmall &L = last_small(); L.n = n; L.K = K; L.p = p; L.ldE = ldE; L.enrp = enrp; }
     WmTask wt; wt.nC = enrp.data(); wt.N = n; wt.C = K; wt.prm = base; wt.prm.N_cluster = a.N_cluster;   // :401
     std::vector<WmTask> wts{wt};
     std::vector<WmResult> wr;
@@ -167,6 +168,7 @@ void sharp_small_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
     out.n_pred = relabel_first(out.pred);                                       // :429-443
     if (a.want_x0) { out.x0 = wr[0].x0; out.x0_cols = wr[0].ncl; }
     stream_sync();
+    last_small().valid = true;
 }
 
 // folds of partition.ncells cells, the last two balanced (R/SHARP.R:513-536)
@@ -204,9 +206,27 @@ struct LargeFront {
     }
 };
 namespace {
-struct PendingFront { std::unique_ptr<LargeFront> f; hipStream_t stream = nullptr; hipEvent_t main_done = nullptr; int parity = 0; };
+// A front prepared for the NEXT SHARP-large call.  It belongs to that call alone: `born` is the number of the call that made it and only
+// call born + 1 may take it (a hinted call that never comes, or comes later, finds it dropped -- an address and a shape that happen to
+// match prove nothing about the bytes behind them).  The side stream reads the hinted block until that next call, or
+// sharp_synchronize(), returns: the caller keeps the buffer alive and unchanged until then.
+struct PendingFront { std::unique_ptr<LargeFront> f; hipStream_t stream = nullptr; hipEvent_t main_done = nullptr; int parity = 0;
+                      unsigned long long born = 0, calls = 0; };
 PendingFront &pending_front() { static PendingFront p; return p; }
 }  // namespace
+
+// Finishes whatever the side streams of this file still have in flight (sharp_synchronize, sharp_shutdown).
+void drain_side_streams() {
+    PendingFront &PF = pending_front();
+    if (PF.stream) (void)hipStreamSynchronize(PF.stream);
+    if (dws().mean_stream) (void)hipStreamSynchronize(dws().mean_stream);
+}
+// Forgets a prepared front (after its stream has drained): error exits, sharp_trim, sharp_shutdown, sharp_projector_destroy.
+void drop_pending_front() {
+    PendingFront &PF = pending_front();
+    if (PF.stream) (void)hipStreamSynchronize(PF.stream);
+    PF.f.reset();
+}
 
 static void large_front(LargeFront &F, const SharpArgs &a, bool ahead, double *E_into = nullptr, int *pos_into = nullptr) {
     const int n = F.n, m = F.m, K = F.K, p = F.p;
@@ -274,7 +294,7 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
             SHARP_HIP_CHECK(hipStreamCreateWithPriority(&ms, hipStreamNonBlocking, hi));
         }
         SHARP_HIP_CHECK(hipEventRecord(dws().mean_go, c.stream));              // E is complete, the base clustering has left the chip
-        hipStream_t run_on = getenv("SHARP_MEAN_INLINE") ? c.stream : ms;      // (A/B knob: in front of the wMetaC kernels as before)
+        hipStream_t run_on = ms;
         SHARP_HIP_CHECK(hipStreamWaitEvent(run_on, dws().mean_go, 0));
         {
             StreamScope scope(run_on);
@@ -382,7 +402,16 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
     stream_sync();
 }
 
+static void sharp_large_dev_body(XRef dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, int ng, HcParams base, SharpOut &out);
 void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, int ng, HcParams base, SharpOut &out) {
+    try {
+        sharp_large_dev_body(dX, m, n, ld, a, K, p, ng, base, out);
+    } catch (...) {                                                             // nothing prepared ahead outlives a failed call
+        drop_pending_front();
+        throw;
+    }
+}
+static void sharp_large_dev_body(XRef dX, int m, int n, long long ld, const SharpArgs &a, int K, int p, int ng, HcParams base, SharpOut &out) {
     HostTimer ht_all("sharp_large_total");
     last_small().valid = false;                                                 // E is about to be overwritten
     HcParams bp = base; bp.N_cluster = a.indN;
@@ -390,8 +419,9 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
     // the front: prepared ahead of time by the previous block's call, or now
     std::unique_ptr<LargeFront> Fp;
     PendingFront &PF = pending_front();
+    const unsigned long long call_no = ++PF.calls;
     if (PF.f) {
-        if (PF.f->matches(dX, m, n, ld, K, p, ng, a, bp)) {
+        if (PF.born + 1 == call_no && PF.f->matches(dX, m, n, ld, K, p, ng, a, bp)) {
             Fp = std::move(PF.f);
             std::swap(dws().E, dws().Eb);                                       // its buffers become the current block's
             std::swap(dws().pos, dws().posb);
@@ -411,8 +441,8 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
     // the next front waits for it: it then runs under this block's statistics and host-bound tail instead of beside the HBM-bound
     // agglomeration (which it only slowed down: 259 -> 246 ms for the ten blocks of cfg3 ungated).
     hipEvent_t after_agglo = nullptr;
-    if (F.hc && a.next_dX.p && !getenv("SHARP_PREFETCH_UNGATED")) { HostTimer ht("base_clustering_total"); after_agglo = hc_prefetch_agglomerate(*F.hc); }
-    if (a.next_dX.p && a.projector && !getenv("SHARP_NO_BLOCK_PREFETCH")) {
+    if (F.hc && a.next_dX.p) { HostTimer ht("base_clustering_total"); after_agglo = hc_prefetch_agglomerate(*F.hc); }
+    if (a.next_dX.p && a.projector && knobs().block_prefetch) {
         const int nn = static_cast<int>(a.next_n);
         const int Tn = (nn + ng - 1) / ng;
         if (a.next_n >= 5000 && a.next_n < (1LL << 31) && static_cast<long long>(K) * Tn <= ctx().num_cu && Tn > 1) {
@@ -420,6 +450,9 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
             N->dX = a.next_dX; N->m = m; N->n = nn; N->ld = a.next_ld; N->K = K; N->p = p; N->ng = ng; N->flag = a.flag;
             N->projector = a.projector; N->rN_seed = a.rN_seed; N->fpart = a.fpart; N->bp = bp;
             if (a.maxN <= 0 && !a.fpart) N->bp.maxN = std::max(40, (nn + 4999) / 5000);   // the next block's own default (R/SHARP.R:144-146)
+            // The prefetch is an optimisation: whatever fails in it (an allocation on a GPU shared with another process, say) must not fail
+            // THIS block, which needs none of it.
+            try {
             if (!PF.stream) {
                 // lowest priority: the tail's small kernels (on the critical path) go first whenever they are ready; at equal priority the
                 // next block's distance GEMM kept every CU busy and they waited (the tail took 12 ms instead of 6.6)
@@ -443,8 +476,13 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
                 large_front(*N, a, true);
                 if (hc_prefetch_possible(N->tasks)) N->hc = hc_prefetch_begin(N->tasks, PF.parity ^= 1);
             }
-            if (N->hc) PF.f = std::move(N);
+            if (N->hc) { PF.f = std::move(N); PF.born = call_no; }
             else SHARP_HIP_CHECK(hipStreamSynchronize(PF.stream));              // (cannot be kept: finish it, the projection is simply redone)
+            } catch (...) {
+                if (PF.stream) (void)hipStreamSynchronize(PF.stream);           // what was enqueued for the next block drains; the block is
+                (void)hipGetLastError();                                        // simply prepared by its own call
+                PF.f.reset();
+            }
         }
     }
     std::vector<HcResult> hr;
@@ -738,6 +776,7 @@ int sharp_trim(void) {
     SHARP_API_BEGIN
     ctx();
     SHARP_HIP_CHECK(hipDeviceSynchronize());
+    drop_pending_front();
     host_block().release();
     upload_release_staging();
     dws().Ebatch.release();                              // a batched SHARP_unlimited window's projections (up to 16 GB)
@@ -868,10 +907,9 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
             // at most ~16 GB of projections.  SHARP_UNLIMITED_BATCH=0: block after block, each preparing the next under its tail.
             int e = b;
             long long rows = 0, ntasks = 0;
-            const char *ub = getenv("SHARP_UNLIMITED_BATCH");
             long long window_bytes = 16LL << 30;
-            if (const char *wb = getenv("SHARP_UNLIMITED_WINDOW_MB")) window_bytes = std::max(1LL, atoll(wb)) << 20;   // (tests: several windows)
-            if (!(ub && ub[0] == '0')) {
+            if (knobs().unlimited_window_mb > 0) window_bytes = static_cast<long long>(knobs().unlimited_window_mb) << 20;   // (tests: several windows)
+            if (knobs().unlimited_batch) {
                 while (e < nblocks && ncb[e] >= 5000 && ncb[e] < (1LL << 31) &&
                        (rows + ncb[e]) * static_cast<long long>(K) * p * 8 <= window_bytes) {
                     rows += ncb[e];

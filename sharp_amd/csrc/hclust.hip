@@ -963,7 +963,9 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     }
 }
 
+#ifdef SHARP_LAB       // the lazy agglomeration (an experiment kept for reference): lab builds only
 #include "hclust_lazy.inc"
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // a5a: cutree for every level k = kmin..kmax (level index L = k - kmin), ids by first appearance.
@@ -1486,6 +1488,7 @@ inline long long rup(long long v, long long a) { return (v + a - 1) / a * a; }
 constexpr int kHcSplitMaxTasks = 136;
 // more candidate levels than this in a chunk: the incremental per-level statistics (ml_*_kernel) instead of stats_kernel
 constexpr int kMlMinLevels = 256;
+static int ml_min_levels() { return knobs().ml_min_levels > 0 ? knobs().ml_min_levels : kMlMinLevels; }   // (SHARP_ML_MIN_LEVELS: tests)
 constexpr int kHcSplitMinObs = 1000;
 
 // model selection, R/get_opt_hclust.R:162-229
@@ -1621,7 +1624,7 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
         any_sym |= tk.symmetric; any_feat |= !tk.symmetric;
     }
     J.oOut = oOut; J.oM = oM; J.oLab = oLab; J.max_n = max_n; J.max_p = max_p; J.max_nk = max_nk; J.max_kpad = max_kpad;
-    SHARP_REQUIRE(max_nk > (getenv("SHARP_ML_MIN_LEVELS") ? std::max(1, atoi(getenv("SHARP_ML_MIN_LEVELS"))) : kMlMinLevels) ||
+    SHARP_REQUIRE(max_nk > ml_min_levels() ||
                   stats_lds_bytes(max_n, std::max(max_kpad, 64)) <= ST_LDS_MAX,
                   "get_opt_hclust: this many observations with this many candidate cluster numbers does not fit the silhouette kernel "
                   "(LDS: 8 B per observation rounded up to a power of two + 36 B per candidate cluster)");
@@ -1639,17 +1642,15 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
     int NS = T >= 194 ? 2 : 1;  // two ranges of more than 96 tasks each (the one-launch agglomeration); 3 or more are slower than one
     {
         // the round-per-launch agglomeration synchronises with the host every few rounds: one range at a time
-        const char *mono = getenv("SHARP_HC_MONO"), *seq = getenv("SHARP_HC_SEQ");
-        const char *splt = getenv("SHARP_HC_SPLIT");
         // (small tasks -- the similarity matrices of wMetaC and of a per-block sMetaC, a few hundred meta-clusters -- have nothing to
         // spread over several workgroups: the per-round launches and the host's look every eight rounds only cost, 0.27 ms per SHARP() call)
-        const bool split = splt ? splt[0] == '1' : (T <= kHcSplitMaxTasks && max_n >= kHcSplitMinObs);
+        const bool split = knobs().hc_split >= 0 ? knobs().hc_split == 1 : (T <= kHcSplitMaxTasks && max_n >= kHcSplitMinObs);
         J.split = split;
-        if (!(seq && seq[0] == '1') && ((!(mono && mono[0] == '1') && split) || max_n > HR_MAXN)) NS = 1;
+        if (!knobs().hc_seq && ((!knobs().hc_mono && split) || max_n > HR_MAXN)) NS = 1;
     }
-    if (const char *e = getenv("SHARP_HC_RANGES")) NS = std::max(1, std::min(8, atoi(e)));
+    if (knobs().hc_ranges > 0) NS = std::max(1, std::min(8, knobs().hc_ranges));
     if (J.pipe || J.one_range) NS = 1;          // the overlap comes from the neighbouring chunks / blocks
-    if (J.max_nk > (getenv("SHARP_ML_MIN_LEVELS") ? std::max(1, atoi(getenv("SHARP_ML_MIN_LEVELS"))) : kMlMinLevels)) NS = 1;   // many levels: one range
+    if (J.max_nk > ml_min_levels()) NS = 1;   // many levels: one range
     NS = std::min(NS, T);
     std::vector<RowPrepTask> &prep = J.prep;
     prep.assign(T, RowPrepTask());
@@ -1700,9 +1701,7 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
     }
     // many candidate levels (> kMlMinLevels; SHARP_ML_MIN_LEVELS for tests): G and T of the whole chunk row-major (n x kpad)
     {
-        int ml_min = kMlMinLevels;
-        if (const char *e = getenv("SHARP_ML_MIN_LEVELS")) ml_min = std::max(1, atoi(e));
-        J.ml = max_nk > ml_min;
+        J.ml = max_nk > ml_min_levels();
     }
     if (J.ml) {
         SHARP_REQUIRE(static_cast<size_t>(max_kpad) * 22 + 64 <= HR_LDS_CU, "get_opt_hclust: too many candidate cluster numbers (more than ~7400)");
@@ -1758,10 +1757,14 @@ void enqueue_chunk(ChunkJob &J, int phases) {
             KernelTimer tm("hclust_sequential");
             const int nal = (max_n + 1) & ~1;
             const size_t lds = (static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16 + 32 * 12 + 16 + 15) / 16 * 16;
-            const char *abl = getenv("SHARP_HC_ABLATE");
-            const char *tim = getenv("SHARP_HC_TIMING");       // debug: per-phase cycle counts of the merge loop
             DevBuf<long long> dbg;
+#ifdef SHARP_LAB                                                // (lab build, tools/build_variant.sh: phase ablation and per-phase cycle counts)
+            const char *abl = getenv("SHARP_HC_ABLATE");
+            const char *tim = getenv("SHARP_HC_TIMING");
             if (tim) { dbg.alloc(static_cast<size_t>(Ts) * 6); dbg.zero(); }
+#else
+            const char *abl = nullptr;
+#endif
             if (max_n <= kHcLdsMaxN) {
                 SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     static_cast<int>(lds)));
@@ -1774,6 +1777,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                                    W.seqstate.p + static_cast<size_t>(R.t0) * lds, static_cast<long long>(lds));
             }
             launch_check("hclust_kernel");
+#ifdef SHARP_LAB
             if (tim) {
                 std::vector<long long> h(static_cast<size_t>(Ts) * 6);
                 dbg.download(h.data(), h.size());
@@ -1783,6 +1787,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                                 "list+barrier %.0f | rescans %.0f | end barrier %.0f\n", Ts, max_n, acc[0] / Ts, acc[1] / Ts, acc[2] / Ts,
                         acc[3] / Ts, acc[4] / Ts, acc[5] / Ts);
             }
+#endif
         };
         if (phases & PH_DIST) {
         if (NS > 1) SHARP_HIP_CHECK(hipStreamWaitEvent(st, ev_in, 0));
@@ -1805,8 +1810,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         // matrices, D stays pristine); whatever it abandons (exact ties, centroid/median, n > 4096) is done by the
         // sequential NN-list kernel, which skips the tasks whose status is 0 -- no host round trip in between.
         {
-            const char *seq = getenv("SHARP_HC_SEQ");           // debug / cross-check: the sequential kernel only
-            const bool use_rnn = !(seq && seq[0] == '1');
+            const bool use_rnn = !knobs().hc_seq;                 // SHARP_HC_SEQ=1 (cross-check): the sequential kernel only
             const bool gs = max_n > HR_MAXN;                    // state arrays in global memory (always round per launch)
             KernelTimer tm("hclust");
             if (use_rnn) {
@@ -1814,19 +1818,19 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                 int npow2 = 1; while (npow2 < max_n - 1) npow2 <<= 1;
                 const size_t state = (static_cast<size_t>(nal) * (16 + 4 + 4 + 2 * 7 + 1) + 16 * 4 + (1024 / 64 + 1) * 4 + 64 + 15) / 16 * 16;
                 const size_t lds = std::max(state, static_cast<size_t>(npow2) * 16);
-                const char *mono = getenv("SHARP_HC_MONO");       // debug / cross-check: the whole agglomeration in one launch
+                const bool mono = knobs().hc_mono;                 // SHARP_HC_MONO=1 (cross-check): the whole agglomeration in one launch
                 // Few tasks (one projection, the wMetaC / sMetaC similarity tasks, a cross-block sMetaC of thousands of meta-clusters):
                 // one round per pair of launches, every task spread over several workgroups -- 25 tasks of 2000: 4.7 ms against
                 // 10.3 ms in one launch, 50 tasks 6.5 against 11.3.  Many tasks (kHcSplitMaxTasks): one launch is faster (the chip is
                 // then at its memory limit either way and the per-round launches only add their gaps).  SHARP_HC_SPLIT = 1 / 0 forces
                 // the choice; it is made for the whole chunk (a range of a larger chunk stays one launch).
                 const bool split = J.split || gs;
-                if ((!(mono && mono[0] == '1') || gs) && split) {
+                if ((!mono || gs) && split) {
                     // workgroups per task in the rebuild launches: eight when there are tens of tasks (measured, 25 - 136 tasks of 2000);
                     // a lone big task (a per-block or cross-block sMetaC of thousands of clusters) gets up to a quarter of the chip
                     int wpt = std::max(1, std::min(8, (5 * c.num_cu / 2 + Ts - 1) / Ts));
                     if (Ts <= 8) wpt = std::max(wpt, std::min(64, c.num_cu / (4 * Ts)));
-                    if (const char *e = getenv("SHARP_HC_WPT")) wpt = std::max(1, atoi(e));
+                    if (knobs().hc_wpt > 0) wpt = knobs().hc_wpt;
                     W0.img.ensure(static_cast<size_t>(Ts) * lds);
                     W0.remaining.ensure(1);
                     const int rem0 = Ts;
@@ -1841,8 +1845,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsl)));
                     const int max_rounds = max_n + 8;               // every round merges at least one pair
                     // after `finish_at` rounds (about a quarter of the clusters left at the usual 10 % per round) the rest runs in ONE launch
-                    int finish_at = 15;
-                    if (const char *e = getenv("SHARP_HC_FINISH_AT")) finish_at = atoi(e);
+                    const int finish_at = knobs().hc_finish_at;
                     auto kc = gs ? hclust_rnn_kernel<1024, 3, true> : hclust_rnn_kernel<1024, 3, false>;
                     if (finish_at >= 0) SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsl)));
                     for (int r = 0; r < max_rounds; ++r) {
@@ -1862,6 +1865,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                             if (rem <= 0) break;
                         }
                     }
+#ifdef SHARP_LAB
                 } else if (Ts <= c.num_cu && max_n <= HL_MAXN && getenv("SHARP_HC_LAZY") && getenv("SHARP_HC_LAZY")[0] == '1') {
                     // SHARP_HC_LAZY=1 (an experiment kept for reference): one workgroup per task, rows rewritten only
                     // when their cluster merges (hclust_lazy.inc) -- half the bytes of hclust_rnn_kernel, same merges, but at four waves
@@ -1873,6 +1877,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                     if (const char *e = getenv("SHARP_HC_LAZY_THETA")) theta = std::max(10, std::min(95, atoi(e)));
                     hipLaunchKernelGGL(hclust_lazy_kernel, dim3(Ts), dim3(HL_THREADS), ldsz, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p,
                                        W.height.p, W.status.p + R.t0, theta);
+#endif
                 } else if (Ts <= c.num_cu) {
                     auto k0 = hclust_rnn_kernel<1024, 0>;
                     // one workgroup per CU: everything the CU has beyond the state stages the pair members' entries
@@ -2009,9 +2014,8 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
     W.h_out.ensure(std::max<long long>(oOut, 1)); W.h_height.ensure(std::max<long long>(oM, 1));
     double *h_out = W.h_out.p, *h_height = W.h_height.p;
     if (c.profiling) {      // which agglomeration kernel did the work (tests assert on it)
-        const char *seq = getenv("SHARP_HC_SEQ");
         int fallback = T;
-        if (!(seq && seq[0] == '1')) {
+        if (!knobs().hc_seq) {
             std::vector<int> st(T);
             W.status.download(st.data(), T);
             fallback = 0;
@@ -2097,7 +2101,7 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
     size_t max_tasks = tasks.size();
     {
         const size_t ncu = static_cast<size_t>(ctx().num_cu);
-        if (const char *e = getenv("SHARP_HC_CHUNK")) max_tasks = std::max<size_t>(1, static_cast<size_t>(atoll(e)));
+        if (knobs().hc_chunk > 0) max_tasks = static_cast<size_t>(knobs().hc_chunk);
         else if (tasks.size() > ncu) {
             size_t nch = (tasks.size() + ncu - 1) / ncu;
             // Many chunks (the blocks of a SHARP_unlimited call as one batch): what counts is the steady state, where chunk j + 1's distance
@@ -2129,8 +2133,7 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
     // agglomeration (HBM-bound, one workgroup per task holding a whole CU: 188 of 256 CUs at cfg2) on the CUs that one leaves free,
     // chunk j's cutree / cluster sums / silhouette statistics beside chunk j + 1's agglomeration, and the host's level selection and
     // label download of chunk j under chunk j + 1's device work.  SHARP_HC_PIPE=0: one chunk at a time.
-    const char *pe = getenv("SHARP_HC_PIPE");
-    const bool pipe = bounds.size() > 1 && !(pe && pe[0] == '0');
+    const bool pipe = bounds.size() > 1 && knobs().hc_pipe;
     if (!pipe) {
         for (const auto &b : bounds) {
             ChunkJob J;
@@ -2169,7 +2172,7 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
         setup_chunk(tasks, J);
         enqueue_chunk(J, PH_DIST);
     };
-    const bool stats_last = R == 3 && !getenv("SHARP_HC_STATS_EARLY");
+    const bool stats_last = R == 3;
     try {
     start_chunk(0);
     for (size_t j = 0; j < nb; ++j) {
@@ -2208,7 +2211,7 @@ struct HcPrefetch {
 };
 
 bool hc_prefetch_possible(const std::vector<HcTask> &tasks) {
-    if (tasks.empty() || tasks.size() > static_cast<size_t>(ctx().num_cu) || getenv("SHARP_HC_CHUNK")) return false;
+    if (tasks.empty() || tasks.size() > static_cast<size_t>(ctx().num_cu) || knobs().hc_chunk > 0) return false;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
     double bytes = 0;
@@ -2216,7 +2219,7 @@ bool hc_prefetch_possible(const std::vector<HcTask> &tasks) {
         const double nld = static_cast<double>(rup(t.n, 128));
         bytes += 8.0 * (nld * nld * 4 + 2 * nld * (t.symmetric ? t.n : t.p));
     }
-    return bytes < 0.25 * static_cast<double>(free_b) || bytes < 8.0e9;
+    return bytes < 0.25 * static_cast<double>(free_b);          // (always against the memory that is free NOW: the GPU may be shared)
 }
 
 std::shared_ptr<HcPrefetch> hc_prefetch_begin(std::vector<HcTask> tasks, int slot) {
@@ -2237,7 +2240,6 @@ hipEvent_t hc_prefetch_agglomerate(HcPrefetch &P) {
     if (!P.agglo_done) SHARP_HIP_CHECK(hipEventCreateWithFlags(&P.agglo_done, hipEventDisableTiming));
     // round-per-launch form: the event sits behind the large rounds (the first eight move 3/4 of the bytes); the remaining small
     // rounds leave most of the chip idle, and the next block's front may as well start there
-    if (const char *e = getenv("SHARP_PREFETCH_ROUND")) P.J.mid_round = atoi(e);
     P.J.mid_event = P.agglo_done;
     enqueue_chunk(P.J, PH_AGGLO);
     P.J.mid_event = nullptr;

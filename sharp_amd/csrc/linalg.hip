@@ -227,8 +227,7 @@ void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_
             // the whole batch had been dispatched (2.4 ms instead of 0.2 for the per-fold wMetaC trees).  Between slices the queue drains.
             long long slice = blocks;
             if (c.polite) {
-                const char *e = getenv("SHARP_GEMM_SLICE");                // workgroups per CU in a slice (0: no slices)
-                const int per_cu = e ? atoi(e) : 8;
+                const int per_cu = knobs().gemm_slice;                     // SHARP_GEMM_SLICE: workgroups per CU in a slice (0: no slices)
                 if (per_cu > 0) slice = static_cast<long long>(c.num_cu) * per_cu;
             }
             for (long long b0 = 0; b0 < blocks; b0 += slice)
@@ -408,7 +407,7 @@ void row_prep_batched(const RowPrepTask *d_tasks, int count, int max_n, int max_
     if (count <= 0 || max_n <= 0) return;
     Ctx &c = ctx();
     KernelTimer tm("row_prep");
-    const bool fused = max_p <= 64 * RP_MAXV && !getenv("SHARP_ROWPREP_SPLIT");
+    const bool fused = max_p <= 64 * RP_MAXV;
     for (int z0 = 0; z0 < count; z0 += 65535) {
         const int nz = std::min(65535, count - z0);
         const int nld_max = (max_n + 127) / 128 * 128;

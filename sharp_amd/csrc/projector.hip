@@ -691,9 +691,8 @@ void ensure_host_lists(Projector &pr, int k) {
 }
 
 std::shared_ptr<Projector> build_projector(int m, int p, int K, const double *seeds) {
-    const char *host = getenv("SHARP_PROJ_HOST");       // debug / cross-check: the host build of the same projector
     const unsigned long long draws = static_cast<unsigned long long>(m) * static_cast<unsigned long long>(p);
-    if ((host && host[0] == '1') || draws >= (1ull << 31) || draws > (static_cast<unsigned long long>(MT_JUMP_COUNT + 1) << MT_JUMP_LOG2))
+    if (knobs().proj_host || draws >= (1ull << 31) || draws > (static_cast<unsigned long long>(MT_JUMP_COUNT + 1) << MT_JUMP_LOG2))
         return build_projector_host(m, p, K, seeds);
     return build_projector_device(m, p, K, seeds);
 }
@@ -731,6 +730,7 @@ int sharp_projector_create(int m, int p, int K, const double *seeds, int *handle
 int sharp_projector_destroy(int handle) {
     SHARP_API_BEGIN
     stream_sync();
+    drop_pending_front();                                // (a front prepared with this projector would outlive its handle)
     drop_projector(handle);
     SHARP_API_END
 }

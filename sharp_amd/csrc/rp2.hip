@@ -22,7 +22,10 @@ namespace sharp {
 
 constexpr int CP_THREADS = 256;
 constexpr int CP_UNIT = 1024;           // genes per wave unit = 64 lanes x 4 float4
-constexpr int AP_THREADS = 512;
+#ifndef SHARP_AP_THREADS
+#define SHARP_AP_THREADS 512
+#endif
+constexpr int AP_THREADS = SHARP_AP_THREADS;
 
 // One unit = 1024 genes = 16 values per lane, fetched with 16-byte loads: fp32 blocks as 4 x float4 (lane l, load j: genes
 // 4 (l + 64 j) ..), fp64 blocks as 8 x double2 (genes 2 (l + 64 j) ..).  gene_of(q) is the gene of a lane's q-th value.
@@ -268,7 +271,7 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t x) {
 // this one spends 11 -- the stage was bound by the vector ALU's issue rate in BOTH its kernels (82 % and 53 % busy), which is why they
 // never overlapped.
 template <int GW, int SLOTS, bool DUAL>
-__global__ __launch_bounds__(AP_THREADS, 4) void rp_apply_kernel(
+__global__ __launch_bounds__(AP_THREADS, AP_THREADS >= 512 ? 4 : 4) void rp_apply_kernel(
     int ncell, long long cell0, int cap, const unsigned int *__restrict__ counts, const uint32_t *__restrict__ genes,
     const long long *__restrict__ fixes, const long long *__restrict__ fixtab, const uint16_t *__restrict__ ent, unsigned int dummy_seg,
     const uint2 *__restrict__ ovf_slot, const uint2 *__restrict__ ovf_info, int novf, int ncomp, int neg_base, double inv_fix, double val,
@@ -465,7 +468,12 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
     // One stream by default: the two kernels do not overlap when they share the chip (each is limited by the memory requests a CU keeps
     // in flight), so chunk c + 1 compacted beside chunk c's apply buys nothing and the cross-stream events between the
     // launches cost 2 % (K = 5: 2.24 against 2.29 ms per stage; K = 15 the same either way).  SHARP_RP_SERIAL=0: two streams.
-    hipStream_t s2 = knobs().rp_two_streams ? c.stream2 : c.stream;
+    // Two streams (chunk c + 1 compacted beside chunk c's apply) where the apply kernel has dual accumulators: with its vector work halved
+    // the two kernels overlap a little (K = 5: 1.88 against 1.97 ms per stage); with signed codes (K = 15) they do not, and the
+    // cross-stream events cost 2 %.  Never for a block prepared under another block's tail (Ctx::polite: stream2 is a high-priority stream).
+    const int ts = knobs().rp_two_streams;
+    const bool two_streams = !c.polite && (ts < 0 ? g.neg_base > 0 : ts > 0);
+    hipStream_t s2 = two_streams ? c.stream2 : c.stream;
     const int cap = (m + 3) / 4 * 4;                         // worst case: every gene non-zero
     // chunks of cells: two (genes, fix, counts) buffers of <= 2 GB each (sized for the worst case, every gene non-zero);
     // few, equal chunks: each launch pays a tail, and a chunk must give every workgroup several cells

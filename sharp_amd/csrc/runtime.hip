@@ -205,12 +205,28 @@ static Knobs read_knobs() {
     Knobs v;
     auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; };
     v.rp_dual = num("SHARP_RP_DUAL", 1) != 0;
-    v.rp_two_streams = num("SHARP_RP_SERIAL", 1) == 0;
+    { const int ser = num("SHARP_RP_SERIAL", -1); v.rp_two_streams = ser < 0 ? -1 : (ser == 0 ? 1 : 0); }
     v.rp_chunk = num("SHARP_RP_CHUNK", 0);
     v.rp_cp_wgs = std::max(1, num("SHARP_RP_CP_WGS", 8));
     v.rp_ap_wgs = std::max(1, num("SHARP_RP_AP_WGS", 4));
     v.rp_shape = num("SHARP_RP_SHAPE", 0);
     if (const char *kv = getenv("SHARP_RP_KERNEL")) v.rp_kernel = !strcmp(kv, "fused") ? 1 : !strcmp(kv, "dense") ? 2 : !strcmp(kv, "sparse") ? 3 : 0;
+    if (const char *xs = getenv("SHARP_X_STORAGE")) v.x_storage = !strcmp(xs, "fp32") ? 32 : !strcmp(xs, "fp64") ? 64 : 0;
+    v.block_prefetch = num("SHARP_NO_BLOCK_PREFETCH", 0) == 0;
+    v.unlimited_batch = num("SHARP_UNLIMITED_BATCH", 1) != 0;
+    v.unlimited_window_mb = num("SHARP_UNLIMITED_WINDOW_MB", 0);
+    v.ml_min_levels = num("SHARP_ML_MIN_LEVELS", 0);
+    v.hc_mono = num("SHARP_HC_MONO", 0) == 1;
+    v.hc_seq = num("SHARP_HC_SEQ", 0) == 1;
+    v.hc_split = num("SHARP_HC_SPLIT", -1);
+    v.hc_ranges = num("SHARP_HC_RANGES", 0);
+    v.hc_wpt = num("SHARP_HC_WPT", 0);
+    v.hc_finish_at = num("SHARP_HC_FINISH_AT", 15);
+    v.hc_chunk = num("SHARP_HC_CHUNK", 0);
+    v.hc_pipe = num("SHARP_HC_PIPE", 1) != 0;
+    v.gemm_slice = num("SHARP_GEMM_SLICE", 8);
+    v.proj_host = num("SHARP_PROJ_HOST", 0) == 1;
+    v.upload_threads = num("SHARP_UPLOAD_THREADS", 0);
     return v;
 }
 static Knobs &knobs_storage() { static Knobs k = read_knobs(); return k; }
@@ -263,8 +279,7 @@ int sharp_init(int device) {
     {   // the second stream of the RP stage: its own priority class, hence its own hardware queue (see aux_stream)
         int lo = 0, hi = 0;
         SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        int pr = hi;
-        if (const char *e = getenv("SHARP_STREAM2_PRIO")) pr = e[0] == 'l' ? lo : e[0] == 'n' ? 0 : hi;   // tuning knob: low / normal / high
+        const int pr = hi;
         SHARP_HIP_CHECK(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, pr));
     }
     c.device = device;
@@ -280,6 +295,8 @@ int sharp_shutdown(void) {
     Ctx &c = ctx_unchecked();
     if (c.ready) {
         (void)hipStreamSynchronize(c.stream);
+        drop_pending_front();
+        drain_side_streams();
         for (auto &p : c.pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         c.pending.clear();
         for (auto e : c.event_pool) (void)hipEventDestroy(e);
@@ -303,6 +320,8 @@ int sharp_reload_options(void) {
 int sharp_synchronize(void) {
     SHARP_API_BEGIN
     stream_sync();
+    drain_side_streams();                                // (the next block's front, the ensemble mean: they may still read caller buffers)
+    if (ctx().stream2) SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream2));
     SHARP_API_END
 }
 

@@ -32,17 +32,11 @@ int &last_storage() { static int s = 0; return s; }
 
 int upload_threads() {
     unsigned hw = std::thread::hardware_concurrency();
-    if (const char *e = getenv("SHARP_UPLOAD_THREADS")) hw = static_cast<unsigned>(std::max(1, atoi(e)));
+    if (knobs().upload_threads > 0) hw = static_cast<unsigned>(knobs().upload_threads);
     return static_cast<int>(std::max(1u, std::min(hw ? hw : 4u, 32u)));
 }
 // 0 auto, 32, 64
-int storage_policy() {
-    const char *e = getenv("SHARP_X_STORAGE");
-    if (!e) return 0;
-    if (!strcmp(e, "fp32")) return 32;
-    if (!strcmp(e, "fp64")) return 64;
-    return 0;
-}
+int storage_policy() { return knobs().x_storage; }       // SHARP_X_STORAGE=fp32 / fp64
 template <typename F>
 void run_threads(int nthr, long long items, F fn) {
     if (nthr == 1 || items < nthr) { for (int t = 0; t < nthr; ++t) fn(t); return; }
@@ -199,7 +193,11 @@ void upload_block(const double *X, int m, long long n, long long ld, HostBlock &
     if (policy != 64) {
         const long long ldd = (static_cast<long long>(m) + 3) / 4 * 4;
         { HostTimer ha("upload_alloc"); hb.f.ensure(static_cast<size_t>(ldd) * n); }
-        if (upload_as<float>(X, m, n, ld, hb.f.p, ldd, policy == 0, &hb.max_abs)) { hb.f64 = false; hb.ld = ldd; last_storage() = 32; return; }
+        if (upload_as<float>(X, m, n, ld, hb.f.p, ldd, policy == 0, &hb.max_abs)) {
+            hb.d.release();                               // (an fp64 copy left by an earlier block of another kind)
+            hb.f64 = false; hb.ld = ldd; last_storage() = 32; return;
+        }
+        hb.f.release();                                   // the fp32 attempt is of no further use: an fp64 block must not cost 1.5 x its bytes
     }
     // a value fp32 cannot hold exactly (or fp64 forced): the block stays in double
     const long long ldd = (static_cast<long long>(m) + 1) / 2 * 2;

@@ -76,4 +76,10 @@ def test_bench_default_line_names_cfg2_and_carries_the_other_configs():
     assert rf["frac"] == pytest.approx(50000 * 20000 * 4 / (rf["stage"]["ms"] * 1e-3) / 8e12, rel=2e-3)
     assert set(rf["by_config"]) == {"cfg3_block", "cfg4_share"} and rf["by_config"]["cfg4_share"]["reduced_dim"] == 508
     assert d["other_configs"]["cfg3"]["reduced_dim"] == 474 and d["other_configs"]["cfg3"]["ari_vs_planted_truth"] > 0.9
-    assert d["cpu_baseline"]["kind"] == "port" and d["parity"]["ari_gpu_vs_oracle_on_sample"] >= 0.99
+    # cfg4 whole on the one GPU: the N = 1 point of the strong-scaling curve, same workload string as the N > 1 runs up to the GPU count
+    c4 = d["other_configs"]["cfg4_one_gpu"]
+    assert c4["scaling"] == "strong" and c4["reduced_dim"] == 508 and c4["ari_vs_planted_truth"] > 0.9
+    assert c4["workload"].startswith("SHARP_unlimited on synthetic 1300000 cells x 27000 genes as 8 blocks of 162500 cells, block b on GPU b mod 1")
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and d["parity"]["ari_gpu_vs_oracle_on_sample"] >= 0.99
+    assert cb["cores"] <= cb["cores_available"] <= cb["cores_present"] and "tasks" in cb["sample"]

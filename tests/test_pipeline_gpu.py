@@ -113,8 +113,18 @@ def test_sharp_large_matches_oracle(sa, oracle):
     assert ari >= 0.99, ari
     assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
     np.testing.assert_allclose(res["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
-    assert res["x0"].shape[0] == n and np.all(res["x0"].max(1) >= 1.0)
+    # enresults$x0 (R/SHARP.R:717-731,761-779): the folds' wMetaC x0 block-diagonal, columns summed per sMetaC cluster, rows un-shuffled
+    refL = oracle.SHARP_large(X, K=5, ng=200, rN_seed=2103, nthreads=4)
+    assert np.array_equal(refL["pred_clusters"], ref["pred_clusters"])
+    assert res["x0"].shape == refL["x0"].shape and np.all(res["x0"].max(1) >= 1.0)
+    np.testing.assert_allclose(res["x0"], refL["x0"], rtol=0, atol=1e-15)
     assert adjusted_rand_score(truth, res["pred_clusters"]) > 0.5
+    # one fold (T == 1, :738-746): x0 is the fold's own wMetaC x0, and every label becomes NA -> one cluster (quirk 2)
+    res1 = sa.SHARP(X, ensize_K=5, base_ncells=300, partition_ncells=2000, rN_seed=2103, logflag=False, prep=False)
+    ref1 = oracle.SHARP_large(X, K=5, ng=2000, rN_seed=2103, nthreads=4)
+    assert res1["path"] == "SHARP_large" and np.array_equal(res1["pred_clusters"], ref1["pred_clusters"])
+    assert res1["x0"].shape == ref1["x0"].shape
+    np.testing.assert_allclose(res1["x0"], ref1["x0"], rtol=0, atol=1e-15)
 
 
 @pytest.mark.parametrize("chunk", [4, 7, 25])
