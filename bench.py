@@ -207,12 +207,14 @@ def main():
     # kernels sharing the chip run slower than alone; one more step with one chunk and one range at a time gives each kernel's own time.
     os.environ["SHARP_HC_RANGES"] = "1"
     os.environ["SHARP_HC_PIPE"] = "0"
+    sharp_amd.reload_options()                           # (the library reads its switches once; this asks it to read them again)
     dev.profile(True)
     step()
     barrier()
     prof = dev.profile_table()
     del os.environ["SHARP_HC_RANGES"]
     del os.environ["SHARP_HC_PIPE"]
+    sharp_amd.reload_options()
     dev.profile(False)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)

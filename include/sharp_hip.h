@@ -89,6 +89,12 @@ int sharp_project(int proj, const double *X, int m, int n, long long ld, int log
  * when ld % 4 == 0), dE fp64 n x ldE row-major (ldE >= K*p). */
 int sharp_project_dev(int proj, const float *dX, int m, int n, long long ld, int log_flag,
                       double *dE, long long ldE);
+/* The same for an fp64 block that is already resident: TPM / CPM-like doubles (the reference's own example data, README.md:88,114;
+ * R/SHARP.R:110-117 computes log2(X + 1) and the projection in double), which the fp32 form would perturb by 6e-8 relative.
+ * dX must be 16-byte aligned with an even ld >= m and hold finite values (one pass over it finds max |x| and checks that).  The
+ * *_dev64 entry points below take the same kind of block. */
+int sharp_project_dev64(int proj, const double *dX, int m, int n, long long ld, int log_flag,
+                        double *dE, long long ldE);
 
 /* ---- a3-a5: get_opt_hclust --------------------------------------------------- */
 /* R/get_opt_hclust.R:33-244.  mat: n x p ROW-major feature rows, or an n x n symmetric similarity
@@ -147,6 +153,11 @@ int sharp_SHARP_dev(const float *dX, int m, long long n, long long ld, int ensiz
                     int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
                     double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred,
                     int *n_pred, double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path);
+/* a resident fp64 block (see sharp_project_dev64) */
+int sharp_SHARP_dev64(const double *dX, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells,
+                      int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
+                      double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred,
+                      int *n_pred, double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path);
 /* host matrix: X double, m x n column-major (ld >= m); kept in HBM as fp32 when that is exact, else as fp64 (sharp_x_storage) */
 int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells,
                 int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
@@ -192,6 +203,17 @@ int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *nc
                               int *p_used);
 int sharp_SHARP_unlimited(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K,
                           int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used);
+/* The same over several GPUs of this node, inside the calling process: the serial block loop of R/SHARP_unlimited.R:125-163
+ * is dealt out, block b to devices[b mod ndevices]; one host thread per device (each with its own context, streams and workspaces) builds
+ * the projectors -- a pure function of m, p and the seeds, :97-104 -- and clusters its blocks; p comes from the GLOBAL cell count (:65-66);
+ * the per-(block, cluster) centroid tables (a few hundred rows x p doubles per block: all sMetaC uses of E1, R/sMetaC.R:58-63) meet in
+ * host memory, the final sMetaC / small-cluster merge / size-ordered relabel (:163-183) run once, on devices[0], and every block's labels
+ * are mapped through the result.  Labels identical to sharp_SHARP_unlimited on one GPU.  A device may be named more than once (several
+ * slots on one GPU: the tests).  rN_seed must be a seed (0.5, the unseeded sentinel, would give every device different projectors).
+ * sharp_SHARP_unlimited / _view themselves take this path when the environment names several devices: SHARP_DEVICES=0,1,2,... */
+int sharp_SHARP_unlimited_multi(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K,
+                                int N_cluster, int minN, int maxN, double rN_seed, const int *devices, int ndevices,
+                                int *pred, int *n_pred, int *p_used, double *viE /* ncells x p row-major, or NULL */);
 /* The same with the viewflag output (R/SHARP_unlimited.R:153,216-228): viE = the blocks' ensemble-mean projections E1,
  * ncells x p row-major in block order (NULL: not wanted).  The 50-dimension reduction the reference applies above 1e5
  * cells is one more sharp_project() call on this matrix (host side: sharp_amd/api.py). */
@@ -208,6 +230,8 @@ int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long lon
  * which returns the final 1-based id of each gathered (block, cluster) row. */
 int sharp_unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
                               double rN_seed, int *pred, int *n_clusters, double *means, int cap_rows, long long *counts);
+int sharp_unlimited_block_dev64(const double *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
+                                double rN_seed, int *pred, int *n_clusters, double *means, int cap_rows, long long *counts);
 /* SHARP_unlimited2 (R/SHARP_unlimited2.R:29-292, with SHARP_fpart :297-544): log10 instead of log2, E1 rounded to one
  * decimal before the base clustering (maxN.cluster = 40 there), and a single sMetaC over the per-fold ensemble clusters of
  * all blocks.  flag: log-transform (the reference's testlog decision); viE: ncells x p row-major E1 or NULL.  0 / negative
@@ -311,6 +335,9 @@ void sharp_C_last_rpinfo(int *dims, int *enrp, double *indE, int *want, int *sta
  * info[2] = n_pred, p_used */
 void sharp_C_SHARP_unlimited(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *N_cluster, int *minN, int *maxN,
                              double *rN_seed, int *pred, double *viE, int *info, int *want, int *status);
+/* sharp_SHARP_unlimited_multi: devices = integer vector of GPU indices (block b on devices[b mod *ndevices]) */
+void sharp_C_SHARP_unlimited_multi(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *N_cluster, int *minN, int *maxN,
+                                   double *rN_seed, int *devices, int *ndevices, int *pred, double *viE, int *info, int *want, int *status);
 /* R/SHARP_unlimited2.R:29-292 */
 void sharp_C_SHARP_unlimited2(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *reduced_ndim, int *partition_ncells,
                               int *hmethod, int *N_cluster, int *enpN, int *indN, int *minN, int *maxN, double *sil_thre,

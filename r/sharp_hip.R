@@ -204,12 +204,23 @@ sMetaC <- function(rerowColor, sE1, folds, hmethod, finalN.cluster, minN.cluster
 # N.genes, reduced.dim, ensize.K, time, paras).  SHARP_small / SHARP_large are the same call with base.ncells = ncells + 1 / 1.
 
 # ---- SHARP_unlimited (R/SHARP_unlimited.R:29-242): replaces :96-183 -----------------------------------------------------------
-.sharp_unlimited_run <- function(scExp, ensize.K, N.cluster, minN.cluster, maxN.cluster, rN.seed, viewflag) {
+# devices: integer vector of GPU indices (default: getOption("sharp.devices"), e.g. options(sharp.devices = 0:7)); with two or more the
+# serial block loop of :125-163 is dealt out, block b to devices[b mod N], inside this R process (sharp_SHARP_unlimited_multi: one host
+# thread and one device context per GPU, nothing crosses between GPUs but the per-block centroid tables).  The .C() route carries the list.
+.sharp_unlimited_run <- function(scExp, ensize.K, N.cluster, minN.cluster, maxN.cluster, rN.seed, viewflag,
+                                 devices = getOption("sharp.devices")) {
     nb <- length(scExp); m <- nrow(scExp[[1]])
     ncb <- vapply(scExp, ncol, 1)
     ncells <- sum(ncb)
     p <- ceiling(log2(ncells)/(0.2^2))
-    if (.sharp_has_glue()) {
+    if (length(devices) >= 2) {
+        r <- .C("sharp_C_SHARP_unlimited_multi", unlist(lapply(scExp, function(b) as.double(data.matrix(b)))), nb, as.double(ncb), m,
+                .sharp_int(ensize.K), .sharp_int(N.cluster), .sharp_int(minN.cluster), .sharp_int(maxN.cluster), as.double(rN.seed),
+                as.integer(devices), length(devices), pred = integer(ncells), viE = double(if (viewflag) ncells * p else 1),
+                info = integer(2), as.integer(viewflag), status = integer(1))
+        .sharp_check(r$status)
+        r <- list(pred = r$pred, viE = if (viewflag) t(matrix(r$viE, nrow = p)) else NULL, p = r$info[2])
+    } else if (.sharp_has_glue()) {
         r <- .Call("R_sharp_unlimited", lapply(scExp, .sharp_dmat), c(.sharp_int(ensize.K), .sharp_int(N.cluster), .sharp_int(minN.cluster),
                                                                        .sharp_int(maxN.cluster)), as.double(rN.seed), as.logical(viewflag))
     } else {

@@ -430,8 +430,10 @@ def SHARP_large(scExp, ncells=None, ensize_K=5, reduced_dim=None, partition_ncel
 
 
 def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster=None, minN_cluster=None,
-                    maxN_cluster=None, rN_seed=None):
-    """R/SHARP_unlimited.R:29-242.  scExp: list of (genes, cells) blocks sharing the gene axis."""
+                    maxN_cluster=None, rN_seed=None, devices=None):
+    """R/SHARP_unlimited.R:29-242.  scExp: list of (genes, cells) blocks sharing the gene axis.
+    devices (no reference counterpart: the reference's block loop is serial, :125-163): GPU indices; block b runs on devices[b mod N],
+    one host thread and one device context per GPU inside this process (sharp_SHARP_unlimited_multi), same labels as on one GPU."""
     import time as _t
     import warnings
 
@@ -463,9 +465,16 @@ def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster
     npred, pu = C.c_int(), C.c_int()
     p = int(np.ceil(np.log2(n) / 0.04))                                   # :65-66, from the TOTAL number of cells
     viE = np.zeros((n, p)) if viewflag else None
-    check(lib().sharp_SHARP_unlimited_view(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), len(blocks), m, int(ensize_K or 0),
-                                           int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0),
-                                           C.c_double(rN_seed), _ip(pred), C.byref(npred), C.byref(pu), _dp(viE)), allow=48)
+    if devices is not None and len(devices) >= 1:
+        dv = np.ascontiguousarray(devices, np.int32)
+        check(lib().sharp_SHARP_unlimited_multi(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), len(blocks), m, int(ensize_K or 0),
+                                                int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0),
+                                                C.c_double(rN_seed), _ip(dv), len(dv), _ip(pred), C.byref(npred), C.byref(pu), _dp(viE)),
+              allow=48)
+    else:
+        check(lib().sharp_SHARP_unlimited_view(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), len(blocks), m, int(ensize_K or 0),
+                                               int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0),
+                                               C.c_double(rN_seed), _ip(pred), C.byref(npred), C.byref(pu), _dp(viE)), allow=48)
     K = int(ensize_K or 5)
     out = _enresults(pred, None, None, n, m, pu.value, K, t0, {}, False, key="N.pred_clusters")
     if viewflag:                                                          # :215-232

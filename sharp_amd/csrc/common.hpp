@@ -85,6 +85,7 @@ struct Knobs {
     int gemm_slice = 8;         // SHARP_GEMM_SLICE: workgroups per CU per slice of a distance GEMM prepared under another block's tail
     bool proj_host = false;     // SHARP_PROJ_HOST=1 (cross-check): the host build of the projectors
     int upload_threads = 0;     // SHARP_UPLOAD_THREADS: host threads narrowing / copying an uploaded block (0: up to 32)
+    std::vector<int> devices;   // SHARP_DEVICES=0,1,2,...: the GPUs sharp_SHARP_unlimited deals a list of blocks to (empty / one: the caller's device)
     int rp_shape = 0;           // SHARP_RP_SHAPE=1: 8 lanes x 4 slots per gene where the default is 16 x 2 (A/B runs)
 };
 const Knobs &knobs();
@@ -118,6 +119,19 @@ struct Ctx {
 };
 Ctx &ctx();          // throws SHARP_ERR_NO_DEVICE if sharp_init() has not succeeded
 Ctx &ctx_unchecked();
+
+// Device slots.  Everything the library keeps between calls -- context, streams, workspaces, projector handles, the front prepared for
+// the next call -- exists once per SLOT, and a host thread works on the slot it is bound to (slot 0 unless told otherwise: the one
+// sharp_init() sets up, which is all a single-GPU host ever sees).  The multi-GPU entry points (sharp_SHARP_unlimited_multi) start one
+// host thread per device and bind each to a slot of its own, so several GPUs -- or, in the tests, several slots on ONE GPU -- run
+// side by side in one process.
+constexpr int kMaxSlots = 17;
+int cur_slot();
+void bind_slot(int slot);                   // the calling thread works on this slot from now on
+void init_slot(int slot, int device);       // bind_slot + hipSetDevice + the slot's context (streams) on that device; idempotent per (slot, device)
+// the per-slot instance of a keep-between-calls object: `T &name() { return per_slot<T>(); }`
+template <typename T>
+T &per_slot() { static T w[kMaxSlots]; return w[cur_slot()]; }
 
 // Times everything enqueued on the library stream during its lifetime (if profiling is on).
 struct KernelTimer {

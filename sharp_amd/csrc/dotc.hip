@@ -158,6 +158,18 @@ void sharp_C_SHARP_unlimited(double *Xcat, int *nblocks, double *ncb, int *m, in
     *status = sharp_SHARP_unlimited_view(ptrs.data(), nc.data(), B, *m, *ensize_K, *N_cluster, *minN, *maxN, *rN_seed, pred, &info[0],
                                          &info[1], (*want & 1) ? viE : nullptr);
 }
+/* the same on several GPUs (sharp_SHARP_unlimited_multi): devices = integer vector of device indices, block b on devices[b mod ndev] */
+void sharp_C_SHARP_unlimited_multi(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *N_cluster, int *minN, int *maxN,
+                                   double *rN_seed, int *devices, int *ndevices, int *pred, double *viE, int *info, int *want, int *status) {
+    const int B = *nblocks;
+    if (B < 1) { sharp::set_error("No expression data is provided!"); *status = SHARP_ERR_ARG; return; }
+    std::vector<const double *> ptrs(static_cast<size_t>(B));
+    std::vector<long long> nc(static_cast<size_t>(B));
+    long long off = 0;
+    for (int b = 0; b < B; ++b) { ptrs[b] = Xcat + off * (*m); nc[b] = as_ll(ncb + b); off += nc[b]; }
+    *status = sharp_SHARP_unlimited_multi(ptrs.data(), nc.data(), B, *m, *ensize_K, *N_cluster, *minN, *maxN, *rN_seed, devices, *ndevices,
+                                          pred, &info[0], &info[1], (*want & 1) ? viE : nullptr);
+}
 /* SHARP_unlimited2 (R/SHARP_unlimited2.R:29-292); same block layout */
 void sharp_C_SHARP_unlimited2(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *reduced_ndim, int *partition_ncells,
                               int *hmethod, int *N_cluster, int *enpN, int *indN, int *minN, int *maxN, double *sil_thre,

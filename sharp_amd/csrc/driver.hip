@@ -66,12 +66,12 @@ struct DriverWs {
     DevBuf<int> posbatch;
     DevBuf<double> fold_means, block_means;      // grow-only: a hipFree in a block's tail would wait for every stream
 };
-DriverWs &dws() { static DriverWs w; return w; }
+DriverWs &dws() { return per_slot<DriverWs>(); }
 
 // allrpinfo of the last SHARP_small run (R/SHARP.R:350-387,446): the colour index of every cell under every random projection; the
 // projections themselves (indE) are still in dws().E until the next SHARP call
 struct LastSmall { bool valid = false; int n = 0, K = 0, p = 0; long long ldE = 0; std::vector<int> enrp; };
-LastSmall &last_small() { static LastSmall l; return l; }
+LastSmall &last_small() { return per_slot<LastSmall>(); }
 
 inline bool lex_less_id(int a, int b) {
     char sa[16], sb[16];
@@ -212,7 +212,7 @@ namespace {
 // sharp_synchronize(), returns: the caller keeps the buffer alive and unchanged until then.
 struct PendingFront { std::unique_ptr<LargeFront> f; hipStream_t stream = nullptr; hipEvent_t main_done = nullptr; int parity = 0;
                       unsigned long long born = 0, calls = 0; };
-PendingFront &pending_front() { static PendingFront p; return p; }
+PendingFront &pending_front() { return per_slot<PendingFront>(); }
 }  // namespace
 
 // Finishes whatever the side streams of this file still have in flight (sharp_synchronize, sharp_shutdown).
@@ -374,6 +374,7 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
     for (int i = 0; i < n; ++i) out.pred[shuffle ? reind[i] - 1 : i] = Slab[i];   // :775-783
     if (a.want_x0) {
         // sx0: block-diagonal per-fold soft matrices (:717-731), columns merged by stf (:761-772), un-shuffled
+        if (T == 1) for (int q = 0; q < nCu; ++q) stf[q] = q + 1;               // x0 = sx0 (:746): one fold, no columns merged
         const int sn = *std::max_element(stf.begin(), stf.end());
         out.x0.assign(static_cast<size_t>(n) * sn, 0.0);
         out.x0_cols = sn;
@@ -677,10 +678,10 @@ namespace {
 
 // The resident copy of a host matrix is kept between calls like every other workspace (freshly allocated HBM costs ~ 30 ms per GB
 // at first touch; run_Mtimes_SHARP and testlog + SHARP call in on the same matrix again and again).
-HostBlock &host_block() { static HostBlock b; return b; }
+HostBlock &host_block() { return per_slot<HostBlock>(); }
 
 struct NextHint { const float *dX = nullptr; long long nb = 0, ld = 0; };
-NextHint &next_hint() { static NextHint h; return h; }
+NextHint &next_hint() { return per_slot<NextHint>(); }
 
 // the body shared by the host-matrix, CSC and device entry points of SHARP()
 int sharp_run_block(XRef dX, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells, int partition_ncells,
@@ -725,6 +726,19 @@ int sharp_SHARP_dev(const float *dX, int m, long long n, long long ld, int ensiz
                     double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred, int *n_pred,
                     double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path) {
     return sharp_run_block(XRef(dX), m, n, ld, ensize_K, reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
+                           indN_cluster, minN, maxN, sil_thre, height_Ntimes, log_flag, projector, rN_seed, pred, n_pred, viE, x0,
+                           x0_cap_cols, x0_cols, p_used, K_used, path);
+}
+
+int sharp_SHARP_dev64(const double *dX, int m, long long n, long long ld, int ensize_K, int reduced_ndim, int base_ncells,
+                      int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster, int minN, int maxN,
+                      double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed, int *pred, int *n_pred,
+                      double *viE, double *x0, int x0_cap_cols, int *x0_cols, int *p_used, int *K_used, int *path) {
+    XRef r;
+    try { ctx(); r = dev64_ref(dX, m, n, ld); }
+    catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
+    catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
+    return sharp_run_block(r, m, n, ld, ensize_K, reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
                            indN_cluster, minN, maxN, sil_thre, height_Ntimes, log_flag, projector, rN_seed, pred, n_pred, viE, x0,
                            x0_cap_cols, x0_cols, p_used, K_used, path);
 }
@@ -851,6 +865,23 @@ int sharp_unlimited_block_dev(const float *dX, int m, long long nb, long long ld
     std::vector<long long> cn;
     unlimited_block_dev(dX, m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, nullptr);
     SHARP_REQUIRE(static_cast<int>(cn.size()) <= cap_rows, "sharp_unlimited_block_dev: centroid buffer too small");
+    std::copy(pr.begin(), pr.end(), pred);
+    std::copy(mn.begin(), mn.end(), means);
+    std::copy(cn.begin(), cn.end(), counts);
+    *n_clusters = static_cast<int>(cn.size());
+    SHARP_API_END
+}
+
+int sharp_unlimited_block_dev64(const double *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K, double rN_seed,
+                                int *pred, int *n_clusters, double *means, int cap_rows, long long *counts) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(pred && n_clusters && means && counts, "sharp_unlimited_block_dev64: null output");
+    std::vector<int> pr;
+    std::vector<double> mn;
+    std::vector<long long> cn;
+    unlimited_block_dev(dev64_ref(dX, m, nb, ld), m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, nullptr);
+    SHARP_REQUIRE(static_cast<int>(cn.size()) <= cap_rows, "sharp_unlimited_block_dev64: centroid buffer too small");
     std::copy(pr.begin(), pr.end(), pred);
     std::copy(mn.begin(), mn.end(), means);
     std::copy(cn.begin(), cn.end(), counts);
@@ -1036,6 +1067,96 @@ struct HostBlocks {
         return SHARP_OK;
     }
 };
+// SHARP_unlimited over several GPUs inside one process (R/SHARP_unlimited.R:125-183): the serial block loop of the reference
+// (:125-163) is dealt out, block b to devices[b mod ndev]; one host thread per device, bound to a device slot of its own (context,
+// streams, workspaces, projector handles: common.hpp), builds the K projectors there (a pure function of m, p and the seeds, :97-104),
+// uploads and clusters its blocks one after the other and keeps, per block, the labels and the per-cluster centroid means and sizes --
+// all the final sMetaC uses of E1 (R/sMetaC.R:58-63).  p comes from the GLOBAL cell count (:65-66).  The centroid tables (a few
+// hundred rows x p doubles per block) meet in host memory, the merge (:163-183) runs once on the first device, and every block's
+// labels are mapped through it.  No other data crosses between devices.
+int unlimited_run_multi(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster, int minN,
+                        int maxN, double rN_seed, const int *devices, int ndev, int *pred, int *n_pred, int *p_used, double *viE) {
+    SHARP_API_BEGIN
+    SHARP_REQUIRE(X_blocks && ncb && pred, "The input should be a LIST of partitioned scRNA-seq expression matrices!");
+    SHARP_REQUIRE(nblocks >= 2, "SHARP is used instead of SHARP_unlimited because the length of the input is 1!");
+    SHARP_REQUIRE(devices && ndev >= 1 && ndev < kMaxSlots, "SHARP_unlimited: the device list must name between 1 and 16 GPUs");
+    if (rN_seed != 0.5) SHARP_REQUIRE(std::fmod(rN_seed, 1.0) == 0.0, "The rN.seed should be an integer!");   // :80-90
+    long long ncells = 0;
+    for (int b = 0; b < nblocks; ++b) { SHARP_REQUIRE(X_blocks[b] && ncb[b] >= 3, "SHARP_unlimited: empty block"); ncells += ncb[b]; }
+    const int p = static_cast<int>(std::ceil(std::log2(static_cast<double>(ncells)) / (0.2 * 0.2)));           // :65-66
+    const int K = ensize_K > 0 ? ensize_K : 5;                                                                 // :92-94
+    std::vector<double> seeds(K);
+    for (int k = 0; k < K; ++k) seeds[k] = (rN_seed == 0.5) ? 0.5 : 50 + rN_seed + (k + 1);                    // :97-104
+    SHARP_REQUIRE(rN_seed != 0.5 || ndev == 1, "SHARP_unlimited on several GPUs needs a seed: unseeded projectors would differ between the devices");
+    const int W = std::min(ndev, nblocks);
+    std::vector<long long> cell0(nblocks + 1, 0);
+    for (int b = 0; b < nblocks; ++b) cell0[b + 1] = cell0[b] + ncb[b];
+    std::vector<std::vector<int>> pb(nblocks);
+    std::vector<std::vector<double>> mb(nblocks);
+    std::vector<std::vector<long long>> cb(nblocks);
+    std::vector<std::string> err(W);
+    std::vector<int> rcs(W, SHARP_OK), warn(W, 0);
+    auto worker = [&](int d) {
+        try {
+            init_slot(1 + d, devices[d]);                // slots 1 .. W: slot 0 stays the caller's own
+            const int proj = register_projector(build_projector(m, p, K, seeds.data()));
+            try {
+                HostBlock &hb = host_block();
+                for (int b = d; b < nblocks; b += W) {
+                    upload_block(X_blocks[b], m, ncb[b], m, hb);
+                    unlimited_block_dev(hb.ref(), m, ncb[b], hb.ld, p, proj, K, rN_seed, pb[b], mb[b], cb[b],
+                                        viE ? viE + static_cast<size_t>(cell0[b]) * p : nullptr);   // E1 rows of this block (:153), viewflag only
+                }
+            } catch (...) { drop_pending_front(); drop_projector(proj); throw; }
+            drop_projector(proj);
+            stream_sync();
+        }
+        catch (const sharp::Error &e) { err[d] = e.what(); rcs[d] = e.code; }
+        catch (const std::exception &e) { err[d] = e.what(); rcs[d] = SHARP_ERR; }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int d = 0; d < W; ++d) th.emplace_back(worker, d);
+        for (auto &t : th) t.join();
+    }
+    for (int d = 0; d < W; ++d)
+        if (rcs[d] != SHARP_OK) throw sharp::Error(rcs[d], "device " + std::to_string(devices[d]) + ": " + err[d]);
+    // the one exchange step: the centroid tables in global block order, then the merge on the first device
+    std::vector<double> means;
+    std::vector<long long> counts;
+    std::vector<int> first(nblocks + 1, 0);
+    for (int b = 0; b < nblocks; ++b) {
+        means.insert(means.end(), mb[b].begin(), mb[b].end());
+        counts.insert(counts.end(), cb[b].begin(), cb[b].end());
+        first[b + 1] = first[b] + static_cast<int>(cb[b].size());
+    }
+    std::vector<int> fid;
+    int nf = 0;
+    {
+        std::string merr;
+        int mrc = SHARP_OK;
+        std::thread mt([&] {
+            try {
+                init_slot(1, devices[0]);
+                unlimited_merge(means.data(), counts.data(), first[nblocks], p, ncells, N_cluster, minN, maxN, fid, nf);
+                stream_sync();
+            }
+            catch (const sharp::Error &e) { merr = e.what(); mrc = e.code; }
+            catch (const std::exception &e) { merr = e.what(); mrc = SHARP_ERR; }
+        });
+        mt.join();
+        if (mrc != SHARP_OK) throw sharp::Error(mrc, merr);
+    }
+    long long off = 0;
+    for (int b = 0; b < nblocks; ++b) {                                         // labels scattered back (:165-183 through the merge's map)
+        for (long long i = 0; i < ncb[b]; ++i) pred[off + i] = fid[first[b] + pb[b][i] - 1];
+        off += ncb[b];
+    }
+    if (n_pred) *n_pred = nf;
+    if (p_used) *p_used = p;
+    SHARP_API_END
+}
+
 std::vector<XRef> f32_refs(const float *const *dX_blocks, int nblocks) {
     std::vector<XRef> r;
     for (int b = 0; dX_blocks && b < nblocks; ++b) r.emplace_back(dX_blocks[b]);
@@ -1078,9 +1199,19 @@ int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *nc
 
 int sharp_SHARP_unlimited_view(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,
                                int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used, double *viE) {
+    const std::vector<int> &dv = knobs().devices;        // SHARP_DEVICES=0,1,2,...: the blocks dealt to these GPUs (one host thread each)
+    if (dv.size() >= 2)
+        return unlimited_run_multi(X_blocks, ncb, nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, dv.data(), static_cast<int>(dv.size()),
+                                   pred, n_pred, p_used, viE);
     HostBlocks H;
     if (const int rc = H.upload(X_blocks, ncb, nblocks, m)) return rc;
     return unlimited_run(H.refs.data(), ncb, H.lds.data(), nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred, p_used, viE);
+}
+
+int sharp_SHARP_unlimited_multi(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,
+                                int minN, int maxN, double rN_seed, const int *devices, int ndevices, int *pred, int *n_pred, int *p_used,
+                                double *viE) {
+    return unlimited_run_multi(X_blocks, ncb, nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, devices, ndevices, pred, n_pred, p_used, viE);
 }
 
 int sharp_SHARP_unlimited(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,

@@ -1478,7 +1478,8 @@ struct Workspace {
 // itself (S0, S1, img, remaining) is only ever used by one chunk at a time and always comes from set 0.
 // Slot 3: the third set of a batch of three chunks or more; slot 2: a batch started from another batch's progress callback;
 // slots 4 and 5: batches whose distance matrices are built ahead of time for the NEXT block of a SHARP_unlimited run (hc_prefetch_*).
-Workspace &ws(int slot = 0) { static Workspace w[6]; return w[slot]; }
+struct WorkspaceSets { Workspace w[6]; };
+Workspace &ws(int slot = 0) { return per_slot<WorkspaceSets>().w[slot]; }
 
 inline long long rup(long long v, long long a) { return (v + a - 1) / a * a; }
 
@@ -1558,7 +1559,7 @@ struct PipeEvents {
     hipEvent_t in = nullptr, out[8] = {nullptr}, gemm[6] = {nullptr}, hc[6] = {nullptr}, done[6] = {nullptr};   // (per workspace slot)
 };
 PipeEvents &pipe_events() {
-    static PipeEvents e;
+    PipeEvents &e = per_slot<PipeEvents>();
     if (!e.in) {
         SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.in, hipEventDisableTiming));
         for (auto &x : e.out) SHARP_HIP_CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
@@ -2071,7 +2072,7 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
 
 }  // namespace
 
-namespace { int g_batch_depth = 0; }         // > 0 while a batch's progress callback runs: a batch started from there is nested
+namespace { thread_local int g_batch_depth = 0; }         // > 0 while a batch's progress callback runs: a batch started from there is nested
 
 void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::vector<HcResult> &out,
                           const std::function<void(size_t)> *progress) {

@@ -180,7 +180,7 @@ struct MetaWs {
     DevBuf<RowPrepTask> prep;
     DevBuf<GemmTask> gemm;
 };
-MetaWs &mws() { static MetaWs w; return w; }
+MetaWs &mws() { return per_slot<MetaWs>(); }
 
 }  // namespace
 

@@ -408,8 +408,11 @@ __global__ void proj_fill_u16_kernel(uint16_t *p, size_t n, uint16_t v) {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) p[i] = v;
 }
 
+// projector handles: a table per device slot (a projector's row lists live on its slot's device); handle numbers are unique across slots
 std::mutex g_mu;
-std::map<int, std::shared_ptr<Projector>> g_table;
+struct ProjTable { std::map<int, std::shared_ptr<Projector>> t; };
+std::map<int, std::shared_ptr<Projector>> &g_table_ref() { return per_slot<ProjTable>().t; }
+#define g_table g_table_ref()
 int g_next = 1;
 
 }  // namespace

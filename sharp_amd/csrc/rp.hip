@@ -221,6 +221,66 @@ __global__ void absmax_kernel(const T *__restrict__ X, int m, int n, long long l
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));  // non-negative floats order as uints
 }
 
+// max |x| of an fp64 block as a double (+inf if any value is NaN or infinite): non-negative doubles order as 64-bit integers
+__global__ void absmax64_kernel(const double *__restrict__ X, int m, int n, long long ld, unsigned long long *out) {
+    double mx = 0.0;
+    const long long total = static_cast<long long>(m) * n;
+    for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < total;
+         i += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long c = i / m;
+        const double v = X[c * ld + (i - c * m)];
+        const double a = v == v ? fabs(v) : __longlong_as_double(0x7ff0000000000000ll);
+        mx = fmax(mx, a);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, static_cast<unsigned long long>(__double_as_longlong(mx)));
+}
+
+// max |x| of a resident block (rounded up to fp32; +inf for a NaN): the raw mode's fixed-point scale, and what an fp64 block handed
+// over already resident needs checked before its log-mode scale is chosen (dev64_ref)
+float device_absmax(XRef X, int m, long long n, long long ld) {
+    Ctx &c = ctx();
+    DevBuf<unsigned int> mx(1);
+    mx.zero();
+    {
+        KernelTimer t("rp_absmax");
+        const int nn = static_cast<int>(n);
+        if (X.f64) hipLaunchKernelGGL(absmax_kernel<double>, dim3(c.num_cu * 4), dim3(256), 0, c.stream, X.d64(), m, nn, ld, mx.p);
+        else hipLaunchKernelGGL(absmax_kernel<float>, dim3(c.num_cu * 4), dim3(256), 0, c.stream, X.f32(), m, nn, ld, mx.p);
+        launch_check("absmax_kernel");
+    }
+    unsigned int bits = 0;
+    mx.download(&bits, 1);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+// An fp64 block that is ALREADY resident (the *_dev64 entry points: TPM / CPM-like doubles, which fp32 would perturb): 16-byte aligned,
+// even leading dimension, finite; one pass over it finds max |x| -- beyond FLT_MAX the log-mode accumulation keeps 41 fixed-point
+// bits instead of 44 (upload.hpp does the same while it copies a host block).
+XRef dev64_ref(const double *dX, int m, long long n, long long ld) {
+    SHARP_REQUIRE(dX, "No expression data is provided!");
+    SHARP_REQUIRE((reinterpret_cast<uintptr_t>(dX) & 15u) == 0 && ld % 2 == 0 && ld >= m,
+                  "an fp64 device block must be 16-byte aligned with an even leading dimension >= the number of genes");
+    SHARP_REQUIRE(n >= 1 && n < (1LL << 31), "block size out of range");
+    XRef r(dX);
+    Ctx &c = ctx();
+    DevBuf<unsigned long long> mx(1);
+    mx.zero();
+    {
+        KernelTimer t("rp_absmax");
+        hipLaunchKernelGGL(absmax64_kernel, dim3(c.num_cu * 4), dim3(256), 0, c.stream, dX, m, static_cast<int>(n), ld, mx.p);
+        launch_check("absmax64_kernel");
+    }
+    unsigned long long bits = 0;
+    mx.download(&bits, 1);
+    double f;
+    memcpy(&f, &bits, 8);
+    SHARP_REQUIRE(std::isfinite(f), "SHARP: the expression block holds NA / NaN / Inf");
+    if (f > 3.4028234663852886e38) r.log_fix_bits = 41;
+    return r;
+}
+
 template <int GW, int SLOTS, bool VEC>
 static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float *dX, int m, int n, long long ld,
                       int log_flag, int fix_bits, double *dE, long long ldE, const int *row_map) {
@@ -269,18 +329,7 @@ void project_dev(const Projector &pr, XRef X, int m, int n, long long ld, int lo
     }
     int fix_bits = std::min(RP_FIX_BITS, X.log_fix_bits);
     if (!log_flag) {
-        DevBuf<unsigned int> mx(1);
-        mx.zero();
-        {
-            KernelTimer t("rp_absmax");
-            if (X.f64) hipLaunchKernelGGL(absmax_kernel<double>, dim3(c.num_cu * 4), dim3(256), 0, c.stream, X.d64(), m, n, ld, mx.p);
-            else hipLaunchKernelGGL(absmax_kernel<float>, dim3(c.num_cu * 4), dim3(256), 0, c.stream, dX, m, n, ld, mx.p);
-            launch_check("absmax_kernel");
-        }
-        unsigned int bits = 0;
-        mx.download(&bits, 1);
-        float f;
-        memcpy(&f, &bits, 4);
+        const float f = device_absmax(X, m, n, ld);
         SHARP_REQUIRE(std::isfinite(f), "project: non-finite expression value");
         int e = 0;
         std::frexp(static_cast<double>(f), &e);          // |x| < 2^e
@@ -361,6 +410,13 @@ int sharp_project_dev(int proj, const float *dX, int m, int n, long long ld, int
     SHARP_API_BEGIN
     auto pr = get_projector(proj);
     project_dev(*pr, dX, m, n, ld, log_flag, dE, ldE, nullptr);
+    SHARP_API_END
+}
+
+int sharp_project_dev64(int proj, const double *dX, int m, int n, long long ld, int log_flag, double *dE, long long ldE) {
+    SHARP_API_BEGIN
+    auto pr = get_projector(proj);
+    project_dev(*pr, dev64_ref(dX, m, n, ld), m, n, ld, log_flag, dE, ldE, nullptr);
     SHARP_API_END
 }
 

@@ -432,7 +432,7 @@ struct SplitWs {
     double fixtab_scale = 0.0;
     hipEvent_t ev_compact[2] = {nullptr, nullptr}, ev_apply[2] = {nullptr, nullptr}, ev_start = nullptr;
 };
-SplitWs &sws() { static SplitWs w; return w; }
+SplitWs &sws() { return per_slot<SplitWs>(); }
 }  // namespace
 
 template <int GW, int SLOTS, bool DUAL>

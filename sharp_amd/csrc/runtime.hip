@@ -15,12 +15,19 @@
 namespace sharp {
 
 static thread_local std::string g_last_error;
-static Ctx g_ctx;
+static thread_local int t_slot = 0;
+static Ctx g_ctxs[kMaxSlots];
 
 void set_error(const std::string &msg) { g_last_error = msg; }
 
-Ctx &ctx_unchecked() { return g_ctx; }
+int cur_slot() { return t_slot; }
+void bind_slot(int slot) {
+    if (slot < 0 || slot >= kMaxSlots) throw Error(SHARP_ERR_ARG, "libsharp_hip: device slot out of range");
+    t_slot = slot;
+}
+Ctx &ctx_unchecked() { return g_ctxs[t_slot]; }
 Ctx &ctx() {
+    Ctx &g_ctx = g_ctxs[t_slot];
     if (!g_ctx.ready)
         throw Error(SHARP_ERR_NO_DEVICE,
                     "libsharp_hip: no device context -- call sharp_init(device) first (a MI355X / gfx950 GPU is required; "
@@ -227,11 +234,62 @@ static Knobs read_knobs() {
     v.gemm_slice = num("SHARP_GEMM_SLICE", 8);
     v.proj_host = num("SHARP_PROJ_HOST", 0) == 1;
     v.upload_threads = num("SHARP_UPLOAD_THREADS", 0);
+    if (const char *dl = getenv("SHARP_DEVICES")) {
+        for (const char *q = dl; *q;) {
+            char *end = nullptr;
+            const long dvc = strtol(q, &end, 10);
+            if (end == q) break;
+            v.devices.push_back(static_cast<int>(dvc));
+            q = *end == ',' ? end + 1 : end;
+        }
+    }
     return v;
 }
 static Knobs &knobs_storage() { static Knobs k = read_knobs(); return k; }
 const Knobs &knobs() { return knobs_storage(); }
 void reload_knobs() { knobs_storage() = read_knobs(); }
+}  // namespace sharp
+
+namespace sharp {
+void init_slot(int slot, int device) {
+    bind_slot(slot);
+    Ctx &c = ctx_unchecked();
+    if (c.ready && c.device == device) { SHARP_HIP_CHECK(hipSetDevice(device)); return; }   // (the device is a per-thread setting)
+    // every workspace a slot keeps between calls (distance matrices, E, pinned stages, events, projector handles) lives on the device
+    // the slot was first initialised on: a slot never changes its device (sharp_shutdown() destroys the streams, not the workspaces)
+    static int bound_device[kMaxSlots];
+    static bool bound[kMaxSlots];
+    if (bound[slot] && bound_device[slot] != device)
+        throw Error(SHARP_ERR_ARG, "sharp_init: this slot is bound to device " + std::to_string(bound_device[slot]) +
+                                   " (its workspaces live there); one device per slot -- several GPUs in one process go through "
+                                   "sharp_SHARP_unlimited_multi, or start one process per GPU");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        throw Error(SHARP_ERR_NO_DEVICE, "libsharp_hip: no HIP device visible (MI355X / gfx950 required; no CPU fallback)");
+    SHARP_REQUIRE(device >= 0 && device < n, "sharp_init: device index out of range");
+    SHARP_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SHARP_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        throw Error(SHARP_ERR_NO_DEVICE, std::string("libsharp_hip is built for gfx950 only; device reports ") + prop.gcnArchName);
+    if (c.ready && c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
+    if (c.ready && c.stream2) { (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
+    for (hipStream_t s : c.aux) (void)hipStreamDestroy(s);
+    c.aux.clear();
+    SHARP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.main_stream = c.stream;
+    {   // the second stream of the RP stage: its own priority class, hence its own hardware queue (see aux_stream)
+        int lo = 0, hi = 0;
+        SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        SHARP_HIP_CHECK(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, hi));
+    }
+    c.device = device;
+    bound_device[slot] = device;
+    bound[slot] = true;
+    c.num_cu = prop.multiProcessorCount;
+    c.lds_per_block = prop.sharedMemPerBlock;
+    c.ready = true;
+}
 }  // namespace sharp
 
 using namespace sharp;
@@ -252,41 +310,7 @@ int sharp_device_count(int *count) {
 
 int sharp_init(int device) {
     SHARP_API_BEGIN
-    Ctx &c = ctx_unchecked();
-    if (c.ready && c.device == device) return SHARP_OK;
-    // every workspace the library keeps between calls (distance matrices, E, pinned stages, events, projector handles) lives on the
-    // device of the first sharp_init(): one device per process -- as one process per GPU is how the sharded runs are laid out
-    // (sharp_shutdown() destroys the streams, not the workspaces: a later sharp_init() must name the same device)
-    static int bound_device = -1;
-    if (bound_device >= 0 && bound_device != device)
-        throw Error(SHARP_ERR_ARG, "sharp_init: this process is bound to device " + std::to_string(bound_device) +
-                                   " (its workspaces live there); one device per process -- start one process per GPU");
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-        throw Error(SHARP_ERR_NO_DEVICE, "libsharp_hip: no HIP device visible (MI355X / gfx950 required; no CPU fallback)");
-    SHARP_REQUIRE(device >= 0 && device < n, "sharp_init: device index out of range");
-    SHARP_HIP_CHECK(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    SHARP_HIP_CHECK(hipGetDeviceProperties(&prop, device));
-    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
-        throw Error(SHARP_ERR_NO_DEVICE, std::string("libsharp_hip is built for gfx950 only; device reports ") + prop.gcnArchName);
-    if (c.ready && c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
-    if (c.ready && c.stream2) { (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
-    for (hipStream_t s : c.aux) (void)hipStreamDestroy(s);
-    c.aux.clear();
-    SHARP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    c.main_stream = c.stream;
-    {   // the second stream of the RP stage: its own priority class, hence its own hardware queue (see aux_stream)
-        int lo = 0, hi = 0;
-        SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const int pr = hi;
-        SHARP_HIP_CHECK(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, pr));
-    }
-    c.device = device;
-    bound_device = device;
-    c.num_cu = prop.multiProcessorCount;
-    c.lds_per_block = prop.sharedMemPerBlock;
-    c.ready = true;
+    init_slot(cur_slot(), device);          // (slot 0 unless this thread was bound elsewhere)
     SHARP_API_END
 }
 

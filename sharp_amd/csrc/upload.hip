@@ -27,7 +27,7 @@ struct UploadStage {
         cap = bytes;
     }
 };
-UploadStage &upload_stage() { static UploadStage u; return u; }
+UploadStage &upload_stage() { return per_slot<UploadStage>(); }
 int &last_storage() { static int s = 0; return s; }
 
 int upload_threads() {

@@ -58,12 +58,14 @@ def csc_to_dev(sp):
 def SHARP_dev(dX, ensize_K=0, reduced_ndim=0, base_ncells=0, partition_ncells=0, hmethod=1, N_cluster=0, enpN_cluster=0,
               indN_cluster=0, minN_cluster=0, maxN_cluster=0, sil_thre=-1.0, height_Ntimes=0.0, flag=True, projector=0,
               rN_seed=0.5):
-    """SHARP() (R/SHARP.R:44-318) on a resident block; returns (pred_clusters, info)."""
+    """SHARP() (R/SHARP.R:44-318) on a resident block (float32, or float64 for TPM / CPM-like values: sharp_SHARP_dev64);
+    returns (pred_clusters, info)."""
     _lib.ensure_init()
     n, m = dX.shape
     pred = np.zeros(n, np.int32)
     npred, pu, Ku, path = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-    rc = check(lib().sharp_SHARP_dev(C.c_void_p(dX.data_ptr()), m, C.c_longlong(n), C.c_longlong(dX.stride(0)), ensize_K,
+    entry = lib().sharp_SHARP_dev64 if str(dX.dtype) == "torch.float64" else lib().sharp_SHARP_dev
+    rc = check(entry(C.c_void_p(dX.data_ptr()), m, C.c_longlong(n), C.c_longlong(dX.stride(0)), ensize_K,
                                      reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
                                      indN_cluster, minN_cluster, maxN_cluster, C.c_double(sil_thre), C.c_double(height_Ntimes),
                                      int(bool(flag)), projector, C.c_double(rN_seed), _ip(pred), C.byref(npred), None, None, 0,

@@ -241,7 +241,8 @@ def test_sharp_unlimited3_streams_a_directory_of_blocks(sa, oracle, digit_free_d
 
 def test_view_reduction_above_1e5_cells(sa, oracle):
     """R/SHARP_unlimited.R:217-225: viE = 1/sqrt(50) * E1 %*% ranM2(p, 50, seed) (the branch itself needs > 1e5 cells;
-    the reduction is checked on a small E1).  Inputs go through the fp32 block format, hence the 1e-6 tolerance."""
+    the reduction is checked on a small E1).  E1 is not fp32-exact, so the block is stored as fp64 (upload.hip) and the
+    projection meets the tolerance of every other one: 2e-12 of the largest entry."""
     from sharp_amd.api import _view_reduce
 
     rng = np.random.default_rng(7)
@@ -250,7 +251,7 @@ def test_view_reduction_above_1e5_cells(sa, oracle):
     got = _view_reduce(E1, seed, K)
     ref = oracle.project(E1.T, oracle.ranM(420, 50, 50 + seed + K + 1), False)     # (1/sqrt(50)) * t(z0) %*% t(E1), cells x 50
     assert got.shape == (300, 50)
-    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6 * np.abs(ref).max())
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-12 * np.abs(ref).max())
 
 
 def test_ARI_five_indices_match_oracle(sa, oracle):

@@ -110,3 +110,52 @@ def test_sparse_input_with_non_fp32_values(sa, oracle):
     sparse = sa.SHARP(sp.csc_matrix(X), ensize_K=3, rN_seed=11, forview=False, logflag=False, prep=False)["pred_clusters"]
     assert sa.lib().sharp_x_storage() == 64
     assert np.array_equal(dense, ref) and np.array_equal(sparse, ref)
+
+
+def test_tpm_block_already_resident_as_fp64(sa, oracle):
+    """The *_dev64 entry points: TPM-like doubles that are ALREADY in HBM (a torch float64 tensor) take the fp64 path without going
+    back through the host -- same labels as the oracle on the same doubles, same projection as the host entry."""
+    import ctypes as C
+
+    import torch
+
+    from sharp_amd import device as dev
+
+    m0, n = 2500, 5400                                         # SHARP_large
+    X = _tpm(oracle, SEED + 5, m0, n, 5, 300)
+    m = X.shape[0]
+    dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()    # (cells, genes) float64
+    if dX.stride(0) % 2:                                       # even leading dimension (16-byte aligned columns)
+        pad = torch.zeros((n, m + 1), dtype=torch.float64, device="cuda")
+        pad[:, :m] = dX
+        dX = pad[:, :m]
+    torch.cuda.synchronize()
+    ref = oracle.SHARP(X, K=3, rN_seed=2103, nthreads=8)
+    pred, info = dev.SHARP_dev(dX, ensize_K=3, rN_seed=2103, flag=True)
+    assert info["path"] == "SHARP_large" and np.array_equal(pred, ref["pred_clusters"])
+    host = sa.SHARP(X, ensize_K=3, rN_seed=2103, logflag=True, prep=False)
+    assert np.array_equal(pred, host["pred_clusters"])
+    # the projection alone: bit-identical to the host entry's fp64 block, oracle tolerance
+    p = 80
+    pr = sa.Projector(m, p, [2154, 2155])
+    dE = torch.zeros((n, 2 * p), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    lib = sa.lib()
+    rc = lib.sharp_project_dev64(pr.handle, C.c_void_p(dX.data_ptr()), m, n, C.c_longlong(dX.stride(0)), 1, C.c_void_p(dE.data_ptr()),
+                                 C.c_longlong(2 * p))
+    assert rc == 0, lib.sharp_last_error()
+    lib.sharp_synchronize()
+    E = dE.cpu().numpy()
+    np.testing.assert_array_equal(E, pr.project(X, logflag=True))
+    refE = oracle.project(X, oracle.ranM(m, p, 2154), True)
+    np.testing.assert_allclose(E[:, :p], refE, rtol=0, atol=2e-12 * np.abs(refE).max())
+    # what the entry refuses: an odd leading dimension, a NaN
+    bad = torch.zeros((8, 101), dtype=torch.float64, device="cuda")
+    assert lib.sharp_project_dev64(pr.handle, C.c_void_p(bad.data_ptr()), 101, 8, C.c_longlong(101), 1, C.c_void_p(dE.data_ptr()),
+                                   C.c_longlong(2 * p)) != 0
+    dX[3, 7] = float("nan")
+    torch.cuda.synchronize()
+    assert lib.sharp_project_dev64(pr.handle, C.c_void_p(dX.data_ptr()), m, n, C.c_longlong(dX.stride(0)), 1, C.c_void_p(dE.data_ptr()),
+                                   C.c_longlong(2 * p)) != 0
+    assert "NaN" in lib.sharp_last_error().decode()
+    pr.close()
