@@ -963,6 +963,8 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     }
 }
 
+#include "hclust_tri.inc"
+
 #ifdef SHARP_LAB       // the lazy agglomeration (an experiment kept for reference): lab builds only
 #include "hclust_lazy.inc"
 #endif
@@ -1879,6 +1881,14 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                     hipLaunchKernelGGL(hclust_lazy_kernel, dim3(Ts), dim3(HL_THREADS), ldsz, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p,
                                        W.height.p, W.status.p + R.t0, theta);
 #endif
+                } else if (Ts <= c.num_cu && max_n <= HT_MAXN && knobs().hc_tri) {
+                    // one workgroup per CU on the upper triangle of the matrix (hclust_tri.inc): half the bytes of hclust_rnn_kernel
+                    const size_t tstate = (static_cast<size_t>(nal) * (16 + 8 + 4 + 4 + 2 * 7 + 1) + 16 * 4 + (1024 / 64 + 1) * 4 + 64 + 15) / 16 * 16;
+                    const size_t ldsl = std::max(std::max(tstate, static_cast<size_t>(npow2) * 16), HR_LDS_CU);
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_tri_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        static_cast<int>(ldsl)));
+                    hipLaunchKernelGGL(hclust_tri_kernel, dim3(Ts), dim3(HT_THREADS), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p,
+                                       W.height.p, W.status.p + R.t0, static_cast<int>(ldsl));
                 } else if (Ts <= c.num_cu) {
                     auto k0 = hclust_rnn_kernel<1024, 0>;
                     // one workgroup per CU: everything the CU has beyond the state stages the pair members' entries

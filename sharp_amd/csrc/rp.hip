@@ -319,7 +319,7 @@ void project_dev(const Projector &pr, XRef X, int m, int n, long long ld, int lo
     SHARP_REQUIRE(ld >= m, "project: leading dimension smaller than m");
     SHARP_REQUIRE(ldE >= static_cast<long long>(pr.K) * pr.p, "project: ldE smaller than K*p");
     if (n <= 0) return;
-    Ctx &c = ctx();
+    ctx();
     {
         // a projector of density 1/sqrt(m) >= 1/4 is not sparse: the dense form on the MFMA (also SHARP_RP_KERNEL=dense, for cross-checks)
         if (knobs().rp_kernel == 2 || (knobs().rp_kernel == 0 && m <= 16)) {

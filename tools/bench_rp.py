@@ -16,7 +16,8 @@ if os.environ.get('SHARP_VARIANT'):
 sharp_amd.init(0)
 lib = sharp_amd.lib()
 SEED = 20261003
-CFGS = [(20000, 50000, 15, 391), (20000, 50000, 5, 474), (27000, 40000, 5, 508), (20000, 50000, 15, 466), (20000, 50000, 15, 441)]   # 3, 4: a rank of an 8- / 4-GPU run
+CFGS = [(20000, 50000, 15, 391), (20000, 50000, 5, 474), (27000, 40000, 5, 508), (20000, 50000, 15, 466), (20000, 50000, 15, 441),   # 3, 4: a rank of an 8- / 4-GPU run
+        (27000, 162500, 5, 508)]   # 5: cfg4's per-GPU share at full size
 if len(sys.argv) > 1:
     CFGS = [CFGS[int(a)] for a in sys.argv[1:]]
 for (m, n, K, p) in CFGS:

@@ -91,7 +91,55 @@ void run(const char *name) {
     CK(hipFree(out)); CK(hipFree(cyc));
 }
 
+template <int KIND>
+__global__ void k64(unsigned long long *out, long long *cyc, int reps) {
+    unsigned long long a0 = threadIdx.x * 0x9e3779b97f4a7c15ull, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7;
+    double d0 = threadIdx.x * 1.5, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3;
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < reps; ++r) {
+#define R4(S) asm volatile(S(0) S(1) S(2) S(3) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "vcc", "s12", "s13");
+#define D4(S) asm volatile(S(0) S(1) S(2) S(3) : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) :: "vcc", "s12", "s13");
+#define J0(n) "v_cmp_lt_u64 vcc, %" #n ", %" #n "\n"
+#define J1(n) "v_cmp_lt_f64 vcc, %" #n ", %" #n "\n"
+#define J2(n) "v_max_f64 %" #n ", %" #n ", %" #n "\n"
+#define J3(n) "v_min_f64 %" #n ", %" #n ", %" #n "\n"
+#define J4(n) "v_mul_f64 %" #n ", %" #n ", %" #n "\n"
+#define J5(n) "v_lshl_add_u64 %" #n ", %" #n ", 3, %" #n "\n"
+#define J6(n) "v_cmp_eq_u64 vcc, %" #n ", %" #n "\n"
+        if constexpr (KIND == 0) { R4(J0) R4(J0) R4(J0) R4(J0) R4(J0) R4(J0) R4(J0) R4(J0) }
+        if constexpr (KIND == 1) { D4(J1) D4(J1) D4(J1) D4(J1) D4(J1) D4(J1) D4(J1) D4(J1) }
+        if constexpr (KIND == 2) { D4(J2) D4(J2) D4(J2) D4(J2) D4(J2) D4(J2) D4(J2) D4(J2) }
+        if constexpr (KIND == 3) { D4(J3) D4(J3) D4(J3) D4(J3) D4(J3) D4(J3) D4(J3) D4(J3) }
+        if constexpr (KIND == 4) { D4(J4) D4(J4) D4(J4) D4(J4) D4(J4) D4(J4) D4(J4) D4(J4) }
+        if constexpr (KIND == 5) { R4(J5) R4(J5) R4(J5) R4(J5) R4(J5) R4(J5) R4(J5) R4(J5) }
+        if constexpr (KIND == 6) { R4(J6) R4(J6) R4(J6) R4(J6) R4(J6) R4(J6) R4(J6) R4(J6) }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + (unsigned long long)(d0 + d1 + d2 + d3);
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+template <int KIND>
+void run64(const char *name) {
+    unsigned long long *out; long long *cyc;
+    CK(hipMalloc(&out, 1024 * 1024 * 8)); CK(hipMalloc(&cyc, 1024 * 16 * 8));
+    const int reps = 2000;
+    for (int wps : {1, 2, 4}) {
+        const int threads = 256 * wps;
+        hipLaunchKernelGGL(k64<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, reps);
+        CK(hipDeviceSynchronize());
+        hipLaunchKernelGGL(k64<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, reps);
+        CK(hipDeviceSynchronize());
+        long long h[16];
+        CK(hipMemcpy(h, cyc, sizeof(long long) * (threads / 64), hipMemcpyDeviceToHost));
+        double mx = 0; for (int i = 0; i < threads / 64; ++i) mx = h[i] > mx ? h[i] : mx;
+        printf("%-14s waves/SIMD %d: %.3f ticks per instr per wave, %.3f per instr per SIMD\n", name, wps, mx / (reps * 32.0), mx / (reps * 32.0) / wps);
+    }
+    CK(hipFree(out)); CK(hipFree(cyc));
+}
+
 int main() {
+    run64<0>("v_cmp_lt_u64"); run64<1>("v_cmp_lt_f64"); run64<2>("v_max_f64"); run64<3>("v_min_f64"); run64<4>("v_mul_f64"); run64<5>("v_lshl_add_u64"); run64<6>("v_cmp_eq_u64");
     run<0>("v_and"); run<1>("v_mov_dpp"); run<2>("v_cndmask"); run<3>("v_cmp->sgpr"); run<4>("v_add_u32"); run<5>("v_lshl_add");
     run<6>("v_cvt_u32_f32"); run<7>("v_mbcnt_lo"); run<8>("and+dpp"); run<9>("cmp+cndmask(pair)"); run<10>("cndmask_e64 sgpr"); run<11>("v_alignbit"); run<12>("cvt_f32_ubyte0"); run<13>("v_and_sdwa"); run<14>("v_add_u32_dpp"); run<15>("v_cmp_ne->vcc"); run<16>("v_lshrrev"); run<17>("v_bfe_u32"); run<18>("v_or3"); run<19>("v_mbcnt_hi"); run<20>("cmpx+s_mov exec"); run<21>("v_addc vcc"); run<22>("v_cmp_neq_f32"); run<23>("v_lshl_or"); run<24>("v_xor lit"); run<25>("v_sub_co");
     return 0;

@@ -4,7 +4,7 @@ REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  SHARP_HC_RANGES=1 timeout 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_hc_$tag -- python3 $REPO/tools/bench_hc.py 1 > $OUT/pmc_hc_$tag.log 2>&1
+  SHARP_HC_RANGES=1 timeout 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_hc_$tag -- python3 $REPO/tools/bench_hc.py ${HC_K:-1} > $OUT/pmc_hc_$tag.log 2>&1
 done
 cd $REPO
 python3 - <<'PY'
@@ -13,7 +13,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob("gpurun_out/pmc_hc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
-        if "hclust_rnn" in k or "gemm_tn_f64_fast" in k:
+        if "hclust_rnn" in k or "hclust_tri" in k or "gemm_tn_f64_fast" in k:
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
 for k, v in agg.items():
     print(k)

@@ -12,7 +12,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob("gpurun_out/pmc_hct_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
-        if "hclust_rnn" in k:
+        if "hclust_rnn" in k or "hclust_tri" in k:
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
 for k, v in agg.items():
     calls = cnt[(k, "FETCH_SIZE")] / 2.0        # two launches (chunks) per SHARP call
