@@ -198,6 +198,27 @@ def test_full_size_block_matches_oracle(env, oracle):
     assert np.array_equal(pred, ref["pred_clusters"])
 
 
+def test_upper_triangle_agglomeration_at_cfg2_size(env, monkeypatch):
+    """BASELINE.json configs[1] (50 000 x 20 000, ensize.K = 15: 375 base tasks of 2000 cells in two chunks of one task per CU) with the
+    upper-triangle agglomeration kernel (SHARP_HC_TRI=1) and with the default full-matrix one: every task done by the bulk-synchronous
+    kernel either way, identical labels."""
+    sa, dev, torch = env
+    n, m, K = 50000, 20000, 15
+    dX = torch.empty((n, m), dtype=torch.float32, device="cuda")
+    dev.synth_fill(dX, SEED, 0)
+    dev.profile(True)
+    pred, info = dev.SHARP_dev(dX, ensize_K=K, rN_seed=RN)
+    tab = dev.profile_table()
+    assert tab.get("host:hclust_tasks_sequential", (0, 0))[1] <= 25 + 1        # (the 25 wMetaC similarity tasks and the sMetaC one have exact ties)
+    monkeypatch.setenv("SHARP_HC_TRI", "1")
+    dev.profile(True)
+    pred_tri, info_tri = dev.SHARP_dev(dX, ensize_K=K, rN_seed=RN)
+    tab_tri = dev.profile_table()
+    dev.profile(False)
+    assert tab_tri.get("host:hclust_tasks_bulk_synchronous", (0, 0))[1] >= 375
+    assert np.array_equal(pred, pred_tri) and info["N.pred_cluster"] == info_tri["N.pred_cluster"]
+
+
 def test_smetac_at_1p2M_cells_matches_oracle(env, oracle):
     """sharp_sMetaC with n >= 1e6 (R/sMetaC.R:110-119: maxN = max(maxN, n/5000), minN = max(minN, n/50000))."""
     sa, dev, torch = env

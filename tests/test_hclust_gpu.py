@@ -169,8 +169,8 @@ def test_bulk_synchronous_and_sequential_agglomeration_agree(sa, oracle, monkeyp
 
 @pytest.mark.parametrize("n", [130, 700, 990])
 def test_upper_triangle_and_full_matrix_agglomeration_agree(sa, oracle, n, monkeypatch):
-    """hclust_tri_kernel (one launch per task on the upper triangle of the distance matrix: half the bytes per round, the default where it
-    applies) against hclust_rnn_kernel on the full matrix (SHARP_HC_TRI=0): same pairs, same ranks, same Lance-Williams arithmetic --
+    """hclust_tri_kernel (SHARP_HC_TRI=1: one launch per task on the upper triangle of the distance matrix, half the bytes per round) against
+    the default hclust_rnn_kernel on the full matrix: same pairs, same ranks, same Lance-Williams arithmetic --
     every cutree level identical, heights to rounding, and both equal to the oracle.  Duplicated observations (exact ties) send either
     to the sequential kernel."""
     from sharp_amd import device as dev
@@ -178,20 +178,21 @@ def test_upper_triangle_and_full_matrix_agglomeration_agree(sa, oracle, n, monke
     rng = np.random.default_rng(100 + n)
     E = rng.standard_normal((n, 40)) + np.repeat(rng.standard_normal((10, 40)) * 2.5, n // 10, axis=0)
     for hm in ["ward.D", "ward.D2", "average", "complete"]:
+        monkeypatch.setenv("SHARP_HC_TRI", "1")
         dev.profile(True)
         a = sa.get_opt_hclust(E, hmethod=hm)
         assert _hc_counts(dev) == (1, 0), hm
-        monkeypatch.setenv("SHARP_HC_TRI", "0")
+        monkeypatch.delenv("SHARP_HC_TRI")
         dev.profile(True)
         b = sa.get_opt_hclust(E, hmethod=hm)
         assert _hc_counts(dev) == (1, 0), hm
-        monkeypatch.delenv("SHARP_HC_TRI")
         assert np.array_equal(a["v"], b["v"]) and np.array_equal(a["f"], b["f"]), hm
         np.testing.assert_allclose(a["height"], b["height"], rtol=1e-12, atol=1e-14)
         ref = oracle.get_opt_hclust(E, hmethod=hm)
         assert np.array_equal(a["f"], ref["f"]) and a["optN_cluster"] == ref["optN"]
         np.testing.assert_allclose(a["height"], ref["height"], rtol=1e-9, atol=1e-12)
     T = np.vstack([E[: n // 2], E[: n // 8]]).copy()            # exact duplicates -> exact ties
+    monkeypatch.setenv("SHARP_HC_TRI", "1")
     dev.profile(True)
     a = sa.get_opt_hclust(T)
     assert _hc_counts(dev) == (0, 1)
