@@ -83,6 +83,7 @@ struct Knobs {
     int hc_ranges = 0, hc_wpt = 0, hc_finish_at = 15, hc_chunk = 0;   // SHARP_HC_RANGES / _WPT / _FINISH_AT / _CHUNK: ranges per chunk, workgroups per task, finishing round, tasks per chunk
     bool hc_tri = false;        // SHARP_HC_TRI=1: the upper-triangle agglomeration kernel (hclust_tri.inc: 44 % of the HBM bytes, the same time alone,
                                 // 8 % slower inside the batched SHARP_unlimited pipeline) where the full-matrix one runs by default
+    bool hc_prep_early = true;  // SHARP_HC_PREP_EARLY=0: a chunk's row preparation behind the previous chunk's distance GEMM instead of beside it
     bool hc_pipe = true;        // SHARP_HC_PIPE=0: one chunk of base-clustering tasks at a time
     int gemm_slice = 8;         // SHARP_GEMM_SLICE: workgroups per CU per slice of a distance GEMM prepared under another block's tail
     bool proj_host = false;     // SHARP_PROJ_HOST=1 (cross-check): the host build of the projectors

@@ -1558,7 +1558,7 @@ struct ChunkJob {
 };
 enum : int { PH_DIST = 1, PH_AGGLO = 2, PH_STATS = 4, PH_ALL = 7 };
 struct PipeEvents {
-    hipEvent_t in = nullptr, out[8] = {nullptr}, gemm[6] = {nullptr}, hc[6] = {nullptr}, done[6] = {nullptr};   // (per workspace slot)
+    hipEvent_t in = nullptr, out[8] = {nullptr}, gemm[6] = {nullptr}, hc[6] = {nullptr}, done[6] = {nullptr}, prep[6] = {nullptr};   // (per workspace slot)
 };
 PipeEvents &pipe_events() {
     PipeEvents &e = per_slot<PipeEvents>();
@@ -1569,6 +1569,7 @@ PipeEvents &pipe_events() {
             SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.gemm[q], hipEventDisableTiming));
             SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.hc[q], hipEventDisableTiming));
             SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.done[q], hipEventDisableTiming));
+            SHARP_HIP_CHECK(hipEventCreateWithFlags(&e.prep[q], hipEventDisableTiming));
         }
     }
     return e;
@@ -1794,11 +1795,17 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         };
         if (phases & PH_DIST) {
         if (NS > 1) SHARP_HIP_CHECK(hipStreamWaitEvent(st, ev_in, 0));
-        // pipelined: this chunk's distance GEMM starts when the previous chunk's has finished, i.e. together with the previous
-        // chunk's agglomeration, and fills the CUs that one leaves free (it holds a whole CU per task)
-        if (J.pipe && !J.first) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.prev_slot], 0));
+        // pipelined: this chunk's row preparation (HBM-bound, 0.75 ms alone) follows the previous chunk's at once, i.e. it runs beside the
+        // previous chunk's distance GEMM (MFMA-bound) -- behind that GEMM it ran beside the previous chunk's agglomeration, took 2.5 ms
+        // there and delayed this chunk's GEMM, which the NEXT agglomeration waits for, by as much (r03 timeline: the second
+        // agglomeration of a cfg2 step started 1.9 ms after the first had ended);
+        if (J.pipe && !J.first) SHARP_HIP_CHECK(hipStreamWaitEvent(st, knobs().hc_prep_early ? EV.prep[J.prev_slot] : EV.gemm[J.prev_slot], 0));
         // a3: rows -> centred/normalised (+ 1 - S for similarity input), then D = 1 - U U^T
         row_prep_batched(W.prep.p + R.t0, Ts, max_n, max_p, !R.any_sym);
+        if (J.pipe) SHARP_HIP_CHECK(hipEventRecord(EV.prep[J.slot], st));
+        // this chunk's distance GEMM starts when the previous chunk's has finished, i.e. together with the previous chunk's
+        // agglomeration, and fills the CUs that one leaves free (it holds a whole CU per task)
+        if (J.pipe && !J.first) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.prev_slot], 0));
         if (R.cnt[0]) gemm_tn_f64_batched(W.gemm.p + R.off[0], R.cnt[0], max_n, max_n, "corr_dist_gemm", true, true);
         if (J.pipe) SHARP_HIP_CHECK(hipEventRecord(EV.gemm[J.slot], st));
         if (R.any_sym) {
