@@ -305,6 +305,8 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
     // enrp per fold (:627-635); labels "<colour>p<t>" only need to be distinct per (k, t): the colour id does
     std::vector<std::vector<int>> enrp(T);
     for (int q = 0; q < K * T; ++q) out.rc |= hr[q].rc;
+    {
+    HostTimer ht("tail_enrp");
     host_parallel_for(T, 8, [&](int t) {
         const int nt = fst[t + 1] - fst[t];
         enrp[t].resize(static_cast<size_t>(nt) * K);
@@ -313,6 +315,7 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
             for (int i = 0; i < nt; ++i) enrp[t][static_cast<size_t>(k) * nt + i] = colour_of(r.f[i]);
         }
     });
+    }
     // per-fold wMetaC (:692-709)
     std::vector<WmTask> wts(T);
     for (int t = 0; t < T; ++t) {
@@ -362,7 +365,7 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
     } else {
         DevBuf<double> &means = dws().fold_means;                               // (kept: hipMalloc / hipFree synchronise the whole device, and in a
         means.ensure(static_cast<size_t>(nCu) * p);                             // batched SHARP_unlimited later chunks' agglomeration is in flight)
-        cluster_means_dev(viE_sh.p, p, n, p, uid, nCu, means.p);                // sMetaC :58-63 on E1 = enE/K
+        { HostTimer ht("tail_fold_means"); cluster_means_dev(viE_sh.p, p, n, p, uid, nCu, means.p); }   // sMetaC :58-63 on E1 = enE/K
         HcParams sp = base; sp.N_cluster = a.N_cluster;
         SmResult sr;
         { HostTimer ht("smetac_total"); sr = smetac_from_means(means.p, nCu, p, n, sp); }   // :754
@@ -370,6 +373,7 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
         stf = sr.tf;
         for (int i = 0; i < n; ++i) Slab[i] = stf[uid[i]];
     }
+    HostTimer ht_fin("tail_finish");
     out.pred.resize(n);
     for (int i = 0; i < n; ++i) out.pred[shuffle ? reind[i] - 1 : i] = Slab[i];   // :775-783
     if (a.want_x0) {

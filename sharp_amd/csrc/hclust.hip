@@ -2110,7 +2110,7 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
         return;
     }
     size_t free_b = 0, total_b = 0;
-    SHARP_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    { HostTimer ht("hc_mem_info"); SHARP_HIP_CHECK(hipMemGetInfo(&free_b, &total_b)); }
     const double budget = std::max(0.5 * static_cast<double>(free_b), 2.0e9);
     // More tasks than CUs: equal chunks of at most one task per CU.  The agglomeration kernel then runs its 1024-thread form
     // (one task per CU, twice the loads in flight) chunk after chunk -- as fast as all tasks at once with two per CU -- and the
@@ -2156,9 +2156,9 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
         for (const auto &b : bounds) {
             ChunkJob J;
             J.i0 = b.first; J.i1 = b.second;
-            setup_chunk(tasks, J);
-            enqueue_chunk(J, PH_ALL);
-            finish_chunk(tasks, J, want_v, out);
+            { HostTimer ht("hc_single_setup"); setup_chunk(tasks, J); }
+            { HostTimer ht("hc_single_enqueue"); enqueue_chunk(J, PH_ALL); }
+            { HostTimer ht("hc_single_finish"); finish_chunk(tasks, J, want_v, out); }
         }
         return;
     }

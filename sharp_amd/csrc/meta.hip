@@ -248,6 +248,7 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
         allCs[t] = allC;
     };
     {
+        HostTimer ht("wmetac_relabel");
         host_parallel_for(T, 8, relabel);
     }
     for (int t = 0; t < T; ++t) {
@@ -270,6 +271,7 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
     SHARP_REQUIRE(max_lds <= 150 * 1024, "wMetaC: N x C label block does not fit in LDS");
     W.cid.ensure(oCid); W.w.ensure(oW); W.S.ensure(oS); W.col.ensure(oCol); W.meta.ensure(T); W.mem.ensure(oCid); W.mstart.ensure(oStart);
     {
+        HostTimer ht("wmetac_upload");
         std::vector<int> hcol(oCol);
         std::vector<int> hstart(oStart);
         for (int t = 0; t < T; ++t) {
@@ -424,7 +426,7 @@ SmResult smetac_from_means(const double *d_means, int nC, int p, long long ncell
     GemmTask g{W.Ut.p, W.Ut.p, W.Smat.p, nC, nC, p, nld, nld, nC, 2, 1, 0};
     W.gemm.upload(&g, 1);
     gemm_tn_f64_batched(W.gemm.p, 1, nC, nC, "smetac_centroid_corr_gemm");
-    stream_sync();
+    { HostTimer ht("smetac_corr_wait"); stream_sync(); }
     // k-range adjustment (R/sMetaC.R:103-119)
     const long long mm = ncells / 10000;
     if (ncells < 1000000) {
