@@ -93,6 +93,9 @@ struct Knobs {
 };
 const Knobs &knobs();
 void reload_knobs();
+#ifdef SHARP_LAB
+inline const char *lab_env(const char *name) { return getenv(name); }   // lab builds (tools/build_variant.sh) only: ablation / timing switches
+#endif
 
 struct KernelStat {
     double ms = 0;

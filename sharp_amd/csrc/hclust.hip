@@ -1763,8 +1763,8 @@ void enqueue_chunk(ChunkJob &J, int phases) {
             const size_t lds = (static_cast<size_t>(nal) * 8 + 32 * 8 + static_cast<size_t>(nal) * 4 * 3 + 32 * 4 + 8 + static_cast<size_t>(max_n) + 16 + 32 * 12 + 16 + 15) / 16 * 16;
             DevBuf<long long> dbg;
 #ifdef SHARP_LAB                                                // (lab build, tools/build_variant.sh: phase ablation and per-phase cycle counts)
-            const char *abl = getenv("SHARP_HC_ABLATE");
-            const char *tim = getenv("SHARP_HC_TIMING");
+            const char *abl = lab_env("SHARP_HC_ABLATE");
+            const char *tim = lab_env("SHARP_HC_TIMING");
             if (tim) { dbg.alloc(static_cast<size_t>(Ts) * 6); dbg.zero(); }
 #else
             const char *abl = nullptr;
@@ -1876,7 +1876,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                         }
                     }
 #ifdef SHARP_LAB
-                } else if (Ts <= c.num_cu && max_n <= HL_MAXN && getenv("SHARP_HC_LAZY") && getenv("SHARP_HC_LAZY")[0] == '1') {
+                } else if (Ts <= c.num_cu && max_n <= HL_MAXN && lab_env("SHARP_HC_LAZY") && lab_env("SHARP_HC_LAZY")[0] == '1') {
                     // SHARP_HC_LAZY=1 (an experiment kept for reference): one workgroup per task, rows rewritten only
                     // when their cluster merges (hclust_lazy.inc) -- half the bytes of hclust_rnn_kernel, same merges, but at four waves
                     // per CU (a 16 KB LDS row buffer each) it runs at a quarter of the bandwidth: 62 ms against 30 ms at cfg2
@@ -1884,7 +1884,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_lazy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         static_cast<int>(ldsz)));
                     int theta = 50;
-                    if (const char *e = getenv("SHARP_HC_LAZY_THETA")) theta = std::max(10, std::min(95, atoi(e)));
+                    if (const char *e = lab_env("SHARP_HC_LAZY_THETA")) theta = std::max(10, std::min(95, atoi(e)));
                     hipLaunchKernelGGL(hclust_lazy_kernel, dim3(Ts), dim3(HL_THREADS), ldsz, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p,
                                        W.height.p, W.status.p + R.t0, theta);
 #endif

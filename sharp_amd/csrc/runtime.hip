@@ -210,15 +210,16 @@ namespace sharp {
 // The one place the library reads its environment: at the first use (sharp_init) and again only when sharp_reload_options() asks for it.
 static Knobs read_knobs() {
     Knobs v;
-    auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; };
+    auto env = [](const char *name) { return getenv(name); };                    // (the library's only getenv outside -DSHARP_LAB code)
+    auto num = [&](const char *name, int dflt) { const char *e = env(name); return e && *e ? atoi(e) : dflt; };
     v.rp_dual = num("SHARP_RP_DUAL", 1) != 0;
     { const int ser = num("SHARP_RP_SERIAL", -1); v.rp_two_streams = ser < 0 ? -1 : (ser == 0 ? 1 : 0); }
     v.rp_chunk = num("SHARP_RP_CHUNK", 0);
     v.rp_cp_wgs = std::max(1, num("SHARP_RP_CP_WGS", 8));
     v.rp_ap_wgs = std::max(1, num("SHARP_RP_AP_WGS", 4));
     v.rp_shape = num("SHARP_RP_SHAPE", 0);
-    if (const char *kv = getenv("SHARP_RP_KERNEL")) v.rp_kernel = !strcmp(kv, "fused") ? 1 : !strcmp(kv, "dense") ? 2 : !strcmp(kv, "sparse") ? 3 : 0;
-    if (const char *xs = getenv("SHARP_X_STORAGE")) v.x_storage = !strcmp(xs, "fp32") ? 32 : !strcmp(xs, "fp64") ? 64 : 0;
+    if (const char *kv = env("SHARP_RP_KERNEL")) v.rp_kernel = !strcmp(kv, "fused") ? 1 : !strcmp(kv, "dense") ? 2 : !strcmp(kv, "sparse") ? 3 : 0;
+    if (const char *xs = env("SHARP_X_STORAGE")) v.x_storage = !strcmp(xs, "fp32") ? 32 : !strcmp(xs, "fp64") ? 64 : 0;
     v.block_prefetch = num("SHARP_NO_BLOCK_PREFETCH", 0) == 0;
     v.unlimited_batch = num("SHARP_UNLIMITED_BATCH", 1) != 0;
     v.unlimited_window_mb = num("SHARP_UNLIMITED_WINDOW_MB", 0);
@@ -236,7 +237,7 @@ static Knobs read_knobs() {
     v.gemm_slice = num("SHARP_GEMM_SLICE", 8);
     v.proj_host = num("SHARP_PROJ_HOST", 0) == 1;
     v.upload_threads = num("SHARP_UPLOAD_THREADS", 0);
-    if (const char *dl = getenv("SHARP_DEVICES")) {
+    if (const char *dl = env("SHARP_DEVICES")) {
         for (const char *q = dl; *q;) {
             char *end = nullptr;
             const long dvc = strtol(q, &end, 10);
