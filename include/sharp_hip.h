@@ -298,6 +298,7 @@ int sharp_dev_download(void *host, const void *dptr, long long bytes);
 void sharp_C_init(int *device, int *status);
 void sharp_C_shutdown(int *status);
 void sharp_C_trim(int *status);
+void sharp_C_reload_options(int *status);   /* sharp_reload_options(): after Sys.setenv() of a SHARP_* switch in a session that has already called sharp_C_init */
 void sharp_C_device_count(int *count, int *status);
 void sharp_C_last_error(char **msg, int *len);                     /* copies the message into the caller's string of *len bytes */
 /* R/ranM.R:11-33, R/ranM2.R:11-35, R/RPmat.R:14-31 */

@@ -41,6 +41,7 @@ extern "C" {
 void sharp_C_init(int *device, int *status) { *status = sharp_init(*device); }
 void sharp_C_shutdown(int *status) { *status = sharp_shutdown(); }
 void sharp_C_trim(int *status) { *status = sharp_trim(); }
+void sharp_C_reload_options(int *status) { *status = sharp_reload_options(); }
 void sharp_C_device_count(int *count, int *status) { *status = sharp_device_count(count); }
 
 /* .C("sharp_C_last_error", msg = paste(rep(" ", 1024), collapse = ""), len = 1024L)$msg : the text is copied into the caller's string */
