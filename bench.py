@@ -49,6 +49,9 @@ def rp_stage_numbers(prof, n, m, K, p, steps_of):
     sms, scalls = prof.get("rp_stage", (0.0, 0))
     if not scalls:
         return None
+    # chunks compacted beside the projector build (rp_compact_ahead, second stream) are the stage's work too: their time is ADDED, as if
+    # they had run where they used to, behind the build
+    sms += prof.get("rp_stage_ahead", (0.0, 0))[0]
     t_stage = sms / scalls * 1e-3
     read_b, write_b = n * m * 4, n * K * p * 4
     out = {"ms": round(t_stage * 1e3, 4), "cells": n, "genes": m, "n_RP": K, "reduced_dim": p,

@@ -240,6 +240,8 @@ static void large_front(LargeFront &F, const SharpArgs &a, bool ahead, double *E
     }
     F.fst = fold_starts(n, F.ng);
     F.T = static_cast<int>(F.fst.size()) - 1;
+    // projectors drawn for this call: the block's compaction (which needs X only) goes out first and runs beside the draw
+    const unsigned ahead_tok = (!a.projector && !ahead) ? rp_compact_ahead(F.dX, m, n, F.ld, a.flag) : 0u;
     { HostTimer ht("projector_build"); F.pr = projector_for(a, m, p, K); }       // :539-549
     F.ldE = static_cast<long long>(F.pr->K) * p;
     if (E_into) {                                                               // (a block of a batch: rows of the batch's own buffers)
@@ -253,7 +255,7 @@ static void large_front(LargeFront &F, const SharpArgs &a, bool ahead, double *E
         F.E = E.p; F.dpos = F.shuffle ? dpos.p : nullptr;
     }
     // E rows are written straight into shuffled order, so fold t is the contiguous row range [fst[t], fst[t+1])
-    project_dev(*F.pr, F.dX, m, n, F.ld, a.flag, F.E, F.ldE, F.dpos);             // :567-585 for every (k, t)
+    project_dev(*F.pr, F.dX, m, n, F.ld, a.flag, F.E, F.ldE, F.dpos, ahead_tok);  // :567-585 for every (k, t)
     if (a.fpart) {                                                              // newE1 = round(newE1, digits = 1)  (unlimited2 :410)
         Ctx &c = ctx();
         hipLaunchKernelGGL(round1_kernel, dim3(c.num_cu * 8), dim3(256), 0, c.stream, F.E, static_cast<long long>(n) * F.ldE);

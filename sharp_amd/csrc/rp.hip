@@ -27,7 +27,6 @@ constexpr int RP_THREADS = 512;
 constexpr int RP_NV = 2;                             // float4 loads per lane per step
 constexpr int RP_STEP = RP_THREADS * 4 * RP_NV;      // genes per step (4096)
 constexpr int RP_CAP = 2048;                         // non-zero slots per scatter batch
-constexpr int RP_FIX_BITS = 44;      // log mode: |log2(1+x)| < 128, < 2^11 terms -> |sum| < 2^18
 
 struct __attribute__((aligned(16))) NzSlot {
     uint32_t gene;   // gene index
@@ -310,10 +309,11 @@ static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float 
 }
 
 void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, int m, int n, long long ld, int log_flag,
-                       int fix_bits, double *dE, long long ldE, const int *d_row_map);   // rp2.hip
+                       int fix_bits, double *dE, long long ldE, const int *d_row_map, unsigned ahead_token);   // rp2.hip
 
 void project_dev(const Projector &pr, XRef X, int m, int n, long long ld, int log_flag, double *dE, long long ldE,
-                 const int *d_row_map) {
+                 const int *d_row_map, unsigned ahead_token) {
+    struct DropAhead { ~DropAhead() { rp_compact_ahead_drop(); } } drop_ahead;   // lists compacted ahead serve this call or none
     const float *dX = X.f32();
     SHARP_REQUIRE(m == pr.m, "project: gene count differs from the projector's");
     SHARP_REQUIRE(ld >= m, "project: leading dimension smaller than m");
@@ -344,7 +344,7 @@ void project_dev(const Projector &pr, XRef X, int m, int n, long long ld, int lo
     else launch_rp<GWV, SL, false>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map)
         const bool fused = knobs().rp_kernel == 1;   // SHARP_RP_KERNEL=fused: the single-kernel form (always used for unaligned X)
         if (vec && m >= 8 && m <= (1 << 20) && (X.f64 || !fused)) {   // (20-bit gene index in the compacted entries)
-            project_dev_split(pr, g, X, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);
+            project_dev_split(pr, g, X, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map, ahead_token);
             continue;
         }
         if (gw == 16 && g.slots == 4) { SHARP_RP_CASE(16, 4); }

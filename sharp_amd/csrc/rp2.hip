@@ -424,16 +424,127 @@ __global__ __launch_bounds__(AP_THREADS, AP_THREADS >= 512 ? 4 : 4) void rp_appl
 }
 
 namespace {
+constexpr int kRing = 16;                // entry buffers: two in rotation, or one per chunk of a block compacted ahead (rp_compact_ahead)
+// What rp_compact_ahead has compacted: consumed by the project_dev call that presents its token, by no other.
+struct Precompact {
+    unsigned token = 0;                  // 0: nothing
+    const void *X = nullptr;
+    bool f64 = false;
+    int m = 0, n = 0, log_flag = 0, fix_bits = 0, nbuf = 0, done = 0;
+    long long ld = 0, chunk = 0;
+};
 struct SplitWs {
     DevBuf<unsigned int> counts;         // entries per cell, all chunks of a call (zeroed once per call)
-    DevBuf<uint32_t> genes[2];
-    DevBuf<long long> fixes[2];
+    DevBuf<uint32_t> genes[kRing];
+    DevBuf<long long> fixes[kRing];
     DevBuf<long long> fixtab;
     double fixtab_scale = 0.0;
-    hipEvent_t ev_compact[2] = {nullptr, nullptr}, ev_apply[2] = {nullptr, nullptr}, ev_start = nullptr;
+    hipEvent_t ev_compact[kRing] = {}, ev_apply[kRing] = {}, ev_start = nullptr;
+    Precompact pre;
+    unsigned next_token = 1;
 };
 SplitWs &sws() { return per_slot<SplitWs>(); }
+
+// cells per chunk of the RP stage: two (genes, fix) buffers of <= 2 GB each, sized for the worst case (every gene non-zero);
+// few, equal chunks: each launch pays a tail, and a chunk must give every workgroup several cells
+long long rp_chunk_cells(int m, int n) {
+    const int cap = (m + 3) / 4 * 4;
+    long long chunk = std::max<long long>(512, (2048LL << 20) / (static_cast<long long>(cap) * 12));
+    chunk = std::min<long long>(chunk, 16384);
+    if (knobs().rp_chunk > 0) chunk = std::max(64, knobs().rp_chunk);
+    chunk = std::min<long long>(chunk, n);
+    const long long nch = (n + chunk - 1) / chunk;
+    return (n + nch - 1) / nch;
+}
+void ensure_fixtab(SplitWs &W, double fix_scale, int log_flag, hipStream_t st) {
+    const double tab_key = log_flag == 2 ? -fix_scale : fix_scale;       // the table depends on the scale and on the log base
+    if (W.fixtab.n == 0 || W.fixtab_scale != tab_key) {
+        W.fixtab.ensure(CP_TAB);
+        hipLaunchKernelGGL(rp_fixtab_kernel, dim3(1), dim3(CP_TAB), 0, st, fix_scale, log_flag == 2 ? 1 : 0, W.fixtab.p);
+        launch_check("rp_fixtab_kernel");
+        W.fixtab_scale = tab_key;
+    }
+}
+void ensure_ring(SplitWs &W, int nbuf, long long chunk, int cap) {
+    for (int q = 0; q < nbuf; ++q) {
+        W.genes[q].ensure(chunk * cap); W.fixes[q].ensure(chunk * cap);
+        if (!W.ev_compact[q]) { SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_compact[q], hipEventDisableTiming)); SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_apply[q], hipEventDisableTiming)); }
+    }
+    if (!W.ev_start) SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_start, hipEventDisableTiming));
+}
+// one chunk's compaction into ring buffer q, on stream st
+void launch_compact(SplitWs &W, XRef dX, int m, long long ld, long long c0, int nc, int log_flag, double fix_scale, int cap, int q, hipStream_t st) {
+    Ctx &c = ctx();
+    const int units = (m + CP_UNIT - 1) / CP_UNIT;
+    const long long waves = static_cast<long long>(nc) * units;
+    // a persistent grid of exactly the workgroups that are resident together (the units are dealt to the waves statically)
+    static int cp_occ[2] = {0, 0};
+    int &occ = cp_occ[dX.f64 ? 1 : 0];
+    if (occ == 0) {
+        const void *kf = dX.f64 ? reinterpret_cast<const void *>(rp_compact_kernel<double>) : reinterpret_cast<const void *>(rp_compact_kernel<float>);
+        SHARP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, CP_THREADS, 0));
+        occ = std::max(1, occ);
+    }
+    const int cp_per_cu = std::min(occ, knobs().rp_cp_wgs);
+    const int blocks = static_cast<int>(std::min<long long>((waves + 3) / 4, static_cast<long long>(c.num_cu) * cp_per_cu));
+    KernelTimer tc("rp_compact", st);
+    if (dX.f64)
+        hipLaunchKernelGGL(rp_compact_kernel<double>, dim3(blocks), dim3(CP_THREADS), 0, st, dX.d64(), m, ld, c0, nc, log_flag, fix_scale,
+                           cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p);
+    else
+        hipLaunchKernelGGL(rp_compact_kernel<float>, dim3(blocks), dim3(CP_THREADS), 0, st, dX.f32(), m, ld, c0, nc, log_flag, fix_scale,
+                           cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p);
+    launch_check("rp_compact_kernel");
+}
 }  // namespace
+
+bool rp_split_eligible(XRef X, int m, long long ld) {
+    const bool vec = (ld % (X.f64 ? 2 : 4) == 0) && ((reinterpret_cast<uintptr_t>(X.p) & 15u) == 0);
+    return vec && m >= 8 && m <= (1 << 20) && (X.f64 || knobs().rp_kernel != 1) && knobs().rp_kernel != 2 && !(knobs().rp_kernel == 0 && m <= 16);
+}
+
+// The compaction needs X only, not the projectors: a caller that is about to BUILD its projectors (1.9 ms of latency-bound kernels at
+// cfg2: Mersenne-Twister draws, packing) starts the compaction of the block first, on the second stream, and it runs beside that build
+// instead of behind it.  Every chunk gets a buffer of its own when the block's entries fit `budget` (worst case: every gene non-zero,
+// 12 B each), else the first two chunks go ahead and the rest keep the rotation.  Returns the token project_dev takes (0: nothing done).
+unsigned rp_compact_ahead(XRef dX, int m, int n, long long ld, int log_flag) {
+    Ctx &c = ctx();
+    SplitWs &W = sws();
+    W.pre = Precompact();
+    if (!knobs().rp_ahead || c.polite || !log_flag || n < 4096 || !rp_split_eligible(dX, m, ld)) return 0;
+    const int cap = (m + 3) / 4 * 4;
+    const long long chunk = rp_chunk_cells(m, n);
+    const int nchunks = static_cast<int>((n + chunk - 1) / chunk);
+    size_t free_b = 0, total_b = 0;
+    SHARP_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const double need = static_cast<double>(nchunks) * chunk * cap * 12.0;
+    const bool have = nchunks <= kRing && W.genes[nchunks - 1].n >= static_cast<size_t>(chunk) * cap;      // (already allocated by an earlier call)
+    const int nbuf = (nchunks <= kRing && (have || (need <= 16.0e9 && need <= 0.25 * static_cast<double>(free_b)))) ? nchunks : 2;
+    const int done = std::min(nbuf, nchunks);
+    const int fix_bits = std::min(RP_FIX_BITS, dX.log_fix_bits);
+    const double fix_scale = std::ldexp(1.0, fix_bits);
+    ensure_ring(W, nbuf, chunk, cap);
+    ensure_fixtab(W, fix_scale, log_flag, c.stream);
+    W.counts.ensure(static_cast<size_t>(n) + nchunks);
+    hipStream_t s2 = c.stream2;
+    SHARP_HIP_CHECK(hipEventRecord(W.ev_start, c.stream));                  // X is complete, the buffers' last readers are enqueued
+    SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_start, 0));
+    {
+        KernelTimer t("rp_stage_ahead", s2);                                // (bench.py adds it to rp_stage: the stage's work, wherever it ran)
+        SHARP_HIP_CHECK(hipMemsetAsync(W.counts.p, 0, (static_cast<size_t>(n) + nchunks) * 4, s2));
+        for (int ch = 0; ch < done; ++ch) {
+            const long long c0 = ch * chunk;
+            const int nc = static_cast<int>(std::min<long long>(chunk, n - c0));
+            launch_compact(W, dX, m, ld, c0, nc, log_flag, fix_scale, cap, ch, s2);
+            SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[ch], s2));
+        }
+    }
+    Precompact &P = W.pre;
+    P.token = W.next_token++; if (W.next_token == 0) W.next_token = 1;
+    P.X = dX.p; P.f64 = dX.f64; P.m = m; P.n = n; P.ld = ld; P.log_flag = log_flag; P.fix_bits = fix_bits; P.nbuf = nbuf; P.done = done; P.chunk = chunk;
+    return P.token;
+}
+void rp_compact_ahead_drop() { sws().pre = Precompact(); }
 
 template <int GW, int SLOTS, bool DUAL>
 static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell, long long cell0, int cap, const unsigned int *counts,
@@ -462,7 +573,7 @@ static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell
 
 // X must be 16-byte aligned with ld % 4 == 0.  One projector group (K*p <= 12288) per call.
 void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, int m, int n, long long ld, int log_flag,
-                       int fix_bits, double *dE, long long ldE, const int *d_row_map) {
+                       int fix_bits, double *dE, long long ldE, const int *d_row_map, unsigned ahead_token) {
     Ctx &c = ctx();
     SplitWs &W = sws();
     // One stream by default: the two kernels do not overlap when they share the chip (each is limited by the memory requests a CU keeps
@@ -475,69 +586,38 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
     const bool two_streams = !c.polite && (ts < 0 ? g.neg_base > 0 : ts > 0);
     hipStream_t s2 = two_streams ? c.stream2 : c.stream;
     const int cap = (m + 3) / 4 * 4;                         // worst case: every gene non-zero
-    // chunks of cells: two (genes, fix, counts) buffers of <= 2 GB each (sized for the worst case, every gene non-zero);
-    // few, equal chunks: each launch pays a tail, and a chunk must give every workgroup several cells
-    long long chunk = std::max<long long>(512, (2048LL << 20) / (static_cast<long long>(cap) * 12));
-    chunk = std::min<long long>(chunk, 16384);
-    if (knobs().rp_chunk > 0) chunk = std::max(64, knobs().rp_chunk);
-    chunk = std::min<long long>(chunk, n);
-    {
-        const long long nch = (n + chunk - 1) / chunk;
-        chunk = (n + nch - 1) / nch;
-    }
-    for (int q = 0; q < 2; ++q) {
-        W.genes[q].ensure(chunk * cap); W.fixes[q].ensure(chunk * cap);
-        if (!W.ev_compact[q]) { SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_compact[q], hipEventDisableTiming)); SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_apply[q], hipEventDisableTiming)); }
-    }
-    if (!W.ev_start) SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.ev_start, hipEventDisableTiming));
+    const long long chunk = rp_chunk_cells(m, n);
+    const int nchunks = static_cast<int>((n + chunk - 1) / chunk);
+    // chunks compacted ahead of the projector build (rp_compact_ahead) by THIS call's front: theirs are the first `done` ring buffers
+    const Precompact &P = W.pre;
+    const bool pre = ahead_token != 0 && P.token == ahead_token && P.X == dX.p && P.f64 == dX.f64 && P.m == m && P.n == n && P.ld == ld &&
+                     P.log_flag == log_flag && P.fix_bits == fix_bits && P.chunk == chunk;
+    const int nbuf = pre ? P.nbuf : 2, done = pre ? P.done : 0;
+    ensure_ring(W, nbuf, chunk, cap);
     const double fix_scale = std::ldexp(1.0, fix_bits), inv_fix = std::ldexp(1.0, -fix_bits);
-    const double tab_key = log_flag == 2 ? -fix_scale : fix_scale;       // the table depends on the scale and on the log base
-    if (W.fixtab.n == 0 || W.fixtab_scale != tab_key) {
-        W.fixtab.ensure(CP_TAB);
-        hipLaunchKernelGGL(rp_fixtab_kernel, dim3(1), dim3(CP_TAB), 0, c.stream, fix_scale, log_flag == 2 ? 1 : 0, W.fixtab.p);
-        launch_check("rp_fixtab_kernel");
-        W.fixtab_scale = tab_key;
-    }
+    ensure_fixtab(W, fix_scale, log_flag, c.stream);
     KernelTimer t("rp_stage");                                 // the whole stage, measured on the main stream
     const bool two = s2 != c.stream;                           // (one stream: its order is all the synchronisation there is to do)
     if (two) {
         SHARP_HIP_CHECK(hipEventRecord(W.ev_start, c.stream));
         SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_start, 0));
     }
-    const int nchunks_all = static_cast<int>((n + chunk - 1) / chunk);
-    W.counts.ensure(static_cast<size_t>(n) + nchunks_all);      // entries per cell, then one cell-queue counter per chunk (apply kernel)
-    SHARP_HIP_CHECK(hipMemsetAsync(W.counts.p, 0, (static_cast<size_t>(n) + nchunks_all) * 4, s2));
-    const int nchunks = static_cast<int>((n + chunk - 1) / chunk);
-    const int units = (m + CP_UNIT - 1) / CP_UNIT;
+    W.counts.ensure(static_cast<size_t>(n) + nchunks);          // entries per cell, then one cell-queue counter per chunk (apply kernel)
+    if (!pre) SHARP_HIP_CHECK(hipMemsetAsync(W.counts.p, 0, (static_cast<size_t>(n) + nchunks) * 4, s2));
+    else SHARP_HIP_CHECK(hipMemsetAsync(W.counts.p + n, 0, static_cast<size_t>(nchunks) * 4, c.stream));   // (the queue counters again: a second projector group re-reads the lists)
     for (int ch = 0; ch < nchunks; ++ch) {
-        const int q = ch & 1;
+        const int q = ch % nbuf;
         const long long c0 = ch * chunk;
         const int nc = static_cast<int>(std::min<long long>(chunk, n - c0));
-        if (two && ch >= 2) SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_apply[q], 0));      // buffer q free again
-        const long long waves = static_cast<long long>(nc) * units;
-        // a persistent grid of exactly the workgroups that are resident together (the units are dealt to the waves statically)
-        static int cp_occ[2] = {0, 0};
-        int &occ = cp_occ[dX.f64 ? 1 : 0];
-        if (occ == 0) {
-            const void *kf = dX.f64 ? reinterpret_cast<const void *>(rp_compact_kernel<double>) : reinterpret_cast<const void *>(rp_compact_kernel<float>);
-            SHARP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, CP_THREADS, 0));
-            occ = std::max(1, occ);
-        }
-        const int cp_per_cu = std::min(occ, knobs().rp_cp_wgs);
-        const int blocks = static_cast<int>(std::min<long long>((waves + 3) / 4, static_cast<long long>(c.num_cu) * cp_per_cu));
-        {
-            KernelTimer tc("rp_compact", s2);
-            if (dX.f64)
-                hipLaunchKernelGGL(rp_compact_kernel<double>, dim3(blocks), dim3(CP_THREADS), 0, s2, dX.d64(), m, ld, c0, nc, log_flag, fix_scale,
-                                   cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p);
-            else
-                hipLaunchKernelGGL(rp_compact_kernel<float>, dim3(blocks), dim3(CP_THREADS), 0, s2, dX.f32(), m, ld, c0, nc, log_flag, fix_scale,
-                                   cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p);
-            launch_check("rp_compact_kernel");
-        }
-        if (two) {
-            SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[q], s2));
-            SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, W.ev_compact[q], 0));
+        if (ch < done) {
+            SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, W.ev_compact[q], 0));                  // compacted ahead, on the second stream
+        } else {
+            if (two && ch >= nbuf) SHARP_HIP_CHECK(hipStreamWaitEvent(s2, W.ev_apply[q], 0));    // buffer q free again
+            launch_compact(W, dX, m, ld, c0, nc, log_flag, fix_scale, cap, q, s2);
+            if (two) {
+                SHARP_HIP_CHECK(hipEventRecord(W.ev_compact[q], s2));
+                SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, W.ev_compact[q], 0));
+            }
         }
 #ifndef SHARP_LAB_CP          // (a lab build of the compaction leaves no valid lists behind: the apply kernel is not launched)
         {
@@ -553,6 +633,8 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
 #endif
         if (two) SHARP_HIP_CHECK(hipEventRecord(W.ev_apply[q], c.stream));
     }
+    // lists that have been overwritten (a rotation shorter than the block) serve no second projector group
+    if (pre && done < nchunks) W.pre = Precompact();
 }
 
 }  // namespace sharp

@@ -148,6 +148,27 @@ def test_sharp_large_pipelined_chunks_match_oracle(sa, oracle, monkeypatch, chun
     np.testing.assert_array_equal(res["x0"], res_serial["x0"])
 
 
+@pytest.mark.parametrize("rp_chunk", [None, "1500", "300"])
+def test_compaction_ahead_of_the_projector_build(sa, oracle, monkeypatch, rp_chunk):
+    # SHARP() draws its projectors per call; the block's compaction (needs X only) is started first and runs beside the draw
+    # (rp_compact_ahead): every chunk in a buffer of its own (one chunk; four chunks), or -- more chunks than ring buffers -- the first
+    # two ahead and the rest in rotation.  Same projections bit for bit as with SHARP_RP_AHEAD=0, same labels as the oracle.
+    m, n, G, nm = 3000, 6000, 6, 300
+    X = oracle.synth_fill(SEED, m, 0, n, G, nm)
+    ref = oracle.SHARP(X, K=3, base_ncells=300, partition_ncells=2000, rN_seed=2103, nthreads=4)
+    kw = dict(ensize_K=3, base_ncells=300, partition_ncells=2000, rN_seed=2103, logflag=False, prep=False)
+    if rp_chunk: monkeypatch.setenv("SHARP_RP_CHUNK", rp_chunk)
+    res = sa.SHARP(X, **kw)
+    res_again = sa.SHARP(X, **kw)
+    monkeypatch.setenv("SHARP_RP_AHEAD", "0")
+    res_plain = sa.SHARP(X, **kw)
+    assert res["path"] == "SHARP_large"
+    for r in (res, res_again, res_plain):
+        assert np.array_equal(r["pred_clusters"], ref["pred_clusters"])
+    np.testing.assert_array_equal(res["viE"], res_plain["viE"])
+    np.testing.assert_array_equal(res_again["viE"], res_plain["viE"])
+
+
 def test_sharp_unlimited_matches_oracle(sa, oracle):
     m, G, nm = 3000, 6, 300
     blocks = [oracle.synth_fill(SEED, m, i * 6000, 6000, G, nm) for i in range(2)]
