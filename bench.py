@@ -51,7 +51,9 @@ def rp_stage_numbers(prof, n, m, K, p, steps_of):
         return None
     # chunks compacted beside the projector build (rp_compact_ahead, second stream) are the stage's work too: their time is ADDED, as if
     # they had run where they used to, behind the build
-    sms += prof.get("rp_stage_ahead", (0.0, 0))[0]
+    ahead_ms = prof.get("rp_stage_ahead", (0.0, 0))[0]
+    main_ms = sms
+    sms += ahead_ms
     t_stage = sms / scalls * 1e-3
     read_b, write_b = n * m * 4, n * K * p * 4
     out = {"ms": round(t_stage * 1e3, 4), "cells": n, "genes": m, "n_RP": K, "reduced_dim": p,
@@ -65,6 +67,9 @@ def rp_stage_numbers(prof, n, m, K, p, steps_of):
                                     "frac": round(bl / tl / 8e12, 4)}
     if acalls:
         out["rp_apply_kernel"] = {"launch_ms": round(ams / acalls, 4)}
+    if ahead_ms:
+        out["ms_main_stream"] = round(main_ms / scalls, 4)           # what the step still sees of the stage
+        out["ms_ahead_stream"] = round(ahead_ms / scalls, 4)         # the chunks compacted beside the projector draw (they share the chip with it)
     return out
 
 
@@ -350,6 +355,9 @@ def extra_configs(np, torch, sharp_amd, dev, lib, synth_block, unlimited_call, A
                                % (CFG3["cells"], m, B, K),
                    "value": round(CFG3["cells"] / dt, 1), "unit": "cells/s", "seconds_per_call": round(dt, 4), "calls_timed": reps,
                    "reduced_dim": p, "clusters_found": int(npred), "ari_vs_planted_truth": round(float(ARI(truth, pred)["HA"]), 4)}
+    # the cfg2 shape (K = 15, p = 391) the same way: the stage alone on an idle chip, projectors resident -- the kernels' own number, beside the
+    # in-step one of `roofline.stage`, where the chunks compacted ahead share the chip with the projector draw and take 1.4x as long
+    by_cfg["cfg2_alone"] = rp_stage_alone(torch, sharp_amd, dev, lib, blocks[0], CFG2["K"], int(np.ceil(np.log2(CFG2["cells"]) / 0.04)))
     by_cfg["cfg3_block"] = rp_stage_alone(torch, sharp_amd, dev, lib, blocks[0], K, p)   # (inside the call above the next block's RP stage runs
     del blocks                                                                             #  on a low-priority stream beside the current block's tail)
     torch.cuda.empty_cache()

@@ -158,17 +158,27 @@ struct HostTimer {
     ~HostTimer();
 };
 
+// A small cache of device blocks for buffers that are allocated and released on EVERY call (the per-call projectors of SHARP() and the
+// temporaries of their build: twelve hipFree per call, each of which synchronises the device: 0.37 ms per cfg2 step).  Opt-in
+// (DevBuf::alloc_pooled): a block handed back is handed out again without any synchronisation, so the owner must have synchronised
+// the stream(s) that used it -- which is what every user of these buffers did before releasing them anyway.  Blocks up to 64 MB, at most
+// 512 MB held per process; sharp_trim() / sharp_shutdown() empty it.
+void *pool_take(size_t bytes, size_t *cap_bytes);      // a cached block of the current device with capacity >= bytes (its size class), or a fresh one
+void pool_give(void *p, size_t cap_bytes);
+void pool_clear();
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    size_t pooled_cap = 0;               // bytes of the pool block behind p (0: a plain hipMalloc)
     DevBuf() = default;
     explicit DevBuf(size_t count) { alloc(count); }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), pooled_cap(o.pooled_cap) { o.p = nullptr; o.n = 0; o.pooled_cap = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; pooled_cap = o.pooled_cap; o.p = nullptr; o.n = 0; o.pooled_cap = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
@@ -177,8 +187,17 @@ struct DevBuf {
         n = count;
         if (count) SHARP_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
     }
+    void alloc_pooled(size_t count) {    // (see pool_take)
+        release();
+        n = count;
+        if (count) p = static_cast<T *>(pool_take(count * sizeof(T), &pooled_cap));
+    }
     void ensure(size_t count) { if (count > n) alloc(count); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void release() {
+        if (!p) return;
+        if (pooled_cap) pool_give(p, pooled_cap); else (void)hipFree(p);
+        p = nullptr; n = 0; pooled_cap = 0;
+    }
     void upload(const T *h, size_t count) {
         SHARP_HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
     }

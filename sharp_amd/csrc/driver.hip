@@ -100,7 +100,7 @@ int relabel_first(std::vector<int> &lab) {
     return k;
 }
 
-std::shared_ptr<Projector> projector_for(const SharpArgs &a, int m, int p, int K) {
+std::shared_ptr<Projector> projector_for(const SharpArgs &a, int m, int p, int K, const std::function<void()> *after_draw = nullptr) {
     if (a.projector) {
         auto pr = get_projector(a.projector);
         SHARP_REQUIRE(pr->m == m && pr->p == p && pr->K >= K, "rM does not match the data (genes, reduced.ndim, ensize.K)");
@@ -108,7 +108,7 @@ std::shared_ptr<Projector> projector_for(const SharpArgs &a, int m, int p, int K
     }
     std::vector<double> seeds(K);
     for (int k = 0; k < K; ++k) seeds[k] = (a.rN_seed == 0.5) ? 0.5 : 50 + a.rN_seed + (k + 1);   // R/SHARP.R:360,545
-    return build_projector(m, p, K, seeds.data());
+    return build_projector(m, p, K, seeds.data(), after_draw);
 }
 
 // R's round(x, 1) (nmath/fround.c, R >= 4.0.0, restated; R core is an unpinned third-party dependency of the reference):
@@ -240,9 +240,12 @@ static void large_front(LargeFront &F, const SharpArgs &a, bool ahead, double *E
     }
     F.fst = fold_starts(n, F.ng);
     F.T = static_cast<int>(F.fst.size()) - 1;
-    // projectors drawn for this call: the block's compaction (which needs X only) goes out first and runs beside the draw
-    const unsigned ahead_tok = (!a.projector && !ahead) ? rp_compact_ahead(F.dX, m, n, F.ld, a.flag) : 0u;
-    { HostTimer ht("projector_build"); F.pr = projector_for(a, m, p, K); }       // :539-549
+    // projectors drawn for this call: the block's compaction (which needs X only) is enqueued behind the draw kernel, on the second stream,
+    // and runs beside the packing of the row lists (small kernels and host round trips: the chip is nearly idle there; beside the draw
+    // kernel itself, which holds every CU's registers, the compaction took 1.45 x as long)
+    unsigned ahead_tok = 0u;
+    const std::function<void()> start_compaction = [&] { if (!a.projector && !ahead) ahead_tok = rp_compact_ahead(F.dX, m, n, F.ld, a.flag); };
+    { HostTimer ht("projector_build"); F.pr = projector_for(a, m, p, K, &start_compaction); }       // :539-549
     F.ldE = static_cast<long long>(F.pr->K) * p;
     if (E_into) {                                                               // (a block of a batch: rows of the batch's own buffers)
         F.E = E_into; F.dpos = F.shuffle ? pos_into : nullptr;
@@ -801,6 +804,8 @@ int sharp_trim(void) {
     upload_release_staging();
     dws().Ebatch.release();                              // a batched SHARP_unlimited window's projections (up to 16 GB)
     dws().posbatch.release();
+    rp_trim();                                           // the per-chunk entry buffers of a block compacted ahead (up to 16 GB)
+    pool_clear();
     SHARP_API_END
 }
 

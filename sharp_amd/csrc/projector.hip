@@ -542,7 +542,7 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
 
 // Device build: draws on the GPU (proj_draw_kernel), per-gene counts, then -- after one 80 KB download to size the
 // segments on the host -- fill + layout kernels.  Same row lists as the host build (tests compare the triplets and the projections).
-static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, const double *seeds) {
+static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, const double *seeds, const std::function<void()> *after_draw) {
     SHARP_REQUIRE(m >= 2 && p >= 1 && K >= 1, "projector: need m >= 2, p >= 1, K >= 1");
     SHARP_REQUIRE(p <= kMaxCompPerGroup, "projector: reduced dimension p too large for one launch group");
     Ctx &c = ctx();
@@ -560,12 +560,13 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
     const double expect = static_cast<double>(std::min<unsigned long long>(total, 1ull << MT_JUMP_LOG2)) / std::sqrt(static_cast<double>(m));
     pr->hit_cap = static_cast<unsigned int>(expect * 1.25 + 8.0 * std::sqrt(expect) + 4096.0);   // per (projector, segment) list
     pr->draw_segments = S;
-    pr->d_hits.alloc(static_cast<size_t>(K) * S * pr->hit_cap);
-    pr->d_nhits.alloc(static_cast<size_t>(K) * S);
+    pr->d_hits.alloc_pooled(static_cast<size_t>(K) * S * pr->hit_cap);
+    pr->d_nhits.alloc_pooled(static_cast<size_t>(K) * S);
     // regenerations between flushes of the LDS stage: about a quarter of its capacity in expected hits
     const int flush_every = std::max(1, static_cast<int>(PD_STAGE / 4 / (624.0 / std::sqrt(static_cast<double>(m)))));
-    DevBuf<uint32_t> d_seed(K);
-    DevBuf<int> d_err(1);
+    DevBuf<uint32_t> d_seed;
+    DevBuf<int> d_err;
+    d_seed.alloc_pooled(K); d_err.alloc_pooled(1);     // (pooled: released every call, and every user synchronises the stream first)
     d_seed.upload(useed.data(), K);
     d_err.zero();
     {
@@ -577,6 +578,7 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
                            pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, d_err.p);
         launch_check("proj_draw_kernel");
     }
+    if (after_draw) (*after_draw)();
     pr->h_nhits.resize(static_cast<size_t>(K) * S);
     const int per_group = std::max(1, kMaxCompPerGroup / p);
     bool first = true;
@@ -587,7 +589,8 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         grp.ncomp = grp.kcount * p;
         grp.neg_base = dual_neg_base(grp.ncomp);
         const int neg_base = grp.neg_base;
-        DevBuf<unsigned int> d_len(static_cast<size_t>(m) + 1), d_fill(static_cast<size_t>(m) + 1);
+        DevBuf<unsigned int> d_len, d_fill;
+        d_len.alloc_pooled(static_cast<size_t>(m) + 1); d_fill.alloc_pooled(static_cast<size_t>(m) + 1);
         d_len.zero(); d_fill.zero();
         hipLaunchKernelGGL(proj_count_kernel, dim3(16, grp.kcount, S), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
                            static_cast<uint32_t>(p), d_len.p);
@@ -634,22 +637,24 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         grp.novf = static_cast<int>(ovf_gene.size());
         ovf_gene.push_back(0xFFFFFFFFu);               // keep the tables non-empty
         ovf_info.push_back(make_uint2(0u, 0u));
-        grp.ovf_gene.alloc(ovf_gene.size());
-        grp.ovf_info.alloc(ovf_info.size());
+        grp.ovf_gene.alloc_pooled(ovf_gene.size());
+        grp.ovf_info.alloc_pooled(ovf_info.size());
         grp.ovf_gene.upload(ovf_gene.data(), ovf_gene.size());
         {
             std::vector<uint2> slot(static_cast<size_t>(m), make_uint2(0u, 0u));
             for (int q = 0; q < grp.novf; ++q) slot[ovf_gene[q]] = ovf_info[q];
-            grp.ovf_slot.alloc(slot.size());
+            grp.ovf_slot.alloc_pooled(slot.size());
             grp.ovf_slot.upload(slot.data(), slot.size());
             stream_sync();                               // (slot is a local)
         }
         grp.ovf_info.upload(ovf_info.data(), ovf_info.size());
-        DevBuf<uint32_t> d_rowptr(rowptr.size());
+        DevBuf<uint32_t> d_rowptr;
+        d_rowptr.alloc_pooled(rowptr.size());
         d_rowptr.upload(rowptr.data(), rowptr.size());
-        DevBuf<uint16_t> d_flat(static_cast<size_t>(std::max<long long>(grp.nnz, 1)));
+        DevBuf<uint16_t> d_flat;
+        d_flat.alloc_pooled(static_cast<size_t>(std::max<long long>(grp.nnz, 1)));
         const size_t nent = static_cast<size_t>(nseg + 1) * span;
-        grp.ent.alloc(nent);
+        grp.ent.alloc_pooled(nent);
         hipLaunchKernelGGL(proj_fill_u16_kernel, dim3(256), dim3(256), 0, c.stream, grp.ent.p, nent, static_cast<uint16_t>(kCodePad));
         hipLaunchKernelGGL(proj_fill_kernel, dim3(16, grp.kcount, S), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
                            static_cast<uint32_t>(p), d_rowptr.p, d_fill.p, d_flat.p);
@@ -693,11 +698,14 @@ void ensure_host_lists(Projector &pr, int k) {
     for (int g = 0; g < pr.m; ++g) rp[g + 1] += rp[g];
 }
 
-std::shared_ptr<Projector> build_projector(int m, int p, int K, const double *seeds) {
+std::shared_ptr<Projector> build_projector(int m, int p, int K, const double *seeds, const std::function<void()> *after_draw) {
     const unsigned long long draws = static_cast<unsigned long long>(m) * static_cast<unsigned long long>(p);
     if (knobs().proj_host || draws >= (1ull << 31) || draws > (static_cast<unsigned long long>(MT_JUMP_COUNT + 1) << MT_JUMP_LOG2))
+    {
+        if (after_draw) (*after_draw)();
         return build_projector_host(m, p, K, seeds);
-    return build_projector_device(m, p, K, seeds);
+    }
+    return build_projector_device(m, p, K, seeds, after_draw);
 }
 
 int register_projector(std::shared_ptr<Projector> pr) {

@@ -545,6 +545,11 @@ unsigned rp_compact_ahead(XRef dX, int m, int n, long long ld, int log_flag) {
     return P.token;
 }
 void rp_compact_ahead_drop() { sws().pre = Precompact(); }
+void rp_trim() {
+    SplitWs &W = sws();
+    W.pre = Precompact();
+    for (int q = 2; q < kRing; ++q) { W.genes[q].release(); W.fixes[q].release(); }
+}
 
 template <int GW, int SLOTS, bool DUAL>
 static void launch_apply(const ProjectorGroup &g, const Projector &pr, int ncell, long long cell0, int cap, const unsigned int *counts,

@@ -192,6 +192,58 @@ static double now_s() {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
+// ---- the block cache behind DevBuf::alloc_pooled (common.hpp) --------------------------------------------------------------------
+namespace {
+struct BlockPool {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void *> blocks;     // (device, capacity) -> block
+    size_t held = 0;
+};
+BlockPool &block_pool() { static BlockPool *P = new BlockPool; return *P; }   // (never destroyed: buffers of static objects come back late)
+constexpr size_t kPoolMaxBlock = 64ull << 20, kPoolMaxHeld = 512ull << 20;
+// four size classes per octave: a block serves requests down to 84 % of its capacity
+size_t pool_class(size_t bytes) {
+    size_t c = 4096;
+    while (c < bytes) c <<= 1;
+    const size_t q = c / 8;
+    for (size_t v = c / 2 + q; v < c; v += q) if (v >= bytes) return v;
+    return c;
+}
+}  // namespace
+void *pool_take(size_t bytes, size_t *cap_bytes) {
+    int dev = 0;
+    SHARP_HIP_CHECK(hipGetDevice(&dev));
+    const size_t cap = bytes <= kPoolMaxBlock ? pool_class(bytes) : bytes;
+    *cap_bytes = cap;
+    if (bytes <= kPoolMaxBlock) {
+        BlockPool &P = block_pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.blocks.find({dev, cap});
+        if (it != P.blocks.end()) { void *p = it->second; P.blocks.erase(it); P.held -= cap; return p; }
+    }
+    void *p = nullptr;
+    SHARP_HIP_CHECK(hipMalloc(&p, cap));
+    return p;
+}
+void pool_give(void *p, size_t cap_bytes) {
+    if (!p) return;
+    int dev = 0;
+    if (cap_bytes <= kPoolMaxBlock && hipGetDevice(&dev) == hipSuccess) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device;   // (the block's own device, whoever hands it back)
+        BlockPool &P = block_pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (P.held + cap_bytes <= kPoolMaxHeld) { P.blocks.insert({{dev, cap_bytes}, p}); P.held += cap_bytes; return; }
+    }
+    (void)hipFree(p);
+}
+void pool_clear() {
+    BlockPool &P = block_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (auto &kv : P.blocks) (void)hipFree(kv.second);
+    P.blocks.clear(); P.held = 0;
+}
+
 HostTimer::HostTimer(const char *n) : name(n), t0(0), on(false) {
     Ctx &c = ctx_unchecked();
     if (c.ready && c.profiling) { on = true; t0 = now_s(); }
@@ -325,6 +377,7 @@ int sharp_shutdown(void) {
         (void)hipStreamSynchronize(c.stream);
         drop_pending_front();
         drain_side_streams();
+        pool_clear();
         for (auto &p : c.pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         c.pending.clear();
         for (auto e : c.event_pool) (void)hipEventDestroy(e);

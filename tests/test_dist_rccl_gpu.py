@@ -74,7 +74,10 @@ def test_bench_default_line_names_cfg2_and_carries_the_other_configs():
     rf = d["roofline"]
     assert rf["kernel"].startswith("RP matmul stage") and rf["peak"] == 8000.0
     assert rf["frac"] == pytest.approx(50000 * 20000 * 4 / (rf["stage"]["ms"] * 1e-3) / 8e12, rel=2e-3)
-    assert set(rf["by_config"]) == {"cfg3_block", "cfg4_share"} and rf["by_config"]["cfg4_share"]["reduced_dim"] == 508
+    assert set(rf["by_config"]) == {"cfg2_alone", "cfg3_block", "cfg4_share"} and rf["by_config"]["cfg4_share"]["reduced_dim"] == 508
+    assert rf["by_config"]["cfg2_alone"]["reduced_dim"] == d["config"]["reduced_dim"] == 391
+    # the chunks compacted beside the projector draw are part of the stage's time
+    assert rf["stage"]["ms"] == pytest.approx(rf["stage"]["ms_main_stream"] + rf["stage"]["ms_ahead_stream"], abs=2e-3)
     assert d["other_configs"]["cfg3"]["reduced_dim"] == 474 and d["other_configs"]["cfg3"]["ari_vs_planted_truth"] > 0.9
     # cfg4 whole on the one GPU: the N = 1 point of the strong-scaling curve, same workload string as the N > 1 runs up to the GPU count
     c4 = d["other_configs"]["cfg4_one_gpu"]
