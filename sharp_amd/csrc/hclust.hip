@@ -387,6 +387,11 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         const uint4 *li = reinterpret_cast<const uint4 *>(sm);
         for (int q = tid; q < lds_bytes / 16; q += HR_THREADS) gi[q] = li[q];
     };
+#ifdef HR_TIMING
+    long long hr_acc_setup = 0, hr_acc_rebuild = 0, hr_acc_barrier = 0, hr_acc_entries = 0, hr_acc_wave_busy = 0;
+    int hr_rounds = 0;
+    const long long hr_start = __builtin_readcyclecounter();
+#endif
     while (na > 1) {
         double *dnn = dnnA + cur * nal;
         uint16_t *cid = cidA + cur * nal, *csz = cszA + cur * nal;
@@ -790,8 +795,14 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                 q = __builtin_amdgcn_readfirstlane(q);
                 if (q >= ns) break;
                 const bool two = step == 2 && q + 1 < ns;
+#ifdef HR_TIMING
+                const long long q2 = __builtin_readcyclecounter();
+#endif
                 if (src < 0) { if (two) staged(std::integral_constant<int, 2>(), std::true_type(), q); else staged(std::integral_constant<int, 1>(), std::true_type(), q); }
                 else         { if (two) staged(std::integral_constant<int, 2>(), std::false_type(), q); else staged(std::integral_constant<int, 1>(), std::false_type(), q); }
+#ifdef HR_TIMING
+                hr_dual += __builtin_readcyclecounter() - q2;
+#endif
             }
         }
         // the gathered forms: rounds whose pairs do not fit the stage even one row at a time (large tasks with little LDS to spare)
@@ -918,8 +929,11 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         __syncthreads();
         if (tid == 0) { ctl[0] = 0; }
 #ifdef HR_TIMING
+        hr_acc_setup += hr_t1 - hr_t0; hr_acc_rebuild += hr_t2 - hr_t1; hr_acc_barrier += (long long)__builtin_readcyclecounter() - hr_t2;
+        hr_acc_entries += static_cast<long long>(na) * na + static_cast<long long>(nb) * nb; ++hr_rounds;
+        hr_acc_wave_busy += hr_dual + hr_slow;
         if (blockIdx.x == 0 && tid == 0 && (done == 0 || (na < 1200 && na > 1100) || (na < 600 && na > 560) || (na < 300 && na > 280) || (na < 100 && na > 90)))
-            printf("round na=%d np=%d nb=%d: setup %lld  rebuild %lld (wave0: dual %lld slow %lld)  tail-barrier %lld cycles\n", na, np, nb,
+            printf("round na=%d np=%d nb=%d: setup %lld  rebuild %lld (wave0: plain rows %lld merged rows %lld)  tail-barrier %lld cycles\n", na, np, nb,
                    hr_t1 - hr_t0, hr_t2 - hr_t1, hr_dual, hr_slow, (long long)__builtin_readcyclecounter() - hr_t2);
 #endif
 #ifdef HR_ROUNDS
@@ -928,6 +942,12 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         done += np; na = nb; cur ^= 1; src = src < 0 ? 0 : (src ^ 1);
         __syncthreads();
     }
+#ifdef HR_TIMING
+    if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0)
+        printf("task %d: %d rounds, total %lld cycles: setup %lld  rebuild(wave 0 view) %lld (in row work %lld)  end-of-round barrier wait %lld; entries read+written %lld (%.3f cycles per entry)\n",
+               (int)blockIdx.x, hr_rounds, (long long)__builtin_readcyclecounter() - hr_start, hr_acc_setup, hr_acc_rebuild, hr_acc_wave_busy, hr_acc_barrier, hr_acc_entries,
+               (double)((long long)__builtin_readcyclecounter() - hr_start) / (double)hr_acc_entries);
+#endif
     // (5) the sequential algorithm's order: ascending height, lowest index first; ward.D2 reports sqrt
     __syncthreads();
     {
