@@ -5,6 +5,7 @@
 #include "linalg.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 namespace sharp {
@@ -137,8 +138,20 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
     const int m0 = ti * FT, n0 = tj * FT;
     __shared__ double As[2][GK][FLD];     // two k tiles: the next one is stored while the current one is read (one barrier per tile)
     __shared__ double Bs[2][GK][FLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = (wave >> 2) * 64, wc = (wave & 3) * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Wave -> block of the tile.  The second wave row takes its column blocks in REVERSE order: waves w and w + 4 share a SIMD, and in the
+    // tiles where some waves have little or nothing to compute (below) the idle column blocks of the two rows then fall on different SIMDs.
+    const int wm = wave >> 2, wn = wm ? 3 - (wave & 3) : (wave & 3);
+    const int wr = wm * 64, wc = wn * 32;
+    // Live sub-tiles of this wave's 4 x 2: those inside the matrix (2000 = 15 x 128 + 80: in the last tile row / column 3 of 8 sub-tile rows /
+    // columns are padding) and, in a diagonal tile of a symmetric product, those not wholly below the diagonal (the mirrored stores of the
+    // sub-tiles above it fill them).  Kept as a rectangle ni x nj from the block's corner; a wave with none only loads, stores and waits.
+    // At cfg2 31 of a task's 136 tiles are such tiles and the busiest SIMD in them does 12 sub-tile products per k step instead of 16.
+    int ni = (t.M - (m0 + wr) + 15) / 16, nj = (t.N - (n0 + wc) + 15) / 16;
+    ni = ni < 0 ? 0 : (ni > 4 ? 4 : ni); nj = nj < 0 ? 0 : (nj > 2 ? 2 : nj);
+    if (t.symmetric && ti == tj) { const int live = wn * 2 + nj - wm * 4; ni = live < ni ? (live < 0 ? 0 : live) : ni; }
+    if (ni == 0 || nj == 0) { ni = 0; nj = 0; }
     v4f64 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -158,39 +171,59 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
     // The second-dispatched half of the workgroup loses instruction arbitration to the older half at every k tile (priority, then age);
     // one static priority for it evens that out: 12.00 -> 11.77 ms at cfg2.  (s_setprio 1 / 0 around every MFMA block: 12.6 ms; all
     // 24 LDS reads of a k tile issued before its 32 MFMAs: 12.15; both: 13.7.)  The guard must be wave-uniform: s_setprio ignores EXEC.
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
-    int buf = 0;
-    for (int k0 = 0; k0 < Kp; k0 += GK) {
-        // next tile into registers (the last iteration re-reads the final tile: unconditional loads keep the waits counted) ...
-        const int kn = k0 + GK < Kp ? k0 + GK : k0;
-        gcdp an = ap + static_cast<long long>(kn) * t.lda;
-        gcdp bn = bp + static_cast<long long>(kn) * t.ldb;
-        ra0 = *(gd2p)(an); ra1 = *(gd2p)(an + 2);
-        rb0 = *(gd2p)(bn); rb1 = *(gd2p)(bn + 2);
-        // ... while the MFMAs run on the current one
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    // the k loop, one copy per shape of the wave's live block
+    auto kloop = [&](auto NI_, auto NJ_) {
+        constexpr int NI = decltype(NI_)::value, NJ = decltype(NJ_)::value;
+        int buf = 0;
+        for (int k0 = 0; k0 < Kp; k0 += GK) {
+            // next tile into registers (the last iteration re-reads the final tile: unconditional loads keep the waits counted) ...
+            const int kn = k0 + GK < Kp ? k0 + GK : k0;
+            gcdp an = ap + static_cast<long long>(kn) * t.lda;
+            gcdp bn = bp + static_cast<long long>(kn) * t.ldb;
+            ra0 = *(gd2p)(an); ra1 = *(gd2p)(an + 2);
+            rb0 = *(gd2p)(bn); rb1 = *(gd2p)(bn + 2);
+            // ... while the MFMAs run on the current one
+            if (NI > 0) {
 #pragma unroll
-        for (int kk = 0; kk < GK; kk += 4) {
-            const int kr = kk + (lane >> 4);
-            double a[4], b[2];
+                for (int kk = 0; kk < GK; kk += 4) {
+                    const int kr = kk + (lane >> 4);
+                    double a[4], b[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[buf][kr][wr + i * 16 + (lane & 15)];
+                    for (int i = 0; i < NI; ++i) a[i] = As[buf][kr][wr + i * 16 + (lane & 15)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[buf][kr][wc + j * 16 + (lane & 15)];
+                    for (int j = 0; j < NJ; ++j) b[j] = Bs[buf][kr][wc + j * 16 + (lane & 15)];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+            // the other LDS tile was last read before the previous barrier: store the next tile there, one barrier per k tile
+            buf ^= 1;
+            As[buf][lrow][lcol] = ra0.x; As[buf][lrow][lcol + 1] = ra0.y; As[buf][lrow][lcol + 2] = ra1.x; As[buf][lrow][lcol + 3] = ra1.y;
+            Bs[buf][lrow][lcol] = rb0.x; Bs[buf][lrow][lcol + 1] = rb0.y; Bs[buf][lrow][lcol + 2] = rb1.x; Bs[buf][lrow][lcol + 3] = rb1.y;
+            lds_barrier();   // lgkmcnt(0); a raw barrier: __syncthreads() would add waits of its own
         }
-        // the other LDS tile was last read before the previous barrier: store the next tile there, one barrier per k tile
-        buf ^= 1;
-        As[buf][lrow][lcol] = ra0.x; As[buf][lrow][lcol + 1] = ra0.y; As[buf][lrow][lcol + 2] = ra1.x; As[buf][lrow][lcol + 3] = ra1.y;
-        Bs[buf][lrow][lcol] = rb0.x; Bs[buf][lrow][lcol + 1] = rb0.y; Bs[buf][lrow][lcol + 2] = rb1.x; Bs[buf][lrow][lcol + 3] = rb1.y;
-        lds_barrier();   // lgkmcnt(0); a raw barrier: __syncthreads() would add waits of its own
+    };
+#define SHARP_GEMM_ROW(I) \
+    if (nj == 2) kloop(std::integral_constant<int, I>(), std::integral_constant<int, 2>()); \
+    else kloop(std::integral_constant<int, I>(), std::integral_constant<int, 1>());
+    switch (ni) {
+        case 0: kloop(std::integral_constant<int, 0>(), std::integral_constant<int, 0>()); break;
+        case 1: SHARP_GEMM_ROW(1) break;
+        case 2: SHARP_GEMM_ROW(2) break;
+        case 3: SHARP_GEMM_ROW(3) break;
+        default: SHARP_GEMM_ROW(4) break;
     }
+#undef SHARP_GEMM_ROW
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            if (i >= ni || j >= nj) continue;
+            // mirrored as well: every sub-tile of an off-diagonal tile, and in a diagonal tile those above the diagonal (their mirror images were not computed)
+            const bool mirror = t.symmetric && (n0 > m0 || wn * 2 + j > wm * 4 + i);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wr + i * 16 + (lane >> 4) + 4 * r;
@@ -206,9 +239,10 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
                         if (row == col) v = 1.0;
                     }
                     ((gdp)t.C)[static_cast<long long>(row) * t.ldc + col] = v;
-                    if (t.symmetric && n0 > m0) ((gdp)t.C)[static_cast<long long>(col) * t.ldc + row] = v;
+                    if (mirror) ((gdp)t.C)[static_cast<long long>(col) * t.ldc + row] = v;
                 }
             }
+        }
 }
 
 void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_N, const char *timer_name, bool fast, bool symmetric) {
