@@ -159,7 +159,8 @@ def test_compaction_ahead_of_the_projector_build(sa, oracle, monkeypatch, rp_chu
     kw = dict(ensize_K=3, base_ncells=300, partition_ncells=2000, rN_seed=2103, logflag=False, prep=False)
     if rp_chunk: monkeypatch.setenv("SHARP_RP_CHUNK", rp_chunk)
     res = sa.SHARP(X, **kw)
-    res_again = sa.SHARP(X, **kw)
+    assert sa.lib().sharp_trim() == 0                    # gives back the per-chunk entry buffers and the cached projector blocks ...
+    res_again = sa.SHARP(X, **kw)                        # ... which the next call allocates anew
     monkeypatch.setenv("SHARP_RP_AHEAD", "0")
     res_plain = sa.SHARP(X, **kw)
     assert res["path"] == "SHARP_large"
