@@ -69,7 +69,8 @@ struct XRef {
 struct Knobs {
     bool rp_dual = true;        // SHARP_RP_DUAL=0: signed row-list codes even where two accumulator arrays would fit
     int rp_two_streams = -1;    // SHARP_RP_SERIAL=0 / 1: the compaction of chunk c + 1 on a second stream beside the apply of chunk c: always / never (default: by kernel form)
-    bool rp_ahead = true;       // SHARP_RP_AHEAD=0: no compaction of the block beside the projector build (SHARP() with projectors drawn per call)
+    int rp_ahead = 2;           // SHARP_RP_AHEAD: the compaction of the block beside the per-call projector build: 0 not at all, 1 behind the draw kernel
+                                // (beside the packing of the row lists), 2 from the start (beside the draw kernel too)
     int rp_chunk = 0;           // SHARP_RP_CHUNK: cells per chunk of the RP stage (0: sized by the library)
     int rp_cp_wgs = 8;          // SHARP_RP_CP_WGS / SHARP_RP_AP_WGS: workgroups per CU of the two RP kernels (upper bounds)
     int rp_ap_wgs = 4;

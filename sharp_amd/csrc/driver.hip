@@ -244,7 +244,9 @@ static void large_front(LargeFront &F, const SharpArgs &a, bool ahead, double *E
     // and runs beside the packing of the row lists (small kernels and host round trips: the chip is nearly idle there; beside the draw
     // kernel itself, which holds every CU's registers, the compaction took 1.45 x as long)
     unsigned ahead_tok = 0u;
-    const std::function<void()> start_compaction = [&] { if (!a.projector && !ahead) ahead_tok = rp_compact_ahead(F.dX, m, n, F.ld, a.flag); };
+    const bool may_go_ahead = !a.projector && !ahead && knobs().rp_ahead > 0;
+    const std::function<void()> start_compaction = [&] { if (may_go_ahead && !ahead_tok) ahead_tok = rp_compact_ahead(F.dX, m, n, F.ld, a.flag); };
+    if (knobs().rp_ahead >= 2) start_compaction();
     { HostTimer ht("projector_build"); F.pr = projector_for(a, m, p, K, &start_compaction); }       // :539-549
     F.ldE = static_cast<long long>(F.pr->K) * p;
     if (E_into) {                                                               // (a block of a batch: rows of the batch's own buffers)

@@ -289,8 +289,10 @@ __global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int
 // The lanes the gene does not use keep kCodePad in every slot; the unused slots of a lane that holds codes get the lane's pad_code
 // (projector.hpp); every slot of a negative lane carries the sign bit, the consumer reads it from slot 0.
 constexpr uint32_t kPlacePerm = 64;   // codes of a gene whose class order fits the caller's scratch (longer lists take the slow loop)
+// seg0: the segment index of the gene's own segment in `ent` (g for the global table; 0 when `ent` is a private image of the gene's segments,
+// whose overflow segments then follow from extra_base = 1)
 __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint32_t gw, uint32_t S /* slots per lane: 2 or 4 */, int ncomp, int neg_base,
-                                           size_t g, size_t extra_base, uint16_t *ent, unsigned char *perm /* kPlacePerm bytes of scratch */) {
+                                           size_t g, size_t extra_base, uint16_t *ent, unsigned char *perm /* kPlacePerm bytes of scratch */, size_t seg0) {
     const uint32_t span = S * gw;
     const bool dual = neg_base > 0;                      // negative entries go to a second accumulator array: no signs, dense lanes
     const int dump_base = dual ? 2 * neg_base : ncomp;   // the dump accumulators sit behind every real one
@@ -302,7 +304,7 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
     unsigned long long colmask = 0ull;                   // classes present per column, 4 x 16 bit
     auto slot_ptr = [&](uint32_t lane, uint32_t q) -> uint16_t * {
         const uint32_t sgm = lane / gw;
-        const size_t seg = sgm == 0 ? g : extra_base + (sgm - 1);
+        const size_t seg = sgm == 0 ? seg0 : extra_base + (sgm - 1);
         return ent + seg * span + S * (lane % gw) + q;
     };
     // codes per class (16 x 16 bit)
@@ -381,28 +383,63 @@ __host__ __device__ inline void place_gene(const uint16_t *src, uint32_t n, uint
             }
             if (l >= lane0[1]) *sp |= static_cast<uint16_t>(kCodeNeg);
         }
-    if (cap[0] + cap[1] > gw) ent[g * span] |= static_cast<uint16_t>(kCodeMore);   // (slot 0 of lane 0: the one slot every consumer masks anyway)
+    if (cap[0] + cap[1] > gw) ent[seg0 * span] |= static_cast<uint16_t>(kCodeMore);   // (slot 0 of lane 0: the one slot every consumer masks anyway)
 }
 
-// one thread per gene: order the gene's codes by component (the order of the host build: projector, then column) and
-// write them into the fixed-stride lane-major segments (+ overflow segments)
-__global__ void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, uint16_t *__restrict__ flat, int gw, int slots, int ncomp, int neg_base,
+// One thread per gene: order the gene's codes by component (the order of the host build: projector, then column) and write them into the
+// fixed-stride lane-major segments (+ overflow segments).  With 20 000 threads on 256 CUs nothing hides a memory access, and sorting and
+// placing in global memory cost ~1500 dependent round trips per thread (0.53 ms at cfg2, as long as half the Mersenne-Twister draw, on the
+// step's critical path): the gene's codes are fetched ONCE into LDS, ranked there (independent compares instead of an insertion sort's
+// chain), placed into an LDS image of the gene's segments, and the image leaves in 16-byte stores.  Genes beyond the LDS room (more than
+// kLayCodes codes or kLaySegs segments: none at the shapes in use) keep the global path.
+constexpr int kLayCodes = 128, kLaySegs = 3, kLaySpan = 64;
+__global__ __launch_bounds__(64) void proj_layout_kernel(int m, const uint32_t *__restrict__ rowptr, uint16_t *__restrict__ flat, int gw, int slots, int ncomp, int neg_base,
                                    const uint2 *__restrict__ ovf_slot, const uint2 *__restrict__ ovf_info, int novf,
                                    uint16_t *__restrict__ ent) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= m) return;
     const uint32_t b = rowptr[g], len = rowptr[g + 1] - b;
     uint16_t *src = flat + b;
+    size_t extra_base = 0;
+    uint32_t extra = 0;
+    if (novf > 0) { const uint2 o = ovf_slot[g]; extra_base = o.x; extra = o.y; }
+    __shared__ unsigned char sperm[64][kPlacePerm];       // (blockDim.x = 64)
+    __shared__ __attribute__((aligned(16))) uint16_t raw[64][kLayCodes], sorted[64][kLayCodes];
+    __shared__ __attribute__((aligned(16))) uint16_t image[64][kLaySegs * kLaySpan];
+    const uint32_t span = static_cast<uint32_t>(slots) * static_cast<uint32_t>(gw);
+    if (len <= static_cast<uint32_t>(kLayCodes) && 1u + extra <= static_cast<uint32_t>(kLaySegs) && span <= static_cast<uint32_t>(kLaySpan)) {
+        uint16_t *rw = raw[threadIdx.x], *so = sorted[threadIdx.x], *im = image[threadIdx.x];
+        for (uint32_t i = 0; i < len; i += 8) {            // eight independent loads at a time
+            uint16_t t[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) t[u] = src[i + u < len ? i + u : len - 1];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) if (i + u < len) rw[i + u] = t[u];
+        }
+        for (uint32_t i = 0; i < len; ++i) {               // rank = position in the order by component (arrival order among equals, like the insertion sort)
+            const uint32_t key = rw[i] & 0x7fffu;
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < len; ++j) { const uint32_t kj = rw[j] & 0x7fffu; rank += (kj < key || (kj == key && j < i)) ? 1u : 0u; }
+            so[rank] = rw[i];
+        }
+        const uint32_t nimg = (1u + extra) * span;
+        for (uint32_t i = 0; i < nimg; ++i) im[i] = static_cast<uint16_t>(kCodePad);
+        place_gene(so, len, static_cast<uint32_t>(gw), static_cast<uint32_t>(slots), ncomp, neg_base, static_cast<size_t>(g), 1, im, sperm[threadIdx.x], 0);
+        // the image out: the gene's own segment, then its overflow segments (span u16 = 32 ... 128 bytes each, 16-byte aligned on both sides)
+        for (uint32_t sgm = 0; sgm <= extra; ++sgm) {
+            uint16_t *dst = ent + (sgm == 0 ? static_cast<size_t>(g) : extra_base + (sgm - 1)) * span;
+            const uint16_t *from = im + sgm * span;
+            for (uint32_t i = 0; i < span; i += 8) *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(from + i);
+        }
+        return;
+    }
     for (uint32_t i = 1; i < len; ++i) {                 // insertion sort: lists are a few dozen entries, nearly sorted
         const uint16_t v = src[i];
         uint32_t j = i;
         while (j > 0 && (src[j - 1] & 0x7fffu) > (v & 0x7fffu)) { src[j] = src[j - 1]; --j; }
         src[j] = v;
     }
-    size_t extra_base = 0;
-    if (novf > 0) extra_base = ovf_slot[g].x;
-    __shared__ unsigned char sperm[64][kPlacePerm];       // (blockDim.x = 64)
-    place_gene(src, len, static_cast<uint32_t>(gw), static_cast<uint32_t>(slots), ncomp, neg_base, static_cast<size_t>(g), extra_base, ent, sperm[threadIdx.x]);
+    place_gene(src, len, static_cast<uint32_t>(gw), static_cast<uint32_t>(slots), ncomp, neg_base, static_cast<size_t>(g), extra_base, ent, sperm[threadIdx.x], static_cast<size_t>(g));
 }
 __global__ void proj_fill_u16_kernel(uint16_t *p, size_t n, uint16_t v) {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) p[i] = v;
@@ -516,7 +553,7 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
             size_t extra_base = 0;
             if (lanes[g] > grp.gw) extra_base = ovf_info[ov++].x;
             unsigned char perm[kPlacePerm];
-            place_gene(src, len, static_cast<uint32_t>(grp.gw), static_cast<uint32_t>(grp.slots), grp.ncomp, grp.neg_base, static_cast<size_t>(g), extra_base, ent.data(), perm);
+            place_gene(src, len, static_cast<uint32_t>(grp.gw), static_cast<uint32_t>(grp.slots), grp.ncomp, grp.neg_base, static_cast<size_t>(g), extra_base, ent.data(), perm, static_cast<size_t>(g));
         }
         grp.ent.alloc(ent.size());
         grp.ent.upload(ent.data(), ent.size());

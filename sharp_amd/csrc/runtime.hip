@@ -267,7 +267,7 @@ static Knobs read_knobs() {
     v.rp_dual = num("SHARP_RP_DUAL", 1) != 0;
     { const int ser = num("SHARP_RP_SERIAL", -1); v.rp_two_streams = ser < 0 ? -1 : (ser == 0 ? 1 : 0); }
     v.rp_chunk = num("SHARP_RP_CHUNK", 0);
-    v.rp_ahead = num("SHARP_RP_AHEAD", 1) != 0;
+    v.rp_ahead = num("SHARP_RP_AHEAD", 2);
     v.rp_cp_wgs = std::max(1, num("SHARP_RP_CP_WGS", 8));
     v.rp_ap_wgs = std::max(1, num("SHARP_RP_AP_WGS", 4));
     v.rp_shape = num("SHARP_RP_SHAPE", 0);

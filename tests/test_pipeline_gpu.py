@@ -161,10 +161,13 @@ def test_compaction_ahead_of_the_projector_build(sa, oracle, monkeypatch, rp_chu
     res = sa.SHARP(X, **kw)
     assert sa.lib().sharp_trim() == 0                    # gives back the per-chunk entry buffers and the cached projector blocks ...
     res_again = sa.SHARP(X, **kw)                        # ... which the next call allocates anew
+    monkeypatch.setenv("SHARP_RP_AHEAD", "1")            # behind the draw kernel only (the default also runs beside it)
+    res_behind = sa.SHARP(X, **kw)
     monkeypatch.setenv("SHARP_RP_AHEAD", "0")
     res_plain = sa.SHARP(X, **kw)
     assert res["path"] == "SHARP_large"
-    for r in (res, res_again, res_plain):
+    np.testing.assert_array_equal(res_behind["viE"], res_plain["viE"])
+    for r in (res, res_again, res_behind, res_plain):
         assert np.array_equal(r["pred_clusters"], ref["pred_clusters"])
     np.testing.assert_array_equal(res["viE"], res_plain["viE"])
     np.testing.assert_array_equal(res_again["viE"], res_plain["viE"])
