@@ -173,6 +173,22 @@ def test_compaction_ahead_of_the_projector_build(sa, oracle, monkeypatch, rp_chu
     np.testing.assert_array_equal(res_again["viE"], res_plain["viE"])
 
 
+def test_compaction_ahead_serves_both_launch_groups(sa, oracle, monkeypatch):
+    # K * reduced.ndim = 9000 components: two launch groups (13 + 2 projectors) read the SAME compacted lists -- with the compaction done
+    # ahead of the projector build the second group must find them intact (every chunk kept its own buffer) and its cell queue rewound
+    m, n, G, nm = 2000, 4500, 5, 200
+    X = oracle.synth_fill(SEED, m, 0, n, G, nm)
+    kw = dict(ensize_K=15, reduced_ndim=600, base_ncells=300, partition_ncells=2300, rN_seed=2103, logflag=False, prep=False)
+    res = sa.SHARP(X, **kw)
+    monkeypatch.setenv("SHARP_RP_AHEAD", "0")
+    res_plain = sa.SHARP(X, **kw)
+    ref = oracle.SHARP(X, K=15, reduced_ndim=600, base_ncells=300, partition_ncells=2300, rN_seed=2103, nthreads=8)
+    assert res["path"] == "SHARP_large" and res["reduced.dim"] == 600
+    np.testing.assert_array_equal(res["viE"], res_plain["viE"])
+    for r in (res, res_plain):
+        assert np.array_equal(r["pred_clusters"], ref["pred_clusters"])
+
+
 def test_sharp_unlimited_matches_oracle(sa, oracle):
     m, G, nm = 3000, 6, 300
     blocks = [oracle.synth_fill(SEED, m, i * 6000, 6000, G, nm) for i in range(2)]
