@@ -295,6 +295,12 @@ def main():
             result["other_configs"], by_cfg = extra_configs(np, torch, sharp_amd, dev, lib, synth_block, unlimited_call, ARI)
             if roof:
                 roof["by_config"] = by_cfg
+                if by_cfg.get("cfg2_alone"):
+                    # `frac` above prices the stage's kernels as they run in the step, a third of them beside the projector draw (slower each,
+                    # faster step); the same kernels with the chip to themselves:
+                    roof["frac_alone"] = by_cfg["cfg2_alone"]["frac_read"]
+                    roof["note"] = ("frac: stage time = main-stream stage + the second stream's compaction beside the projector build (roofline.stage.ms_*); "
+                                    "frac_alone: the same stage enqueued alone on an idle chip (by_config.cfg2_alone); SHARP_RP_AHEAD=0 gives the latter in the step, 2.5 ms slower")
             dX = synth_block(0, n_total, m)
         if world == 1 and tag == "cfg2" and not args.no_cpu_baseline:
             result["cpu_baseline"], result["parity"] = cpu_baseline(np, dX, m, K)
