@@ -633,12 +633,14 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
                            static_cast<uint32_t>(p), d_len.p);
         launch_check("proj_count_kernel");
         std::vector<unsigned int> len(static_cast<size_t>(m) + 1);
+        int err = 0;
+        if (first) {                                     // (all three copies behind ONE synchronisation: each one costs a wake-up of the host thread)
+            SHARP_HIP_CHECK(hipMemcpyAsync(&err, d_err.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+            SHARP_HIP_CHECK(hipMemcpyAsync(pr->h_nhits.data(), pr->d_nhits.p, pr->h_nhits.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, c.stream));
+        }
         d_len.download(len.data(), len.size());          // synchronises the stream
         if (first) {
-            int err = 0;
-            d_err.download(&err, 1);
             SHARP_REQUIRE(err == 0, "projector: hit list overflow in the device build");
-            pr->d_nhits.download(pr->h_nhits.data(), pr->h_nhits.size());
             first = false;
         }
         std::vector<uint32_t> rowptr(static_cast<size_t>(m) + 1, 0);
@@ -677,13 +679,10 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         grp.ovf_gene.alloc_pooled(ovf_gene.size());
         grp.ovf_info.alloc_pooled(ovf_info.size());
         grp.ovf_gene.upload(ovf_gene.data(), ovf_gene.size());
-        {
-            std::vector<uint2> slot(static_cast<size_t>(m), make_uint2(0u, 0u));
-            for (int q = 0; q < grp.novf; ++q) slot[ovf_gene[q]] = ovf_info[q];
-            grp.ovf_slot.alloc_pooled(slot.size());
-            grp.ovf_slot.upload(slot.data(), slot.size());
-            stream_sync();                               // (slot is a local)
-        }
+        std::vector<uint2> slot(static_cast<size_t>(m), make_uint2(0u, 0u));   // (alive until the synchronisation at the end of the group)
+        for (int q = 0; q < grp.novf; ++q) slot[ovf_gene[q]] = ovf_info[q];
+        grp.ovf_slot.alloc_pooled(slot.size());
+        grp.ovf_slot.upload(slot.data(), slot.size());
         grp.ovf_info.upload(ovf_info.data(), ovf_info.size());
         DevBuf<uint32_t> d_rowptr;
         d_rowptr.alloc_pooled(rowptr.size());
