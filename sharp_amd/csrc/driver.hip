@@ -420,6 +420,8 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
         sharp_large_dev_body(dX, m, n, ld, a, K, p, ng, base, out);
     } catch (...) {                                                             // nothing prepared ahead outlives a failed call
         drop_pending_front();
+        rp_compact_ahead_drop();
+        if (ctx_unchecked().stream2) (void)hipStreamSynchronize(ctx_unchecked().stream2);   // (the block's compaction may still be reading the caller's X)
         throw;
     }
 }
