@@ -808,6 +808,7 @@ int sharp_trim(void) {
     upload_release_staging();
     dws().Ebatch.release();                              // a batched SHARP_unlimited window's projections (up to 16 GB)
     dws().posbatch.release();
+    rp_pc_trim();
     rp_trim();                                           // the per-chunk entry buffers of a block compacted ahead (up to 16 GB)
     pool_clear();
     SHARP_API_END

@@ -986,7 +986,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
 #include "hclust_tri.inc"
 
 #ifdef SHARP_LAB       // the lazy agglomeration (an experiment kept for reference): lab builds only
-#include "hclust_lazy.inc"
+#include "../../tools/lab/hclust_lazy.inc"
 #endif
 
 // ---------------------------------------------------------------------------------------------

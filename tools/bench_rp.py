@@ -48,7 +48,7 @@ for (m, n, K, p) in CFGS:
     wr = n * K * p * 8
     nzfrac = float((dX[:2000] != 0).float().mean())
     per = []
-    for nm in (b"rp_compact", b"rp_apply"):
+    for nm in (b"rp_compact", b"rp_apply", b"rp_pc"):
         lib.sharp_profile_get(nm, C.byref(ms), C.byref(cnt))
         per.append("%s %.1f us x%d" % (nm.decode(), ms.value / max(cnt.value, 1) * 1e3, cnt.value // reps))
     print(f"m={m} n={n} K={K} p={p} nnz={pr.nnz()} proj_build={tproj:.2f}s  rp={t*1e3:.3f} ms  read {rd/t/1e12:.2f} TB/s "

@@ -1,3 +1,4 @@
+// rp2_lab.hip (lab copy: keeps the SHARP_LAB_CP / SHARP_LAB_AP_L1 ablation switches the product source no longer has; built by tools/build_variant.sh with its path as the third argument)
 // rp2.hip -- the RP matmul (R/RPmat.R:32, R/SHARP.R:343-345,569-585) as a two-kernel
 // producer/consumer pipeline over chunks of cells:
 //   rp_compact_kernel: streams X once (the only HBM-bound part) and appends one entry per non-zero to its cell's list
@@ -12,7 +13,7 @@
 // The chunks go compact(0) apply(0) compact(1) ... on one stream (two chunk buffers; SHARP_RP_SERIAL=0: compaction on a second
 // stream, beside the previous chunk's apply -- no faster, see project_dev_split); integer accumulation keeps E bit-reproducible
 // whatever the interleaving.
-#include "rp_shared.hpp"
+#include "../../sharp_amd/csrc/projector.hpp"
 
 #include <cmath>
 #include <cstdlib>
@@ -21,10 +22,44 @@
 namespace sharp {
 
 constexpr int CP_THREADS = 256;
+constexpr int CP_UNIT = 1024;           // genes per wave unit = 64 lanes x 4 float4
 #ifndef SHARP_AP_THREADS
 #define SHARP_AP_THREADS 512
 #endif
 constexpr int AP_THREADS = SHARP_AP_THREADS;
+
+// One unit = 1024 genes = 16 values per lane, fetched with 16-byte loads: fp32 blocks as 4 x float4 (lane l, load j: genes
+// 4 (l + 64 j) ..), fp64 blocks as 8 x double2 (genes 2 (l + 64 j) ..).  gene_of(q) is the gene of a lane's q-th value.
+template <typename T> struct CpVals { T v[16]; };
+template <typename T> struct CpLayout;
+template <> struct CpLayout<float> {
+    static constexpr int VEC = 4, LOADS = 4;
+    __device__ static __forceinline__ int gene_of(int lane, int q) { return 4 * lane + 256 * (q >> 2) + (q & 3); }
+};
+template <> struct CpLayout<double> {
+    static constexpr int VEC = 2, LOADS = 8;
+    __device__ static __forceinline__ int gene_of(int lane, int q) { return 2 * lane + 128 * (q >> 1) + (q & 1); }
+};
+
+// `unit` points at the unit's first gene.  CLAMP (only a cell's last, ragged unit): a load that would run past the column's `lim`
+// values (the leading dimension, a multiple of VEC) reads the unit's first values instead -- every load is unconditional -- and the
+// caller zeroes what lies beyond the last gene.  The other units need no address arithmetic at all: one lane offset, the load's
+// immediate offset, a scalar base.
+template <typename T, bool CLAMP>
+__device__ __forceinline__ CpVals<T> cp_load_unit(const T *unit, int lim, int lane) {
+    typedef T tv __attribute__((ext_vector_type(CpLayout<T>::VEC)));
+    constexpr int V = CpLayout<T>::VEC;
+    CpVals<T> r;
+#pragma unroll
+    for (int j = 0; j < CpLayout<T>::LOADS; ++j) {
+        int g = V * (lane + 64 * j);
+        if (CLAMP) g = g + V - 1 < lim ? g : 0;
+        const tv t = __builtin_nontemporal_load(reinterpret_cast<const tv *>(unit + g));
+#pragma unroll
+        for (int e = 0; e < V; ++e) r.v[V * j + e] = t[e];
+    }
+    return r;
+}
 
 constexpr int CP_TAB = 256;             // log2(1+x) fixed-point table for integer counts x < CP_TAB
 // compacted entry: bits 19..0 gene, bits 27..20 the count (table entries), bit 31: the 64-bit term is stored beside the word
@@ -108,7 +143,11 @@ __global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 6 : 3) void rp_compact
     // leaves the fetch in flight.
     auto reserve = [&](int cc, int n) -> unsigned int {
         unsigned int ret = 0u;
+#if defined(SHARP_LAB_CP) && (SHARP_LAB_CP == 2 || SHARP_LAB_CP == 4)   // (lab build: no reservation)
+        if (false) {
+#else
         if (lane == 0 && cc < ncell) {
+#endif
             unsigned int *cp = counts + cc;
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ret) : "v"(cp), "v"(static_cast<unsigned int>(n)) : "memory");
         }
@@ -133,6 +172,12 @@ __global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 6 : 3) void rp_compact
         uint32_t *gout = genes + static_cast<long long>(c) * cap;
         long long *fout = fixes + static_cast<long long>(c) * cap;
         // a unit goes out in two halves of eight candidates per lane: a half has at most CP_UNIT / 2 non-zeros, the window's size
+#if defined(SHARP_LAB_CP) && (SHARP_LAB_CP == 2 || SHARP_LAB_CP == 4)
+        base = static_cast<unsigned int>(u) * 128u;
+#endif
+#if defined(SHARP_LAB_CP) && SHARP_LAB_CP >= 3                              // (lab build: count only)
+        if (cnt1 == 0x7fffffff)
+#endif
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             int run = 0;
@@ -172,7 +217,11 @@ __global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 6 : 3) void rp_compact
                 } else {
                     fx = __double2ll_rn(static_cast<double>(x) * fix_scale);
                 }
+#if defined(SHARP_LAB_CP) && SHARP_LAB_CP == 1                              // (lab build: no list stores)
+                if (live && entry == 0x12345u) { gout[base + e] = entry; if (full) fout[base + e] = fx; }
+#else
                 if (live) { gout[base + e] = entry; if (full) fout[base + e] = fx; }
+#endif
             }
             __builtin_amdgcn_wave_barrier();
             base += static_cast<unsigned int>(run);
@@ -183,6 +232,34 @@ __global__ __launch_bounds__(CP_THREADS, sizeof(T) == 4 ? 6 : 3) void rp_compact
         advance(cn, un);
         b2 = fetch();
     }
+}
+
+// compile-time loop: body(std::integral_constant<int, u>) for u = 0 .. N-1 (a DPP control word must be a constant expression)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F &&body) {
+    if constexpr (I < N) {
+        body(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(body);
+    }
+}
+
+// Entry u of a lane group's own GW entries, broadcast to the group's GW lanes without touching the LDS: the group's entries sit in
+// the group's own lanes, a group is (part of) one DPP row of 16 lanes, and `row_newbcast:n` copies lane n of every row to the row's
+// lanes; groups narrower than a row take their own part through the bank mask (one bank = 4 lanes).
+template <int GW, int U_>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t x) {
+    static_assert(GW == 16 || GW == 8 || GW == 4, "a lane group is 4, 8 or 16 lanes");
+    // (the first move leaves the lanes outside its bank mask undefined -- no zero-initialised destination register -- and the
+    // following moves complete them: together the bank masks cover the row)
+    int v = __builtin_amdgcn_mov_dpp(static_cast<int>(x), 0x150 + U_, 0xf, GW == 16 ? 0xf : (GW == 8 ? 0x3 : 0x1), true);
+    if constexpr (GW == 8) {
+        v = __builtin_amdgcn_update_dpp(v, static_cast<int>(x), 0x150 + 8 + U_, 0xf, 0xc, true);
+    } else if constexpr (GW == 4) {
+        v = __builtin_amdgcn_update_dpp(v, static_cast<int>(x), 0x150 + 4 + U_, 0xf, 0x2, true);
+        v = __builtin_amdgcn_update_dpp(v, static_cast<int>(x), 0x150 + 8 + U_, 0xf, 0x4, true);
+        v = __builtin_amdgcn_update_dpp(v, static_cast<int>(x), 0x150 + 12 + U_, 0xf, 0x8, true);
+    }
+    return static_cast<uint32_t>(v);
 }
 
 // A batch = 64 list entries, one per lane; lane group `grp` (GW lanes) works through ITS OWN lanes' entries (u = 0 .. GW-1): gene and
@@ -235,7 +312,11 @@ __global__ __launch_bounds__(AP_THREADS, AP_THREADS >= 512 ? 4 : 4) void rp_appl
     };
     const unsigned char *entb = reinterpret_cast<const unsigned char *>(ent);
     auto load_lists = [&](uint32_t g, Row (&dst)[U]) {
+#ifdef SHARP_LAB_AP_L1        // (lab build: every row list from one of 64 segments, i.e. from the CU's L1 -- what the L2 gathers cost)
+        const uint32_t gofs = (g & 63u) * static_cast<uint32_t>(SPAN * 2);
+#else
         const uint32_t gofs = g * static_cast<uint32_t>(SPAN * 2);    // byte offset of the lane's own entry's segment (32 bits: < 2^21 segments)
+#endif
         static_for<U>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             dst[u] = load_row_word<SLOTS>(entb + (group_bcast<GW, u>(gofs) + static_cast<uint32_t>(2 * SLOTS * lg)));
@@ -544,6 +625,7 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
                 SHARP_HIP_CHECK(hipStreamWaitEvent(c.stream, W.ev_compact[q], 0));
             }
         }
+#ifndef SHARP_LAB_CP          // (a lab build of the compaction leaves no valid lists behind: the apply kernel is not launched)
         {
             KernelTimer ta("rp_apply");
 #define SHARP_AP(GWV, SL, DU) launch_apply<GWV, SL, DU>(g, pr, nc, c0, cap, W.counts.p + c0, W.genes[q].p, W.fixes[q].p, inv_fix, dE, ldE, d_row_map, W.counts.p + n + ch, c.stream)
@@ -554,6 +636,7 @@ void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, in
             else { if (dual) SHARP_AP(4, 4, true); else SHARP_AP(4, 4, false); }
 #undef SHARP_AP
         }
+#endif
         if (two) SHARP_HIP_CHECK(hipEventRecord(W.ev_apply[q], c.stream));
     }
     // lists that have been overwritten (a rotation shorter than the block) serve no second projector group
