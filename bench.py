@@ -17,7 +17,7 @@ A "step" is one pass of the hot path over one batch of synthetic input already r
           every N ("scaling": "strong"), so `--gpus 1 --config cfg4` is the N = 1 point of the curve the N > 1 runs draw (the default
           run reports it under "other_configs.cfg4_one_gpu").  The only data-path collective is the all-gather of the per-block
           centroid table before the final sMetaC (sharp_amd/dist.py).
-The JSON carries `roofline` for the RP matmul stage (rp_compact_kernel + rp_apply_kernel; HBM-bound: X is read once for
+The JSON carries `roofline` for the RP matmul stage (rp_pc_kernel, rp3.hip; HBM-bound: X is read once for
 all K projectors) from HIP events on the library's streams inside the timed region, the same stage at the
 K = 5 shapes of cfg3 and of cfg4's per-GPU share (`roofline.by_config`), and `cpu_baseline`: the fp64 CPU oracle (a
 port of the reference's R path, not R itself) timed on the host cores on a bounded sample."""
@@ -47,6 +47,7 @@ def rp_stage_numbers(prof, n, m, K, p, steps_of):
     cms, ccalls = prof.get("rp_compact", (0.0, 0))
     ams, acalls = prof.get("rp_apply", (0.0, 0))
     sms, scalls = prof.get("rp_stage", (0.0, 0))
+    pms, pcalls = prof.get("rp_pc", (0.0, 0))            # the stage as ONE producer / consumer kernel (rp3.hip): the default form
     if not scalls:
         return None
     # chunks compacted beside the projector build (rp_compact_ahead, second stream) are the stage's work too: their time is ADDED, as if
@@ -59,7 +60,12 @@ def rp_stage_numbers(prof, n, m, K, p, steps_of):
     out = {"ms": round(t_stage * 1e3, 4), "cells": n, "genes": m, "n_RP": K, "reduced_dim": p,
            "algorithmic_read_bytes": read_b, "algorithmic_write_bytes": write_b,
            "achieved_read": round(read_b / t_stage / 1e9, 1), "frac_read": round(read_b / t_stage / 8e12, 4),
-           "frac_read_write": round((read_b + write_b) / t_stage / 8e12, 4), "launches_per_stage": round((ccalls + acalls) / scalls, 2)}
+           "frac_read_write": round((read_b + write_b) / t_stage / 8e12, 4), "launches_per_stage": round((ccalls + acalls + pcalls) / scalls, 2)}
+    if pcalls:
+        tl = pms / pcalls * 1e-3
+        bl = read_b / (pcalls / scalls)
+        out["rp_pc_kernel"] = {"launch_ms": round(tl * 1e3, 4), "algorithmic_bytes": int(bl), "achieved": round(bl / tl / 1e9, 1),
+                               "frac": round(bl / tl / 8e12, 4)}
     if ccalls:
         tl = cms / ccalls * 1e-3
         bl = read_b / (ccalls / scalls)
@@ -246,7 +252,8 @@ def main():
                 tj = json.load(open(tf))
                 traffic = tj.get("hbm_bytes_per_launch")
                 tsrc = "profiles/rp_traffic.json: rocprofv3 --pmc passes of this command on the builder's box (not measured in this run)"
-            roof = {"kernel": "RP matmul stage = rp_compact_kernel + rp_apply_kernel, per SHARP() call (per block)", "bound": "hbm",
+            roof = {"kernel": ("RP matmul stage = rp_pc_kernel (one persistent producer / consumer kernel), per SHARP() call (per block)" if "rp_pc_kernel" in st
+                               else "RP matmul stage = rp_compact_kernel + rp_apply_kernel, per SHARP() call (per block)"), "bound": "hbm",
                     "achieved": st["achieved_read"], "peak": 8000.0, "unit": "GB/s", "frac": st["frac_read"],
                     "traffic": traffic, "traffic_source": tsrc,
                     "what": "algorithmic bytes = X read once for all K projectors (cells x genes x 4 B, SURVEY.md 8d: the HBM-read roofline "

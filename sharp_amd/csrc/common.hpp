@@ -77,6 +77,7 @@ struct Knobs {
     int rp_kernel = 0;          // SHARP_RP_KERNEL: "fused" (1) the single-kernel RP form, "dense" (2) the MFMA form, "sparse" (3) never the dense form,
                                 // "pc" (4) always the producer / consumer kernel (rp3.hip), "split" (5) always the two-kernel form (rp2.hip)
     int rp_pc_wgs = 2;          // SHARP_RP_PC_WGS: workgroups per CU of the producer / consumer kernel
+    int rp_pc_shape = 0;        // SHARP_RP_PC_SHAPE=a / b: its workgroup shape (rp3.hip: 8 waves, 2 producers / 12 waves, 4 producers; default by row-list width)
     int x_storage = 0;          // SHARP_X_STORAGE=fp32 / fp64: force the storage of uploaded blocks (0: fp32 when exact, else fp64)
     bool block_prefetch = true; // SHARP_NO_BLOCK_PREFETCH=1: a block's front is not prepared under the previous block's tail
     bool unlimited_batch = true;   // SHARP_UNLIMITED_BATCH=0: SHARP_unlimited block after block instead of one pipelined batch per window

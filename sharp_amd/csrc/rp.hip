@@ -343,7 +343,7 @@ void project_dev(const Projector &pr, XRef X, int m, int n, long long ld, int lo
     if (vec) launch_rp<GWV, SL, true>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);      \
     else launch_rp<GWV, SL, false>(g, pr, dX, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map)
         const bool fused = knobs().rp_kernel == 1;   // SHARP_RP_KERNEL=fused: the single-kernel form (always used for unaligned X)
-        if (knobs().rp_kernel == 4 && rp_pc_eligible(X, m, ld)) {   // SHARP_RP_KERNEL=pc: the producer / consumer kernel (rp3.hip)
+        if (rp_pc_eligible(X, m, ld)) {   // the producer / consumer kernel (rp3.hip): the default wherever X can be read with 16-byte loads
             project_dev_pc(pr, g, X, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);
             continue;
         }

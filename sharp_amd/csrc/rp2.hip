@@ -431,7 +431,7 @@ unsigned rp_compact_ahead(XRef dX, int m, int n, long long ld, int log_flag) {
     Ctx &c = ctx();
     SplitWs &W = sws();
     W.pre = Precompact();
-    if (!knobs().rp_ahead || c.polite || !log_flag || n < 4096 || !rp_split_eligible(dX, m, ld)) return 0;
+    if (!knobs().rp_ahead || c.polite || !log_flag || n < 4096 || !rp_split_eligible(dX, m, ld) || rp_pc_eligible(dX, m, ld)) return 0;
     const int cap = (m + 3) / 4 * 4;
     const long long chunk = rp_chunk_cells(m, n);
     const int nchunks = static_cast<int>((n + chunk - 1) / chunk);

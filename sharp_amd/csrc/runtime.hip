@@ -273,6 +273,7 @@ static Knobs read_knobs() {
     v.rp_shape = num("SHARP_RP_SHAPE", 0);
     if (const char *kv = env("SHARP_RP_KERNEL")) v.rp_kernel = !strcmp(kv, "fused") ? 1 : !strcmp(kv, "dense") ? 2 : !strcmp(kv, "sparse") ? 3 : !strcmp(kv, "pc") ? 4 : !strcmp(kv, "split") ? 5 : 0;
     v.rp_pc_wgs = std::max(1, num("SHARP_RP_PC_WGS", 2));
+    if (const char *ps = env("SHARP_RP_PC_SHAPE")) v.rp_pc_shape = (*ps == 'a' || *ps == 'A') ? 1 : (*ps == 'b' || *ps == 'B') ? 2 : 0;
     if (const char *xs = env("SHARP_X_STORAGE")) v.x_storage = !strcmp(xs, "fp32") ? 32 : !strcmp(xs, "fp64") ? 64 : 0;
     v.block_prefetch = num("SHARP_NO_BLOCK_PREFETCH", 0) == 0;
     v.unlimited_batch = num("SHARP_UNLIMITED_BATCH", 1) != 0;

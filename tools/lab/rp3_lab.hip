@@ -1,3 +1,4 @@
+// rp3_lab.hip (lab copy of sharp_amd/csrc/rp3.hip with the per-phase cycle stamps of -DSHARP_PC_TIMING and the compile-time -DSHARP_PC_THREADS / _NP / _D / _PRIO switches the product source no longer has; tools/build_variant.sh NAME "flags" ../../tools/lab/rp3_lab.hip)
 // rp3.hip -- the RP matmul (R/RPmat.R:32, R/SHARP.R:343-345,569-585) as ONE persistent kernel with
 // specialised waves.  A workgroup of eight waves owns one cell at a time:
 //   * its NP producer waves stream the NEXT cell's column of X (1024-gene units, D units in flight per wave, non-temporal 16-byte
@@ -14,19 +15,25 @@
 // launch and one tail per chunk -- and the two instruction streams (HBM stream + compaction, L2 gathers + LDS atomics) interleave
 // inside every CU instead of two grids competing for it.  The sum is the same integer sum: E is bit for bit what rp2.hip / rp.hip
 // produce (tests/test_rp_gpu.py).
-#include "rp_shared.hpp"
+#include "../../sharp_amd/csrc/rp_shared.hpp"
 
 #include <cmath>
 #include <cstdlib>
 
 namespace sharp {
 
-constexpr int PC_MAX_THREADS = 768;
-// Workgroup shapes (two workgroups per CU either way), chosen per projector group by launch_pc:
-//   A = 8 waves: 2 producers with 3 units in flight each + 6 consumers (128 registers per lane: the 16-lane x 4-slot row lists of K = 15),
-//   B = 12 waves: 4 producers with 2 units in flight + 8 consumers (80 registers per lane: the K = 5 shapes -- 24 waves per CU keep
-//       the LDS and the vector memory path busier: cfg3 block 1.44 -> 1.35 ms, cfg4 share 5.71 -> 5.29 ms on one box).
-// The producers run at a raised wave priority: the consumers wait for them at the cell's first barrier, never the other way round.
+#ifndef SHARP_PC_THREADS
+#define SHARP_PC_THREADS 512
+#endif
+constexpr int PC_THREADS = SHARP_PC_THREADS, PC_NW = PC_THREADS / 64;
+constexpr int PC_WAVES_PER_SIMD = 2 * PC_NW / 4;      // two workgroups per CU
+// producer waves per workgroup and units in flight per producer wave (compile-time: tools/build_variant.sh -DSHARP_PC_NP=.. -DSHARP_PC_D=..)
+#ifndef SHARP_PC_NP
+#define SHARP_PC_NP 2
+#endif
+#ifndef SHARP_PC_D
+#define SHARP_PC_D 3
+#endif
 // Entry word: bits 19..0 gene, bits 29..20 table index, bit 31: the term is in the scratch block (value outside the table).
 // The table holds fix(f(x)) for every float x in [1, 256) whose low 16 bits are zero -- every integer count below 256 is one --
 // indexed by (bits(x) - bits(1.0f)) >> 16: the index IS the high half of the value's bits, no conversion on either side.
@@ -79,6 +86,9 @@ struct PcParams {
     int cap;                  // entries per scratch list (>= m)
     uint32_t *sw;             // scratch per workgroup: [2][cap] entry words (those beyond lcap) ...
     long long *st;            // ... and [2][cap] 64-bit terms (first the value as a double, then its term)
+#ifdef SHARP_PC_TIMING
+    unsigned long long *dbg;
+#endif
 };
 
 // A unit in flight: the destination registers of LOADS 16-byte loads issued by inline assembly and waited for by a COUNTED
@@ -126,11 +136,11 @@ __device__ __forceinline__ void pc_wait(PcUnit<double> &u) {
     asm volatile("s_waitcnt vmcnt(%8)" : "+v"(u.r[0]), "+v"(u.r[1]), "+v"(u.r[2]), "+v"(u.r[3]), "+v"(u.r[4]), "+v"(u.r[5]), "+v"(u.r[6]), "+v"(u.r[7]) : "n"(N));
 }
 
-// PC_THREADS / 64 waves: NP producer waves with D units in flight each; the other waves consume.
-template <typename T, int GW, int SLOTS, bool DUAL, int PC_THREADS, int NP, int D>
-__global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_kernel(const PcParams P) {
+// SHARP_PC_NP producer waves with SHARP_PC_D units in flight each; the other waves consume.
+template <typename T, int GW, int SLOTS, bool DUAL>
+__global__ __launch_bounds__(PC_THREADS, PC_WAVES_PER_SIMD) void rp_pc_kernel(const PcParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PC_NW = PC_THREADS / 64;
+    constexpr int NP = SHARP_PC_NP, D = sizeof(T) == 8 ? 2 : SHARP_PC_D;     // (an fp64 unit is 32 registers per lane)
     constexpr int NC = PC_NW - NP, SPAN = SLOTS * GW, U = GW;
     typedef RowWord<SLOTS> Row;
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
@@ -146,6 +156,13 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
     const int G = static_cast<int>(gridDim.x);
     const int nmine = (P.ncell - static_cast<int>(blockIdx.x) + G - 1) / G;
     auto cell_of = [&](int j) __attribute__((always_inline)) -> long long { return static_cast<long long>(blockIdx.x) + static_cast<long long>(j) * G; };
+#ifdef SHARP_PC_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#define PC_STAMP(slot) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[slot] += tn - tlast; tlast = tn; } while (0)
+#else
+#define PC_STAMP(slot) do {} while (0)
+#endif
     uint32_t *const sw = P.sw + static_cast<size_t>(blockIdx.x) * 2 * P.cap;
     long long *const st = P.st + static_cast<size_t>(blockIdx.x) * 2 * P.cap;
 
@@ -155,7 +172,9 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
     // operations would make the compiler's wait-count pass drain the units they have in flight (mixed loads and stores count as
     // out of order), and the E row index reaches everybody through LDS (ctl[2], put there by the first consumer wave) for the same reason.
     auto cell_end = [&](int it) __attribute__((always_inline)) {
+        PC_STAMP(3);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        PC_STAMP(4);
         if (it >= 0 && wave >= NP) {
             const long long row = static_cast<long long>(static_cast<int>(ctl[2]));
             double *erow = P.E + row * P.ldE + P.comp0;
@@ -166,7 +185,9 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
             }
             if (tid == NP * 64) ctl[it & 1] = 0u;     // that list has been consumed: the cell after next appends to it
         }
+        PC_STAMP(5);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        PC_STAMP(6);
     };
 
     if (wave >= NP) {
@@ -266,6 +287,7 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
                     decode(cw + NC, w1, gL, fL);
                     load_lists(gC, cd);
                 }
+                PC_STAMP(0);
                 for (int bt = cw; bt < nb; bt += 2 * NC) {          // two steps per trip: the two row-list sets swap roles
                     step(bt, cd, cdn);
                     if (bt + NC < nb) step(bt + NC, cdn, cd);
@@ -275,7 +297,9 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
         }
     } else {
         // ------------------------------------------------------------------ producers
-        __builtin_amdgcn_s_setprio(3);
+#ifdef SHARP_PC_PRIO
+        __builtin_amdgcn_s_setprio(SHARP_PC_PRIO);
+#endif
         const T *X = static_cast<const T *>(P.X);
         const int units = (P.m + CP_UNIT - 1) / CP_UNIT;
         const int upp = (units + NP - 1) / NP;            // items (units) per cell and producer; unit = wave + k * NP
@@ -296,7 +320,9 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
         // in flight when the next fetch overwrites its register, and the compiler protects that write with a wait that drains
         // the other units in flight as well.
         auto process = [&](PcUnit<T> &u, int j, int k, bool live) __attribute__((always_inline)) {
+            PC_STAMP(3);
             pc_wait<(D - 1) * CpLayout<T>::LOADS>(u);      // the unit has arrived; the D - 1 units fetched after it stay in flight
+            PC_STAMP(0);
             CpVals<T> b;
 #pragma unroll
             for (int q = 0; q < 16; ++q) b.v[q] = pc_val(u, q);
@@ -317,6 +343,7 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
             uint32_t base = 0u;
             if (lane == 0) base = atomicAdd(&ctl[b01], static_cast<uint32_t>(tot));
             base = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
+            PC_STAMP(1);
             uint32_t *lst = lists + b01 * P.lcap;
             if constexpr (std::is_same<T, float>::value) {
                 if (base + static_cast<uint32_t>(tot) <= static_cast<uint32_t>(P.lcap)) {
@@ -332,7 +359,7 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
                         }
                         run += static_cast<uint32_t>(__popcll(mk[q]));
                     }
-                    if (__ballot(bad != 0u) == 0ull) return;
+                    if (__ballot(bad != 0u) == 0ull) { PC_STAMP(2); return; }
                 }
             }
             // The general path (a value outside the table somewhere in the unit, an fp64 block, or a list beyond the LDS room): every
@@ -389,6 +416,9 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
         static_for<D>([&](auto ic) { pc_wait<0>(buf[decltype(ic)::value]); });      // (nothing of this wave's is in flight when it ends)
         cell_end(nmine - 1);
     }
+#ifdef SHARP_PC_TIMING
+    if (lane == 0 && P.dbg) for (int q = 0; q < 8; ++q) P.dbg[(static_cast<size_t>(blockIdx.x) * PC_NW + wave) * 8 + q] = tacc[q];
+#endif
 }
 
 namespace {
@@ -406,15 +436,6 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
     Ctx &c = ctx();
     PcWs &W = pws();
     PcParams P = P0;
-    // the workgroup shape (see PC_MAX_THREADS): B for the narrow row lists (K = 5), A for 16 lanes x 4 slots (K = 15) and fp64 blocks
-    // (an fp64 unit is 32 registers per lane); SHARP_RP_PC_SHAPE=a / b forces one for fp32 blocks
-    const bool wide = g.gw == 16 && g.slots == 4;
-    const bool shape_b = !std::is_same<T, double>::value && (knobs().rp_pc_shape == 2 || (knobs().rp_pc_shape == 0 && !wide));
-    const int threads = shape_b ? 768 : 512;
-    const void *kern = nullptr;
-    if constexpr (std::is_same<T, double>::value) kern = reinterpret_cast<const void *>(rp_pc_kernel<T, GW, SLOTS, DUAL, 512, 2, 2>);
-    else kern = shape_b ? reinterpret_cast<const void *>(rp_pc_kernel<T, GW, SLOTS, DUAL, 768, 4, 2>)
-                        : reinterpret_cast<const void *>(rp_pc_kernel<T, GW, SLOTS, DUAL, 512, 2, 3>);
     // LDS per workgroup: accumulators + dump slots, four control words, two entry lists; two workgroups per CU
     const size_t acc_bytes = static_cast<size_t>(g.acc_slots() + kDumpSlots) * 8 + 16;
     const size_t budget = 80 * 1024;
@@ -423,6 +444,7 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
     lcap = std::min(lcap, (P.m + 63) / 64 * 64);
     P.lcap = lcap;
     const size_t lds = acc_bytes + static_cast<size_t>(lcap) * 8;
+    const void *kern = reinterpret_cast<const void *>(rp_pc_kernel<T, GW, SLOTS, DUAL>);
     SHARP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     {   // scatter_row_word<0, ...>: the accumulators sit at LDS address 0, i.e. the kernel must not have static LDS in front of the dynamic block
         hipFuncAttributes fa;
@@ -430,7 +452,7 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
         SHARP_REQUIRE(fa.sharedSizeBytes == 0, "rp_pc_kernel: static LDS in front of the accumulators");
     }
     int per_cu = 1;
-    SHARP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
+    SHARP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PC_THREADS, lds));
     per_cu = std::max(1, std::min(per_cu, 2));
     per_cu = std::min(per_cu, std::max(1, knobs().rp_pc_wgs));
     const int blocks = static_cast<int>(std::min<long long>(n, static_cast<long long>(c.num_cu) * per_cu));
@@ -439,18 +461,39 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
     W.st.ensure(static_cast<size_t>(c.num_cu) * 2 * 2 * P.cap);
     P.sw = W.sw.p;
     P.st = W.st.p;
+#ifdef SHARP_PC_TIMING
+    static DevBuf<unsigned long long> dbg;
+    dbg.ensure(static_cast<size_t>(blocks) * PC_NW * 8);
+    P.dbg = dbg.p;
+#endif
     void *args[] = {&P};
-    SHARP_HIP_CHECK(hipLaunchKernel(kern, dim3(static_cast<unsigned>(blocks)), dim3(static_cast<unsigned>(threads)), args, lds, st));
+    SHARP_HIP_CHECK(hipLaunchKernel(kern, dim3(static_cast<unsigned>(blocks)), dim3(PC_THREADS), args, lds, st));
     launch_check("rp_pc_kernel");
+#ifdef SHARP_PC_TIMING
+    {
+        std::vector<unsigned long long> h(static_cast<size_t>(blocks) * PC_NW * 8);
+        SHARP_HIP_CHECK(hipStreamSynchronize(st));
+        SHARP_HIP_CHECK(hipMemcpy(h.data(), dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+        double prod[8] = {0}, cons[8] = {0};
+        for (int b = 0; b < blocks; ++b)
+            for (int w = 0; w < PC_NW; ++w)
+                for (int q = 0; q < 8; ++q) (w < SHARP_PC_NP ? prod : cons)[q] += static_cast<double>(h[(static_cast<size_t>(b) * PC_NW + w) * 8 + q]);
+        static int shown = 0;
+        if (shown++ < 2) {
+            fprintf(stderr, "pc timing (mean cycles per wave): producer wait %.0f pass1+reserve %.0f pass2 %.0f fetch/other %.0f barrierA %.0f mid %.0f barrierB %.0f\n",
+                    prod[0] / blocks / SHARP_PC_NP, prod[1] / blocks / SHARP_PC_NP, prod[2] / blocks / SHARP_PC_NP, prod[3] / blocks / SHARP_PC_NP, prod[4] / blocks / SHARP_PC_NP, prod[5] / blocks / SHARP_PC_NP, prod[6] / blocks / SHARP_PC_NP);
+            const int nc = PC_NW - SHARP_PC_NP;
+            fprintf(stderr, "pc timing (mean cycles per wave): consumer begin %.0f steps %.0f barrierA %.0f epilogue %.0f barrierB %.0f\n",
+                    cons[0] / blocks / nc, cons[3] / blocks / nc, cons[4] / blocks / nc, cons[5] / blocks / nc, cons[6] / blocks / nc);
+        }
+    }
+#endif
 }
 }  // namespace
 
-// The default form of the RP matmul (SHARP_RP_KERNEL unset or "pc") wherever X can be read with 16-byte loads and a gene index fits
-// the entry word; "split" / "fused" / "dense" name the other forms.
 bool rp_pc_eligible(XRef X, int m, long long ld) {
     const bool vec = (ld % (X.f64 ? 2 : 4) == 0) && ((reinterpret_cast<uintptr_t>(X.p) & 15u) == 0);
-    const int k = knobs().rp_kernel;
-    return (k == 0 || k == 3 || k == 4) && vec && m > 16 && m <= (1 << 20);
+    return vec && m >= 8 && m <= (1 << 20);
 }
 
 // One projector group per call; X 16-byte aligned with ld % 4 == 0 (fp32) / ld % 2 == 0 (fp64).
