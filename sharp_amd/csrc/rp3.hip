@@ -63,6 +63,7 @@ struct PcParams {
     const void *X;
     int m;
     long long ld;
+    long long cell0;          // this launch covers cells [cell0, cell0 + ncell) of the block
     int ncell, log_flag;
     double fix_scale;
     const long long *fixtab;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
     // cell j of this workgroup (static: a workgroup takes ~100 cells, their costs average out)
     const int G = static_cast<int>(gridDim.x);
     const int nmine = (P.ncell - static_cast<int>(blockIdx.x) + G - 1) / G;
-    auto cell_of = [&](int j) __attribute__((always_inline)) -> long long { return static_cast<long long>(blockIdx.x) + static_cast<long long>(j) * G; };
+    auto cell_of = [&](int j) __attribute__((always_inline)) -> long long { return P.cell0 + static_cast<long long>(blockIdx.x) + static_cast<long long>(j) * G; };
     uint32_t *const sw = P.sw + static_cast<size_t>(blockIdx.x) * 2 * P.cap;
     long long *const st = P.st + static_cast<size_t>(blockIdx.x) * 2 * P.cap;
 
@@ -433,15 +434,24 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
     SHARP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
     per_cu = std::max(1, std::min(per_cu, 2));
     per_cu = std::min(per_cu, std::max(1, knobs().rp_pc_wgs));
-    const int blocks = static_cast<int>(std::min<long long>(n, static_cast<long long>(c.num_cu) * per_cu));
+    const int grid = c.num_cu * per_cu;
     P.cap = (P.m + 3) / 4 * 4;
     W.sw.ensure(static_cast<size_t>(c.num_cu) * 2 * 2 * P.cap);
     W.st.ensure(static_cast<size_t>(c.num_cu) * 2 * 2 * P.cap);
     P.sw = W.sw.p;
     P.st = W.st.p;
-    void *args[] = {&P};
-    SHARP_HIP_CHECK(hipLaunchKernel(kern, dim3(static_cast<unsigned>(blocks)), dim3(static_cast<unsigned>(threads)), args, lds, st));
-    launch_check("rp_pc_kernel");
+    // One launch for the whole block -- except for a block prepared under another block's tail (Ctx::polite, SHARP_unlimited block
+    // after block): a persistent grid that holds every CU's LDS for milliseconds keeps the tail's whole-CU workgroups waiting whatever
+    // the stream priorities, so there it goes out in slices of sixteen cells per workgroup and the queue drains between them.
+    const long long slice = c.polite ? static_cast<long long>(grid) * 16 : static_cast<long long>(n);
+    for (long long c0 = 0; c0 < n; c0 += slice) {
+        P.cell0 = c0;
+        P.ncell = static_cast<int>(std::min<long long>(slice, n - c0));
+        const int blocks = std::min(P.ncell, grid);
+        void *args[] = {&P};
+        SHARP_HIP_CHECK(hipLaunchKernel(kern, dim3(static_cast<unsigned>(blocks)), dim3(static_cast<unsigned>(threads)), args, lds, st));
+        launch_check("rp_pc_kernel");
+    }
 }
 }  // namespace
 
@@ -467,7 +477,7 @@ void project_dev_pc(const Projector &pr, const ProjectorGroup &g, XRef dX, int m
         W.fixtab_mode = log_flag;
     }
     PcParams P;
-    P.X = dX.p; P.m = m; P.ld = ld; P.ncell = n; P.log_flag = log_flag; P.fix_scale = fix_scale; P.fixtab = W.fixtab.p;
+    P.X = dX.p; P.m = m; P.ld = ld; P.cell0 = 0; P.ncell = n; P.log_flag = log_flag; P.fix_scale = fix_scale; P.fixtab = W.fixtab.p;
     P.ent = g.ent.p; P.dummy_seg = static_cast<unsigned int>(g.nseg); P.ovf_slot = g.ovf_slot.p; P.ncomp = g.ncomp; P.neg_base = g.neg_base;
     P.inv_fix = inv_fix; P.val = pr.val; P.out_scale = 1.0 / std::sqrt(static_cast<double>(pr.p));
     P.E = dE; P.ldE = ldE; P.comp0 = g.k0 * pr.p; P.row_map = d_row_map;
