@@ -209,11 +209,37 @@ int sharp_SHARP_unlimited(const double *const *X_blocks, const long long *ncb, i
  * the per-(block, cluster) centroid tables (a few hundred rows x p doubles per block: all sMetaC uses of E1, R/sMetaC.R:58-63) meet in
  * host memory, the final sMetaC / small-cluster merge / size-ordered relabel (:163-183) run once, on devices[0], and every block's labels
  * are mapped through the result.  Labels identical to sharp_SHARP_unlimited on one GPU.  A device may be named more than once (several
- * slots on one GPU: the tests).  rN_seed must be a seed (0.5, the unseeded sentinel, would give every device different projectors).
- * sharp_SHARP_unlimited / _view themselves take this path when the environment names several devices: SHARP_DEVICES=0,1,2,... */
+ * slots on one GPU: the tests), and successive calls may name different lists (a worker's context is found by device, not by position).
+ * rN_seed must be a seed (0.5, the unseeded sentinel, would give every device different projectors).  Each GPU has a second host thread
+ * that uploads block b + ndevices while block b is clustered.  sharp_SHARP_unlimited / _view themselves take this path when the
+ * environment names several devices (SHARP_DEVICES=0,1,2,...) and the call is seeded; an unseeded call stays on the caller's GPU.
+ * sharp_trim() / sharp_shutdown() release what every worker context keeps between calls, on every GPU. */
 int sharp_SHARP_unlimited_multi(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K,
                                 int N_cluster, int minN, int maxN, double rN_seed, const int *devices, int ndevices,
                                 int *pred, int *n_pred, int *p_used, double *viE /* ncells x p row-major, or NULL */);
+/* A list of SPARSE blocks (R/SHARP_unlimited.R:125-135 hands each block to SHARP() as it is, and log2(scExp + 1) / %*% take a
+ * Matrix::dgCMatrix, R/SHARP.R:343-345,579): colptr[b] = block b's @p (ncb[b] + 1 ints), rowidx[b] = @i (0-based), val[b] = @x.  Only
+ * a block's non-zeros cross PCIe (8 bytes each for count data); csc_expand_kernel builds the dense block on its GPU, the very block the
+ * dense entry builds, so labels and viE are those of sharp_SHARP_unlimited_multi on the same values.  Block b + W is uploaded (second
+ * host thread per GPU, own stream and pinned staging, two resident copies in rotation) while block b is clustered.  devices = NULL /
+ * ndevices = 0 (and sharp_SHARP_unlimited_csc): the caller's GPU, or the SHARP_DEVICES list. */
+int sharp_SHARP_unlimited_csc(const int *const *colptr, const int *const *rowidx, const double *const *val, const long long *ncb,
+                              int nblocks, int m, int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred,
+                              int *n_pred, int *p_used, double *viE /* or NULL */);
+int sharp_SHARP_unlimited_csc_multi(const int *const *colptr, const int *const *rowidx, const double *const *val, const long long *ncb,
+                                    int nblocks, int m, int ensize_K, int N_cluster, int minN, int maxN, double rN_seed,
+                                    const int *devices, int ndevices, int *pred, int *n_pred, int *p_used, double *viE /* or NULL */);
+/* Blocks ALREADY resident on the GPUs of the device list (the foreach loop of R/SHARP_unlimited.R:125-163 over data that never leaves
+ * HBM): block b is an m x ncb[b] column-major matrix (column stride ldb[b]; fp32, or fp64 where is_f64[b] != 0: 16-byte aligned, even
+ * stride) on devices[device_of_block[b]].  Every GPU's worker runs its blocks in list order, each block's RP stage and first distance
+ * matrices prepared under the previous block's tail.  is_f64 = NULL: all fp32. */
+int sharp_SHARP_unlimited_multi_dev(const void *const *dX_blocks, const int *is_f64, const long long *ncb, const long long *ldb,
+                                    const int *device_of_block, int nblocks, int m, int ensize_K, int N_cluster, int minN, int maxN,
+                                    double rN_seed, const int *devices, int ndevices, int *pred, int *n_pred, int *p_used,
+                                    double *viE /* or NULL */);
+/* What the most recent in-process multi-device call did when: one row per block -- worker, block, upload start, upload end, clustering
+ * start, clustering end (seconds since the call began; the upload columns are 0 for a resident block).  rows: room for cap_rows x 6. */
+int sharp_multi_timeline(double *rows, int cap_rows, int *nrows);
 /* The same with the viewflag output (R/SHARP_unlimited.R:153,216-228): viE = the blocks' ensemble-mean projections E1,
  * ncells x p row-major in block order (NULL: not wanted).  The 50-dimension reduction the reference applies above 1e5
  * cells is one more sharp_project() call on this matrix (host side: sharp_amd/api.py). */
@@ -339,6 +365,11 @@ void sharp_C_SHARP_unlimited(double *Xcat, int *nblocks, double *ncb, int *m, in
 /* sharp_SHARP_unlimited_multi: devices = integer vector of GPU indices (block b on devices[b mod *ndevices]) */
 void sharp_C_SHARP_unlimited_multi(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *N_cluster, int *minN, int *maxN,
                                    double *rN_seed, int *devices, int *ndevices, int *pred, double *viE, int *info, int *want, int *status);
+/* sharp_SHARP_unlimited_csc_multi for a list of dgCMatrix blocks: pcat / icat / xcat = the blocks' @p / @i / @x one after the other;
+ * *ndevices = 0: the caller's GPU (R/SHARP_unlimited.R:125-135, R/SHARP.R:343-345,579) */
+void sharp_C_SHARP_unlimited_csc(int *pcat, int *icat, double *xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *N_cluster,
+                                 int *minN, int *maxN, double *rN_seed, int *devices, int *ndevices, int *pred, double *viE, int *info,
+                                 int *want, int *status);
 /* R/SHARP_unlimited2.R:29-292 */
 void sharp_C_SHARP_unlimited2(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *reduced_ndim, int *partition_ncells,
                               int *hmethod, int *N_cluster, int *enpN, int *indN, int *minN, int *maxN, double *sil_thre,

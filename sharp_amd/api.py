@@ -456,15 +456,41 @@ def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster
     else:
         rN_seed = 0.5
     _lib.ensure_init()
-    blocks = [np.asfortranarray(b, dtype=np.float64) for b in scExp]
+    sparse = all(_is_sparse(b) for b in scExp)                            # a list of dgCMatrix-like blocks (:125-135 hands them on as they are)
+    if sparse:
+        blocks = [b.tocsc() for b in scExp]
+        for b in blocks:
+            b.sum_duplicates()
+    else:
+        blocks = [np.asfortranarray(b.toarray() if _is_sparse(b) else b, dtype=np.float64) for b in scExp]
     m = blocks[0].shape[0]
     ncb = np.array([b.shape[1] for b in blocks], np.int64)
-    ptrs = (C.POINTER(C.c_double) * len(blocks))(*[_dp(b) for b in blocks])
     n = int(ncb.sum())
     pred = np.zeros(n, np.int32)
     npred, pu = C.c_int(), C.c_int()
     p = int(np.ceil(np.log2(n) / 0.04))                                   # :65-66, from the TOTAL number of cells
     viE = np.zeros((n, p)) if viewflag else None
+    if sparse:
+        # only the non-zeros of a block cross PCIe, block b + W while block b is clustered (sharp_SHARP_unlimited_csc_multi)
+        cps = [np.ascontiguousarray(b.indptr, np.int32) for b in blocks]
+        ris = [np.ascontiguousarray(b.indices, np.int32) for b in blocks]
+        vxs = [np.ascontiguousarray(b.data, np.float64) for b in blocks]
+        B = len(blocks)
+        cpp = (C.POINTER(C.c_int) * B)(*[_ip(a) for a in cps])
+        rip = (C.POINTER(C.c_int) * B)(*[_ip(a) if a.size else C.cast(None, C.POINTER(C.c_int)) for a in ris])
+        vxp = (C.POINTER(C.c_double) * B)(*[_dp(a) if a.size else C.cast(None, C.POINTER(C.c_double)) for a in vxs])
+        dv = np.ascontiguousarray(devices if devices is not None else [], np.int32)
+        check(lib().sharp_SHARP_unlimited_csc_multi(cpp, rip, vxp, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), B, m, int(ensize_K or 0),
+                                                    int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0), C.c_double(rN_seed),
+                                                    _ip(dv) if dv.size else None, int(dv.size), _ip(pred), C.byref(npred), C.byref(pu),
+                                                    _dp(viE)), allow=48)
+        K = int(ensize_K or 5)
+        out = _enresults(pred, None, None, n, m, pu.value, K, t0, {}, False, key="N.pred_clusters")
+        if viewflag:                                                      # :215-232
+            out["viE"] = _view_reduce(viE, rN_seed, K) if n > 1e5 else viE
+            out["x0"] = _one_hot(pred, npred.value)
+        return out
+    ptrs = (C.POINTER(C.c_double) * len(blocks))(*[_dp(b) for b in blocks])
     if devices is not None and len(devices) >= 1:
         dv = np.ascontiguousarray(devices, np.int32)
         check(lib().sharp_SHARP_unlimited_multi(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), len(blocks), m, int(ensize_K or 0),

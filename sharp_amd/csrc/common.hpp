@@ -136,10 +136,12 @@ Ctx &ctx_unchecked();
 // sharp_init() sets up, which is all a single-GPU host ever sees).  The multi-GPU entry points (sharp_SHARP_unlimited_multi) start one
 // host thread per device and bind each to a slot of its own, so several GPUs -- or, in the tests, several slots on ONE GPU -- run
 // side by side in one process.
-constexpr int kMaxSlots = 17;
+constexpr int kMaxSlots = 49;        // the caller's + (compute, upload) slots of up to 16 GPUs, with room for repeated devices
 int cur_slot();
 void bind_slot(int slot);                   // the calling thread works on this slot from now on
 void init_slot(int slot, int device);       // bind_slot + hipSetDevice + the slot's context (streams) on that device; idempotent per (slot, device)
+int acquire_slot(int device, int occurrence, int role);   // the worker slot (>= 1) of that device / occurrence in the device list / role (0 compute, 1 upload)
+void for_each_ready_slot(const std::function<void()> &fn);   // fn() with the calling thread bound to each initialised slot in turn
 // the per-slot instance of a keep-between-calls object: `T &name() { return per_slot<T>(); }`
 template <typename T>
 T &per_slot() { static T w[kMaxSlots]; return w[cur_slot()]; }

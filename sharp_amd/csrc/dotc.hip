@@ -171,6 +171,27 @@ void sharp_C_SHARP_unlimited_multi(double *Xcat, int *nblocks, double *ncb, int 
     *status = sharp_SHARP_unlimited_multi(ptrs.data(), nc.data(), B, *m, *ensize_K, *N_cluster, *minN, *maxN, *rN_seed, devices, *ndevices,
                                           pred, &info[0], &info[1], (*want & 1) ? viE : nullptr);
 }
+/* a list of dgCMatrix blocks (R/SHARP_unlimited.R:125-135 hands each block to SHARP() as it is; R/SHARP.R:343-345,579 take a dgCMatrix):
+ * pcat = the blocks' @p one after the other (ncb[b] + 1 ints each), icat / xcat = their @i / @x one after the other.  *ndevices = 0: the
+ * caller's GPU (or SHARP_DEVICES); else block b on devices[b mod *ndevices]. */
+void sharp_C_SHARP_unlimited_csc(int *pcat, int *icat, double *xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *N_cluster,
+                                 int *minN, int *maxN, double *rN_seed, int *devices, int *ndevices, int *pred, double *viE, int *info,
+                                 int *want, int *status) {
+    const int B = *nblocks;
+    if (B < 1) { sharp::set_error("No expression data is provided!"); *status = SHARP_ERR_ARG; return; }
+    std::vector<const int *> cp(static_cast<size_t>(B)), ri(static_cast<size_t>(B));
+    std::vector<const double *> vx(static_cast<size_t>(B));
+    std::vector<long long> nc(static_cast<size_t>(B));
+    long long poff = 0, eoff = 0;
+    for (int b = 0; b < B; ++b) {
+        nc[b] = as_ll(ncb + b);
+        cp[b] = pcat + poff; ri[b] = icat + eoff; vx[b] = xcat + eoff;
+        eoff += static_cast<long long>(cp[b][nc[b]]) - cp[b][0];
+        poff += nc[b] + 1;
+    }
+    *status = sharp_SHARP_unlimited_csc_multi(cp.data(), ri.data(), vx.data(), nc.data(), B, *m, *ensize_K, *N_cluster, *minN, *maxN, *rN_seed,
+                                              *ndevices > 0 ? devices : nullptr, *ndevices, pred, &info[0], &info[1], (*want & 1) ? viE : nullptr);
+}
 /* SHARP_unlimited2 (R/SHARP_unlimited2.R:29-292); same block layout */
 void sharp_C_SHARP_unlimited2(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *reduced_ndim, int *partition_ncells,
                               int *hmethod, int *N_cluster, int *enpN, int *indN, int *minN, int *maxN, double *sil_thre,

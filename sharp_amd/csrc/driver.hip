@@ -13,6 +13,10 @@
 #include <numeric>
 #include <random>
 #include <thread>
+#include <atomic>
+#include <condition_variable>
+#include <ctime>
+#include <mutex>
 #include <vector>
 
 #include "meta.hpp"
@@ -422,6 +426,9 @@ void sharp_large_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
         drop_pending_front();
         rp_compact_ahead_drop();
         if (ctx_unchecked().stream2) (void)hipStreamSynchronize(ctx_unchecked().stream2);   // (the block's compaction may still be reading the caller's X)
+        // the main stream too: the front's per-call projector goes back to the block pool during unwinding WITHOUT a synchronisation of
+        // its own, and another slot on this device could take those blocks while this slot's kernels still read them
+        if (ctx_unchecked().stream) (void)hipStreamSynchronize(ctx_unchecked().stream);
         throw;
     }
 }
@@ -802,14 +809,17 @@ int sharp_last_rpinfo(int *n, int *K, int *p, int *enrp, double *indE) {
 int sharp_trim(void) {
     SHARP_API_BEGIN
     ctx();
-    SHARP_HIP_CHECK(hipDeviceSynchronize());
-    drop_pending_front();
-    host_block().release();
-    upload_release_staging();
-    dws().Ebatch.release();                              // a batched SHARP_unlimited window's projections (up to 16 GB)
-    dws().posbatch.release();
-    rp_pc_trim();
-    rp_trim();                                           // the per-chunk entry buffers of a block compacted ahead (up to 16 GB)
+    for_each_ready_slot([] {                             // the caller's slot and every worker slot a multi-GPU run has left behind
+        SHARP_HIP_CHECK(hipDeviceSynchronize());
+        drop_pending_front();
+        host_block().release();
+        { HostBlockPair &hp = per_slot<HostBlockPair>(); hp.hb[0].release(); hp.hb[1].release(); }
+        upload_release_staging();
+        dws().Ebatch.release();                          // a batched SHARP_unlimited window's projections (up to 16 GB)
+        dws().posbatch.release();
+        rp_pc_trim();
+        rp_trim();                                       // the per-chunk entry buffers of a block compacted ahead (up to 16 GB)
+    });
     pool_clear();
     SHARP_API_END
 }
@@ -1083,94 +1093,249 @@ struct HostBlocks {
         return SHARP_OK;
     }
 };
+// One block of a list-of-blocks call, wherever it lives: a dense host matrix (R's numeric matrix), the three slots of a dgCMatrix,
+// or a block already resident on one of the call's GPUs.
+struct BlockSrc {
+    enum Kind { HostDense, HostCsc, DevF32, DevF64 } kind = HostDense;
+    const double *host = nullptr;                          // HostDense: m x n doubles, column stride m
+    const int *colptr = nullptr, *rowidx = nullptr;        // HostCsc: @p (n + 1), @i
+    const double *val = nullptr;                           //          @x
+    const void *dev = nullptr;                             // DevF32 / DevF64
+    long long ld = 0;
+    int worker = -1;                                       // DevF32 / DevF64: index into the call's device list (the GPU the block lives on)
+    long long n = 0;
+    bool on_host() const { return kind == HostDense || kind == HostCsc; }
+};
+
+HostBlockPair &host_block_pair() { return per_slot<HostBlockPair>(); }
+
+// What the last in-process multi-device call did when: one row per block -- worker, block, upload start / end, clustering start / end,
+// seconds since the call began (sharp_multi_timeline; profiles/r04_multi_timeline.txt).
+struct MultiTimeline { std::mutex mu; std::vector<double> rows; };
+MultiTimeline &multi_timeline() { static MultiTimeline *t = new MultiTimeline; return *t; }
+double wall_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
 // SHARP_unlimited over several GPUs inside one process (R/SHARP_unlimited.R:125-183): the serial block loop of the reference
-// (:125-163) is dealt out, block b to devices[b mod ndev]; one host thread per device, bound to a device slot of its own (context,
-// streams, workspaces, projector handles: common.hpp), builds the K projectors there (a pure function of m, p and the seeds, :97-104),
-// uploads and clusters its blocks one after the other and keeps, per block, the labels and the per-cluster centroid means and sizes --
-// all the final sMetaC uses of E1 (R/sMetaC.R:58-63).  p comes from the GLOBAL cell count (:65-66).  The centroid tables (a few
-// hundred rows x p doubles per block) meet in host memory, the merge (:163-183) runs once on the first device, and every block's
-// labels are mapped through it.  No other data crosses between devices.
-int unlimited_run_multi(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster, int minN,
-                        int maxN, double rN_seed, const int *devices, int ndev, int *pred, int *n_pred, int *p_used, double *viE) {
+// (:125-163) is dealt out, block b to worker b mod W (a resident block: to the worker of the GPU it lives on).  A worker is a host thread
+// bound to a device slot of its own (context, streams, workspaces, projector handles: common.hpp): it builds the K projectors on its GPU
+// (a pure function of m, p and the seeds, :97-104; p from the GLOBAL cell count, :65-66) and clusters its blocks one after the other, each
+// prepared under the previous one's tail when it is already resident.  Host blocks -- dense or sparse -- reach the GPU through a second
+// thread per worker with a slot of its own (own stream, pinned staging, two resident copies in rotation): block i + W crosses PCIe while
+// block i is clustered.  Per block the worker keeps the labels and the per-cluster centroid means and sizes -- all the final sMetaC uses
+// of E1 (R/sMetaC.R:58-63); the tables (a few hundred rows x p doubles per block) meet in host memory, worker 0 runs the merge (:163-183)
+// once the others are done, and every block's labels are mapped through it.  No other data crosses between devices.
+int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K, int N_cluster, int minN, int maxN, double rN_seed,
+                        const int *devices, int ndev, int *pred, int *n_pred, int *p_used, double *viE) {
     SHARP_API_BEGIN
-    SHARP_REQUIRE(X_blocks && ncb && pred, "The input should be a LIST of partitioned scRNA-seq expression matrices!");
+    const int nblocks = static_cast<int>(blocks.size());
+    SHARP_REQUIRE(pred, "The input should be a LIST of partitioned scRNA-seq expression matrices!");
     SHARP_REQUIRE(nblocks >= 2, "SHARP is used instead of SHARP_unlimited because the length of the input is 1!");
-    SHARP_REQUIRE(devices && ndev >= 1 && ndev < kMaxSlots, "SHARP_unlimited: the device list must name between 1 and 16 GPUs");
+    SHARP_REQUIRE(devices && ndev >= 1 && ndev <= 16, "SHARP_unlimited: the device list must name between 1 and 16 GPUs");
     if (rN_seed != 0.5) SHARP_REQUIRE(std::fmod(rN_seed, 1.0) == 0.0, "The rN.seed should be an integer!");   // :80-90
     long long ncells = 0;
-    for (int b = 0; b < nblocks; ++b) { SHARP_REQUIRE(X_blocks[b] && ncb[b] >= 3, "SHARP_unlimited: empty block"); ncells += ncb[b]; }
+    for (int b = 0; b < nblocks; ++b) {
+        const BlockSrc &s = blocks[b];
+        SHARP_REQUIRE(s.n >= 3 && (s.kind == BlockSrc::HostDense ? s.host != nullptr : s.kind == BlockSrc::HostCsc ? s.colptr != nullptr : s.dev != nullptr),
+                      "SHARP_unlimited: empty block");
+        SHARP_REQUIRE(s.on_host() || (s.worker >= 0 && s.worker < ndev), "SHARP_unlimited: a resident block names a device outside the device list");
+        ncells += s.n;
+    }
     const int p = static_cast<int>(std::ceil(std::log2(static_cast<double>(ncells)) / (0.2 * 0.2)));           // :65-66
     const int K = ensize_K > 0 ? ensize_K : 5;                                                                 // :92-94
     std::vector<double> seeds(K);
     for (int k = 0; k < K; ++k) seeds[k] = (rN_seed == 0.5) ? 0.5 : 50 + rN_seed + (k + 1);                    // :97-104
-    SHARP_REQUIRE(rN_seed != 0.5 || ndev == 1, "SHARP_unlimited on several GPUs needs a seed: unseeded projectors would differ between the devices");
-    const int W = std::min(ndev, nblocks);
+    bool resident = false;
+    for (const BlockSrc &s : blocks) resident |= !s.on_host();
+    const int W = resident ? ndev : std::min(ndev, nblocks);
+    SHARP_REQUIRE(rN_seed != 0.5 || W == 1, "SHARP_unlimited on several GPUs needs a seed: unseeded projectors would differ between the devices");
     std::vector<long long> cell0(nblocks + 1, 0);
-    for (int b = 0; b < nblocks; ++b) cell0[b + 1] = cell0[b] + ncb[b];
+    for (int b = 0; b < nblocks; ++b) cell0[b + 1] = cell0[b] + blocks[b].n;
+    std::vector<std::vector<int>> mine(W);                // the blocks of each worker, in block order
+    for (int b = 0; b < nblocks; ++b) mine[blocks[b].on_host() ? b % W : blocks[b].worker].push_back(b);
+    std::vector<int> occ(W, 0);                           // which occurrence of its device a worker is (a device may be listed repeatedly)
+    for (int w = 0; w < W; ++w) for (int v = 0; v < w; ++v) occ[w] += devices[v] == devices[w];
     std::vector<std::vector<int>> pb(nblocks);
     std::vector<std::vector<double>> mb(nblocks);
     std::vector<std::vector<long long>> cb(nblocks);
     std::vector<std::string> err(W);
-    std::vector<int> rcs(W, SHARP_OK), warn(W, 0);
-    auto worker = [&](int d) {
-        try {
-            init_slot(1 + d, devices[d]);                // slots 1 .. W: slot 0 stays the caller's own
-            const int proj = register_projector(build_projector(m, p, K, seeds.data()));
-            try {
-                HostBlock &hb = host_block();
-                for (int b = d; b < nblocks; b += W) {
-                    upload_block(X_blocks[b], m, ncb[b], m, hb);
-                    unlimited_block_dev(hb.ref(), m, ncb[b], hb.ld, p, proj, K, rN_seed, pb[b], mb[b], cb[b],
-                                        viE ? viE + static_cast<size_t>(cell0[b]) * p : nullptr);   // E1 rows of this block (:153), viewflag only
+    std::vector<int> rcs(W, SHARP_OK);
+    const double t_begin = wall_s();
+    std::vector<double> tl(static_cast<size_t>(nblocks) * 6, 0.0);
+    std::mutex done_mu;
+    std::condition_variable done_cv;
+    int done_workers = 0;
+    std::atomic<int> failed{0};
+    std::vector<int> fid;
+    int nf = 0;
+    std::vector<int> first(nblocks + 1, 0);
+    std::vector<double> means;
+    std::vector<long long> counts;
+
+    auto worker = [&](int w) {
+        // ---- the upload thread of this worker: host blocks into the two resident copies of its own slot, in block order
+        struct Feed {
+            std::mutex mu;
+            std::condition_variable cv;
+            std::vector<char> ready;                      // per position in mine[w]: uploaded
+            std::vector<XRef> ref;
+            std::vector<long long> ld;
+            int consumed = 0;                             // host blocks the compute thread has finished with
+            bool stop = false;
+            std::string err;
+            int rc = SHARP_OK;
+        } feed;
+        const std::vector<int> &my = mine[w];
+        feed.ready.assign(my.size(), 0);
+        feed.ref.resize(my.size());
+        feed.ld.assign(my.size(), 0);
+        std::vector<int> hostpos;                         // positions in `my` that hold host blocks
+        for (size_t i = 0; i < my.size(); ++i) if (blocks[my[i]].on_host()) hostpos.push_back(static_cast<int>(i));
+        std::thread up;
+        if (!hostpos.empty())
+            up = std::thread([&] {
+                try {
+                    init_slot(acquire_slot(devices[w], occ[w], 1), devices[w]);
+                    HostBlockPair &P = host_block_pair();
+                    for (size_t h = 0; h < hostpos.size(); ++h) {
+                        {   // copy h % 2 is free once the compute thread is done with host block h - 2
+                            std::unique_lock<std::mutex> lk(feed.mu);
+                            feed.cv.wait(lk, [&] { return feed.stop || feed.consumed + 2 > static_cast<int>(h); });
+                            if (feed.stop) return;
+                        }
+                        const int i = hostpos[h], b = my[i];
+                        const BlockSrc &s = blocks[b];
+                        HostBlock &hb = P.hb[h & 1];
+                        tl[static_cast<size_t>(b) * 6 + 2] = wall_s() - t_begin;
+                        if (s.kind == BlockSrc::HostDense) upload_block(s.host, m, s.n, m, hb);
+                        else upload_block_csc(s.colptr, s.rowidx, s.val, m, s.n, hb);
+                        stream_sync();
+                        tl[static_cast<size_t>(b) * 6 + 3] = wall_s() - t_begin;
+                        std::lock_guard<std::mutex> lk(feed.mu);
+                        feed.ref[i] = hb.ref(); feed.ld[i] = hb.ld; feed.ready[i] = 1;
+                        feed.cv.notify_all();
+                    }
                 }
-            } catch (...) { drop_pending_front(); drop_projector(proj); throw; }
-            drop_projector(proj);
+                catch (const sharp::Error &e) { std::lock_guard<std::mutex> lk(feed.mu); feed.err = e.what(); feed.rc = e.code; feed.cv.notify_all(); }
+                catch (const std::exception &e) { std::lock_guard<std::mutex> lk(feed.mu); feed.err = e.what(); feed.rc = SHARP_ERR; feed.cv.notify_all(); }
+            });
+        auto stop_feed = [&] {
+            { std::lock_guard<std::mutex> lk(feed.mu); feed.stop = true; }
+            feed.cv.notify_all();
+            if (up.joinable()) up.join();
+        };
+        // where block position i of this worker is, once it is on the GPU (waits for its upload; a resident block is there already)
+        auto block_ref = [&](size_t i, bool wait, XRef &ref, long long &ld) -> bool {
+            const BlockSrc &s = blocks[my[i]];
+            if (!s.on_host()) {
+                ref = s.kind == BlockSrc::DevF64 ? dev64_ref(static_cast<const double *>(s.dev), m, s.n, s.ld) : XRef(static_cast<const float *>(s.dev));
+                ld = s.ld;
+                return true;
+            }
+            std::unique_lock<std::mutex> lk(feed.mu);
+            if (wait) feed.cv.wait(lk, [&] { return feed.ready[i] || feed.rc != SHARP_OK; });
+            if (feed.rc != SHARP_OK) throw sharp::Error(feed.rc, feed.err);
+            if (!feed.ready[i]) return false;
+            ref = feed.ref[i]; ld = feed.ld[i];
+            return true;
+        };
+        try {
+            init_slot(acquire_slot(devices[w], occ[w], 0), devices[w]);
+            const int proj = my.empty() ? 0 : register_projector(build_projector(m, p, K, seeds.data()));
+            try {
+                for (size_t i = 0; i < my.size(); ++i) {
+                    if (failed.load()) break;
+                    const int b = my[i];
+                    XRef ref, nref;
+                    long long ld = 0, nld = 0;
+                    block_ref(i, true, ref, ld);
+                    // the next block's front goes under this block's tail if that block is on the GPU by now (a resident block always is)
+                    const bool more = i + 1 < my.size() && block_ref(i + 1, false, nref, nld);
+                    tl[static_cast<size_t>(b) * 6 + 4] = wall_s() - t_begin;
+                    unlimited_block_dev(ref, m, blocks[b].n, ld, p, proj, K, rN_seed, pb[b], mb[b], cb[b],
+                                        viE ? viE + static_cast<size_t>(cell0[b]) * p : nullptr,   // E1 rows of this block (:153), viewflag only
+                                        1, nullptr, more ? nref : XRef(), more ? blocks[my[i + 1]].n : 0, more ? nld : 0);
+                    tl[static_cast<size_t>(b) * 6 + 5] = wall_s() - t_begin;
+                    tl[static_cast<size_t>(b) * 6 + 0] = w; tl[static_cast<size_t>(b) * 6 + 1] = b;
+                    if (blocks[b].on_host()) {
+                        std::lock_guard<std::mutex> lk(feed.mu);
+                        ++feed.consumed;
+                        feed.cv.notify_all();
+                    }
+                }
+            } catch (...) { drop_pending_front(); if (proj) drop_projector(proj); throw; }
+            drop_pending_front();
+            if (proj) drop_projector(proj);
             stream_sync();
+            stop_feed();
+            if (w == 0) {
+                // the one exchange step: worker 0 waits for the others, then the centroid tables in global block order and the merge on its GPU
+                {
+                    std::unique_lock<std::mutex> lk(done_mu);
+                    done_cv.wait(lk, [&] { return done_workers == W - 1; });
+                }
+                if (!failed.load()) {
+                    for (int b = 0; b < nblocks; ++b) {
+                        means.insert(means.end(), mb[b].begin(), mb[b].end());
+                        counts.insert(counts.end(), cb[b].begin(), cb[b].end());
+                        first[b + 1] = first[b] + static_cast<int>(cb[b].size());
+                    }
+                    unlimited_merge(means.data(), counts.data(), first[nblocks], p, ncells, N_cluster, minN, maxN, fid, nf);
+                    stream_sync();
+                }
+            }
         }
-        catch (const sharp::Error &e) { err[d] = e.what(); rcs[d] = e.code; }
-        catch (const std::exception &e) { err[d] = e.what(); rcs[d] = SHARP_ERR; }
+        catch (const sharp::Error &e) { err[w] = e.what(); rcs[w] = e.code; failed.store(1); stop_feed(); }
+        catch (const std::exception &e) { err[w] = e.what(); rcs[w] = SHARP_ERR; failed.store(1); stop_feed(); }
+        if (w != 0) {
+            std::lock_guard<std::mutex> lk(done_mu);
+            ++done_workers;
+            done_cv.notify_all();
+        } else if (rcs[0] != SHARP_OK) {                  // (worker 0 failed before it waited: the others still have to be counted out)
+            std::unique_lock<std::mutex> lk(done_mu);
+            done_cv.wait(lk, [&] { return done_workers == W - 1; });
+        }
     };
     {
         std::vector<std::thread> th;
-        for (int d = 0; d < W; ++d) th.emplace_back(worker, d);
+        for (int w = 0; w < W; ++w) th.emplace_back(worker, w);
         for (auto &t : th) t.join();
     }
-    for (int d = 0; d < W; ++d)
-        if (rcs[d] != SHARP_OK) throw sharp::Error(rcs[d], "device " + std::to_string(devices[d]) + ": " + err[d]);
-    // the one exchange step: the centroid tables in global block order, then the merge on the first device
-    std::vector<double> means;
-    std::vector<long long> counts;
-    std::vector<int> first(nblocks + 1, 0);
-    for (int b = 0; b < nblocks; ++b) {
-        means.insert(means.end(), mb[b].begin(), mb[b].end());
-        counts.insert(counts.end(), cb[b].begin(), cb[b].end());
-        first[b + 1] = first[b] + static_cast<int>(cb[b].size());
-    }
-    std::vector<int> fid;
-    int nf = 0;
     {
-        std::string merr;
-        int mrc = SHARP_OK;
-        std::thread mt([&] {
-            try {
-                init_slot(1, devices[0]);
-                unlimited_merge(means.data(), counts.data(), first[nblocks], p, ncells, N_cluster, minN, maxN, fid, nf);
-                stream_sync();
-            }
-            catch (const sharp::Error &e) { merr = e.what(); mrc = e.code; }
-            catch (const std::exception &e) { merr = e.what(); mrc = SHARP_ERR; }
-        });
-        mt.join();
-        if (mrc != SHARP_OK) throw sharp::Error(mrc, merr);
+        MultiTimeline &T = multi_timeline();
+        std::lock_guard<std::mutex> lk(T.mu);
+        T.rows = tl;
     }
+    for (int w = 0; w < W; ++w)
+        if (rcs[w] != SHARP_OK) throw sharp::Error(rcs[w], "device " + std::to_string(devices[w]) + ": " + err[w]);
     long long off = 0;
     for (int b = 0; b < nblocks; ++b) {                                         // labels scattered back (:165-183 through the merge's map)
-        for (long long i = 0; i < ncb[b]; ++i) pred[off + i] = fid[first[b] + pb[b][i] - 1];
-        off += ncb[b];
+        for (long long i = 0; i < blocks[b].n; ++i) pred[off + i] = fid[first[b] + pb[b][i] - 1];
+        off += blocks[b].n;
     }
     if (n_pred) *n_pred = nf;
     if (p_used) *p_used = p;
     SHARP_API_END
+}
+
+std::vector<BlockSrc> dense_sources(const double *const *X_blocks, const long long *ncb, int nblocks) {
+    std::vector<BlockSrc> v;
+    for (int b = 0; X_blocks && ncb && b < nblocks; ++b) { BlockSrc s; s.kind = BlockSrc::HostDense; s.host = X_blocks[b]; s.n = ncb[b]; v.push_back(s); }
+    return v;
+}
+std::vector<BlockSrc> csc_sources(const int *const *colptr, const int *const *rowidx, const double *const *val, const long long *ncb, int nblocks) {
+    std::vector<BlockSrc> v;
+    for (int b = 0; colptr && rowidx && val && ncb && b < nblocks; ++b) {
+        BlockSrc s;
+        s.kind = BlockSrc::HostCsc; s.colptr = colptr[b]; s.rowidx = rowidx[b]; s.val = val[b]; s.n = ncb[b];
+        v.push_back(s);
+    }
+    return v;
+}
+// the devices of a host-block call: the caller's list, else SHARP_DEVICES, else the caller's own device (one worker: upload and clustering still overlap)
+std::vector<int> call_devices(const int *devices, int ndevices) {
+    if (devices && ndevices > 0) return std::vector<int>(devices, devices + ndevices);
+    if (!knobs().devices.empty()) return knobs().devices;
+    return std::vector<int>(1, ctx().device);
 }
 
 std::vector<XRef> f32_refs(const float *const *dX_blocks, int nblocks) {
@@ -1216,9 +1381,9 @@ int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *nc
 int sharp_SHARP_unlimited_view(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,
                                int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used, double *viE) {
     const std::vector<int> &dv = knobs().devices;        // SHARP_DEVICES=0,1,2,...: the blocks dealt to these GPUs (one host thread each)
-    if (dv.size() >= 2)
-        return unlimited_run_multi(X_blocks, ncb, nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, dv.data(), static_cast<int>(dv.size()),
-                                   pred, n_pred, p_used, viE);
+    if (dv.size() >= 2 && rN_seed != 0.5)                // (an unseeded call stays on the caller's GPU: every device would draw its own projectors)
+        return unlimited_run_multi(dense_sources(X_blocks, ncb, nblocks), m, ensize_K, N_cluster, minN, maxN, rN_seed, dv.data(),
+                                   static_cast<int>(dv.size()), pred, n_pred, p_used, viE);
     HostBlocks H;
     if (const int rc = H.upload(X_blocks, ncb, nblocks, m)) return rc;
     return unlimited_run(H.refs.data(), ncb, H.lds.data(), nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred, p_used, viE);
@@ -1227,7 +1392,53 @@ int sharp_SHARP_unlimited_view(const double *const *X_blocks, const long long *n
 int sharp_SHARP_unlimited_multi(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,
                                 int minN, int maxN, double rN_seed, const int *devices, int ndevices, int *pred, int *n_pred, int *p_used,
                                 double *viE) {
-    return unlimited_run_multi(X_blocks, ncb, nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, devices, ndevices, pred, n_pred, p_used, viE);
+    if (!X_blocks || !ncb) { sharp::set_error("The input should be a LIST of partitioned scRNA-seq expression matrices!"); return SHARP_ERR_ARG; }
+    return unlimited_run_multi(dense_sources(X_blocks, ncb, nblocks), m, ensize_K, N_cluster, minN, maxN, rN_seed, devices, ndevices, pred, n_pred, p_used, viE);
+}
+
+/* a list of dgCMatrix blocks: only the non-zeros of a block cross PCIe, block i + W while block i is clustered */
+int sharp_SHARP_unlimited_csc_multi(const int *const *colptr, const int *const *rowidx, const double *const *val, const long long *ncb,
+                                    int nblocks, int m, int ensize_K, int N_cluster, int minN, int maxN, double rN_seed,
+                                    const int *devices, int ndevices, int *pred, int *n_pred, int *p_used, double *viE) {
+    if (!colptr || !rowidx || !val || !ncb) { sharp::set_error("The input should be a LIST of partitioned scRNA-seq expression matrices!"); return SHARP_ERR_ARG; }
+    std::vector<int> dv;
+    try { dv = call_devices(devices, ndevices); }
+    catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
+    if (rN_seed == 0.5 && dv.size() > 1) dv.resize(1);
+    return unlimited_run_multi(csc_sources(colptr, rowidx, val, ncb, nblocks), m, ensize_K, N_cluster, minN, maxN, rN_seed, dv.data(),
+                               static_cast<int>(dv.size()), pred, n_pred, p_used, viE);
+}
+int sharp_SHARP_unlimited_csc(const int *const *colptr, const int *const *rowidx, const double *const *val, const long long *ncb,
+                              int nblocks, int m, int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred,
+                              int *n_pred, int *p_used, double *viE) {
+    return sharp_SHARP_unlimited_csc_multi(colptr, rowidx, val, ncb, nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, nullptr, 0,
+                                           pred, n_pred, p_used, viE);
+}
+
+/* blocks already resident on the GPUs of the device list: block b lives on devices[device_of_block[b]] */
+int sharp_SHARP_unlimited_multi_dev(const void *const *dX_blocks, const int *is_f64, const long long *ncb, const long long *ldb,
+                                    const int *device_of_block, int nblocks, int m, int ensize_K, int N_cluster, int minN, int maxN,
+                                    double rN_seed, const int *devices, int ndevices, int *pred, int *n_pred, int *p_used, double *viE) {
+    if (!dX_blocks || !ncb || !ldb || !device_of_block) { sharp::set_error("The input should be a LIST of partitioned scRNA-seq expression matrices!"); return SHARP_ERR_ARG; }
+    std::vector<BlockSrc> v;
+    for (int b = 0; b < nblocks; ++b) {
+        BlockSrc s;
+        s.kind = (is_f64 && is_f64[b]) ? BlockSrc::DevF64 : BlockSrc::DevF32;
+        s.dev = dX_blocks[b]; s.ld = ldb[b]; s.worker = device_of_block[b]; s.n = ncb[b];
+        v.push_back(s);
+    }
+    return unlimited_run_multi(v, m, ensize_K, N_cluster, minN, maxN, rN_seed, devices, ndevices, pred, n_pred, p_used, viE);
+}
+
+/* the last in-process multi-device call, block by block: rows of (worker, block, upload start, upload end, clustering start, clustering end),
+ * seconds since the call began */
+int sharp_multi_timeline(double *rows, int cap_rows, int *nrows) {
+    MultiTimeline &T = multi_timeline();
+    std::lock_guard<std::mutex> lk(T.mu);
+    const int n = static_cast<int>(T.rows.size() / 6);
+    if (nrows) *nrows = n;
+    if (rows) std::copy(T.rows.begin(), T.rows.begin() + static_cast<size_t>(std::min(n, cap_rows)) * 6, rows);
+    return SHARP_OK;
 }
 
 int sharp_SHARP_unlimited(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,

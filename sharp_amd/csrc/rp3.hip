@@ -21,7 +21,6 @@
 
 namespace sharp {
 
-constexpr int PC_MAX_THREADS = 768;
 // Workgroup shapes (two workgroups per CU either way), chosen per projector group by launch_pc:
 //   A = 8 waves: 2 producers with 3 units in flight each + 6 consumers (128 registers per lane: the 16-lane x 4-slot row lists of K = 15),
 //   B = 12 waves: 4 producers with 2 units in flight + 8 consumers (80 registers per lane: the K = 5 shapes -- 24 waves per CU keep
@@ -407,7 +406,7 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
     Ctx &c = ctx();
     PcWs &W = pws();
     PcParams P = P0;
-    // the workgroup shape (see PC_MAX_THREADS): B for the narrow row lists (K = 5), A for 16 lanes x 4 slots (K = 15) and fp64 blocks
+    // the workgroup shape (above rp_pc_kernel): B for the narrow row lists (K = 5), A for 16 lanes x 4 slots (K = 15) and fp64 blocks
     // (an fp64 unit is 32 registers per lane); SHARP_RP_PC_SHAPE=a / b forces one for fp32 blocks
     const bool wide = g.gw == 16 && g.slots == 4;
     const bool shape_b = !std::is_same<T, double>::value && (knobs().rp_pc_shape == 2 || (knobs().rp_pc_shape == 0 && !wide));

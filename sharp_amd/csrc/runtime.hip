@@ -164,14 +164,17 @@ struct HostPool {
 }  // namespace
 
 namespace {
-// The pool and its job lock live behind pointers so that a forked child can start afresh: the child has the objects but not the
-// threads, and a mutex that another thread of the parent held at fork() time would stay locked forever in the child.
-struct PoolState { HostPool *pool = nullptr; std::mutex *one_job = nullptr; bool atfork = false; };
-PoolState &pool_state() { static PoolState s; return s; }
+// One pool per device slot (the host tails of several GPUs -- one driver thread per slot in sharp_SHARP_unlimited_multi -- run side by
+// side, and each slot has its one driver thread).  Pools, job locks and the table's own lock live behind pointers so that a forked
+// child can start afresh: the child has the objects but not the threads, and a mutex that another thread of the parent held at
+// fork() time would stay locked forever in the child.  Everything is created under the table lock: two slots' first calls may race.
+struct PoolState { HostPool *pool = nullptr; std::mutex *one_job = nullptr; };
+struct PoolTable { std::mutex *mu = new std::mutex; PoolState s[kMaxSlots]; bool atfork = false; };
+PoolTable &pool_table() { static PoolTable *t = new PoolTable; return *t; }   // (never destroyed)
 void pool_atfork_child() {
-    PoolState &S = pool_state();
-    S.pool = nullptr;                                     // the parent's objects are abandoned in the child (their threads do not exist there)
-    S.one_job = new std::mutex;
+    PoolTable &T = pool_table();
+    T.mu = new std::mutex;                                // the parent's objects are abandoned in the child (their threads do not exist there)
+    for (PoolState &S : T.s) { S.pool = nullptr; S.one_job = nullptr; }
 }
 }  // namespace
 
@@ -180,11 +183,17 @@ void host_parallel_for(int n, int max_threads, const std::function<void(int)> &f
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 4;
     if (n == 1 || max_threads <= 1 || hw <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-    PoolState &S = pool_state();
-    if (!S.atfork) { S.atfork = true; S.one_job = new std::mutex; pthread_atfork(nullptr, nullptr, pool_atfork_child); }
-    std::lock_guard<std::mutex> lk(*S.one_job);           // one job at a time (the library is driven from one thread anyway)
-    if (!S.pool) S.pool = new HostPool(static_cast<int>(std::min<unsigned>(hw - 1, 15)));   // leaked on purpose
-    S.pool->parallel_for(n, max_threads, fn);
+    PoolTable &T = pool_table();
+    PoolState *S = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(*T.mu);
+        if (!T.atfork) { T.atfork = true; pthread_atfork(nullptr, nullptr, pool_atfork_child); }
+        S = &T.s[cur_slot()];
+        if (!S->one_job) S->one_job = new std::mutex;
+        if (!S->pool) S->pool = new HostPool(static_cast<int>(std::min<unsigned>(hw - 1, 15)));   // leaked on purpose
+    }
+    std::lock_guard<std::mutex> lk(*S->one_job);          // one job at a time per slot
+    S->pool->parallel_for(n, max_threads, fn);
 }
 
 static double now_s() {
@@ -309,6 +318,40 @@ void reload_knobs() { knobs_storage() = read_knobs(); }
 }  // namespace sharp
 
 namespace sharp {
+// The slot a worker of the in-process multi-GPU run uses: keyed on (device, which occurrence of that device in the caller's list, role),
+// so that a later call with another device list -- {0, 1} then {1, 0}, or the tests' {0, 0} followed by a real {0, 1} -- finds the slots
+// whose workspaces already live on the right GPU instead of rebinding one (a slot never changes its device).  Slot 0 is the caller's.
+int acquire_slot(int device, int occurrence, int role) {
+    static std::mutex mu;
+    static int key[kMaxSlots][3];
+    static int used = 1;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int s = 1; s < used; ++s)
+        if (key[s][0] == device && key[s][1] == occurrence && key[s][2] == role) return s;
+    if (used >= kMaxSlots)
+        throw Error(SHARP_ERR_ARG, "libsharp_hip: out of device slots (" + std::to_string(kMaxSlots - 1) + " worker contexts in one process)");
+    key[used][0] = device; key[used][1] = occurrence; key[used][2] = role;
+    return used++;
+}
+// fn() once for every initialised slot, the calling thread bound to it and to its device; the caller's slot and device are restored
+void for_each_ready_slot(const std::function<void()> &fn) {
+    const int keep = cur_slot();
+    int keep_dev = -1;
+    (void)hipGetDevice(&keep_dev);
+    std::exception_ptr err;
+    for (int s = 0; s < kMaxSlots; ++s) {
+        bind_slot(s);
+        Ctx &c = ctx_unchecked();
+        if (!c.ready) continue;
+        try {
+            SHARP_HIP_CHECK(hipSetDevice(c.device));
+            fn();
+        } catch (...) { if (!err) err = std::current_exception(); }
+    }
+    bind_slot(keep);
+    if (keep_dev >= 0) (void)hipSetDevice(keep_dev);
+    if (err) std::rethrow_exception(err);
+}
 void init_slot(int slot, int device) {
     bind_slot(slot);
     Ctx &c = ctx_unchecked();
@@ -374,12 +417,11 @@ int sharp_init(int device) {
 
 int sharp_shutdown(void) {
     SHARP_API_BEGIN
-    Ctx &c = ctx_unchecked();
-    if (c.ready) {
+    for_each_ready_slot([] {                              // the caller's slot and every worker slot of a multi-GPU run
+        Ctx &c = ctx_unchecked();
         (void)hipStreamSynchronize(c.stream);
         drop_pending_front();
         drain_side_streams();
-        pool_clear();
         for (auto &p : c.pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         c.pending.clear();
         for (auto e : c.event_pool) (void)hipEventDestroy(e);
@@ -390,7 +432,8 @@ int sharp_shutdown(void) {
         for (hipStream_t s : c.aux) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
         c.aux.clear();
         c.ready = false;
-    }
+    });
+    pool_clear();
     SHARP_API_END
 }
 

@@ -21,6 +21,9 @@ struct HostBlock {               // the resident copy of a host matrix; kept bet
     void release() { f.release(); d.release(); }
 };
 
+// the two resident copies an upload slot rotates through (sharp_SHARP_unlimited_multi: block i + W is uploaded while block i is clustered)
+struct HostBlockPair { HostBlock hb[2]; };
+
 // X: m x n column-major doubles, column stride ld >= m (pageable memory).  Threaded narrowing / copying into pinned slabs, DMA'd
 // while the next slab is prepared.
 void upload_block(const double *X, int m, long long n, long long ld, HostBlock &hb);

@@ -95,6 +95,43 @@ def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag
     return pred, means[: G.value].copy(), counts[: G.value].copy()
 
 
+def unlimited_multi_dev(blocks, device_of_block, devices, ensize_K=0, N_cluster=0, minN_cluster=0, maxN_cluster=0, rN_seed=0.5,
+                        viewflag=False):
+    """sharp_SHARP_unlimited_multi_dev: SHARP_unlimited (R/SHARP_unlimited.R:125-183) over blocks that already live on the GPUs of
+    `devices`; blocks[b] is a (cells, genes) row-major tensor (fp32 or fp64) on devices[device_of_block[b]].
+    -> (pred, n_pred, p, viE or None)"""
+    import torch
+
+    B = len(blocks)
+    m = int(blocks[0].shape[1])
+    ptrs = (C.c_void_p * B)(*[b.data_ptr() for b in blocks])
+    f64 = np.array([1 if b.dtype == torch.float64 else 0 for b in blocks], np.int32)
+    ncb = np.array([b.shape[0] for b in blocks], np.int64)
+    ldb = np.array([b.stride(0) for b in blocks], np.int64)
+    dob = np.ascontiguousarray(device_of_block, np.int32)
+    dv = np.ascontiguousarray(devices, np.int32)
+    n = int(ncb.sum())
+    p = int(np.ceil(np.log2(n) / 0.04))
+    pred = np.zeros(n, np.int32)
+    viE = np.zeros((n, p)) if viewflag else None
+    npred, pu = C.c_int(), C.c_int()
+    for b in blocks:
+        torch.cuda.synchronize(b.device)
+    check(lib().sharp_SHARP_unlimited_multi_dev(ptrs, _ip(f64), ncb.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                                ldb.ctypes.data_as(C.POINTER(C.c_longlong)), _ip(dob), B, m, int(ensize_K), int(N_cluster),
+                                                int(minN_cluster), int(maxN_cluster), C.c_double(rN_seed), _ip(dv), len(dv), _ip(pred),
+                                                C.byref(npred), C.byref(pu), _dp(viE) if viE is not None else None), allow=48)
+    return pred, npred.value, pu.value, viE
+
+
+def multi_timeline(cap=4096):
+    """sharp_multi_timeline: rows of (worker, block, upload start, upload end, clustering start, clustering end) of the last multi-device call"""
+    rows = np.zeros((cap, 6))
+    n = C.c_int()
+    check(lib().sharp_multi_timeline(_dp(rows), cap, C.byref(n)))
+    return rows[:min(n.value, cap)]
+
+
 def unlimited_merge(means, counts, ncells, N_cluster=0, minN_cluster=0, maxN_cluster=0):
     """Cross-block sMetaC on gathered centroids -> final 1-based id per (block, cluster) row."""
     _lib.ensure_init()
