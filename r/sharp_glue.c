@@ -139,12 +139,82 @@ SEXP R_sharp_unlimited(SEXP blocks, SEXP ipar, SEXP seed, SEXP viewflag_) {
     return out;
 }
 
+/* SHARP_unlimited() over the GPUs of `devices` inside this R process, the list read in place (R/SHARP_unlimited.R:125-163: the block loop
+ * dealt out, block b to devices[b mod N]).  blocks = list whose elements are numeric matrices (genes x cells) or lists
+ * list(p = <@p>, i = <@i>, x = <@x>, dim = <@Dim>) made from a Matrix::dgCMatrix by r/sharp_hip.R::.sharp_block -- all dense or all
+ * sparse; devices = integer vector of GPU indices (length 0: the library's own choice: its current GPU, or SHARP_DEVICES).  Nothing is
+ * copied on the R side and no vector length passes through an int: a 162 500 x 27 000 block (4.39e9 doubles) goes through, which
+ * .C() -- whose arguments are duplicated and may not be long vectors -- cannot carry.
+ * ipar = ensize.K, N.cluster, minN.cluster, maxN.cluster */
+static SEXP list_elt(SEXP lst, const char *name) {
+    SEXP nm = getAttrib(lst, R_NamesSymbol);
+    for (R_xlen_t q = 0; q < XLENGTH(lst); ++q)
+        if (nm != R_NilValue && strcmp(CHAR(STRING_ELT(nm, q)), name) == 0) return VECTOR_ELT(lst, q);
+    return R_NilValue;
+}
+SEXP R_sharp_unlimited_multi(SEXP blocks, SEXP ipar, SEXP seed, SEXP viewflag_, SEXP devices) {
+    const int nb = LENGTH(blocks), *ip = INTEGER(ipar), viewflag = asLogical(viewflag_), ndev = LENGTH(devices);
+    if (nb < 1) error("No expression data is provided!");
+    const int sparse = isNewList(VECTOR_ELT(blocks, 0));
+    long long *ncb = (long long *)R_alloc((size_t)nb, sizeof(long long));
+    const double **ptrs = (const double **)R_alloc((size_t)nb, sizeof(double *));      /* dense: the matrices; sparse: the @x slots */
+    const int **cp = (const int **)R_alloc((size_t)nb, sizeof(int *)), **ri = (const int **)R_alloc((size_t)nb, sizeof(int *));
+    long long ncells = 0;
+    int m = -1;
+    for (int b = 0; b < nb; ++b) {
+        SEXP B = VECTOR_ELT(blocks, b);
+        if (sparse != isNewList(B)) error("The input should be a LIST of partitioned scRNA-seq expression matrices!");
+        if (sparse) {
+            SEXP P = list_elt(B, "p"), I = list_elt(B, "i"), X = list_elt(B, "x"), D = list_elt(B, "dim");
+            if (!isInteger(P) || !isInteger(I) || !isReal(X) || !isInteger(D) || LENGTH(D) != 2 || XLENGTH(P) != (R_xlen_t)INTEGER(D)[1] + 1)
+                error("The input should be a LIST of partitioned scRNA-seq expression matrices!");
+            if (m < 0) m = INTEGER(D)[0];
+            if (INTEGER(D)[0] != m) error("The input should be a LIST of partitioned scRNA-seq expression matrices!");
+            cp[b] = INTEGER(P); ri[b] = INTEGER(I); ptrs[b] = REAL(X); ncb[b] = INTEGER(D)[1];
+        } else {
+            if (!isReal(B)) error("The input should be a LIST of partitioned scRNA-seq expression matrices!");
+            if (m < 0) m = nrows(B);
+            if (nrows(B) != m) error("The input should be a LIST of partitioned scRNA-seq expression matrices!");
+            ptrs[b] = REAL(B); ncb[b] = ncols(B);
+        }
+        ncells += ncb[b];
+    }
+    const int p = (int)ceil(log2((double)ncells) / 0.04);
+    SEXP pred = PROTECT(allocVector(INTSXP, (R_xlen_t)ncells));
+    SEXP viE = PROTECT(allocVector(REALSXP, viewflag ? (R_xlen_t)ncells * p : 1));
+    int npred = 0, pu = 0;
+    if (sparse)
+        chk(sharp_SHARP_unlimited_csc_multi(cp, ri, ptrs, ncb, nb, m, ip[0], ip[1], ip[2], ip[3], asReal(seed), ndev ? INTEGER(devices) : NULL,
+                                            ndev, INTEGER(pred), &npred, &pu, viewflag ? REAL(viE) : NULL));
+    else if (ndev >= 1)
+        chk(sharp_SHARP_unlimited_multi(ptrs, ncb, nb, m, ip[0], ip[1], ip[2], ip[3], asReal(seed), INTEGER(devices), ndev, INTEGER(pred),
+                                        &npred, &pu, viewflag ? REAL(viE) : NULL));
+    else
+        chk(sharp_SHARP_unlimited_view(ptrs, ncb, nb, m, ip[0], ip[1], ip[2], ip[3], asReal(seed), INTEGER(pred), &npred, &pu,
+                                       viewflag ? REAL(viE) : NULL));
+    const char *names[] = {"pred", "viE", "p", ""};
+    SEXP out = PROTECT(mkNamed(VECSXP, names));
+    SET_VECTOR_ELT(out, 0, pred);
+    if (viewflag) {
+        SEXP v = PROTECT(allocMatrix(REALSXP, (int)ncells, pu));
+        const double *s = REAL(viE);
+        double *d = REAL(v);
+        for (long long i = 0; i < ncells; ++i) for (int c = 0; c < pu; ++c) d[(size_t)c * (size_t)ncells + (size_t)i] = s[(size_t)i * pu + c];
+        SET_VECTOR_ELT(out, 1, v);
+        UNPROTECT(1);
+    }
+    SET_VECTOR_ELT(out, 2, ScalarInteger(pu));
+    UNPROTECT(3);
+    return out;
+}
+
 static const R_CallMethodDef call_methods[] = {
     {"R_sharp_init", (DL_FUNC)&R_sharp_init, 1},
     {"R_sharp_trim", (DL_FUNC)&R_sharp_trim, 0},
     {"R_sharp_SHARP", (DL_FUNC)&R_sharp_SHARP, 4},
     {"R_sharp_SHARP_csc", (DL_FUNC)&R_sharp_SHARP_csc, 7},
     {"R_sharp_unlimited", (DL_FUNC)&R_sharp_unlimited, 4},
+    {"R_sharp_unlimited_multi", (DL_FUNC)&R_sharp_unlimited_multi, 5},
     {NULL, NULL, 0}};
 
 void R_init_sharp_glue(DllInfo *dll) {

@@ -204,30 +204,48 @@ sMetaC <- function(rerowColor, sE1, folds, hmethod, finalN.cluster, minN.cluster
 # N.genes, reduced.dim, ensize.K, time, paras).  SHARP_small / SHARP_large are the same call with base.ncells = ncells + 1 / 1.
 
 # ---- SHARP_unlimited (R/SHARP_unlimited.R:29-242): replaces :96-183 -----------------------------------------------------------
-# devices: integer vector of GPU indices (default: getOption("sharp.devices"), e.g. options(sharp.devices = 0:7)); with two or more the
-# serial block loop of :125-163 is dealt out, block b to devices[b mod N], inside this R process (sharp_SHARP_unlimited_multi: one host
-# thread and one device context per GPU, nothing crosses between GPUs but the per-block centroid tables).  The .C() route carries the list.
+# devices: integer vector of GPU indices (default: getOption("sharp.devices"), e.g. options(sharp.devices = 0:7)); the serial block loop
+# of :125-163 is dealt out, block b to devices[b mod N], inside this R process (sharp_SHARP_unlimited_multi: per GPU one host thread that
+# clusters and one that uploads the next block meanwhile; nothing crosses between GPUs but the per-block centroid tables).
+# With the .Call glue loaded (r/sharp_glue.c) the list -- numeric matrices or Matrix::dgCMatrix blocks -- is read in place by
+# R_sharp_unlimited_multi, whatever the number of devices.  The .C() fallback duplicates its arguments, needs the blocks unlist()-ed into
+# ONE vector and does not take long vectors: it carries at most 2^31 - 1 values per call (a list of 1.3 M cells x 27 000 genes, 3.5e10
+# values, cannot pass -- one cfg4 block, 4.39e9, already cannot), i.e. it is for small inputs and for installations without a compiler.
+.sharp_block <- function(b) {                          # a block as the glue takes it: a double matrix, or the slots of a dgCMatrix
+    if (inherits(b, "dgCMatrix")) list(p = b@p, i = b@i, x = b@x, dim = b@Dim)
+    else if (inherits(b, "sparseMatrix")) { b <- methods::as(b, "CsparseMatrix"); list(p = b@p, i = b@i, x = as.double(b@x), dim = b@Dim) }
+    else .sharp_dmat(b)
+}
 .sharp_unlimited_run <- function(scExp, ensize.K, N.cluster, minN.cluster, maxN.cluster, rN.seed, viewflag,
                                  devices = getOption("sharp.devices")) {
     nb <- length(scExp); m <- nrow(scExp[[1]])
     ncb <- vapply(scExp, ncol, 1)
     ncells <- sum(ncb)
     p <- ceiling(log2(ncells)/(0.2^2))
-    if (length(devices) >= 2) {
-        r <- .C("sharp_C_SHARP_unlimited_multi", unlist(lapply(scExp, function(b) as.double(data.matrix(b)))), nb, as.double(ncb), m,
-                .sharp_int(ensize.K), .sharp_int(N.cluster), .sharp_int(minN.cluster), .sharp_int(maxN.cluster), as.double(rN.seed),
-                as.integer(devices), length(devices), pred = integer(ncells), viE = double(if (viewflag) ncells * p else 1),
-                info = integer(2), as.integer(viewflag), status = integer(1))
+    ipar <- c(.sharp_int(ensize.K), .sharp_int(N.cluster), .sharp_int(minN.cluster), .sharp_int(maxN.cluster))
+    sparse <- all(vapply(scExp, function(b) inherits(b, "sparseMatrix"), TRUE))
+    if (.sharp_has_glue()) {
+        blocks <- if (sparse) lapply(scExp, .sharp_block) else lapply(scExp, .sharp_dmat)
+        r <- .Call("R_sharp_unlimited_multi", blocks, ipar, as.double(rN.seed), as.logical(viewflag), as.integer(devices))
+    } else if (sparse) {
+        cs <- lapply(scExp, .sharp_block)
+        if (sum(as.numeric(vapply(cs, function(b) length(b$x), 1))) >= 2^31) stop("SHARP_unlimited: this input needs the .Call glue (r/sharp_glue.c): .C() carries at most 2^31 - 1 values")
+        r <- .C("sharp_C_SHARP_unlimited_csc", unlist(lapply(cs, `[[`, "p")), unlist(lapply(cs, `[[`, "i")), unlist(lapply(cs, `[[`, "x")), nb,
+                as.double(ncb), m, ipar[1], ipar[2], ipar[3], ipar[4], as.double(rN.seed), as.integer(c(devices, 0L)), length(devices),
+                pred = integer(ncells), viE = double(if (viewflag) ncells * p else 1), info = integer(2), as.integer(viewflag), status = integer(1))
         .sharp_check(r$status)
         r <- list(pred = r$pred, viE = if (viewflag) t(matrix(r$viE, nrow = p)) else NULL, p = r$info[2])
-    } else if (.sharp_has_glue()) {
-        r <- .Call("R_sharp_unlimited", lapply(scExp, .sharp_dmat), c(.sharp_int(ensize.K), .sharp_int(N.cluster), .sharp_int(minN.cluster),
-                                                                       .sharp_int(maxN.cluster)), as.double(rN.seed), as.logical(viewflag))
     } else {
-        r <- .C("sharp_C_SHARP_unlimited", unlist(lapply(scExp, function(b) as.double(data.matrix(b)))), nb, as.double(ncb), m,
-                .sharp_int(ensize.K), .sharp_int(N.cluster), .sharp_int(minN.cluster), .sharp_int(maxN.cluster), as.double(rN.seed),
-                pred = integer(ncells), viE = double(if (viewflag) ncells * p else 1), info = integer(2), as.integer(viewflag),
-                status = integer(1))
+        if (as.numeric(m) * ncells >= 2^31) stop("SHARP_unlimited: this input needs the .Call glue (r/sharp_glue.c): .C() carries at most 2^31 - 1 values")
+        xcat <- unlist(lapply(scExp, function(b) as.double(data.matrix(b))))
+        if (length(devices) >= 2)
+            r <- .C("sharp_C_SHARP_unlimited_multi", xcat, nb, as.double(ncb), m, ipar[1], ipar[2], ipar[3], ipar[4], as.double(rN.seed),
+                    as.integer(devices), length(devices), pred = integer(ncells), viE = double(if (viewflag) ncells * p else 1),
+                    info = integer(2), as.integer(viewflag), status = integer(1))
+        else
+            r <- .C("sharp_C_SHARP_unlimited", xcat, nb, as.double(ncb), m, ipar[1], ipar[2], ipar[3], ipar[4], as.double(rN.seed),
+                    pred = integer(ncells), viE = double(if (viewflag) ncells * p else 1), info = integer(2), as.integer(viewflag),
+                    status = integer(1))
         .sharp_check(r$status)
         r <- list(pred = r$pred, viE = if (viewflag) t(matrix(r$viE, nrow = p)) else NULL, p = r$info[2])
     }
