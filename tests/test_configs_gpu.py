@@ -198,6 +198,61 @@ def test_full_size_block_matches_oracle(env, oracle):
     assert np.array_equal(pred, ref["pred_clusters"])
 
 
+def test_cfg2_full_size_matches_oracle(env, oracle):
+    """BASELINE.json configs[1] whole: 50 000 x 20 000, ensize.K = 15, p = 391 (the reduced dimension SHARP() derives from 50 000 cells),
+    SHARP_large with 375 base tasks: labels identical to the oracle's, cell for cell (R/SHARP.R:478-851)."""
+    sa, dev, torch = env
+    n, m, K = 50000, 20000, 15
+    dX = torch.empty((n, m), dtype=torch.float32, device="cuda")
+    dev.synth_fill(dX, SEED, 0)
+    pred, info = dev.SHARP_dev(dX, ensize_K=K, rN_seed=RN)
+    assert info["path"] == "SHARP_large" and info["reduced.dim"] == 391
+    X = dX.cpu().numpy().T.astype(np.float64)                             # (genes, cells), column-major: 8 GB
+    del dX
+    torch.cuda.empty_cache()
+    cores = min(len(os.sched_getaffinity(0)), 64)                         # 375 tasks; every thread holds a 320 MB fold copy
+    t0 = time.perf_counter()
+    ref = oracle.SHARP(X, K=K, rN_seed=RN, nthreads=cores, want_view=False)
+    print("oracle: %.1f s on %d threads (%.0f cells/s)" % (time.perf_counter() - t0, cores, n / (time.perf_counter() - t0)))
+    assert ref["rc"] in (0, 16)
+    assert info["N.pred_cluster"] == ref["pred_clusters"].max()
+    assert np.array_equal(pred, ref["pred_clusters"])
+
+
+def test_cfg1_shaped_call_matches_oracle(env, oracle):
+    """BASELINE.json configs[0] is the reference's own example (479 cells of TPM values, default ensize.K = 15, rN.seed = 2103,
+    README.md:88-114); its data blob is not in the repository, so the SHAPE is run: 479 cells x 20 000 genes of TPM-like doubles,
+    p = ceiling(log2(479) / 0.04) = 223, prep = TRUE (all-zero genes removed, R/SHARP.R:104-106), testlog with fixed cells (:877-924),
+    SHARP_small (:339-454) -- labels, viE, x0 and allrpinfo against the oracle on the same prepared matrix."""
+    sa, dev, torch = env
+    n, m, K = 479, 20000, 15
+    X = oracle.synth_fill(SEED, m, 0, n, 5, 1500)
+    X = X / np.maximum(X.sum(0, keepdims=True), 1.0) * 1e6               # TPM: non-fp32-exact doubles -> an fp64 block in HBM
+    X[[17, 4040, 19999]] = 0.0                                            # all-zero genes
+    cells = np.arange(0, n, 5)[:90]
+    res = sa.SHARP(X, exp_type="TPM", prep=True, rN_seed=RN, forview=True, testlog_cells=cells)
+    assert sa.lib().sharp_x_storage() == 64
+    assert res["path"] == "SHARP_small" and res["paras"]["ensize.K"] == K and res["reduced.dim"] == 223 and res["N.cells"] == n
+    keep = X.sum(1) != 0
+    assert res["N.genes"] == int(keep.sum()) == m - 3
+    Xp = X[keep]
+    flag_ref, _ms = oracle.testlog(Xp, 223, cells)
+    assert bool(res["paras"]["logmark"]) == flag_ref
+    ref = oracle.SHARP_small(Xp, K=K, p=223, flag=flag_ref, rN_seed=RN, want_view=True)
+    assert ref["rc"] in (0, 16)
+    assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+    np.testing.assert_allclose(res["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
+    np.testing.assert_allclose(res["x0"], ref["x0"], rtol=0, atol=1e-15)
+    rp = res["allrpinfo"]
+    assert len(rp) == K
+    from sharp_amd.api import colorL
+    for k in range(K):
+        e = oracle.project(Xp, oracle.ranM(Xp.shape[0], 223, 50 + RN + k + 1), flag_ref)
+        np.testing.assert_allclose(rp[k]["indE"], e, rtol=0, atol=2e-12 * np.abs(e).max())
+        assert rp[k]["rowColor"] == [colorL[j - 1] for j in ref["enrp"][:, k]]
+        assert rp[k]["N.cluster"] == len(set(rp[k]["rowColor"]))
+
+
 def test_upper_triangle_agglomeration_at_cfg2_size(env, monkeypatch):
     """BASELINE.json configs[1] (50 000 x 20 000, ensize.K = 15: 375 base tasks of 2000 cells in two chunks of one task per CU) with the
     upper-triangle agglomeration kernel (SHARP_HC_TRI=1) and with the default full-matrix one: every task done by the bulk-synchronous
