@@ -234,7 +234,7 @@ def test_cfg1_shaped_call_matches_oracle(env, oracle):
     assert sa.lib().sharp_x_storage() == 64
     assert res["path"] == "SHARP_small" and res["paras"]["ensize.K"] == K and res["reduced.dim"] == 223 and res["N.cells"] == n
     keep = X.sum(1) != 0
-    assert res["N.genes"] == int(keep.sum()) == m - 3
+    assert res["N.genes"] == m and int(keep.sum()) == m - 3                 # (N.genes is taken before prep, R/SHARP.R:56,293)
     Xp = X[keep]
     flag_ref, _ms = oracle.testlog(Xp, 223, cells)
     assert bool(res["paras"]["logmark"]) == flag_ref
