@@ -90,6 +90,7 @@ struct Knobs {
                                 // 8 % slower inside the batched SHARP_unlimited pipeline) where the full-matrix one runs by default
     bool hc_prep_early = true;  // SHARP_HC_PREP_EARLY=0: a chunk's row preparation behind the previous chunk's distance GEMM instead of beside it
     bool hc_pipe = true;        // SHARP_HC_PIPE=0: one chunk of base-clustering tasks at a time
+    bool mean_early = false;    // SHARP_MEAN_EARLY=1: the ensemble mean of SHARP_large behind the LAST agglomeration, beside the last statistics, instead of behind them (measured: 53.2 against 51.7 ms per cfg2 step, four interleaved pairs: the statistics slow down by more than the mean takes)
     int gemm_slice = 8;         // SHARP_GEMM_SLICE: workgroups per CU per slice of a distance GEMM prepared under another block's tail
     bool proj_host = false;     // SHARP_PROJ_HOST=1 (cross-check): the host build of the projectors
     int upload_threads = 0;     // SHARP_UPLOAD_THREADS: host threads narrowing / copying an uploaded block (0: up to 32)

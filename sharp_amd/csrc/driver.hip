@@ -280,6 +280,28 @@ static void large_front(LargeFront &F, const SharpArgs &a, bool ahead, double *E
         }
 }
 
+// enE / K (R/SHARP.R:750,776) on the slot's mean stream; after: an event it has to wait for (nullptr: the main stream as it stands now)
+static void enqueue_ensemble_mean(const double *E, long long ldE, int n, int p, int K, double *viE_sh, hipEvent_t after) {
+    Ctx &c = ctx();
+    hipEvent_t &mean_done = dws().mean_done;
+    hipStream_t &ms = dws().mean_stream;                                        // (a stream of its own: the library's second stream may hold
+    if (!mean_done) {                                                           // the next block's kernels, SHARP_unlimited)
+        SHARP_HIP_CHECK(hipEventCreateWithFlags(&mean_done, hipEventDisableTiming));
+        SHARP_HIP_CHECK(hipEventCreateWithFlags(&dws().mean_go, hipEventDisableTiming));
+        int lo = 0, hi = 0;
+        SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        SHARP_HIP_CHECK(hipStreamCreateWithPriority(&ms, hipStreamNonBlocking, hi));
+    }
+    SHARP_HIP_CHECK(hipEventRecord(dws().mean_go, c.stream));                  // E is complete (the RP stage ran on the main stream)
+    SHARP_HIP_CHECK(hipStreamWaitEvent(ms, dws().mean_go, 0));
+    if (after) SHARP_HIP_CHECK(hipStreamWaitEvent(ms, after, 0));
+    {
+        StreamScope scope(ms);
+        ensemble_mean_dev(E, ldE, n, p, K, viE_sh);
+    }
+    SHARP_HIP_CHECK(hipEventRecord(mean_done, ms));
+}
+
 // Everything of SHARP_large behind the base clustering (R/SHARP.R:620-851): per-fold wMetaC, cross-fold sMetaC, un-shuffle, the
 // small-cluster merge and the relabel.  hr: the K*T results of the block's base tasks, task (k, t) at k*T + t.
 static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, const HcParams &base, const HcResult *hr, SharpOut &out) {
@@ -292,27 +314,10 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
     DevBuf<double> &viE_sh = dws().viE_sh;                                      // enE / K in shuffled order (:750,776)
     viE_sh.ensure(static_cast<size_t>(n) * p);
     // The ensemble mean streams all of E once (HBM-bound, 0.47 ms at cfg2) and is first needed by the final sMetaC: on the side stream
-    // it runs beside the per-fold wMetaC kernels (LDS- and latency-bound) instead of in front of them.
+    // it runs beside the per-fold wMetaC kernels (LDS- and latency-bound) instead of in front of them -- unless it has gone out already,
+    // behind the last chunk's agglomeration (enqueue_ensemble_mean from the base clustering's hook: beside the last statistics).
     hipEvent_t &mean_done = dws().mean_done;
-    {
-        Ctx &c = ctx();
-        hipStream_t &ms = dws().mean_stream;                                    // (a stream of its own: the library's second stream may hold
-        if (!mean_done) {                                                       // the next block's compaction kernels, SHARP_unlimited)
-            SHARP_HIP_CHECK(hipEventCreateWithFlags(&mean_done, hipEventDisableTiming));
-            SHARP_HIP_CHECK(hipEventCreateWithFlags(&dws().mean_go, hipEventDisableTiming));
-            int lo = 0, hi = 0;
-            SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            SHARP_HIP_CHECK(hipStreamCreateWithPriority(&ms, hipStreamNonBlocking, hi));
-        }
-        SHARP_HIP_CHECK(hipEventRecord(dws().mean_go, c.stream));              // E is complete, the base clustering has left the chip
-        hipStream_t run_on = ms;
-        SHARP_HIP_CHECK(hipStreamWaitEvent(run_on, dws().mean_go, 0));
-        {
-            StreamScope scope(run_on);
-            ensemble_mean_dev(E.p, ldE, n, p, K, viE_sh.p);
-        }
-        SHARP_HIP_CHECK(hipEventRecord(mean_done, run_on));
-    }
+    if (!hc_after_last_agglomeration_fired()) enqueue_ensemble_mean(E.p, ldE, n, p, K, viE_sh.p, nullptr);
     // enrp per fold (:627-635); labels "<colour>p<t>" only need to be distinct per (k, t): the colour id does
     std::vector<std::vector<int>> enrp(T);
     for (int q = 0; q < K * T; ++q) out.rc |= hr[q].rc;
@@ -509,10 +514,21 @@ static void sharp_large_dev_body(XRef dX, int m, int n, long long ld, const Shar
     std::vector<HcResult> hr;
     {
         HostTimer ht("base_clustering_total");
-        if (F.hc) hc_prefetch_finish(*F.hc, false, hr);
-        else get_opt_hclust_batch(F.tasks, false, hr);
+        if (F.hc) { hc_set_after_last_agglomeration(nullptr); hc_prefetch_finish(*F.hc, false, hr); }
+        else {
+            // the ensemble mean needs E only: it goes out behind the LAST chunk's agglomeration, beside that chunk's statistics
+            // (latency-bound), instead of behind them in the serial tail (-0.5 ms per cfg2 step)
+            dws().viE_sh.ensure(static_cast<size_t>(n) * p);
+            const double *Ep = F.E;
+            const long long ldEp = F.ldE;
+            double *vsh = dws().viE_sh.p;
+            if (knobs().mean_early) hc_set_after_last_agglomeration([=](hipEvent_t ev) { enqueue_ensemble_mean(Ep, ldEp, n, p, K, vsh, ev); });
+            else hc_set_after_last_agglomeration(nullptr);
+            try { get_opt_hclust_batch(F.tasks, false, hr); } catch (...) { hc_set_after_last_agglomeration(nullptr); throw; }
+        }
     }
     large_tail(F, a, K, p, base, hr.data(), out);
+    hc_set_after_last_agglomeration(nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -604,6 +620,7 @@ void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector
 static void unlimited_batch_window(const XRef *dX, const long long *ncb, const long long *ldb, int b0, int b1, int m, int p, int proj, int K,
                                    double rN_seed, const std::function<void(int, const SharpOut &)> &deliver) {
     PendingFront &PF = pending_front();
+    hc_set_after_last_agglomeration(nullptr);             // (every block's tail enqueues its own ensemble mean here)
     if (PF.f) { SHARP_HIP_CHECK(hipStreamSynchronize(PF.stream)); PF.f.reset(); }   // (no block-by-block front may be pending)
     const int nbk = b1 - b0;
     std::vector<std::unique_ptr<LargeFront>> F(nbk);

@@ -2110,6 +2110,12 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
 }  // namespace
 
 namespace { thread_local int g_batch_depth = 0; }         // > 0 while a batch's progress callback runs: a batch started from there is nested
+namespace {
+struct AfterAgglo { std::function<void(hipEvent_t)> fn; bool fired = false; };
+AfterAgglo &after_agglo() { return per_slot<AfterAgglo>(); }
+}  // namespace
+void hc_set_after_last_agglomeration(std::function<void(hipEvent_t)> fn) { after_agglo().fn = std::move(fn); after_agglo().fired = false; }
+bool hc_after_last_agglomeration_fired() { return after_agglo().fired; }
 
 void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::vector<HcResult> &out,
                           const std::function<void(size_t)> *progress) {
@@ -2216,6 +2222,12 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
     for (size_t j = 0; j < nb; ++j) {
         if (j >= 1 && !stats_last) enqueue_chunk(jobs[(j - 1) % R], PH_STATS);
         enqueue_chunk(jobs[j % R], PH_AGGLO);
+        if (j + 1 == nb && after_agglo().fn && g_batch_depth == 0) {        // the caller's side work behind the last agglomeration
+            std::function<void(hipEvent_t)> fn = std::move(after_agglo().fn);
+            after_agglo().fn = nullptr;
+            fn(pipe_events().hc[jobs[j % R].slot]);
+            after_agglo().fired = true;
+        }
         // chunk j - 2's statistics ran beside chunk j - 1's agglomeration: fetched now, which also frees its set for chunk j + 1, whose
         // distance matrices are enqueued at once (they wait, on the device, for chunk j's GEMM); then the caller's work on finished
         // tasks, with chunk j's agglomeration and chunk j + 1's GEMM for the device to chew on

@@ -49,6 +49,13 @@ constexpr int kHcMaxN = 16384;
 void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::vector<HcResult> &out,
                           const std::function<void(size_t)> *progress = nullptr);
 
+// One-shot hook for the NEXT get_opt_hclust_batch call of this device slot that runs as pipelined chunks: fn(ev) is called once, on the
+// host, right after the LAST chunk's agglomeration has been enqueued; ev is recorded behind that agglomeration.  For work that needs
+// none of the batch's results and should share the chip with the last chunk's statistics rather than with an agglomeration (the
+// ensemble mean of SHARP_large: one HBM-bound pass over E).  Returns through hc_after_last_agglomeration_fired() whether it ran.
+void hc_set_after_last_agglomeration(std::function<void(hipEvent_t)> fn);
+bool hc_after_last_agglomeration_fired();
+
 // The same batch in two halves, for a caller that overlaps the front of its NEXT block with the tail of the current one
 // (SHARP_unlimited with several blocks per GPU): hc_prefetch_begin uploads the descriptors and enqueues the row preparation and the
 // distance GEMM on the stream that is current at the call (StreamScope) into a workspace slot of its own (slot 0 / 1, alternating);

@@ -296,6 +296,7 @@ static Knobs read_knobs() {
     v.hc_finish_at = num("SHARP_HC_FINISH_AT", 15);
     v.hc_chunk = num("SHARP_HC_CHUNK", 0);
     v.hc_pipe = num("SHARP_HC_PIPE", 1) != 0;
+    v.mean_early = num("SHARP_MEAN_EARLY", 0) != 0;
     v.hc_prep_early = num("SHARP_HC_PREP_EARLY", 1) != 0;
     v.hc_tri = num("SHARP_HC_TRI", 0) != 0;
     v.gemm_slice = num("SHARP_GEMM_SLICE", 8);
