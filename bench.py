@@ -549,7 +549,7 @@ def cpu_baseline(np, dX, m, K):
                       "the K*T task grid; best of %s threads = %d, of the %d cores this process may use), %.1f s"
                       % (ns, m, folds, K, folds * K, "/".join(str(c) for c in sorted(tried)), cores, avail, t)}
     return base, {"ari_gpu_vs_oracle_on_sample": round(ari, 4), "sample_cells": ns,
-                  "full_size": "tests/test_configs_gpu.py::test_full_size_block_matches_oracle: a whole 50 000 x 20 000 block, labels identical"}
+                  "full_size": "tests/test_configs_gpu.py::test_cfg2_full_size_matches_oracle: this workload whole (50 000 x 20 000, K = 15, 375 base tasks), labels identical to the oracle's; ::test_full_size_block_matches_oracle: the same block at K = 5"}
 
 
 if __name__ == "__main__":

@@ -57,7 +57,7 @@ with open(os.path.join(prof, tag + "_pmc_hbm_traffic.csv"), "w") as fh:
              "hbm_bytes_total(2xFETCH gfx950 correction + WRITE),hbm_bytes_per_SHARP_call\n" % steps)
     for r in rows:
         fh.write(",".join(str(x) for x in r) + "\n")
-rp = [r for r in rows if "rp_compact_kernel" in r[0] or "rp_apply_kernel" in r[0]]
+rp = [r for r in rows if "rp_compact_kernel" in r[0] or "rp_apply_kernel" in r[0] or "rp_pc_kernel" in r[0]]
 if rp:
     per_call = sum(r[5] for r in rp)
     launches = {r[0]: r[1] // steps for r in rp}
@@ -65,7 +65,7 @@ if rp:
                "hbm_bytes_per_kernel_per_SHARP_call": {r[0]: r[5] for r in rp},
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python3 bench.py --steps 3 --warmup 1 "
                          "--no-cpu-baseline` (tools/profile_round.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports "
-                         "half of wide coalesced reads); summed over the compact+apply launches of one RP stage (one SHARP() call)",
+                         "half of wide coalesced reads); summed over the RP stage's launches of one SHARP() call (rp_pc_kernel: one launch; the two-kernel form: compact + apply launches)",
                "workload": "bench.py default (50000 cells x 20000 genes, K=15, p=391)"},
               open(os.path.join(prof, "rp_traffic.json"), "w"), indent=1)
     print("rp traffic per SHARP call: %.3f GB" % (per_call / 1e9))
