@@ -293,6 +293,16 @@ int sharp_marker_genes(const double *X, int m, long long n, long long ld, const 
                        double *out);
 int sharp_marker_genes_dev(const float *dX, int m, long long n, long long ld, const int *label, int n_cluster, double theta, int ng,
                            double *out);
+/* The same per-gene pass over the cells of a LIST of blocks, as get_marker_genes_unlimited runs it on the list SHARP_unlimited
+ * clustered (R/get_marker_genes_unlimited.R:95-118: a gene's values across every block, one rank over all cells; ng = 1 there) and as
+ * get_marker_genes_unlimited2 runs it (R/get_marker_genes_unlimited2.R:152-190, ng = min(10, N.cluster)).  label: the labels of all
+ * cells in block order.  _dev: resident fp32 blocks (m x ncb[b], column stride ldb[b]); _csc: dgCMatrix blocks on the host
+ * (colptr[b] = @p, rowidx[b] = @i, val[b] = @x) -- the stored entries go over as they are and are scattered straight into the
+ * per-gene lists of non-zero cells, no dense block is built.  Values are compared as fp32, like sharp_marker_genes. */
+int sharp_marker_genes_blocks_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                                  const int *label, int n_cluster, double theta, int ng, double *out);
+int sharp_marker_genes_blocks_csc(const int *const *colptr, const int *const *rowidx, const double *const *val, const long long *ncb,
+                                  int nblocks, int m, const int *label, int n_cluster, double theta, int ng, double *out);
 
 /* ---- synthetic inputs (bench / tests; not part of the reference) ------------ */
 /* Counter-based generator, value = f(seed, gene, cell): bit-identical to

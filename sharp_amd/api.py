@@ -4,6 +4,7 @@ Function names, argument names/meaning and error behaviour follow the R package
 (dots in R argument names become underscores).  Everything is computed by
 libsharp_hip.so through ctypes; arrays are numpy on the host boundary."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -717,6 +718,108 @@ def get_marker_genes(scExp, y, theta=1e-4, auc=0.7, pvalue=0.01, FC=2, ng=1, n_c
     rows = np.array([idx[nm] for nm in s["gene"].tolist()], dtype=np.int64)
     return {"mginfo": s, "gallinfo": gall, "mat": X[rows] if rows.size else X[:0], "label": label,
             "logmark": (y.get("paras", {}) or {}).get("logmark") if isinstance(y, dict) else None}
+
+
+def _marker_select(out, names, theta, auc, pvalue, ncols=4):
+    """R/get_marker_genes_unlimited.R:131-146 (the same lines in _unlimited2 :193-214): sparsity / NaN filters, Holm adjustment,
+    adauc = min(auc, min over clusters of the best auc), selection by adjusted p-value and auc."""
+    cols = {"gene": names, "auc": out[:, 0], "icluster": out[:, 1].astype(np.int64), "pvalue": out[:, 2].copy(), "sparsity": out[:, 3]}
+    sel = (cols["sparsity"] > theta) & ~np.isnan(cols["pvalue"])
+    g = {k: v[sel] for k, v in cols.items()}
+    g["pvalue"] = _p_adjust_holm(g["pvalue"])
+    gall = {k: v.copy() for k, v in g.items()}
+    if g["auc"].size:
+        adauc = min(auc, min(g["auc"][g["icluster"] == c].max() for c in np.unique(g["icluster"])))
+    else:
+        adauc = auc
+    pick = (g["pvalue"] < pvalue) & (g["auc"] > adauc)
+    return {k: v[pick] for k, v in g.items()}, gall
+
+
+def _marker_labels(y):
+    pred = np.asarray(y["pred_clusters"] if isinstance(y, dict) else y)
+    uy = np.unique(pred)                                                  # the index among the unique ids (R: match(y$pred_clusters, uy))
+    return (np.searchsorted(uy, pred) + 1).astype(np.int32), int(uy.size)
+
+
+def get_marker_genes_unlimited(scExp, y, theta=1e-5, auc=0.85, pvalue=0.01, n_cores=None, gene_names=None):
+    """R/get_marker_genes_unlimited.R:25-187.  scExp: the LIST of (genes, cells) blocks SHARP_unlimited clustered (dense arrays or
+    scipy.sparse matrices standing in for the reference's dgCMatrix blocks); y: its result.  Genes that are zero in every block are
+    dropped (:44-57); per remaining gene the values across all blocks are ranked over ALL cells, the cluster of highest mean rank
+    gets the Wilcoxon p-value and the AUROC (:95-118; sharp_marker_genes_blocks_*: one pass per block into per-gene lists of non-zero
+    cells, one segmented sort, one statistics pass); Holm adjustment and selection :131-146.
+    Returns dict(mginfo, mat, label): mat = the selected genes' rows across all cells (:151-155)."""
+    _lib.ensure_init()
+    if not isinstance(scExp, (list, tuple)) or len(scExp) < 1:
+        raise SharpError("The input should be a LIST of partitioned scRNA-seq expression matrices!")
+    label, G = _marker_labels(y)
+    sparse = all(_is_sparse(b) for b in scExp)
+    m = scExp[0].shape[0]
+    ncb = np.array([b.shape[1] for b in scExp], np.int64)
+    if int(ncb.sum()) != label.size:
+        raise SharpError("get_marker_genes_unlimited: the labels do not match the blocks' cells")
+    names = np.arange(m) if gene_names is None else np.asarray(gene_names)
+    out = np.zeros((m, 5))
+    B = len(scExp)
+    if sparse:
+        blocks = [b.tocsc() for b in scExp]
+        for b in blocks:
+            b.sum_duplicates()
+        cps = [np.ascontiguousarray(b.indptr, np.int32) for b in blocks]
+        ris = [np.ascontiguousarray(b.indices, np.int32) for b in blocks]
+        vxs = [np.ascontiguousarray(b.data, np.float64) for b in blocks]
+        cpp = (C.POINTER(C.c_int) * B)(*[_ip(v) for v in cps])
+        rip = (C.POINTER(C.c_int) * B)(*[_ip(v) if v.size else C.cast(None, C.POINTER(C.c_int)) for v in ris])
+        vxp = (C.POINTER(C.c_double) * B)(*[_dp(v) if v.size else C.cast(None, C.POINTER(C.c_double)) for v in vxs])
+        check(lib().sharp_marker_genes_blocks_csc(cpp, rip, vxp, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), B, m, _ip(label), G,
+                                                  C.c_double(theta), 1, _dp(out)))
+    else:
+        import torch
+
+        dbl = [torch.from_numpy(np.ascontiguousarray(np.asarray(b.toarray() if _is_sparse(b) else b).T.astype(np.float32))).cuda() for b in scExp]
+        torch.cuda.synchronize()
+        ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in dbl])
+        ldb = np.array([t.stride(0) for t in dbl], np.int64)
+        check(lib().sharp_marker_genes_blocks_dev(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), ldb.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                                  B, m, _ip(label), G, C.c_double(theta), 1, _dp(out)))
+    nonzero = out[:, 3] > 0                                               # :44-57: a gene that is zero in every block is not a row of g5 at all
+    s, _gall = _marker_select(out[nonzero], names[nonzero], theta, auc, pvalue)
+    rows = np.array([int(np.nonzero(names == nm)[0][0]) for nm in s["gene"].tolist()], dtype=np.int64)
+    if rows.size:
+        mat = np.concatenate([np.asarray(b[rows].toarray() if _is_sparse(b) else np.asarray(b)[rows], dtype=np.float64) for b in scExp], axis=1)
+    else:
+        mat = np.zeros((0, label.size))
+    return {"mginfo": s, "mat": mat, "label": label}
+
+
+def get_marker_genes_unlimited2(gdinfo, y, theta=1e-5, auc=0.85, pvalue=0.05, n_cores=None):
+    """R/get_marker_genes_unlimited2.R:25-411.  gdinfo: a directory of GENE-wise partitions -- file i holds some genes' values over ALL
+    cells (the reference: .rds matrices, genes x cells; here the block files of sharp_amd.blocks.write_block, a (genes_i, cells) array
+    each), taken in the order of the first number in their path (:139-142).  Per gene: rank over all cells, the min(10, N.cluster)
+    clusters of highest mean rank tried, the best AUROC kept with its Wilcoxon p-value (:152-190: sharp_marker_genes per file, which is
+    the same per-gene pass with ng = min(10, N.cluster)); Holm adjustment and selection :193-214.
+    Returns dict(mginfo, label, gallinfo)."""
+    from . import blocks as _blocks
+
+    _lib.ensure_init()
+    label, G = _marker_labels(y)
+    n = label.size
+    files = _blocks.list_block_files(gdinfo)
+    rr = min(10, G)
+    outs, names = [], []
+    for f in files:
+        X = _blocks.read_block(f)                                         # (genes_i, cells)
+        if X.shape[1] != n:
+            raise SharpError("get_marker_genes_unlimited2: %s holds %d cells, the labels %d" % (f, X.shape[1], n))
+        Xf = np.asfortranarray(X, dtype=np.float64)
+        mi = Xf.shape[0]
+        o = np.zeros((mi, 5))
+        check(lib().sharp_marker_genes(_dp(Xf), mi, C.c_longlong(n), C.c_longlong(mi), _ip(label), G, C.c_double(theta), rr, _dp(o)))
+        outs.append(o)
+        names.extend("%s:%d" % (os.path.basename(f), j) for j in range(mi))
+    out = np.concatenate(outs) if outs else np.zeros((0, 5))
+    s, gall = _marker_select(out, np.asarray(names), theta, auc, pvalue)
+    return {"mginfo": s, "label": label, "gallinfo": gall}
 
 
 def _p_adjust_holm(p):

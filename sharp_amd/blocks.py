@@ -43,6 +43,13 @@ def read_header(path):
     return {"genes": int(m), "cells": int(n), "ld": int(ld)}
 
 
+def read_block(path):
+    """-> the (genes, cells) float32 array a block file holds (what write_block was given)."""
+    h = read_header(path)
+    buf = np.fromfile(path, dtype=np.float32, offset=HEADER_BYTES, count=h["cells"] * h["ld"]).reshape(h["cells"], h["ld"])
+    return np.ascontiguousarray(buf[:, :h["genes"]].T)
+
+
 def list_block_files(directory):
     """list.files() ordered by the first run of digits of each path (R/SHARP_unlimited3.R:59-61)."""
     d = directory[:-1] if directory.endswith("/") else directory

@@ -168,10 +168,53 @@ __global__ __launch_bounds__(256) void mg_stats_kernel(const unsigned long long 
     o[0] = best_auc; o[1] = static_cast<double>(best_c + 1); o[2] = mg_two_sided_p(z); o[3] = dp; o[4] = y1 / y2;
 }
 
-void marker_genes_dev(const float *dX, int m, long long n, long long ld, const int *h_label, int G, double theta, int ng, double *h_out) {
+// the same two passes over a block held as the slots of a dgCMatrix (colptr / rowidx / val of the block's cells, resident): one wave per
+// cell walks the cell's stored entries -- no dense block is ever built (R/get_marker_genes_unlimited.R:44-48 reads a@i the same way)
+__global__ void mg_count_csc_kernel(const long long *__restrict__ colptr, const int *__restrict__ rowidx, const double *__restrict__ val,
+                                    long long ncell, int m, unsigned int *__restrict__ counts, int *__restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x) >> 6;
+    const long long nwave = (static_cast<long long>(gridDim.x) * blockDim.x) >> 6;
+    for (long long c = wave; c < ncell; c += nwave)
+        for (long long e = colptr[c] + lane; e < colptr[c + 1]; e += 64) {
+            const int g = rowidx[e];
+            if (g < 0 || g >= m) { atomicAdd(bad, 1); continue; }
+            if (static_cast<float>(val[e]) != 0.0f) atomicAdd(&counts[g], 1u);
+        }
+}
+__global__ void mg_fill_csc_kernel(const long long *__restrict__ colptr, const int *__restrict__ rowidx, const double *__restrict__ val,
+                                   long long ncell, int m, const int *__restrict__ label, const unsigned long long *__restrict__ offsets,
+                                   unsigned int *__restrict__ cursor, unsigned long long *__restrict__ keys) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x) >> 6;
+    const long long nwave = (static_cast<long long>(gridDim.x) * blockDim.x) >> 6;
+    for (long long c = wave; c < ncell; c += nwave) {
+        const unsigned long long lab = static_cast<unsigned long long>(static_cast<unsigned int>(label[c] - 1));
+        for (long long e = colptr[c] + lane; e < colptr[c + 1]; e += 64) {
+            const int g = rowidx[e];
+            const float v = static_cast<float>(val[e]);
+            if (g < 0 || g >= m || v == 0.0f) continue;
+            const unsigned int slot = atomicAdd(&cursor[g], 1u);
+            keys[offsets[g] + slot] = (static_cast<unsigned long long>(mg_key(v)) << 32) | lab;
+        }
+    }
+}
+
+// One block of a list: a dense resident fp32 block (cells x ld), or the resident slots of a sparse one.
+struct MgBlock {
+    const float *dX = nullptr; long long ld = 0;                                  // dense
+    const long long *colptr = nullptr; const int *rowidx = nullptr; const double *val = nullptr;   // sparse
+    long long n = 0;
+};
+
+// get_marker_genes' per-gene pass (R/get_marker_genes.R:120-152) over the cells of ALL blocks (R/get_marker_genes_unlimited.R:95-118:
+// dd = the gene's values across every block): every block adds its non-zeros to the per-gene lists, one sort, one statistics pass.
+void marker_genes_blocks_dev(const std::vector<MgBlock> &blocks, int m, const int *h_label, int G, double theta, int ng, double *h_out) {
     Ctx &c = ctx();
     SHARP_REQUIRE(G >= 2 && G <= MG_MAXG, "get_marker_genes: between 2 and 1024 clusters are supported");
-    SHARP_REQUIRE(n >= 2 && m >= 1, "get_marker_genes: empty input");
+    long long n = 0;
+    for (const MgBlock &b : blocks) n += b.n;
+    SHARP_REQUIRE(n >= 2 && m >= 1 && !blocks.empty(), "get_marker_genes: empty input");
     std::vector<long long> csize(G, 0);
     for (long long i = 0; i < n; ++i) {
         SHARP_REQUIRE(h_label[i] >= 1 && h_label[i] <= G, "get_marker_genes: labels must be 1..N.pred_cluster");
@@ -183,27 +226,54 @@ void marker_genes_dev(const float *dX, int m, long long n, long long ld, const i
     DevBuf<long long> d_csize(G);
     d_csize.upload(csize.data(), G);
     DevBuf<unsigned int> d_counts(m), d_cursor(m);
-    d_counts.zero(); d_cursor.zero();
-    const int cells_per_block = static_cast<int>(std::max<long long>(16, (n + 4 * c.num_cu - 1) / (4 * c.num_cu)));
-    const dim3 grid(static_cast<unsigned>((n + cells_per_block - 1) / cells_per_block), (m + MG_TILE - 1) / MG_TILE);
+    DevBuf<int> d_bad(1);
+    d_counts.zero(); d_cursor.zero(); d_bad.zero();
+    auto dense_grid = [&](const MgBlock &b, int &cells_per_block) {
+        cells_per_block = static_cast<int>(std::max<long long>(16, (b.n + 4 * c.num_cu - 1) / (4 * c.num_cu)));
+        return dim3(static_cast<unsigned>((b.n + cells_per_block - 1) / cells_per_block), (m + MG_TILE - 1) / MG_TILE);
+    };
+    const int csc_blocks = c.num_cu * 16;
     {
         KernelTimer t("marker_count");
-        hipLaunchKernelGGL(mg_count_kernel, grid, dim3(MG_THREADS), 0, c.stream, dX, m, n, ld, cells_per_block, d_counts.p);
-        launch_check("mg_count_kernel");
+        for (const MgBlock &b : blocks) {
+            if (b.dX) {
+                int cpb = 0;
+                const dim3 grid = dense_grid(b, cpb);
+                hipLaunchKernelGGL(mg_count_kernel, grid, dim3(MG_THREADS), 0, c.stream, b.dX, m, b.n, b.ld, cpb, d_counts.p);
+            } else {
+                hipLaunchKernelGGL(mg_count_csc_kernel, dim3(csc_blocks), dim3(256), 0, c.stream, b.colptr, b.rowidx, b.val, b.n, m, d_counts.p, d_bad.p);
+            }
+            launch_check("mg_count_kernel");
+        }
     }
     std::vector<unsigned int> cnt(m);
+    int bad = 0;
+    SHARP_HIP_CHECK(hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     d_counts.download(cnt.data(), m);
+    SHARP_REQUIRE(bad == 0, "sparse input: row index outside [0, genes)");
     std::vector<unsigned long long> off(static_cast<size_t>(m) + 1, 0);
     for (int g = 0; g < m; ++g) off[g + 1] = off[g] + cnt[g];
     const unsigned long long nnz = off[m];
+    SHARP_REQUIRE(nnz < (1ull << 32), "get_marker_genes: more than 2^32 - 1 non-zero values (the segmented sort's index type)");
     DevBuf<unsigned long long> d_off(off.size());
     d_off.upload(off.data(), off.size());
     DevBuf<unsigned long long> d_keys(std::max<unsigned long long>(nnz, 1)), d_sorted(std::max<unsigned long long>(nnz, 1));
     {
         KernelTimer t("marker_fill");
-        hipLaunchKernelGGL(mg_fill_kernel, grid, dim3(MG_THREADS), 0, c.stream, dX, m, n, ld, cells_per_block, d_label.p, d_off.p, d_cursor.p,
-                           d_keys.p);
-        launch_check("mg_fill_kernel");
+        long long c0 = 0;
+        for (const MgBlock &b : blocks) {
+            if (b.dX) {
+                int cpb = 0;
+                const dim3 grid = dense_grid(b, cpb);
+                hipLaunchKernelGGL(mg_fill_kernel, grid, dim3(MG_THREADS), 0, c.stream, b.dX, m, b.n, b.ld, cpb, d_label.p + c0, d_off.p, d_cursor.p,
+                                   d_keys.p);
+            } else {
+                hipLaunchKernelGGL(mg_fill_csc_kernel, dim3(csc_blocks), dim3(256), 0, c.stream, b.colptr, b.rowidx, b.val, b.n, m, d_label.p + c0,
+                                   d_off.p, d_cursor.p, d_keys.p);
+            }
+            launch_check("mg_fill_kernel");
+            c0 += b.n;
+        }
     }
     if (nnz > 0) {
         KernelTimer t("marker_sort");
@@ -225,6 +295,12 @@ void marker_genes_dev(const float *dX, int m, long long n, long long ld, const i
     d_out.download(h_out, static_cast<size_t>(m) * 5);
 }
 
+void marker_genes_dev(const float *dX, int m, long long n, long long ld, const int *h_label, int G, double theta, int ng, double *h_out) {
+    MgBlock b;
+    b.dX = dX; b.ld = ld; b.n = n;
+    marker_genes_blocks_dev(std::vector<MgBlock>(1, b), m, h_label, G, theta, ng, h_out);
+}
+
 }  // namespace sharp
 
 using namespace sharp;
@@ -238,6 +314,47 @@ int sharp_marker_genes_dev(const float *dX, int m, long long n, long long ld, co
     SHARP_REQUIRE(dX && label && out, "sharp_marker_genes_dev: null argument");
     SHARP_REQUIRE(static_cast<unsigned long long>(n) * static_cast<unsigned long long>(m) < (1ull << 40), "get_marker_genes: matrix too large");
     marker_genes_dev(dX, m, n, ld, label, n_cluster, theta, ng, out);
+    SHARP_API_END
+}
+
+/* the per-gene pass over the cells of a LIST of blocks (R/get_marker_genes_unlimited.R:95-118): resident fp32 blocks */
+int sharp_marker_genes_blocks_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                                  const int *label, int n_cluster, double theta, int ng, double *out) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(dX_blocks && ncb && ldb && label && out && nblocks >= 1, "sharp_marker_genes_blocks_dev: null argument");
+    std::vector<MgBlock> v(static_cast<size_t>(nblocks));
+    for (int b = 0; b < nblocks; ++b) { SHARP_REQUIRE(dX_blocks[b] && ldb[b] >= m && ncb[b] >= 0, "sharp_marker_genes_blocks_dev: bad block"); v[b].dX = dX_blocks[b]; v[b].ld = ldb[b]; v[b].n = ncb[b]; }
+    marker_genes_blocks_dev(v, m, label, n_cluster, theta, ng, out);
+    SHARP_API_END
+}
+
+/* the same for a list of dgCMatrix blocks on the host (colptr[b]: ncb[b] + 1 ints, rowidx[b] 0-based, val[b]): the stored entries are
+ * uploaded as they are and scattered straight into the per-gene lists -- no dense block is built */
+int sharp_marker_genes_blocks_csc(const int *const *colptr, const int *const *rowidx, const double *const *val, const long long *ncb,
+                                  int nblocks, int m, const int *label, int n_cluster, double theta, int ng, double *out) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(colptr && rowidx && val && ncb && label && out && nblocks >= 1, "sharp_marker_genes_blocks_csc: null argument");
+    std::vector<MgBlock> v(static_cast<size_t>(nblocks));
+    std::vector<DevBuf<long long>> dcp(static_cast<size_t>(nblocks));
+    std::vector<DevBuf<int>> dri(static_cast<size_t>(nblocks));
+    std::vector<DevBuf<double>> dvx(static_cast<size_t>(nblocks));
+    std::vector<std::vector<long long>> cp(static_cast<size_t>(nblocks));
+    for (int b = 0; b < nblocks; ++b) {
+        const long long n = ncb[b];
+        SHARP_REQUIRE(colptr[b] && n >= 0, "sparse input: null pointer");
+        cp[b].resize(static_cast<size_t>(n) + 1);
+        for (long long q = 0; q <= n; ++q) { cp[b][q] = static_cast<long long>(colptr[b][q]) - colptr[b][0]; SHARP_REQUIRE(q == 0 || cp[b][q] >= cp[b][q - 1], "sparse input: column pointers must be non-decreasing"); }
+        const long long ne = cp[b][n];
+        SHARP_REQUIRE(ne == 0 || (rowidx[b] && val[b]), "sparse input: null pointer");
+        dcp[b].alloc(cp[b].size()); dcp[b].upload(cp[b].data(), cp[b].size());
+        dri[b].alloc(static_cast<size_t>(std::max<long long>(ne, 1))); dvx[b].alloc(static_cast<size_t>(std::max<long long>(ne, 1)));
+        if (ne) { dri[b].upload(rowidx[b] + colptr[b][0], static_cast<size_t>(ne)); dvx[b].upload(val[b] + colptr[b][0], static_cast<size_t>(ne)); }
+        v[b].colptr = dcp[b].p; v[b].rowidx = dri[b].p; v[b].val = dvx[b].p; v[b].n = n;
+    }
+    stream_sync();
+    marker_genes_blocks_dev(v, m, label, n_cluster, theta, ng, out);
     SHARP_API_END
 }
 
