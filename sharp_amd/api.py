@@ -12,7 +12,8 @@ from . import _lib
 from ._lib import SharpError, check, lib
 
 __all__ = ["ranM", "ranM2", "RPmat", "Projector", "SharpError", "get_opt_hclust", "getrowColor", "colorL", "HMETHODS",
-           "wMetaC", "sMetaC", "SHARP", "SHARP_small", "SHARP_large", "SHARP_unlimited", "SHARP_unlimited2", "SHARP_unlimited3", "run_Mtimes_SHARP", "get_marker_genes", "testlog", "ARI"]
+           "wMetaC", "sMetaC", "SHARP", "SHARP_small", "SHARP_large", "SHARP_unlimited", "SHARP_unlimited2", "SHARP_unlimited3", "run_Mtimes_SHARP", "get_marker_genes", "get_marker_genes_unlimited",
+           "get_marker_genes_unlimited2", "testlog", "ARI"]
 
 
 def _dp(a):
