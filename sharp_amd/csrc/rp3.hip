@@ -175,101 +175,119 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
         const int lg = lane % GW;
         const unsigned char *entb = reinterpret_cast<const unsigned char *>(P.ent);
         cell_end(-1);                                   // (the producers compact the first cell)
-        for (int it = 0; it < nmine; ++it) {
-            const int b01 = it & 1;
-            const uint32_t *lst = lists + b01 * P.lcap;
-            const uint32_t *swb = sw + static_cast<size_t>(b01) * P.cap;
-            const long long *stb = st + static_cast<size_t>(b01) * P.cap;
-            const int nnz = __builtin_amdgcn_readfirstlane(static_cast<int>(ctl[b01]));
-            const int nb = (nnz + 63) >> 6;
-            if (cw == 0 && lane == 0) ctl[2] = static_cast<uint32_t>(P.row_map ? P.row_map[cell_of(it)] : static_cast<int>(cell_of(it)));
+        // The cell being consumed: its list, its entry count, and this wave's four-stage pipeline over the list's batches (while the
+        // atomics of batch b run, the row lists of batch b + NC, the terms of batch b + 2 NC and the entry words of batch b + 3 NC are in
+        // flight).  A cell's first batches are set up BEFORE the previous cell's barriers and epilogue whenever the producers have
+        // that cell's list complete by then (ctl[3] counts their completions; they normally run a cell ahead): the dependent round
+        // trips -- entry word, term, row list -- then travel under the barriers and the epilogue instead of behind them.
+        const uint32_t *lst = lists;
+        const uint32_t *swb = sw;
+        const long long *stb = st;
+        int nnz = 0, nb = 0;
+        uint32_t gC = 0u, gL = 0u, wR = 0u;   // genes of the batch being added / of the one after the next; entry words of the one after that
+        long long fC = 0ll, fL = 0ll;         // their terms
+        Row cd[U], cdn[U];
+        auto load_word = [&](int bt) __attribute__((always_inline)) -> uint32_t {                 // lane = entry of batch bt; unconditional, clamped
+            const int e = (bt << 6) + lane;
+            const int ec = e < nnz ? e : 0;
+            if ((bt << 6) + 64 <= P.lcap) return *(const pc_lds_u32 *)(lst + ec);
+            return pc_get_word(lst, swb, static_cast<uint32_t>(P.lcap), static_cast<uint32_t>(ec));
+        };
+        auto decode = [&](int bt, uint32_t w, uint32_t &g, long long &f) __attribute__((always_inline)) {
+            const int e = (bt << 6) + lane;
+            long long ff = P.fixtab[(w >> 20) & 0x3ffu];            // 8 KB, cache resident
+            if (__ballot((w & kPcFull) != 0u) != 0ull) {           // rare, wave-uniform test: a value outside the table
+                if (w & kPcFull) ff = __builtin_nontemporal_load((const pc_glb_i64 *)(stb + (e < nnz ? e : 0)));
+            }
+            g = e < nnz ? (w & kPcGeneMask) : P.dummy_seg;
+            f = e < nnz ? ff : 0ll;
+        };
+        auto load_lists = [&](uint32_t g, Row (&dst)[U]) __attribute__((always_inline)) {
+            const uint32_t gofs = g * static_cast<uint32_t>(SPAN * 2);
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                dst[u] = load_row_word<SLOTS>(entb + (group_bcast<GW, u>(gofs) + static_cast<uint32_t>(2 * SLOTS * lg)));
+            });
+        };
+        auto step = [&](int bt, Row (&cur)[U], Row (&nxt)[U]) __attribute__((always_inline)) {
+            const uint32_t gN = gL;
+            const long long fN = fL;
+            load_lists(gN, nxt);
+            decode(bt + 2 * NC, wR, gL, fL);
+            asm volatile("" : "+v"(gL));
+            wR = load_word(bt + 3 * NC);
+            const uint32_t plo = static_cast<uint32_t>(fC), phi = static_cast<uint32_t>(static_cast<unsigned long long>(fC) >> 32);
+            uint32_t more = 0u;
+            if constexpr (DUAL) {
+                static_for<U>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    const uint32_t lo = group_bcast<GW, u>(plo), hi = group_bcast<GW, u>(phi);
+                    scatter_row_word<0, SLOTS, false>(cur[u], (static_cast<unsigned long long>(hi) << 32) | lo);
+                    more |= cur[u].x;
+                });
+            } else {
+                const long long fneg = -fC;
+                const uint32_t nlo = static_cast<uint32_t>(fneg), nhi = static_cast<uint32_t>(static_cast<unsigned long long>(fneg) >> 32);
+                static_for<U>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    const bool neg = (cur[u].x & kCodeNeg) != 0u;     // a lane's codes share their sign
+                    const uint32_t bpl = group_bcast<GW, u>(plo), bph = group_bcast<GW, u>(phi);
+                    const uint32_t bnl = group_bcast<GW, u>(nlo), bnh = group_bcast<GW, u>(nhi);
+                    const uint32_t lo = neg ? bnl : bpl, hi = neg ? bnh : bph;
+                    scatter_row_word<0, SLOTS, true>(cur[u], (static_cast<unsigned long long>(hi) << 32) | lo);
+                    more |= cur[u].x;
+                });
+            }
+            // rare: a gene continues in overflow segments (flag in slot 0 of its first lane); one scalar test per batch
+            if (__ballot((more & kCodeMore) != 0u) != 0ull) {
+                static_for<U>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    const unsigned long long full = __ballot((cur[u].x & kCodeMore) != 0u);
+                    const uint32_t g = group_bcast<GW, u>(gC);
+                    const uint32_t bpl = group_bcast<GW, u>(plo), bph = group_bcast<GW, u>(phi);
+                    if ((full >> (lane & ~(GW - 1))) & 1ull) {
+                        const long long f = static_cast<long long>((static_cast<unsigned long long>(bph) << 32) | bpl);
+                        const uint2 oi = P.ovf_slot[g];
+                        for (uint32_t sg = 0; sg < oi.y; ++sg) {
+                            const Row c2 = load_row_word<SLOTS>(P.ent + (static_cast<size_t>(oi.x) + sg) * SPAN + SLOTS * lg);
+                            if constexpr (DUAL) scatter_row_word<0, SLOTS, false>(c2, static_cast<unsigned long long>(f));
+                            else scatter_row_word<0, SLOTS, true>(c2, static_cast<unsigned long long>((c2.x & kCodeNeg) ? -f : f));
+                        }
+                    }
+                });
+            }
+            gC = gN;
+            fC = fN;
+        };
+        auto begin_cell = [&](int it2) __attribute__((always_inline)) {     // the list of cell it2 is complete
+            const int b2 = it2 & 1;
+            lst = lists + b2 * P.lcap;
+            swb = sw + static_cast<size_t>(b2) * P.cap;
+            stb = st + static_cast<size_t>(b2) * P.cap;
+            nnz = __builtin_amdgcn_readfirstlane(static_cast<int>(ctl[b2]));
+            nb = (nnz + 63) >> 6;
             if (cw < nb) {
-                uint32_t gC = 0u, gL = 0u, wR = 0u;   // genes of the batch being added / of the one after the next; entry words of the one after that
-                long long fC = 0ll, fL = 0ll;         // their terms
-                Row cd[U], cdn[U];
-                auto load_word = [&](int bt) __attribute__((always_inline)) -> uint32_t {                 // lane = entry of batch bt; unconditional, clamped
-                    const int e = (bt << 6) + lane;
-                    const int ec = e < nnz ? e : 0;
-                    if ((bt << 6) + 64 <= P.lcap) return *(const pc_lds_u32 *)(lst + ec);
-                    return pc_get_word(lst, swb, static_cast<uint32_t>(P.lcap), static_cast<uint32_t>(ec));
-                };
-                auto decode = [&](int bt, uint32_t w, uint32_t &g, long long &f) __attribute__((always_inline)) {
-                    const int e = (bt << 6) + lane;
-                    long long ff = P.fixtab[(w >> 20) & 0x3ffu];            // 8 KB, cache resident
-                    if (__ballot((w & kPcFull) != 0u) != 0ull) {           // rare, wave-uniform test: a value outside the table
-                        if (w & kPcFull) ff = __builtin_nontemporal_load((const pc_glb_i64 *)(stb + (e < nnz ? e : 0)));
-                    }
-                    g = e < nnz ? (w & kPcGeneMask) : P.dummy_seg;
-                    f = e < nnz ? ff : 0ll;
-                };
-                auto load_lists = [&](uint32_t g, Row (&dst)[U]) __attribute__((always_inline)) {
-                    const uint32_t gofs = g * static_cast<uint32_t>(SPAN * 2);
-                    static_for<U>([&](auto uc) {
-                        constexpr int u = decltype(uc)::value;
-                        dst[u] = load_row_word<SLOTS>(entb + (group_bcast<GW, u>(gofs) + static_cast<uint32_t>(2 * SLOTS * lg)));
-                    });
-                };
-                auto step = [&](int bt, Row (&cur)[U], Row (&nxt)[U]) __attribute__((always_inline)) {
-                    const uint32_t gN = gL;
-                    const long long fN = fL;
-                    load_lists(gN, nxt);
-                    decode(bt + 2 * NC, wR, gL, fL);
-                    asm volatile("" : "+v"(gL));
-                    wR = load_word(bt + 3 * NC);
-                    const uint32_t plo = static_cast<uint32_t>(fC), phi = static_cast<uint32_t>(static_cast<unsigned long long>(fC) >> 32);
-                    uint32_t more = 0u;
-                    if constexpr (DUAL) {
-                        static_for<U>([&](auto uc) {
-                            constexpr int u = decltype(uc)::value;
-                            const uint32_t lo = group_bcast<GW, u>(plo), hi = group_bcast<GW, u>(phi);
-                            scatter_row_word<0, SLOTS, false>(cur[u], (static_cast<unsigned long long>(hi) << 32) | lo);
-                            more |= cur[u].x;
-                        });
-                    } else {
-                        const long long fneg = -fC;
-                        const uint32_t nlo = static_cast<uint32_t>(fneg), nhi = static_cast<uint32_t>(static_cast<unsigned long long>(fneg) >> 32);
-                        static_for<U>([&](auto uc) {
-                            constexpr int u = decltype(uc)::value;
-                            const bool neg = (cur[u].x & kCodeNeg) != 0u;     // a lane's codes share their sign
-                            const uint32_t bpl = group_bcast<GW, u>(plo), bph = group_bcast<GW, u>(phi);
-                            const uint32_t bnl = group_bcast<GW, u>(nlo), bnh = group_bcast<GW, u>(nhi);
-                            const uint32_t lo = neg ? bnl : bpl, hi = neg ? bnh : bph;
-                            scatter_row_word<0, SLOTS, true>(cur[u], (static_cast<unsigned long long>(hi) << 32) | lo);
-                            more |= cur[u].x;
-                        });
-                    }
-                    // rare: a gene continues in overflow segments (flag in slot 0 of its first lane); one scalar test per batch
-                    if (__ballot((more & kCodeMore) != 0u) != 0ull) {
-                        static_for<U>([&](auto uc) {
-                            constexpr int u = decltype(uc)::value;
-                            const unsigned long long full = __ballot((cur[u].x & kCodeMore) != 0u);
-                            const uint32_t g = group_bcast<GW, u>(gC);
-                            const uint32_t bpl = group_bcast<GW, u>(plo), bph = group_bcast<GW, u>(phi);
-                            if ((full >> (lane & ~(GW - 1))) & 1ull) {
-                                const long long f = static_cast<long long>((static_cast<unsigned long long>(bph) << 32) | bpl);
-                                const uint2 oi = P.ovf_slot[g];
-                                for (uint32_t sg = 0; sg < oi.y; ++sg) {
-                                    const Row c2 = load_row_word<SLOTS>(P.ent + (static_cast<size_t>(oi.x) + sg) * SPAN + SLOTS * lg);
-                                    if constexpr (DUAL) scatter_row_word<0, SLOTS, false>(c2, static_cast<unsigned long long>(f));
-                                    else scatter_row_word<0, SLOTS, true>(c2, static_cast<unsigned long long>((c2.x & kCodeNeg) ? -f : f));
-                                }
-                            }
-                        });
-                    }
-                    gC = gN;
-                    fC = fN;
-                };
-                {
-                    const uint32_t w0 = load_word(cw), w1 = load_word(cw + NC);
-                    wR = load_word(cw + 2 * NC);
-                    decode(cw, w0, gC, fC);
-                    decode(cw + NC, w1, gL, fL);
-                    load_lists(gC, cd);
-                }
+                const uint32_t w0 = load_word(cw), w1 = load_word(cw + NC);
+                wR = load_word(cw + 2 * NC);
+                decode(cw, w0, gC, fC);
+                decode(cw + NC, w1, gL, fL);
+                load_lists(gC, cd);
+            }
+        };
+        bool ahead = false;                              // the cell about to be consumed has been set up already
+        for (int it = 0; it < nmine; ++it) {
+            if (cw == 0 && lane == 0) ctl[2] = static_cast<uint32_t>(P.row_map ? P.row_map[cell_of(it)] : static_cast<int>(cell_of(it)));
+            if (!ahead) begin_cell(it);
+            if (cw < nb) {
                 for (int bt = cw; bt < nb; bt += 2 * NC) {          // two steps per trip: the two row-list sets swap roles
                     step(bt, cd, cdn);
                     if (bt + NC < nb) step(bt + NC, cdn, cd);
                 }
+            }
+            ahead = false;
+            if (it + 1 < nmine) {
+                const int done = __builtin_amdgcn_readfirstlane(static_cast<int>(ctl[3]));
+                if (done >= NP * (it + 2)) { begin_cell(it + 1); ahead = true; }
             }
             cell_end(it);
         }
@@ -381,6 +399,7 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
                 fetch(buf[i]);                            // (unconditional: the loads in flight are the same on every path)
                 if (live && ++pk == upp) {
                     pk = 0;
+                    if (lane == 0) atomicAdd(&ctl[3], 1u);    // this wave's entries of cell pj are in the list (LDS operations of a wave execute in order)
                     cell_end(pj - 1);
                     ++pj;
                 }
