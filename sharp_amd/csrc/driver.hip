@@ -323,7 +323,7 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
     for (int q = 0; q < K * T; ++q) out.rc |= hr[q].rc;
     {
     HostTimer ht("tail_enrp");
-    host_parallel_for(T, 8, [&](int t) {
+    host_parallel_for(T, 16, [&](int t) {
         const int nt = fst[t + 1] - fst[t];
         enrp[t].resize(static_cast<size_t>(nt) * K);
         for (int k = 0; k < K; ++k) {

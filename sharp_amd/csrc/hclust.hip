@@ -2070,7 +2070,7 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
     std::vector<long long> poff(T);
     long long ptot = 0;
     for (int t = 0; t < T; ++t) { poff[t] = ptot; ptot += metas[t].n; }
-    host_parallel_for(T, T >= 16 ? 8 : 1, [&](int t) {     // (each task writes its own result only)
+    host_parallel_for(T, T >= 16 ? 16 : 1, [&](int t) {     // (each task writes its own result only)
         const HcTask &tk = tasks[i0 + t];
         const HcMeta &M = metas[t];
         HcResult &R = out[i0 + t];
@@ -2098,7 +2098,7 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
     W.packed.download(h_packed, ptot);
     std::vector<int> h_lab;
     if (want_v) { h_lab.resize(oLab); W.lab.download(h_lab.data(), oLab); }
-    host_parallel_for(T, T >= 16 ? 8 : 1, [&](int t) {
+    host_parallel_for(T, T >= 16 ? 16 : 1, [&](int t) {
         const HcMeta &M = metas[t];
         HcResult &R = out[i0 + t];
         R.f.assign(h_packed + poff[t], h_packed + poff[t] + M.n);

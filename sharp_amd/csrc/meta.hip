@@ -249,7 +249,7 @@ void wmetac_batch(const std::vector<WmTask> &tasks, bool want_x0, bool want_debu
     };
     {
         HostTimer ht("wmetac_relabel");
-        host_parallel_for(T, 8, relabel);
+        host_parallel_for(T, 16, relabel);
     }
     for (int t = 0; t < T; ++t) {
         const WmTask &tk = tasks[t];
