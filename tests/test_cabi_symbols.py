@@ -98,3 +98,46 @@ def test_product_does_not_import_oracle():
                 if re.search(r"(import\s+oracle|from\s+oracle|liboracle|sharp_oracle\.c|oracle/)", txt):
                     bad.append(f)
     assert not bad, f"product files referencing the oracle: {bad}"
+
+
+def test_list_of_blocks_entry_points_fail_loudly_without_a_device(so):
+    """The round-4 entry points (lists of sparse blocks, the in-process multi-device runner with its worker and upload threads, marker
+    genes over block lists) report the missing device through their status and sharp_last_error(); nothing computes on the CPU."""
+    import numpy as np
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    so.sharp_last_error.restype = C.c_char_p
+    m, sizes = 50, [7, 9]
+    rng = np.random.default_rng(0)
+    dense = [np.asfortranarray(rng.integers(0, 3, size=(m, n)).astype(np.float64)) for n in sizes]
+    ncb = np.array(sizes, np.int64)
+    pred = np.zeros(sum(sizes), np.int32)
+    npred, pu = C.c_int(), C.c_int()
+    dv = np.array([0, 0], np.int32)
+    ptrs = (C.POINTER(C.c_double) * 2)(*[d.ctypes.data_as(C.POINTER(C.c_double)) for d in dense])
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))     # noqa: E731
+    rc = so.sharp_SHARP_unlimited_multi(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), 2, m, 3, 0, 0, 0, C.c_double(7.0), ip(dv), 2, ip(pred),
+                                        C.byref(npred), C.byref(pu), None)
+    assert rc != 0 and b"no HIP device" in so.sharp_last_error()
+    import scipy.sparse as sp
+
+    cs = [sp.csc_matrix(d) for d in dense]
+    cps = [c.indptr.astype(np.int32) for c in cs]
+    ris = [c.indices.astype(np.int32) for c in cs]
+    vxs = [c.data.astype(np.float64) for c in cs]
+    cpp = (C.POINTER(C.c_int) * 2)(*[ip(a) for a in cps])
+    rip = (C.POINTER(C.c_int) * 2)(*[ip(a) for a in ris])
+    vxp = (C.POINTER(C.c_double) * 2)(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in vxs])
+    rc = so.sharp_SHARP_unlimited_csc(cpp, rip, vxp, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), 2, m, 3, 0, 0, 0, C.c_double(7.0), ip(pred),
+                                      C.byref(npred), C.byref(pu), None)
+    assert rc != 0 and b"no device context" in so.sharp_last_error()
+    out = np.zeros((m, 5))
+    lab = np.ones(sum(sizes), np.int32)
+    lab[::2] = 2
+    rc = so.sharp_marker_genes_blocks_csc(cpp, rip, vxp, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), 2, m, ip(lab), 2, C.c_double(1e-5), 1,
+                                          out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc != 0 and b"no device context" in so.sharp_last_error()
+    n = C.c_int(-1)
+    assert so.sharp_multi_timeline(None, 0, C.byref(n)) == 0 and n.value >= 0
