@@ -190,7 +190,7 @@ def test_full_size_block_matches_oracle(env, oracle):
     X = dX.cpu().numpy().T.astype(np.float64)                             # (genes, cells), column-major: 8 GB
     del dX
     torch.cuda.empty_cache()
-    cores = min(os.cpu_count() or 1, 64)                                  # 125 tasks; every thread holds a 320 MB fold copy
+    cores = min(os.cpu_count() or 1, 32)                                  # 125 tasks; every thread holds a 320 MB fold copy (32 threads beat 64: memory-bound)
     t0 = time.perf_counter()
     ref = oracle.SHARP(X, K=K, reduced_ndim=p, rN_seed=RN, nthreads=cores, want_view=False)
     print("oracle: %.1f s on %d threads (%.0f cells/s)" % (time.perf_counter() - t0, cores, n / (time.perf_counter() - t0)))
@@ -210,7 +210,7 @@ def test_cfg2_full_size_matches_oracle(env, oracle):
     X = dX.cpu().numpy().T.astype(np.float64)                             # (genes, cells), column-major: 8 GB
     del dX
     torch.cuda.empty_cache()
-    cores = min(len(os.sched_getaffinity(0)), 64)                         # 375 tasks; every thread holds a 320 MB fold copy
+    cores = min(len(os.sched_getaffinity(0)), 32)                         # 375 tasks; every thread holds a 320 MB fold copy; the oracle is memory-bound: 32 threads beat 64 (bench.py cpu_baseline)
     t0 = time.perf_counter()
     ref = oracle.SHARP(X, K=K, rN_seed=RN, nthreads=cores, want_view=False)
     print("oracle: %.1f s on %d threads (%.0f cells/s)" % (time.perf_counter() - t0, cores, n / (time.perf_counter() - t0)))
