@@ -89,6 +89,9 @@ struct Knobs {
     bool hc_mono = false, hc_seq = false;   // SHARP_HC_MONO=1 / SHARP_HC_SEQ=1 (cross-checks): one-launch agglomeration / sequential kernel only
     int hc_split = -1;          // SHARP_HC_SPLIT=1 / 0: round-per-launch agglomeration forced on / off (-1: by task count)
     int hc_ranges = 0, hc_wpt = 0, hc_finish_at = 15, hc_chunk = 0;   // SHARP_HC_RANGES / _WPT / _FINISH_AT / _CHUNK: ranges per chunk, workgroups per task, finishing round, tasks per chunk
+    int tail_threads = 4;       // SHARP_TAIL_THREADS: host threads (each with its own slot) that run the blocks' tails of a batched SHARP_unlimited window;
+                                // 0: from the batch's progress callback on the calling thread, one after the other (the round-3 form)
+    bool tail_priority = true;  // SHARP_TAIL_PRIORITY=0: the helpers' streams in the normal priority class
     bool hc_tri = false;        // SHARP_HC_TRI=1: the upper-triangle agglomeration kernel (hclust_tri.inc: 44 % of the HBM bytes, the same time alone,
                                 // 8 % slower inside the batched SHARP_unlimited pipeline) where the full-matrix one runs by default
     bool hc_prep_early = true;  // SHARP_HC_PREP_EARLY=0: a chunk's row preparation behind the previous chunk's distance GEMM instead of beside it
@@ -140,11 +143,12 @@ Ctx &ctx_unchecked();
 // sharp_init() sets up, which is all a single-GPU host ever sees).  The multi-GPU entry points (sharp_SHARP_unlimited_multi) start one
 // host thread per device and bind each to a slot of its own, so several GPUs -- or, in the tests, several slots on ONE GPU -- run
 // side by side in one process.
-constexpr int kMaxSlots = 49;        // the caller's + (compute, upload) slots of up to 16 GPUs, with room for repeated devices
+constexpr int kMaxSlots = 132;       // the caller's slot and its 4 tail helpers' + (compute, upload, 4 tail helpers) of up to 16 GPUs, with room for repeated devices
 int cur_slot();
 void bind_slot(int slot);                   // the calling thread works on this slot from now on
-void init_slot(int slot, int device);       // bind_slot + hipSetDevice + the slot's context (streams) on that device; idempotent per (slot, device)
-int acquire_slot(int device, int occurrence, int role);   // the worker slot (>= 1) of that device / occurrence in the device list / role (0 compute, 1 upload)
+void init_slot(int slot, int device, bool high_priority = false);   // (high_priority: the slot's main stream in the high class, tail helpers)
+                                            // bind_slot + hipSetDevice + the slot's context (streams) on that device; idempotent per (slot, device)
+int acquire_slot(int device, int occurrence, int role);   // the worker slot (>= 1) of that device / occurrence in the device list / role (0 compute, 1 upload, 2 tail helper occurrence % 4 of slot occurrence / 4)
 void for_each_ready_slot(const std::function<void()> &fn);   // fn() with the calling thread bound to each initialised slot in turn
 // the per-slot instance of a keep-between-calls object: `T &name() { return per_slot<T>(); }`
 template <typename T>

@@ -616,7 +616,7 @@ void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector
 // agglomeration) instead of block after block: the tasks of all blocks are independent, and a block's own tail -- per-fold wMetaC,
 // sMetaC, relabels: small kernels and host loops -- runs from the batch's progress callback while later chunks' agglomeration keeps
 // the HBM busy.  Every block is the same SHARP() call as in the block-by-block form (same shuffle, folds, parameters): same labels.
-// deliver(b, out): called once per block, in block order.
+// deliver(b, out): called once per block; with SHARP_TAIL_THREADS > 0 (the default) from helper threads, in no particular order.
 static void unlimited_batch_window(const XRef *dX, const long long *ncb, const long long *ldb, int b0, int b1, int m, int p, int proj, int K,
                                    double rN_seed, const std::function<void(int, const SharpOut &)> &deliver) {
     PendingFront &PF = pending_front();
@@ -653,23 +653,99 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
         r0 += n;
     }
     std::vector<HcResult> hr;
-    int next = 0;
-    const std::function<void(size_t)> progress = [&](size_t done) {
-        while (next < nbk && first[next + 1] <= done) {
-            SharpOut o;
-            o.path = 1;
-            large_tail(*F[next], A[next], K, p, base[next], hr.data() + first[next], o);
-            o.p = p; o.K = K;
-            deliver(b0 + next, o);
-            F[next].reset();
-            ++next;
-        }
+    const auto tail_of = [&](int q) {
+        SharpOut o;
+        o.path = 1;
+        large_tail(*F[q], A[q], K, p, base[q], hr.data() + first[q], o);
+        o.p = p; o.K = K;
+        deliver(b0 + q, o);
+        F[q].reset();
     };
-    {
-        HostTimer ht("base_clustering_total");
-        get_opt_hclust_batch(tasks, false, hr, &progress);
+    int next = 0;
+    if (knobs().tail_threads <= 0 || nbk < 2) {
+        const std::function<void(size_t)> progress = [&](size_t done) {
+            while (next < nbk && first[next + 1] <= done) tail_of(next++);
+        };
+        {
+            HostTimer ht("base_clustering_total");
+            get_opt_hclust_batch(tasks, false, hr, &progress);
+        }
+        progress(tasks.size());
+        return;
     }
-    progress(tasks.size());
+    // The blocks' tails on host threads of their own, each bound to its own slot (own streams, own workspaces) on the same GPU.  A tail is a
+    // chain of small kernels with host decisions in between: 3.8 ms of wall time on an idle GPU, 6-10 ms beside a saturating
+    // agglomeration.  Run from the progress callback they kept THIS thread from enqueueing the next chunk's work, and the blocks whose
+    // last tasks sit in the final chunks -- four of cfg3's ten -- ran their tails one after the other behind the last agglomeration
+    // (27 ms of a 186 ms call, profiles/r04_cfg3_timeline.txt); several helpers run those side by side.  A tail reads only what is final
+    // when its block is reported done (its rows of E, its entries of hr) and writes only its own block's outputs; deliver() is called
+    // from the helpers, in no particular order.
+    struct TailQueue {
+        std::mutex mu;
+        std::condition_variable cv;
+        int ready = 0, taken = 0;    // blocks [0, ready) may run their tails; [0, taken) have been handed to a helper
+        bool stop = false;
+        std::exception_ptr err;
+    } Q;
+    Ctx &mc = ctx();
+    const int dev = mc.device, owner = cur_slot();
+    const bool prof = mc.profiling;
+    const int H = std::max(1, std::min({knobs().tail_threads, nbk, 4}));
+    std::vector<int> tslot(H);
+    for (int h = 0; h < H; ++h) tslot[h] = acquire_slot(dev, owner * 4 + h, 2);
+    std::vector<std::thread> helpers;
+    for (int h = 0; h < H; ++h)
+        helpers.emplace_back([&, h] {
+            try {
+                init_slot(tslot[h], dev, knobs().tail_priority);
+                ctx().profiling = prof;
+                for (;;) {
+                    int q;
+                    {
+                        std::unique_lock<std::mutex> lk(Q.mu);
+                        Q.cv.wait(lk, [&] { return Q.ready > Q.taken || Q.stop; });
+                        if (Q.ready <= Q.taken) break;
+                        q = Q.taken++;
+                    }
+                    tail_of(q);
+                }
+                SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+                ctx().resolve_pending();
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(Q.mu);
+                if (!Q.err) Q.err = std::current_exception();
+            }
+        });
+    const std::function<void(size_t)> progress = [&](size_t done) {
+        int r = next;
+        while (r < nbk && first[r + 1] <= done) ++r;
+        if (r == next) return;
+        next = r;
+        { std::lock_guard<std::mutex> lk(Q.mu); Q.ready = r; }
+        Q.cv.notify_all();
+    };
+    std::exception_ptr err;
+    try {
+        {
+            HostTimer ht("base_clustering_total");
+            get_opt_hclust_batch(tasks, false, hr, &progress);
+        }
+        progress(tasks.size());
+    } catch (...) { err = std::current_exception(); }
+    { std::lock_guard<std::mutex> lk(Q.mu); Q.stop = true; }
+    Q.cv.notify_all();
+    for (std::thread &t : helpers) t.join();
+    if (prof) {                                            // the tails' stage times belong to this call's table
+        for (int h = 0; h < H; ++h) {
+            bind_slot(tslot[h]);
+            std::map<std::string, KernelStat> ts;
+            ts.swap(ctx_unchecked().stats);
+            bind_slot(owner);
+            for (const auto &kv : ts) { KernelStat &d = mc.stats[kv.first]; d.ms += kv.second.ms; d.launches += kv.second.launches; }
+        }
+    }
+    if (err) std::rethrow_exception(err);
+    if (Q.err) std::rethrow_exception(Q.err);
 }
 
 // cross-block sMetaC on the gathered centroids, small-cluster merge and size-ordered relabel (:163-183)
@@ -992,13 +1068,15 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
                 }
             }
             if (e - b >= 2 && ntasks > 2LL * ctx().num_cu) {
+                struct Got { std::vector<int> pb; std::vector<double> mb; std::vector<long long> cb; };
+                std::vector<Got> got(e - b);                                    // (the window's tails finish on helper threads, in any order)
+                std::vector<long long> at(e - b + 1, off);
+                for (int q = b; q < e; ++q) at[q - b + 1] = at[q - b] + ncb[q];
                 unlimited_batch_window(dX_blocks, ncb, ldb, b, e, m, p, proj, K, rN_seed, [&](int bb, const SharpOut &o) {
-                    std::vector<int> pb;
-                    std::vector<double> mb;
-                    std::vector<long long> cb;
-                    unlimited_block_summary(o, ncb[bb], p, pb, mb, cb, viE ? viE + static_cast<size_t>(off) * p : nullptr);
-                    take(bb, pb, mb, cb);
+                    Got &g = got[bb - b];
+                    unlimited_block_summary(o, ncb[bb], p, g.pb, g.mb, g.cb, viE ? viE + static_cast<size_t>(at[bb - b]) * p : nullptr);
                 });
+                for (int q = b; q < e; ++q) take(q, got[q - b].pb, got[q - b].mb, got[q - b].cb);
                 b = e;
                 continue;
             }

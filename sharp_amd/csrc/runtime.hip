@@ -300,6 +300,8 @@ static Knobs read_knobs() {
     v.mean_early = num("SHARP_MEAN_EARLY", 0) != 0;
     v.hc_prep_early = num("SHARP_HC_PREP_EARLY", 1) != 0;
     v.hc_tri = num("SHARP_HC_TRI", 0) != 0;
+    v.tail_threads = num("SHARP_TAIL_THREADS", 4);
+    v.tail_priority = num("SHARP_TAIL_PRIORITY", 1) != 0;
     v.gemm_slice = num("SHARP_GEMM_SLICE", 8);
     v.proj_host = num("SHARP_PROJ_HOST", 0) == 1;
     v.upload_threads = num("SHARP_UPLOAD_THREADS", 0);
@@ -354,7 +356,7 @@ void for_each_ready_slot(const std::function<void()> &fn) {
     if (keep_dev >= 0) (void)hipSetDevice(keep_dev);
     if (err) std::rethrow_exception(err);
 }
-void init_slot(int slot, int device) {
+void init_slot(int slot, int device, bool high_priority) {
     bind_slot(slot);
     Ctx &c = ctx_unchecked();
     if (c.ready && c.device == device) { SHARP_HIP_CHECK(hipSetDevice(device)); return; }   // (the device is a per-thread setting)
@@ -379,13 +381,14 @@ void init_slot(int slot, int device) {
     if (c.ready && c.stream2) { (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
     for (hipStream_t s : c.aux) (void)hipStreamDestroy(s);
     c.aux.clear();
-    SHARP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    int lo = 0, hi = 0;
+    SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    // (a tail helper's small kernels go ahead of the pipeline's GEMM workgroups when a CU frees up: they are what a finished block waits for)
+    if (high_priority) SHARP_HIP_CHECK(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, hi));
+    else SHARP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     c.main_stream = c.stream;
-    {   // the second stream of the RP stage: its own priority class, hence its own hardware queue (see aux_stream)
-        int lo = 0, hi = 0;
-        SHARP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        SHARP_HIP_CHECK(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, hi));
-    }
+    // the second stream of the RP stage: its own priority class, hence its own hardware queue (see aux_stream)
+    SHARP_HIP_CHECK(hipStreamCreateWithPriority(&c.stream2, hipStreamNonBlocking, hi));
     c.device = device;
     bound_device[slot] = device;
     bound[slot] = true;
