@@ -375,3 +375,30 @@ def test_unlimited_batched_base_clustering_equals_block_by_block(env, monkeypatc
         pw, nw, _ = run()
         monkeypatch.delenv("SHARP_UNLIMITED_WINDOW_MB")
         assert nw == n1 and np.array_equal(pw, p1)
+    # the blocks' tails of a batched window run on helper threads with their own device slots (four by default; they finish in any
+    # order): none (the calling thread, from the batch's progress callback), one and three must give the same call
+    for h in ("0", "1", "3"):
+        monkeypatch.setenv("SHARP_TAIL_THREADS", h)
+        ph, nh, _ = run()
+        monkeypatch.delenv("SHARP_TAIL_THREADS")
+        assert nh == n1 and np.array_equal(ph, p1), h
+
+    def run_view():                                      # the viewflag form: every block's E1 rows, written by whichever helper ran its tail
+        ptrs = (C.c_void_p * B)(*[x.data_ptr() for x in blocks])
+        ncb = np.array([x.shape[0] for x in blocks], np.int64)
+        ldb = np.array([x.stride(0) for x in blocks], np.int64)
+        pred = np.zeros(int(ncb.sum()), np.int32)
+        viE = np.zeros((int(ncb.sum()), pu1), np.float64)
+        npred, pu = C.c_int(), C.c_int()
+        rc = lib.sharp_SHARP_unlimited_view_dev(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), ldb.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                                B, m, K, 0, 0, 0, C.c_double(2103), pred.ctypes.data_as(C.POINTER(C.c_int)),
+                                                C.byref(npred), C.byref(pu), viE.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc in (0, 16, 32, 48), lib.sharp_last_error()
+        return pred, viE
+
+    pv, v4 = run_view()
+    monkeypatch.setenv("SHARP_TAIL_THREADS", "0")
+    pv0, v0 = run_view()
+    monkeypatch.delenv("SHARP_TAIL_THREADS")
+    assert np.array_equal(pv, p1) and np.array_equal(pv0, p1)
+    assert np.array_equal(v4, v0) and np.abs(v4).max() > 0
