@@ -241,6 +241,7 @@ inline void stream_sync() { SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream));
 // fn(0) .. fn(n-1) on the calling thread plus up to max_threads - 1 workers of a persistent pool (items handed out dynamically).
 // For the short host loops between kernels (per-fold relabelling and votes): starting std::threads anew cost more than the loops.
 // fn must not call HIP and must not throw.
+void host_pool_threads_hint(int n);   // the calling thread's slot gets a pool of n workers if its pool does not exist yet (tail helpers: several run side by side)
 void host_parallel_for(int n, int max_threads, const std::function<void(int)> &fn);
 inline void launch_check(const char *what) {
     hipError_t e = hipGetLastError();

@@ -698,6 +698,7 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
         helpers.emplace_back([&, h] {
             try {
                 init_slot(tslot[h], dev, knobs().tail_priority);
+                host_pool_threads_hint(5);                 // (up to four helpers per GPU run their tails' host loops side by side)
                 ctx().profiling = prof;
                 for (;;) {
                     int q;

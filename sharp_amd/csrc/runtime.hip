@@ -178,6 +178,9 @@ void pool_atfork_child() {
 }
 }  // namespace
 
+static thread_local int g_pool_threads_hint = 0;
+void host_pool_threads_hint(int n) { g_pool_threads_hint = n; }
+
 void host_parallel_for(int n, int max_threads, const std::function<void(int)> &fn) {
     if (n <= 0) return;
     unsigned hw = std::thread::hardware_concurrency();
@@ -190,7 +193,8 @@ void host_parallel_for(int n, int max_threads, const std::function<void(int)> &f
         if (!T.atfork) { T.atfork = true; pthread_atfork(nullptr, nullptr, pool_atfork_child); }
         S = &T.s[cur_slot()];
         if (!S->one_job) S->one_job = new std::mutex;
-        if (!S->pool) S->pool = new HostPool(static_cast<int>(std::min<unsigned>(hw - 1, 15)));   // leaked on purpose
+        const unsigned want = g_pool_threads_hint > 0 ? static_cast<unsigned>(g_pool_threads_hint) : 15u;
+        if (!S->pool) S->pool = new HostPool(static_cast<int>(std::min<unsigned>(hw - 1, want)));   // leaked on purpose
     }
     std::lock_guard<std::mutex> lk(*S->one_job);          // one job at a time per slot
     S->pool->parallel_for(n, max_threads, fn);
