@@ -316,6 +316,11 @@ int sharp_synth_labels(unsigned seed, long long cell0, int ncell, int G, int *la
  * with a zero diagonal (correlation distance), 2 = clamp(v) with a unit diagonal; symmetric: Bt is ignored (C = At^T At, upper
  * triangle computed and mirrored); fast: the 128 x 128-tile kernel on zero-padded copies, else the generic 64 x 64 kernel. */
 int sharp_gemm_tn_f64(const double *At, const double *Bt, double *C, int M, int N, int K, int epilogue, int symmetric, int fast);
+/* Test hook: D = 1 - U U^T (n x n row-major) of n unit rows U (n x p row-major) through the sliced-integer distance GEMM
+ * (gemm_i8.hip: seven 7-bit digits per entry, exact int8 products on the matrix cores; R/get_opt_hclust.R:66-74 is what it serves). */
+int sharp_dist_i8(const double *U, int n, int p, double *D);
+/* Bench hook: `count` tasks of n x p unit rows; ms[0] rows -> digits, ms[1] digits -> D, ms[2] the fp64 MFMA kernel on the same tasks. */
+int sharp_dist_i8_bench(int n, int p, int count, int reps, double *ms);
 
 /* ---- device memory helpers for non-torch hosts (R glue, tests) -------------- */
 int sharp_dev_alloc(long long bytes, void **dptr);

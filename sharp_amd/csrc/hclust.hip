@@ -1495,6 +1495,9 @@ struct Workspace {
     DevBuf<HcMeta> meta;
     DevBuf<RowPrepTask> prep;
     DevBuf<GemmTask> gemm;
+    DevBuf<DistI8Task> i8;              // the sliced-integer form of the distance GEMM (gemm_i8.hip): descriptors, digits, row scales
+    DevBuf<signed char> sl;
+    DevBuf<double> slscale;
 };
 // Two sets of buffers so that consecutive chunks of tasks can be in flight together (run_chunks); the scratch of the agglomeration
 // itself (S0, S1, img, remaining) is only ever used by one chunk at a time and always comes from set 0.
@@ -1555,6 +1558,7 @@ struct ChunkJob {
     size_t i0 = 0, i1 = 0;
     int T = 0, slot = 0;
     bool pipe = false, first = true;
+    bool i8 = false;          // the distance matrices through the sliced-integer GEMM
     std::vector<HcMeta> metas;
     std::vector<RowPrepTask> prep;
     std::vector<GemmTask> g;
@@ -1573,7 +1577,7 @@ struct ChunkJob {
     hipEvent_t mid_event = nullptr;            // recorded behind round `mid_round` of the round-per-launch agglomeration (if it gets that far)
     int mid_round = 8;
     bool mid_recorded = false;
-    struct Range { int t0, t1; int off[5], cnt[5]; bool any_sym, any_feat; };
+    struct Range { int t0, t1; int off[5], cnt[5]; int off8 = 0; bool any_sym, any_feat; };
     std::vector<Range> ranges;
 };
 enum : int { PH_DIST = 1, PH_AGGLO = 2, PH_STATS = 4, PH_ALL = 7 };
@@ -1723,6 +1727,25 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
             R.cnt[kind] = static_cast<int>(g.size()) - R.off[kind];
         }
     }
+    J.i8 = knobs().dist_i8 && max_p <= 8192;
+    if (J.i8) {
+        std::vector<DistI8Task> d8;
+        size_t oSl = 0, oSc = 0;
+        for (int t = 0; t < T; ++t) if (!metas[t].symmetric) { oSl += dist_i8_slice_bytes(metas[t].nld, metas[t].p); oSc += metas[t].nld; }
+        W.sl.ensure(std::max<size_t>(oSl, 1)); W.slscale.ensure(std::max<size_t>(oSc, 1));
+        oSl = 0; oSc = 0;
+        for (int s = 0; s < NS; ++s) {
+            ranges[s].off8 = static_cast<int>(d8.size());
+            for (int t = ranges[s].t0; t < ranges[s].t1; ++t) {
+                const HcMeta &M = metas[t];
+                if (M.symmetric) continue;
+                d8.push_back(DistI8Task{W.Cr.p + M.oCr, W.D.p + M.oD, W.sl.p + oSl, W.slscale.p + oSc, M.n, M.p, M.nld, (M.p + 31) / 32});
+                oSl += dist_i8_slice_bytes(M.nld, M.p); oSc += M.nld;
+            }
+        }
+        W.i8.ensure(std::max<size_t>(d8.size(), 1));
+        if (!d8.empty()) W.i8.upload(d8.data(), d8.size());
+    }
     // many candidate levels (> kMlMinLevels; SHARP_ML_MIN_LEVELS for tests): G and T of the whole chunk row-major (n x kpad)
     {
         J.ml = max_nk > ml_min_levels();
@@ -1826,7 +1849,8 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         // this chunk's distance GEMM starts when the previous chunk's has finished, i.e. together with the previous chunk's
         // agglomeration, and fills the CUs that one leaves free (it holds a whole CU per task)
         if (J.pipe && !J.first) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.prev_slot], 0));
-        if (R.cnt[0]) gemm_tn_f64_batched(W.gemm.p + R.off[0], R.cnt[0], max_n, max_n, "corr_dist_gemm", true, true);
+        if (R.cnt[0] && J.i8) dist_i8_batched(W.i8.p + R.off8, R.cnt[0], max_n);
+        else if (R.cnt[0]) gemm_tn_f64_batched(W.gemm.p + R.off[0], R.cnt[0], max_n, max_n, "corr_dist_gemm", true, true);
         if (J.pipe) SHARP_HIP_CHECK(hipEventRecord(EV.gemm[J.slot], st));
         if (R.any_sym) {
             KernelTimer tm("copy_d");

@@ -349,3 +349,14 @@ def test_randomised_sharp_parity(sa, oracle, trial):
     # logflag=False: no testlog (the reference samples its cells with an unseeded RNG), log2 on -- what the oracle runs
     res = sa.SHARP(X, ensize_K=K, rN_seed=rs, hmethod=hm, forview=False, logflag=False)
     assert np.array_equal(res["pred_clusters"], ref["pred_clusters"]), (seed, n, m, G, K, hm, rs)
+
+
+def test_labels_with_the_integer_distance_gemm(sa, oracle, monkeypatch):
+    """SHARP_DIST_I8=1: the distance matrices of the base clustering through gemm_i8.hip (exact int8 products of 7-bit digits) instead
+    of the fp64 MFMA kernel: same labels as the oracle, SHARP_small (one task of all cells) and SHARP_large (ragged folds)."""
+    monkeypatch.setenv("SHARP_DIST_I8", "1")
+    for n, m, K, seed in ((1500, 1800, 5, 11), (7300, 2100, 3, 12)):
+        X = oracle.synth_fill(20261004 + seed, m, 0, n, 5, 120)
+        ref = oracle.SHARP(X, K=K, rN_seed=77, nthreads=8)
+        res = sa.SHARP(X, ensize_K=K, rN_seed=77, forview=False, logflag=False)
+        assert np.array_equal(res["pred_clusters"], ref["pred_clusters"]), (n, m, K)
