@@ -9,7 +9,7 @@ for r in csv.DictReader(open(files[-1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), r["Kernel_Name"]))
 rows.sort()
 anchors = [r[0] for r in rows if anchor in r[3]]
-t0 = anchors[-1] - back * 1e6
+t0 = anchors[int(__import__("os").environ.get("ANCHOR_IDX", "-1"))] - back * 1e6
 for s, e, q, name in rows:
     if s < t0 or s > t0 + span * 1e6 or (e - s) / 1e3 < min_us:
         continue
