@@ -1024,6 +1024,58 @@ int sharp_unlimited_merge(const double *means, const long long *counts, int nC, 
 
 }  // extern "C"
 
+// The blocks of a SHARP_unlimited call (R/SHARP_unlimited.R:125-149) on one GPU, each one the SHARP() call of :135: several large-path
+// blocks whose base tasks outnumber the CUs go as ONE pipelined batch (unlimited_batch_window), in windows of at most ~16 GB of
+// projections; SHARP_UNLIMITED_BATCH=0 or blocks that do not qualify: block after block, each preparing the next under its tail.
+// take(b, labels, cluster means, cluster sizes) is called once per block, in block order.
+static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m, int p, int proj, int K,
+                                  double rN_seed, double *viE,
+                                  const std::function<void(int, std::vector<int> &, std::vector<double> &, std::vector<long long> &)> &take) {
+    long long off = 0;                                   // cells in front of block b (the row of viE its E1 starts at)
+    {
+        int b = 0;
+        while (b < nblocks) {                                                                                  // :125-149
+            // Several large-path blocks whose base tasks outnumber the CUs: one pipelined batch (unlimited_batch_window), in windows of
+            // at most ~16 GB of projections.  SHARP_UNLIMITED_BATCH=0: block after block, each preparing the next under its tail.
+            int e = b;
+            long long rows = 0, ntasks = 0;
+            long long window_bytes = 16LL << 30;
+            if (knobs().unlimited_window_mb > 0) window_bytes = static_cast<long long>(knobs().unlimited_window_mb) << 20;   // (tests: several windows)
+            if (knobs().unlimited_batch) {
+                while (e < nblocks && ncb[e] >= 5000 && ncb[e] < (1LL << 31) &&
+                       (rows + ncb[e]) * static_cast<long long>(K) * p * 8 <= window_bytes) {
+                    rows += ncb[e];
+                    ntasks += static_cast<long long>(K) * ((ncb[e] + 1999) / 2000);
+                    ++e;
+                }
+            }
+            if (e - b >= 2 && ntasks > 2LL * ctx().num_cu) {
+                struct Got { std::vector<int> pb; std::vector<double> mb; std::vector<long long> cb; };
+                std::vector<Got> got(e - b);                                    // (the window's tails finish on helper threads, in any order)
+                std::vector<long long> at(e - b + 1, off);
+                for (int q = b; q < e; ++q) at[q - b + 1] = at[q - b] + ncb[q];
+                unlimited_batch_window(dX_blocks, ncb, ldb, b, e, m, p, proj, K, rN_seed, [&](int bb, const SharpOut &o) {
+                    Got &g = got[bb - b];
+                    unlimited_block_summary(o, ncb[bb], p, g.pb, g.mb, g.cb, viE ? viE + static_cast<size_t>(at[bb - b]) * p : nullptr);
+                });
+                for (int q = b; q < e; ++q) { take(q, got[q - b].pb, got[q - b].mb, got[q - b].cb); off += ncb[q]; }
+                b = e;
+                continue;
+            }
+            std::vector<int> pb;
+            std::vector<double> mb;
+            std::vector<long long> cb;
+            const bool more = b + 1 < nblocks;
+            unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb,
+                                viE ? viE + static_cast<size_t>(off) * p : nullptr, 1, nullptr, more ? dX_blocks[b + 1] : XRef(),
+                                more ? ncb[b + 1] : 0, more ? ldb[b + 1] : 0);
+            take(b, pb, mb, cb);
+            off += ncb[b];
+            ++b;
+        }
+    }
+}
+
 // SHARP_unlimited on resident blocks (fp32 or fp64 each)
 static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
                          int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used,
@@ -1052,45 +1104,7 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
             first[b + 1] = first[b] + static_cast<int>(cb.size());
             off += ncb[b];
         };
-        int b = 0;
-        while (b < nblocks) {                                                                                  // :125-149
-            // Several large-path blocks whose base tasks outnumber the CUs: one pipelined batch (unlimited_batch_window), in windows of
-            // at most ~16 GB of projections.  SHARP_UNLIMITED_BATCH=0: block after block, each preparing the next under its tail.
-            int e = b;
-            long long rows = 0, ntasks = 0;
-            long long window_bytes = 16LL << 30;
-            if (knobs().unlimited_window_mb > 0) window_bytes = static_cast<long long>(knobs().unlimited_window_mb) << 20;   // (tests: several windows)
-            if (knobs().unlimited_batch) {
-                while (e < nblocks && ncb[e] >= 5000 && ncb[e] < (1LL << 31) &&
-                       (rows + ncb[e]) * static_cast<long long>(K) * p * 8 <= window_bytes) {
-                    rows += ncb[e];
-                    ntasks += static_cast<long long>(K) * ((ncb[e] + 1999) / 2000);
-                    ++e;
-                }
-            }
-            if (e - b >= 2 && ntasks > 2LL * ctx().num_cu) {
-                struct Got { std::vector<int> pb; std::vector<double> mb; std::vector<long long> cb; };
-                std::vector<Got> got(e - b);                                    // (the window's tails finish on helper threads, in any order)
-                std::vector<long long> at(e - b + 1, off);
-                for (int q = b; q < e; ++q) at[q - b + 1] = at[q - b] + ncb[q];
-                unlimited_batch_window(dX_blocks, ncb, ldb, b, e, m, p, proj, K, rN_seed, [&](int bb, const SharpOut &o) {
-                    Got &g = got[bb - b];
-                    unlimited_block_summary(o, ncb[bb], p, g.pb, g.mb, g.cb, viE ? viE + static_cast<size_t>(at[bb - b]) * p : nullptr);
-                });
-                for (int q = b; q < e; ++q) take(q, got[q - b].pb, got[q - b].mb, got[q - b].cb);
-                b = e;
-                continue;
-            }
-            std::vector<int> pb;
-            std::vector<double> mb;
-            std::vector<long long> cb;
-            const bool more = b + 1 < nblocks;
-            unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb,
-                                viE ? viE + static_cast<size_t>(off) * p : nullptr, 1, nullptr, more ? dX_blocks[b + 1] : XRef(),
-                                more ? ncb[b + 1] : 0, more ? ldb[b + 1] : 0);
-            take(b, pb, mb, cb);
-            ++b;
-        }
+        unlimited_blocks_loop(dX_blocks, ncb, ldb, nblocks, m, p, proj, K, rN_seed, viE, take);
     } catch (...) { drop_projector(proj); throw; }
     drop_projector(proj);
     std::vector<int> fid;
@@ -1163,6 +1177,39 @@ static int unlimited2_run(const XRef *dX_blocks, const long long *ncb, const lon
     if (p_used) *p_used = p;
     SHARP_API_END
 }
+
+extern "C" {
+// SEVERAL blocks of one rank of a sharded SHARP_unlimited run in one call (sharp_unlimited_block_dev per block, but with the base
+// clustering of all of them as one pipelined batch and their tails on helper threads: 17 instead of 25 ms per 50 000-cell block).
+int sharp_unlimited_blocks_dev(const void *const *dX_blocks, const int *is_f64, const long long *ncb, const long long *ldb, int nblocks, int m,
+                               int p, int projector, int ensize_K, double rN_seed, int *pred, int *n_clusters, double *means, int cap_rows,
+                               long long *counts) {
+    SHARP_API_BEGIN
+    ctx();
+    SHARP_REQUIRE(dX_blocks && ncb && ldb && pred && n_clusters && means && counts && nblocks >= 1, "sharp_unlimited_blocks_dev: null argument");
+    SHARP_REQUIRE(p >= 1 && cap_rows >= 1, "sharp_unlimited_blocks_dev: bad sizes");
+    const int K = ensize_K > 0 ? ensize_K : 5;
+    std::vector<XRef> refs(nblocks);
+    for (int b = 0; b < nblocks; ++b) {
+        SHARP_REQUIRE(dX_blocks[b] && ncb[b] >= 1 && ldb[b] >= m, "sharp_unlimited_blocks_dev: bad block");
+        refs[b] = (is_f64 && is_f64[b]) ? dev64_ref(static_cast<const double *>(dX_blocks[b]), m, ncb[b], ldb[b])
+                                        : XRef(static_cast<const float *>(dX_blocks[b]));
+    }
+    long long off = 0;
+    int rows = 0;
+    unlimited_blocks_loop(refs.data(), ncb, ldb, nblocks, m, p, projector, K, rN_seed, nullptr,
+                          [&](int b, std::vector<int> &pb, std::vector<double> &mb, std::vector<long long> &cb) {
+        SHARP_REQUIRE(rows + static_cast<int>(cb.size()) <= cap_rows, "sharp_unlimited_blocks_dev: centroid buffer too small");
+        std::copy(pb.begin(), pb.end(), pred + off);
+        std::copy(mb.begin(), mb.end(), means + static_cast<size_t>(rows) * p);
+        std::copy(cb.begin(), cb.end(), counts + rows);
+        n_clusters[b] = static_cast<int>(cb.size());
+        rows += static_cast<int>(cb.size());
+        off += ncb[b];
+    });
+    SHARP_API_END
+}
+}  // extern "C"
 
 namespace {
 // host blocks of a list-of-matrices call: each is stored as fp32 or fp64 on its own merits

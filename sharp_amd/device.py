@@ -95,6 +95,34 @@ def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag
     return pred, means[: G.value].copy(), counts[: G.value].copy()
 
 
+def unlimited_blocks_dev(blocks, p, projector, ensize_K, rN_seed, cap_rows=4096):
+    """Several resident blocks of one rank in one call (sharp_unlimited_blocks_dev): a list of (labels, cluster means G x p, cluster
+    sizes), one per block -- what unlimited_block_dev returns block by block, with the base clustering of all blocks as one pipelined
+    batch and their tails on helper threads."""
+    _lib.ensure_init()
+    import torch
+
+    B = len(blocks)
+    m = blocks[0].shape[1]
+    ptrs = (C.c_void_p * B)(*[b.data_ptr() for b in blocks])
+    f64 = np.array([1 if b.dtype == torch.float64 else 0 for b in blocks], np.int32)
+    ncb = np.array([b.shape[0] for b in blocks], np.int64)
+    ldb = np.array([b.stride(0) for b in blocks], np.int64)
+    pred = np.zeros(int(ncb.sum()), np.int32)
+    ncl = np.zeros(B, np.int32)
+    means = np.empty((cap_rows * B, p))
+    counts = np.empty(cap_rows * B, np.int64)
+    check(lib().sharp_unlimited_blocks_dev(ptrs, _ip(f64), ncb.ctypes.data_as(C.POINTER(C.c_longlong)), ldb.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                           B, m, p, projector, ensize_K, C.c_double(rN_seed), _ip(pred), _ip(ncl), _dp(means), cap_rows * B,
+                                           counts.ctypes.data_as(C.POINTER(C.c_longlong))))
+    out, o, r = [], 0, 0
+    for b in range(B):
+        g = int(ncl[b])
+        out.append((pred[o:o + int(ncb[b])].copy(), means[r:r + g].copy(), counts[r:r + g].copy()))
+        o += int(ncb[b]); r += g
+    return out
+
+
 def unlimited_multi_dev(blocks, device_of_block, devices, ensize_K=0, N_cluster=0, minN_cluster=0, maxN_cluster=0, rN_seed=0.5,
                         viewflag=False):
     """sharp_SHARP_unlimited_multi_dev: SHARP_unlimited (R/SHARP_unlimited.R:125-183) over blocks that already live on the GPUs of

@@ -58,13 +58,14 @@ def _gather_tables(means_list, counts_list, p, group=None, device="cpu"):
 
 
 def unlimited_sharded(local_blocks, local_block_ids, ncells_per_block, run_block, merge, group=None, device="cpu",
-                      N_cluster=0, minN_cluster=0, maxN_cluster=0):
+                      N_cluster=0, minN_cluster=0, maxN_cluster=0, run_blocks=None):
     """Run this rank's blocks and combine across ranks.
 
     local_blocks      : this rank's block objects (passed to run_block)
     local_block_ids   : their global block indices (block b is owned by rank b % world)
     ncells_per_block  : cells of EVERY global block (needed for p and the k-range rules)
     run_block(block, p[, next_block]) -> (pred (nb,), means (G, p), counts (G,))
+    run_blocks(blocks, p) -> one such triple per block: all of the rank's blocks in ONE call (device.unlimited_blocks_dev)
     merge(means, counts, ncells_total, N_cluster, minN, maxN) -> (final_id (nC,), n_final)
     Returns {global block id: final labels of that block} for the local blocks, and n_final."""
     ncells_total = int(sum(ncells_per_block))
@@ -73,6 +74,12 @@ def unlimited_sharded(local_blocks, local_block_ids, ncells_per_block, run_block
     import inspect
 
     takes_next = len(inspect.signature(run_block).parameters) >= 3      # run_block(block, p, next_block): lets the library prepare the
+    if run_blocks is not None and len(local_blocks) > 1:                # all of the rank's blocks in one library call (one pipelined batch)
+        for pr, mn, cn in run_blocks(local_blocks, p):
+            preds.append(pr)
+            means_list.append(np.asarray(mn, np.float64).reshape(-1, p))
+            counts_list.append(np.asarray(cn, np.int64))
+        local_blocks = []
     for i, blk in enumerate(local_blocks):                               # rank's next block under the current one's tail
         if takes_next:
             pr, mn, cn = run_block(blk, p, local_blocks[i + 1] if i + 1 < len(local_blocks) else None)

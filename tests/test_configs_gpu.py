@@ -42,13 +42,35 @@ def _purity(truth, pred):
     return tab.max(1).sum() / truth.size
 
 
-def _block_steps(sa, dev, torch, m, nb, nblocks, p, K=5):
+def _block_steps(sa, dev, torch, m, nb, nblocks, p, K=5, window=1):
     """every block in turn through sharp_unlimited_block_dev (what a rank of the sharded run does with its blocks); the blocks
-    are generated into ONE device buffer.  Returns per-block labels, centroid tables, counts, planted labels, seconds."""
+    are generated into ONE device buffer.  window > 1: `window` blocks at a time through sharp_unlimited_blocks_dev (a rank that
+    holds several blocks: one pipelined batch per window).  Returns per-block labels, centroid tables, counts, planted labels, seconds."""
     proj = sa.Projector(m, p, [50 + RN + k for k in range(1, K + 1)])
-    dX = torch.empty((nb, m), dtype=torch.float32, device="cuda")
     preds, means, counts, truth = [], [], [], []
     t_run = 0.0
+    if window > 1:
+        bufs = [torch.empty((nb, m), dtype=torch.float32, device="cuda") for _ in range(window)]
+        try:
+            for b0 in range(0, nblocks, window):
+                cur = bufs[: min(window, nblocks - b0)]
+                for q, x in enumerate(cur):
+                    dev.synth_fill(x, SEED, (b0 + q) * nb)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = dev.unlimited_blocks_dev(cur, p, proj.handle, K, RN)
+                t_run += time.perf_counter() - t0
+                for q, (pr, mn, cn) in enumerate(res):
+                    assert pr.min() == 1 and pr.max() == mn.shape[0] == cn.size and cn.sum() == nb
+                    np.testing.assert_array_equal(np.bincount(pr)[1:], cn)
+                    preds.append(pr); means.append(mn); counts.append(cn)
+                    truth.append(dev.synth_labels(SEED, (b0 + q) * nb, nb))
+        finally:
+            proj.close()
+            del bufs
+            torch.cuda.empty_cache()
+        return preds, means, counts, truth, t_run
+    dX = torch.empty((nb, m), dtype=torch.float32, device="cuda")
     try:
         for b in range(nblocks):
             dev.synth_fill(dX, SEED, b * nb)
@@ -156,7 +178,7 @@ def test_cfg5_two_hundred_streamed_blocks_and_merge_at_1e7_cells(env, oracle):
     nb, m, B, p = 50000, 20000, 200, 582                                  # BASELINE.json configs[4]: 10 M x 20 000, 25 blocks per GPU
     ncells = nb * B
     assert p == int(np.ceil(np.log2(ncells) / 0.04))
-    preds, means, counts, truth, t_run = _block_steps(sa, dev, torch, m, nb, B, p)
+    preds, means, counts, truth, t_run = _block_steps(sa, dev, torch, m, nb, B, p, window=10)   # (a rank's 25 blocks: windows of ten resident blocks)
     M, Cn = np.concatenate(means, 0), np.concatenate(counts, 0)
     t0 = time.perf_counter()
     fid, nf = dev.unlimited_merge(M, Cn, ncells)
@@ -395,6 +417,18 @@ def test_unlimited_batched_base_clustering_equals_block_by_block(env, monkeypatc
                                                 C.byref(npred), C.byref(pu), viE.ctypes.data_as(C.POINTER(C.c_double)))
         assert rc in (0, 16, 32, 48), lib.sharp_last_error()
         return pred, viE
+
+    # a rank's blocks in one call (sharp_unlimited_blocks_dev: one pipelined batch, tails on helpers) = block after block
+    # (sharp_unlimited_block_dev), table for table
+    proj = sa.Projector(m, pu1, [50 + 2103 + k for k in range(1, K + 1)])
+    try:
+        many = dev.unlimited_blocks_dev(blocks, pu1, proj.handle, K, 2103)
+        for b in (0, 5, 11):
+            pr, mn, cn = dev.unlimited_block_dev(blocks[b], pu1, proj.handle, K, 2103)
+            assert np.array_equal(many[b][0], pr) and np.array_equal(many[b][2], cn) and np.array_equal(many[b][1], mn), b
+    finally:
+        proj.close()
+    assert sum(len(t[0]) for t in many) == len(p1)
 
     pv, v4 = run_view()
     monkeypatch.setenv("SHARP_TAIL_THREADS", "0")
