@@ -1029,9 +1029,8 @@ int sharp_unlimited_merge(const double *means, const long long *counts, int nC, 
 // projections; SHARP_UNLIMITED_BATCH=0 or blocks that do not qualify: block after block, each preparing the next under its tail.
 // take(b, labels, cluster means, cluster sizes) is called once per block, in block order.
 static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m, int p, int proj, int K,
-                                  double rN_seed, double *viE,
+                                  double rN_seed, double *const *viE_of,   // NULL, or per block where its E1 rows go (NULL: not wanted)
                                   const std::function<void(int, std::vector<int> &, std::vector<double> &, std::vector<long long> &)> &take) {
-    long long off = 0;                                   // cells in front of block b (the row of viE its E1 starts at)
     {
         int b = 0;
         while (b < nblocks) {                                                                                  // :125-149
@@ -1052,13 +1051,11 @@ static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, c
             if (e - b >= 2 && ntasks > 2LL * ctx().num_cu) {
                 struct Got { std::vector<int> pb; std::vector<double> mb; std::vector<long long> cb; };
                 std::vector<Got> got(e - b);                                    // (the window's tails finish on helper threads, in any order)
-                std::vector<long long> at(e - b + 1, off);
-                for (int q = b; q < e; ++q) at[q - b + 1] = at[q - b] + ncb[q];
                 unlimited_batch_window(dX_blocks, ncb, ldb, b, e, m, p, proj, K, rN_seed, [&](int bb, const SharpOut &o) {
                     Got &g = got[bb - b];
-                    unlimited_block_summary(o, ncb[bb], p, g.pb, g.mb, g.cb, viE ? viE + static_cast<size_t>(at[bb - b]) * p : nullptr);
+                    unlimited_block_summary(o, ncb[bb], p, g.pb, g.mb, g.cb, viE_of ? viE_of[bb] : nullptr);
                 });
-                for (int q = b; q < e; ++q) { take(q, got[q - b].pb, got[q - b].mb, got[q - b].cb); off += ncb[q]; }
+                for (int q = b; q < e; ++q) take(q, got[q - b].pb, got[q - b].mb, got[q - b].cb);
                 b = e;
                 continue;
             }
@@ -1067,10 +1064,9 @@ static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, c
             std::vector<long long> cb;
             const bool more = b + 1 < nblocks;
             unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb,
-                                viE ? viE + static_cast<size_t>(off) * p : nullptr, 1, nullptr, more ? dX_blocks[b + 1] : XRef(),
+                                viE_of ? viE_of[b] : nullptr, 1, nullptr, more ? dX_blocks[b + 1] : XRef(),
                                 more ? ncb[b + 1] : 0, more ? ldb[b + 1] : 0);
             take(b, pb, mb, cb);
-            off += ncb[b];
             ++b;
         }
     }
@@ -1104,7 +1100,10 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
             first[b + 1] = first[b] + static_cast<int>(cb.size());
             off += ncb[b];
         };
-        unlimited_blocks_loop(dX_blocks, ncb, ldb, nblocks, m, p, proj, K, rN_seed, viE, take);
+        std::vector<double *> viE_of(nblocks, nullptr);
+        long long at = 0;
+        for (int b = 0; b < nblocks; ++b) { if (viE) viE_of[b] = viE + static_cast<size_t>(at) * p; at += ncb[b]; }
+        unlimited_blocks_loop(dX_blocks, ncb, ldb, nblocks, m, p, proj, K, rN_seed, viE ? viE_of.data() : nullptr, take);
     } catch (...) { drop_projector(proj); throw; }
     drop_projector(proj);
     std::vector<int> fid;
@@ -1385,7 +1384,27 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
             init_slot(acquire_slot(devices[w], occ[w], 0), devices[w]);
             const int proj = my.empty() ? 0 : register_projector(build_projector(m, p, K, seeds.data()));
             try {
-                for (size_t i = 0; i < my.size(); ++i) {
+                if (hostpos.empty() && my.size() >= 2) {
+                    // all of this worker's blocks are on its GPU already: one call for the lot (pipelined batch windows where the blocks
+                    // qualify, tails on helper threads), instead of block after block
+                    std::vector<XRef> refs(my.size());
+                    std::vector<long long> nn(my.size()), ll(my.size());
+                    std::vector<double *> vo(my.size(), nullptr);
+                    for (size_t i = 0; i < my.size(); ++i) {
+                        block_ref(i, true, refs[i], ll[i]);
+                        nn[i] = blocks[my[i]].n;
+                        if (viE) vo[i] = viE + static_cast<size_t>(cell0[my[i]]) * p;
+                    }
+                    const double t_go = wall_s() - t_begin;
+                    unlimited_blocks_loop(refs.data(), nn.data(), ll.data(), static_cast<int>(my.size()), m, p, proj, K, rN_seed, viE ? vo.data() : nullptr,
+                                          [&](int i, std::vector<int> &a, std::vector<double> &c, std::vector<long long> &d) {
+                        const int b = my[i];
+                        pb[b].swap(a); mb[b].swap(c); cb[b].swap(d);
+                        tl[static_cast<size_t>(b) * 6 + 0] = w; tl[static_cast<size_t>(b) * 6 + 1] = b;
+                        tl[static_cast<size_t>(b) * 6 + 4] = t_go; tl[static_cast<size_t>(b) * 6 + 5] = wall_s() - t_begin;
+                    });
+                }
+                for (size_t i = hostpos.empty() && my.size() >= 2 ? my.size() : 0; i < my.size(); ++i) {
                     if (failed.load()) break;
                     const int b = my[i];
                     XRef ref, nref;

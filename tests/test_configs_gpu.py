@@ -436,3 +436,8 @@ def test_unlimited_batched_base_clustering_equals_block_by_block(env, monkeypatc
     monkeypatch.delenv("SHARP_TAIL_THREADS")
     assert np.array_equal(pv, p1) and np.array_equal(pv0, p1)
     assert np.array_equal(v4, v0) and np.abs(v4).max() > 0
+    # the in-process multi-device entry with blocks that are resident already: a worker takes all of its blocks in one go (batch windows
+    # where they qualify).  One worker with all twelve; two workers (two slots on this one GPU) with eight (a window) and four
+    for dob, devs in (([0] * B, [0]), ([0] * 8 + [1] * 4, [0, 0])):
+        pm, nm, _, vm = dev.unlimited_multi_dev(blocks, dob, devs, ensize_K=K, rN_seed=2103, viewflag=True)
+        assert nm == n1 and np.array_equal(pm, p1) and np.array_equal(vm, v4), devs
