@@ -1,6 +1,6 @@
 // gemm_i8.hip -- the correlation-distance matrix D = 1 - U U^T (R/get_opt_hclust.R:66-74) on the INTEGER matrix cores.
 // An alternative to the fp64 MFMA kernel (linalg.hip gemm_tn_f64_fast_kernel), OFF by default (SHARP_DIST_I8=1): correct, tested,
-// and at the end of round 4 slower -- 0.9 ms for the digits + 5.3 ms for the products per chunk of 188 tasks of 2000 x 391 against
+// and at the end of round 4 slower -- 0.9 ms for the digits + 5.1 ms for the products per chunk of 188 tasks of 2000 x 391 against
 // 5.1 ms for the fp64 kernel (tools/bench_i8.py); DESIGN.md 5 "Round 4: the distance GEMM on the integer matrix cores" has the account.
 //
 // The rows of U are centred unit vectors in fp64.  Each row is scaled by a power of two so that its entries lie in (-1, 1) and cut
@@ -37,8 +37,8 @@ constexpr int NS = kDistI8Slices;
 constexpr int BM = 64, BN = 128;                       // workgroup tile: 2 x 4 waves, a 32 x 32 block each
 constexpr int PIECES_A = NS * 2 * BM, PIECES_B = NS * 2 * BN, PIECES = PIECES_A + PIECES_B;   // 16-byte pieces of a k step's panel
 constexpr int DI_THREADS = 512;
-constexpr int LOADS = (PIECES + DI_THREADS - 1) / DI_THREADS;
-constexpr int PAD = LOADS * DI_THREADS;                 // pieces of a panel in LDS (the last round's spare slots included)
+constexpr int RLOADS = (PIECES + 255) / 256;             // requests per panel of each of the four requesting waves
+constexpr int PAD = RLOADS * 256;                       // pieces of a panel in LDS (the last round's spare slots included)
 
 // ---- rows -> digits ---------------------------------------------------------------------------------------------------------------------
 // One workgroup per 32 rows of a task: 8 threads per row, each 4 consecutive k of every k step.
@@ -103,14 +103,17 @@ __global__ __launch_bounds__(DI_THREADS) void dist_i8_kernel(const DistI8Task *_
     // a wave's block is computed when it is not wholly below the diagonal and not wholly padding
     const bool live = colb + 31 >= rowb && rowb < t.n && colb < t.n;
     // Staging: the panel of a k step goes from HBM / L2 straight into LDS (global_load_lds_dwordx4: a wave-instruction fills 64 consecutive
-    // 16-byte pieces, which is the panel's own order), three panels in rotation, the panel of step ks + 2 requested when step ks starts:
-    // with one workgroup per CU a request issued one step ahead came back after the step's MFMAs were done (1.5 us against 1.1).
-    // Piece q of the A part is (slice-half sh = q / BM, row q % BM), of the B part (q' / BN, q' % BN); every thread issues LOADS
-    // requests per panel (the spare slots of the last round re-load the last piece into the panel's padding) so that the waits count.
-    unsigned int src[LOADS];                                      // (in 16-byte pieces: a task's digits are below 2^32 pieces)
+    // 16-byte pieces, which is the panel's own order), three panels in rotation, the panel of step ks + 3 requested when step ks starts.
+    // Piece q of the A part is (slice-half sh = q / BM, row q % BM), of the B part (q' / BN, q' % BN).  Only waves 0 .. 3 -- one per
+    // SIMD -- make requests, RLOADS each per panel (the spare slots of the last round re-load the last piece into the panel's padding, so
+    // that the waits count): the other wave of every SIMD starts its MFMAs right behind the barrier while the CU's one address unit works
+    // through the 48 requests; with all eight waves requesting, no MFMA issued until they were through (2630 cycles per step against
+    // 1830 for the MFMAs and the barrier alone).
+    const bool requester = wave < 4;
+    unsigned int src[RLOADS];                                     // (in 16-byte pieces: a task's digits are below 2^32 pieces)
 #pragma unroll
-    for (int u = 0; u < LOADS; ++u) {
-        int q = tid + u * DI_THREADS;
+    for (int u = 0; u < RLOADS; ++u) {
+        int q = (tid & 255) + u * 256;
         if (q >= PIECES) q = PIECES - 1;
         unsigned int o;
         if (q < PIECES_A) o = static_cast<unsigned int>(q / BM) * t.nld + m0 + q % BM;
@@ -121,9 +124,13 @@ __global__ __launch_bounds__(DI_THREADS) void dist_i8_kernel(const DistI8Task *_
     gv4p base = (gv4p)t.sl;
     typedef __attribute__((address_space(3))) v4i *lv4p;
     auto request = [&](int ks, int buf) __attribute__((always_inline)) {
+        if (!requester) return;
 #pragma unroll
-        for (int u = 0; u < LOADS; ++u)
-            __builtin_amdgcn_global_load_lds(base + (src[u] + static_cast<unsigned int>(ks) * kstride), (lv4p)(panel + buf * PAD + u * DI_THREADS + wave * 64), 16, 0, 0);
+        for (int u = 0; u < RLOADS; ++u)
+            __builtin_amdgcn_global_load_lds(base + (src[u] + static_cast<unsigned int>(ks) * kstride), (lv4p)(panel + buf * PAD + u * 256 + wave * 64), 16, 0, 0);
+    };
+    auto landed = [&]() __attribute__((always_inline)) {          // all but the newest panel's requests of this wave have landed; its LDS reads too
+        if (requester) __builtin_amdgcn_s_waitcnt(0x0070 | RLOADS); else __builtin_amdgcn_s_waitcnt(0x0070);
     };
     const int last = t.ksteps - 1;
     v16i acc[NS];
@@ -153,14 +160,14 @@ __global__ __launch_bounds__(DI_THREADS) void dist_i8_kernel(const DistI8Task *_
     };
     request(0, 0);
     request(last < 1 ? last : 1, 1);
-    __builtin_amdgcn_s_waitcnt(0x0f70 | LOADS);                   // panel 0 is in LDS
+    landed();                                                     // panel 0 is in LDS
     __builtin_amdgcn_s_barrier();
     request(last < 2 ? last : 2, 2);
     if (live) read_frags(0, 0);
     // one step: wait for panel ks + 1, ask for panel ks + 3 into the buffer panel ks has left, read the fragments of ks + 1, multiply ks
     // one step: wait for panel ks + 1, ask for panel ks + 3 into the buffer panel ks has left, read the fragments of ks + 1, multiply ks
     auto step = [&](int ks, int set, int bufn, int buff) __attribute__((always_inline)) {   // bufn: buffer of panel ks + 1, buff: of panel ks
-        __builtin_amdgcn_s_waitcnt(0x0070 | LOADS);               // vmcnt(LOADS): this wave's part of panel ks + 1 has landed; lgkmcnt(0): its fragment reads of panel ks are done
+        landed();                                                 // this wave's part of panel ks + 1 has landed (vmcnt), its fragment reads of panel ks are done (lgkmcnt)
         __builtin_amdgcn_s_barrier();
         request(ks + 3 < last ? ks + 3 : last, buff);
         if (live) {

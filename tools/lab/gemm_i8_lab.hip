@@ -1,3 +1,5 @@
+// LAB SNAPSHOT of sharp_amd/csrc/gemm_i8.hip with the ablation switches (-DI8_NOMFMA, -DI8_NOSTORE, -DI8_NOMIRROR, -DI8_NOREQ, -DI8_NOREAD) and the
+// per-phase cycle stamps (-DI8_TIMING) of DESIGN.md 5; taken before the requests moved to one wave per SIMD.  tools/build_variant.sh NAME "-D..." ../../tools/lab/gemm_i8_lab.hip
 // gemm_i8.hip -- the correlation-distance matrix D = 1 - U U^T (R/get_opt_hclust.R:66-74) on the INTEGER matrix cores.
 //
 // The rows of U are centred unit vectors in fp64.  Each row is scaled by a power of two so that its entries lie in (-1, 1) and cut
