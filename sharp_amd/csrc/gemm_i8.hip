@@ -21,6 +21,7 @@
 // 16-byte pieces of LDS.
 #include "linalg.hpp"
 #include <functional>
+#include <map>
 #include <vector>
 
 namespace sharp {
@@ -244,13 +245,16 @@ void dist_i8_slices(const DistI8Task *d_tasks, int count, int max_n) {
 // side by side, and the digits of a task (5.4 MB at cfg2) do not fit its 4 MB L2: row block after row block every sweep streamed most
 // of them from HBM again (86 MB per task, 16 GB per chunk of 188: the kernel ran at the HBM rate, 5.5 ms).  In SUPER-TILES of 8 x 4
 // tiles (512 x 512 entries: 3 MB of digits for 32 tiles) the panels of the tiles in flight stay in L2.
-struct TileList { DevBuf<unsigned int> d; int n = -1, count = 0; };
-static TileList &tile_list() { return per_slot<TileList>(); }
+struct TileList { DevBuf<unsigned int> d; int count = 0; };
+struct TileLists { std::map<int, TileList> by_n; };     // one list per task size seen, never rewritten: launches on other streams may still read one
+static TileLists &tile_lists() { return per_slot<TileLists>(); }
 constexpr int SUP_R = 8, SUP_C = 4;
 
-static void make_tile_list(int max_n) {
-    TileList &T = tile_list();
-    if (T.n == max_n) return;
+static const TileList &tile_list_for(int max_n) {
+    TileLists &L = tile_lists();
+    auto it = L.by_n.find(max_n);
+    if (it != L.by_n.end()) return it->second;
+    if (L.by_n.size() >= 64) { stream_sync(); SHARP_HIP_CHECK(hipDeviceSynchronize()); L.by_n.clear(); }   // (a run with that many task sizes: start over)
     const int ntm = (max_n + BM - 1) / BM, ntn = (max_n + BN - 1) / BN;
     std::vector<unsigned int> h;
     for (int I = 0; I * SUP_R < ntm; ++I)
@@ -258,18 +262,19 @@ static void make_tile_list(int max_n) {
             for (int ti = I * SUP_R; ti < std::min(ntm, (I + 1) * SUP_R); ++ti)
                 for (int tj = J * SUP_C; tj < std::min(ntn, (J + 1) * SUP_C); ++tj)
                     if (tj * BN + BN - 1 >= ti * BM) h.push_back(static_cast<unsigned int>(ti) << 16 | static_cast<unsigned int>(tj));
-    stream_sync();                                       // (a list of another size may still be read by a launch in flight)
+    TileList &T = L.by_n[max_n];
+    T.count = static_cast<int>(h.size());
     h.resize(h.size() + 8, 0u);                          // (room for the lab build's phase counters)
     T.d.ensure(h.size());
     T.d.upload(h.data(), h.size());
-    h.resize(h.size() - 8);
-    T.n = max_n; T.count = static_cast<int>(h.size());
+    stream_sync();                                       // (once per size: launches on OTHER streams will read this list)
+    return T;
 }
 
 void dist_i8_products(const DistI8Task *d_tasks, int count, int max_n) {
     Ctx &c = ctx();
-    make_tile_list(max_n);
-    const int tiles_max = tile_list().count;
+    const TileList &TL = tile_list_for(max_n);
+    const int tiles_max = TL.count;
     const size_t lds = static_cast<size_t>(3) * PAD * 16;
     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(dist_i8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     const long long blocks = static_cast<long long>((count + 7) / 8) * 8 * tiles_max;
@@ -280,7 +285,7 @@ void dist_i8_products(const DistI8Task *d_tasks, int count, int max_n) {
     }
     for (long long b0 = 0; b0 < blocks; b0 += slice)
         hipLaunchKernelGGL(dist_i8_kernel, dim3(static_cast<unsigned>(std::min(slice, blocks - b0))), dim3(DI_THREADS), lds, c.stream, d_tasks, count,
-                           tile_list().d.p, tiles_max, b0);
+                           TL.d.p, tiles_max, b0);
     launch_check("dist_i8_kernel");
 }
 
