@@ -177,8 +177,9 @@ int sharp_x_storage(void);
 int sharp_last_rpinfo(int *n, int *K, int *p, int *enrp, double *indE);
 
 /* Releases the resident copy of the last host matrix, the pinned staging buffers that sharp_SHARP / sharp_SHARP_csc keep
- * between calls and the projections of the last batched sharp_SHARP_unlimited window (the analogue of R's gc() after a run; no
- * reference counterpart). */
+ * between calls and the projections of the last batched sharp_SHARP_unlimited window; the worker and helper slots that in-process
+ * multi-GPU runs and batched windows have left behind also give back their clustering workspaces (the analogue of R's gc() after a
+ * run; no reference counterpart). */
 int sharp_trim(void);
 
 /* Sparse input: the reference takes whatever `log2(scExp + 1)` and `%*%` accept (R/SHARP.R:343-345,579), which includes the

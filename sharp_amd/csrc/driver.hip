@@ -913,6 +913,9 @@ int sharp_trim(void) {
         dws().posbatch.release();
         rp_pc_trim();
         rp_trim();                                       // the per-chunk entry buffers of a block compacted ahead (up to 16 GB)
+        // worker and helper slots (in-process multi-GPU runs, tail helpers) also give back their clustering workspaces -- tens of GB per
+        // slot, which add up when several slots share one GPU; the caller's own slot keeps them (the next SHARP() call would pay for them again)
+        if (cur_slot() != 0) { hc_release_workspaces(); dws().E.release(); dws().Eb.release(); dws().viE_sh.release(); dws().viE_out.release(); }
     });
     pool_clear();
     SHARP_API_END

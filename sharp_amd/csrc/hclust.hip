@@ -1505,6 +1505,16 @@ struct Workspace {
 // slots 4 and 5: batches whose distance matrices are built ahead of time for the NEXT block of a SHARP_unlimited run (hc_prefetch_*).
 struct WorkspaceSets { Workspace w[6]; };
 Workspace &ws(int slot = 0) { return per_slot<WorkspaceSets>().w[slot]; }
+// The device buffers of every set of the calling thread's slot go back to the driver (sharp_trim for worker and helper slots: a process
+// that ran several slots on ONE GPU -- the tests do -- otherwise keeps tens of GB per slot); the caller has synchronised the device.
+static void release_workspaces_of_slot() {
+    for (Workspace &W : per_slot<WorkspaceSets>().w) {
+        for (DevBuf<double> *b : {&W.D, &W.D0, &W.S0, &W.S1, &W.Cr, &W.Ct, &W.nrm, &W.height, &W.H, &W.T, &W.G, &W.CSt, &W.Q, &W.out,
+                                  &W.mlS, &W.mlcn2m, &W.mlB, &W.mlcn2F, &W.mltot2, &W.slscale}) b->release();
+        for (DevBuf<int> *b : {&W.ia, &W.ib, &W.lab, &W.chosen, &W.packed, &W.status, &W.remaining, &W.mlr1, &W.mlr2, &W.mlcntF}) b->release();
+        W.img.release(); W.seqstate.release(); W.sl.release();
+    }
+}
 
 inline long long rup(long long v, long long a) { return (v + a - 1) / a * a; }
 
@@ -2138,6 +2148,7 @@ namespace {
 struct AfterAgglo { std::function<void(hipEvent_t)> fn; bool fired = false; };
 AfterAgglo &after_agglo() { return per_slot<AfterAgglo>(); }
 }  // namespace
+void hc_release_workspaces() { release_workspaces_of_slot(); }
 void hc_set_after_last_agglomeration(std::function<void(hipEvent_t)> fn) { after_agglo().fn = std::move(fn); after_agglo().fired = false; }
 bool hc_after_last_agglomeration_fired() { return after_agglo().fired; }
 

@@ -53,6 +53,7 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
 // host, right after the LAST chunk's agglomeration has been enqueued; ev is recorded behind that agglomeration.  For work that needs
 // none of the batch's results and should share the chip with the last chunk's statistics rather than with an agglomeration (the
 // ensemble mean of SHARP_large: one HBM-bound pass over E).  Returns through hc_after_last_agglomeration_fired() whether it ran.
+void hc_release_workspaces();   // the clustering workspaces of the calling thread's slot (sharp_trim; the device is idle)
 void hc_set_after_last_agglomeration(std::function<void(hipEvent_t)> fn);
 bool hc_after_last_agglomeration_fired();
 

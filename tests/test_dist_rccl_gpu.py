@@ -63,6 +63,15 @@ def test_bench_default_line_names_cfg2_and_carries_the_other_configs():
     """`python bench.py` (N = 1): the headline is BASELINE.json configs[1]; the same line carries cfg3 end to end and the RP-stage roofline
     at the K = 5 shapes (cfg3's block, cfg4's per-GPU share), and the CPU baseline."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # the bench is a process of its own on the same GPU: this one gives back what earlier tests left in its worker / helper slots and in
+    # torch's cache first (cfg4 whole on one GPU needs ~150 GB)
+    import sharp_amd
+    import torch
+
+    if torch.cuda.is_initialized():
+        sharp_amd.init(0)
+        assert sharp_amd.lib().sharp_trim() == 0
+        torch.cuda.empty_cache()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"], env=env, timeout=1200,
                        capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
