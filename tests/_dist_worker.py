@@ -56,6 +56,15 @@ def main():
     blocks = [orc.synth_fill(seed, m, b * nb, nb, G, nm) for b in mine]
     run_block, merge = oracle_callbacks(orc, m, K, 2103)
     out, nfin, p = sdist.unlimited_sharded(blocks, mine, ncb, run_block, merge, device="cpu")
+    # the same with all of the rank's blocks handed over in ONE call (run_blocks: what device.unlimited_blocks_dev is on a GPU)
+    calls = []
+
+    def run_blocks(bs, p_):
+        calls.append(len(bs))
+        return [run_block(b, p_) for b in bs]
+
+    out2, nfin2, p2 = sdist.unlimited_sharded(blocks, mine, ncb, run_block, merge, device="cpu", run_blocks=run_blocks)
+    assert calls == [len(blocks)] and nfin2 == nfin and p2 == p and all(np.array_equal(out2[b], out[b]) for b in mine)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), blocks=np.array(mine), nfin=nfin, p=p,
              **{f"pred{b}": out[b] for b in mine})
     dist.barrier()
