@@ -435,7 +435,6 @@ def extra_configs(np, torch, sharp_amd, dev, lib, synth_block, unlimited_call, A
     truth = np.concatenate([dev.synth_labels(DATA_SEED, b * nb, nb, G_TRUE) for b in range(B)])
     torch.cuda.synchronize()
     unlimited_call(blocks, K)                                            # warm-up (workspaces)
-    dev.profile(True)
     reps = 2
     lib.sharp_synchronize()
     t0 = time.perf_counter()
@@ -443,8 +442,6 @@ def extra_configs(np, torch, sharp_amd, dev, lib, synth_block, unlimited_call, A
         pred, npred, p = unlimited_call(blocks, K)
     lib.sharp_synchronize()
     dt = (time.perf_counter() - t0) / reps
-    prof = dev.profile_table()
-    dev.profile(False)
     out["cfg3"] = {"workload": "SHARP_unlimited on synthetic %d cells x %d genes as %d blocks, ensize.K=%d (BASELINE.json configs[2])"
                                % (CFG3["cells"], m, B, K),
                    "value": round(CFG3["cells"] / dt, 1), "unit": "cells/s", "seconds_per_call": round(dt, 4), "calls_timed": reps,
@@ -461,15 +458,12 @@ def extra_configs(np, torch, sharp_amd, dev, lib, synth_block, unlimited_call, A
     x = synth_block(0, nb, m)
     proj = sharp_amd.Projector(m, p, [50 + RN_SEED + k for k in range(1, K + 1)])
     dev.unlimited_block_dev(x, p, proj.handle, K, RN_SEED)              # warm-up
-    dev.profile(True)
     lib.sharp_synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         pr, mn, cn = dev.unlimited_block_dev(x, p, proj.handle, K, RN_SEED)
     lib.sharp_synchronize()
     dt = (time.perf_counter() - t0) / reps
-    prof = dev.profile_table()
-    dev.profile(False)
     proj.close()
     out["cfg4_share"] = {"workload": "one GPU's block of BASELINE.json configs[3] at N = 8: %d cells x %d genes, ensize.K=%d, p=%d, "
                                      "sharp_unlimited_block_dev (projectors resident)" % (nb, m, K, p),
