@@ -57,6 +57,13 @@ def init(device=None):
     return device
 
 
+def shutdown():
+    """sharp_shutdown(): the streams of every slot are destroyed (workspaces stay); the next call initialises the library again."""
+    global _initialised_device
+    check(lib().sharp_shutdown())
+    _initialised_device = None
+
+
 def ensure_init():
     if _initialised_device is None:
         init()

@@ -167,3 +167,21 @@ def test_device_lists_may_change_between_calls_and_trim_reaches_every_slot(sa, o
     monkeypatch.setenv("SHARP_DEVICES", "0,0")
     unseeded = sa.SHARP_unlimited(blocks, ensize_K=3, viewflag=False)          # rN.seed = NULL: the reference's default call
     assert unseeded["pred_clusters"].shape == one["pred_clusters"].shape
+
+
+def test_shutdown_and_reinit_reach_every_slot(sa, oracle):
+    """sharp_shutdown destroys the streams of the caller's slot AND of every worker / helper slot earlier calls have left behind; after
+    sharp_init the same calls run again (streams are recreated on first use of a slot, workspaces are kept) and give the same labels."""
+    blocks = _blocks(oracle, [700, 800, 900], m=1200, G=3, nm=150)
+    one = sa.SHARP_unlimited(blocks, ensize_K=3, rN_seed=7, viewflag=False)
+    two = sa.SHARP_unlimited(blocks, ensize_K=3, rN_seed=7, viewflag=False, devices=[0, 0])
+    assert np.array_equal(one["pred_clusters"], two["pred_clusters"])
+    lib = sa.lib()
+    for _ in range(2):
+        sa.shutdown()
+        assert lib.sharp_synchronize() != 0                   # no context: every entry fails loudly until sharp_init
+        sa.init(0)
+        again = sa.SHARP_unlimited(blocks, ensize_K=3, rN_seed=7, viewflag=False, devices=[0, 0])
+        assert np.array_equal(again["pred_clusters"], one["pred_clusters"])
+        alone = sa.SHARP(blocks[0], ensize_K=3, rN_seed=7, logflag=False)
+        assert alone["pred_clusters"].shape == (700,)
