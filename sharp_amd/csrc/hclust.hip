@@ -1051,6 +1051,59 @@ __global__ void onehot_kernel(const HcMeta *__restrict__ metas, const int *__res
     }
 }
 
+// The finest level's cluster sums WITHOUT the one-hot matrix and its skinny GEMM (48 clusters wide: 75 % of a 64-wide MFMA tile, a K
+// loop of 2000 cells; 0.61 ms per chunk of 188 tasks, 0.43 as below, and the 0.04 ms one-hot pass goes too):
+//   cluster_sums_kernel     CSt[j][c] = sum over the cells i of finest cluster c of Cr[i][j]   (p x kpad), one workgroup per (64
+//                           columns, task): a wave walks every SS_WAVES-th row, adds its 64 entries to the cluster's row of the
+//                           wave's LDS table (the label is wave-uniform), the tables are added in wave order at the end.
+// It sums in a fixed order (rows ascending per wave, waves in order): the same bits every run.  (The rows' products with the sums,
+// G = CS C^T, stay on the MFMA: one thread per cell with the 48 sums of a row j through the scalar cache took 0.77 ms against 0.50.)
+constexpr int SS_WAVES = 2, SS_KMAX = 144;            // LDS: SS_WAVES * kpad * 512 B
+__global__ __launch_bounds__(64 * SS_WAVES) void cluster_sums_kernel(const HcMeta *__restrict__ metas, const int *__restrict__ lab_all,
+                                                                     const double *__restrict__ Cr_all, double *__restrict__ CSt_all) {
+    const HcMeta M = metas[blockIdx.y];
+    const int j0 = blockIdx.x * 64;
+    if (j0 >= M.p) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ss_sm[];
+    double *acc = reinterpret_cast<double *>(ss_sm);                       // [SS_WAVES][kpad][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kpad = M.kpad, n = M.n, p = M.p;
+    for (int q = tid; q < SS_WAVES * kpad * 64; q += 64 * SS_WAVES) acc[q] = 0.0;
+    __syncthreads();
+    const int *lab = lab_all + M.oLab + static_cast<long long>(M.nk - 1) * n;
+    const double *Cr = Cr_all + M.oCr;
+    const int j = j0 + lane;
+    const bool live = j < p;
+    double *mine = acc + static_cast<size_t>(wave) * kpad * 64 + lane;
+    int i = wave;
+    for (; i + 3 * SS_WAVES < n; i += 4 * SS_WAVES) {                     // four rows' loads in flight
+        double x[4];
+        int c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c[u] = __builtin_amdgcn_readfirstlane(lab[i + u * SS_WAVES]) - 1;
+            x[u] = live ? Cr[static_cast<long long>(i + u * SS_WAVES) * p + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mine[c[u] * 64] += x[u];
+    }
+    for (; i < n; i += SS_WAVES) {
+        const int c = __builtin_amdgcn_readfirstlane(lab[i]) - 1;
+        mine[c * 64] += live ? Cr[static_cast<long long>(i) * p + j] : 0.0;
+    }
+    __syncthreads();
+    double *CSt = CSt_all + M.oCSt;
+    for (int q = tid; q < kpad * 64; q += 64 * SS_WAVES) {
+        const int c = q >> 6, l = q & 63;
+        if (j0 + l >= p) continue;
+        double v = acc[c * 64 + l];
+#pragma unroll
+        for (int w = 1; w < SS_WAVES; ++w) v += acc[(w * kpad + c) * 64 + l];
+        CSt[static_cast<long long>(j0 + l) * kpad + c] = v;
+    }
+}
+
 // copy the pristine distances of symmetric tasks (hclust updates D in place)
 __global__ void copy_d_kernel(const HcMeta *__restrict__ metas, const double *__restrict__ Dall, double *__restrict__ D0all) {
     const HcMeta M = metas[blockIdx.y];
@@ -1994,12 +2047,21 @@ void enqueue_chunk(ChunkJob &J, int phases) {
             hipLaunchKernelGGL(cutree_kernel, dim3(Ts), dim3(HC_THREADS), lds, st, dmeta, W.ia.p, W.ib.p, W.lab.p);
             launch_check("cutree_kernel");
         }
-        {
+        // the finest level's cluster sums: a dedicated kernel (SHARP_STATS_SUMS=0: the one-hot matrix and a skinny GEMM); the many-levels
+        // form and clusterings of more than SS_KMAX clusters keep the GEMM
+        const bool sums = knobs().stats_sums && !J.ml && max_kpad <= SS_KMAX;
+        if (!sums || R.any_sym) {
             KernelTimer tm("onehot");
             hipLaunchKernelGGL(onehot_kernel, dim3(64, Ts), dim3(256), 0, st, dmeta, W.lab.p, W.H.p);
             launch_check("onehot_kernel");
         }
-        if (R.cnt[1]) gemm_tn_f64_batched(W.gemm.p + R.off[1], R.cnt[1], max_p, max_kpad, "cluster_sums_gemm");
+        if (sums) {
+            KernelTimer tm("cluster_sums_gemm");
+            const size_t lds = static_cast<size_t>(SS_WAVES) * max_kpad * 64 * 8;
+            SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cluster_sums_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            hipLaunchKernelGGL(cluster_sums_kernel, dim3((max_p + 63) / 64, Ts), dim3(64 * SS_WAVES), lds, st, dmeta, W.lab.p, W.Cr.p, W.CSt.p);
+            launch_check("cluster_sums_kernel");
+        } else if (R.cnt[1]) gemm_tn_f64_batched(W.gemm.p + R.off[1], R.cnt[1], max_p, max_kpad, "cluster_sums_gemm");
         if (J.ml) {
             // a5b, many levels.  (The chunk is one range here: NS = 1 whenever J.ml, see setup_chunk.)
             if (R.cnt[3]) gemm_tn_f64_batched(W.gemm.p + R.off[3], R.cnt[3], max_kpad, max_kpad, "cluster_gram_gemm");

@@ -304,6 +304,7 @@ static Knobs read_knobs() {
     v.mean_early = num("SHARP_MEAN_EARLY", 0) != 0;
     v.hc_prep_early = num("SHARP_HC_PREP_EARLY", 1) != 0;
     v.hc_tri = num("SHARP_HC_TRI", 0) != 0;
+    v.stats_sums = num("SHARP_STATS_SUMS", 1) != 0;
     v.dist_i8 = num("SHARP_DIST_I8", 0) != 0;
     v.tail_threads = num("SHARP_TAIL_THREADS", 4);
     v.tail_priority = num("SHARP_TAIL_PRIORITY", 1) != 0;

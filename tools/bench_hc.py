@@ -23,6 +23,6 @@ for K in Ks:
     for _ in range(reps):
         dev.SHARP_dev(dX, ensize_K=K, rN_seed=2103)
     prof = dev.profile_table()
-    keys = ["hclust", "corr_dist_gemm", "sil_ch_stats", "row_prep", "rp_stage", "host:sharp_large_total"]
+    keys = ["hclust", "corr_dist_gemm", "sil_ch_stats", "cluster_sums_gemm", "row_cluster_dot_gemm", "onehot", "row_prep", "rp_stage", "host:sharp_large_total"]
     print("K=%d tasks=%d  " % (K, K * 25) + "  ".join("%s %.2f" % (k, prof.get(k, (0, 0))[0] / reps) for k in keys), flush=True)
     dev.profile(False)
