@@ -170,6 +170,19 @@ SEXP R_sharp_unlimited_multi(SEXP blocks, SEXP ipar, SEXP seed, SEXP viewflag_, 
                 error("The input should be a LIST of partitioned scRNA-seq expression matrices!");
             if (m < 0) m = INTEGER(D)[0];
             if (INTEGER(D)[0] != m) error("The input should be a LIST of partitioned scRNA-seq expression matrices!");
+            /* the three slots go to the upload threads as raw pointers: a hand-built list(p, i, x, dim) must not make them read past
+             * the R vectors (a dgCMatrix satisfies all of this by its validity method) */
+            {
+                const int *pp = INTEGER(P), nc = INTEGER(D)[1];
+                if (pp[0] != 0) error("sparse block %d: slot p does not start at 0", b + 1);
+                for (int c = 0; c < nc; ++c)
+                    if (pp[c + 1] < pp[c]) error("sparse block %d: slot p is not non-decreasing", b + 1);
+                if (XLENGTH(I) != XLENGTH(X) || XLENGTH(I) < (R_xlen_t)pp[nc])
+                    error("sparse block %d: slots i and x must have equal length, at least p[ncol + 1]", b + 1);
+                const int *ii = INTEGER(I);
+                for (int q = 0; q < pp[nc]; ++q)
+                    if (ii[q] < 0 || ii[q] >= m) error("sparse block %d: a row index of slot i is outside 0 .. nrow - 1", b + 1);
+            }
             cp[b] = INTEGER(P); ri[b] = INTEGER(I); ptrs[b] = REAL(X); ncb[b] = INTEGER(D)[1];
         } else {
             if (!isReal(B)) error("The input should be a LIST of partitioned scRNA-seq expression matrices!");

@@ -243,6 +243,16 @@ def _is_sparse(x):
     return hasattr(x, "tocsc") and hasattr(x, "nnz")
 
 
+def _csc_int_slots(blocks):
+    """The @p / @i slots of a list of CSC blocks as the int32 vectors the C ABI takes (a dgCMatrix holds ints too).  scipy switches to
+    int64 index arrays beyond 2^31 - 1 stored entries; such a block cannot be passed at all and must fail loudly, not wrap."""
+    for q, b in enumerate(blocks):
+        if int(b.indptr[-1]) >= 2**31 or b.shape[0] >= 2**31 or b.shape[1] >= 2**31 - 1:
+            raise SharpError("sparse block %d: more than 2^31 - 1 stored entries, rows or columns (the C ABI, like R's dgCMatrix, "
+                             "indexes with int): split the block" % (q + 1))
+    return ([np.ascontiguousarray(b.indptr, np.int32) for b in blocks], [np.ascontiguousarray(b.indices, np.int32) for b in blocks])
+
+
 def testlog(scExp, ncells, p, sncells=100, n_cores=None, cells=None):
     """R/SHARP.R:877-924.  The reference draws the test cells with the unseeded global RNG (:884), so its
     result is not reproducible; pass `cells` (0-based indices) to fix them."""
@@ -474,8 +484,7 @@ def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster
     viE = np.zeros((n, p)) if viewflag else None
     if sparse:
         # only the non-zeros of a block cross PCIe, block b + W while block b is clustered (sharp_SHARP_unlimited_csc_multi)
-        cps = [np.ascontiguousarray(b.indptr, np.int32) for b in blocks]
-        ris = [np.ascontiguousarray(b.indices, np.int32) for b in blocks]
+        cps, ris = _csc_int_slots(blocks)
         vxs = [np.ascontiguousarray(b.data, np.float64) for b in blocks]
         B = len(blocks)
         cpp = (C.POINTER(C.c_int) * B)(*[_ip(a) for a in cps])
@@ -766,8 +775,7 @@ def get_marker_genes_unlimited(scExp, y, theta=1e-5, auc=0.85, pvalue=0.01, n_co
         blocks = [b.tocsc() for b in scExp]
         for b in blocks:
             b.sum_duplicates()
-        cps = [np.ascontiguousarray(b.indptr, np.int32) for b in blocks]
-        ris = [np.ascontiguousarray(b.indices, np.int32) for b in blocks]
+        cps, ris = _csc_int_slots(blocks)
         vxs = [np.ascontiguousarray(b.data, np.float64) for b in blocks]
         cpp = (C.POINTER(C.c_int) * B)(*[_ip(v) for v in cps])
         rip = (C.POINTER(C.c_int) * B)(*[_ip(v) if v.size else C.cast(None, C.POINTER(C.c_int)) for v in ris])

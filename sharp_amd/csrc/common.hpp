@@ -68,9 +68,6 @@ struct XRef {
 // Tuning switches, read from the environment ONCE (the first sharp_init) and kept: the kernels' hosts never call getenv per launch.
 struct Knobs {
     bool rp_dual = true;        // SHARP_RP_DUAL=0: signed row-list codes even where two accumulator arrays would fit
-    bool rp_class = false;      // SHARP_RP_CLASS=1: count-class accumulators (ProjectorGroup::cls, rp3.hip) where dual accumulators would go.  Built, bit-identical, and
-                                // measured SLOWER on one box: cfg3 block 1.65 against 1.33 ms, cfg4 share 6.23 against 5.16 (3 / 5 / 6 producer waves: 1.91 / 1.63 / 1.75 ms):
-                                // the second list costs the producer waves 75 % more vector instructions per unit and the general entries fall back to signed codes
     int rp_two_streams = -1;    // SHARP_RP_SERIAL=0 / 1: the compaction of chunk c + 1 on a second stream beside the apply of chunk c: always / never (default: by kernel form)
     int rp_ahead = 2;           // SHARP_RP_AHEAD: the compaction of the block beside the per-call projector build: 0 not at all, 1 behind the draw kernel
                                 // (beside the packing of the row lists), 2 from the start (beside the draw kernel too)

@@ -694,8 +694,8 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
     std::vector<int> tslot(H);
     for (int h = 0; h < H; ++h) tslot[h] = acquire_slot(dev, owner * 4 + h, 2);
     std::vector<std::thread> helpers;
-    for (int h = 0; h < H; ++h)
-        helpers.emplace_back([&, h] {
+    helpers.reserve(H);
+    auto helper_body = [&](int h) {
             try {
                 init_slot(tslot[h], dev, knobs().tail_priority);
                 host_pool_threads_hint(5);                 // (up to four helpers per GPU run their tails' host loops side by side)
@@ -713,10 +713,24 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
                 SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream));
                 ctx().resolve_pending();
             } catch (...) {
+                // The caller rethrows after the join and unwinds F[], the batch's E and pooled buffers; this slot's kernels may still be
+                // reading them, and pool_give() hands blocks to other slots of the GPU without a synchronisation: drain first.
+                Ctx &hc = ctx_unchecked();
+                if (hc.stream) (void)hipStreamSynchronize(hc.stream);
+                if (hc.stream2) (void)hipStreamSynchronize(hc.stream2);
+                try { drain_side_streams(); } catch (...) {}
                 std::lock_guard<std::mutex> lk(Q.mu);
                 if (!Q.err) Q.err = std::current_exception();
             }
-        });
+    };
+    try {
+        for (int h = 0; h < H; ++h) helpers.emplace_back(helper_body, h);
+    } catch (...) {                                        // std::thread could not start: the started, joinable helpers must not be destroyed
+        { std::lock_guard<std::mutex> lk(Q.mu); Q.stop = true; }
+        Q.cv.notify_all();
+        for (std::thread &t : helpers) t.join();
+        throw;
+    }
     const std::function<void(size_t)> progress = [&](size_t done) {
         int r = next;
         while (r < nbk && first[r + 1] <= done) ++r;

@@ -255,23 +255,16 @@ __global__ __launch_bounds__(PD_THREADS) void proj_draw_kernel(const uint32_t *_
 }
 
 // entries per gene over the projectors [k0, k0+kcount) of one group
-// ... and per (column, sign) of the group (colsign[(kk p + c) 2 + sign]: what bounds a count-class field, projector.hpp)
 __global__ void proj_count_kernel(const uint32_t *__restrict__ hits, unsigned int cap, const unsigned int *__restrict__ nhits, int k0,
-                                  uint32_t p, unsigned int *__restrict__ len, unsigned int *__restrict__ colsign) {
+                                  uint32_t p, unsigned int *__restrict__ len) {
     const int k = k0 + blockIdx.y;
     const size_t list = static_cast<size_t>(k) * gridDim.z + blockIdx.z;      // (projector, draw segment)
     const unsigned int n = nhits[list];
     const uint32_t *h = hits + list * cap;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t idx = h[i] & 0x7fffffffu, g = idx / p, c = idx - g * p, neg = h[i] >> 31;
+        const uint32_t idx = h[i] & 0x7fffffffu, g = idx / p, neg = h[i] >> 31;
         atomicAdd(&len[g], neg ? 0x10000u : 1u);                                // low half: positive codes, high half: negative
-        atomicAdd(&colsign[(static_cast<size_t>(blockIdx.y) * p + c) * 2 + neg], 1u);
     }
-}
-__global__ void proj_max_kernel(const unsigned int *__restrict__ v, size_t n, unsigned int *__restrict__ out) {
-    unsigned int mx = 0u;
-    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) mx = v[i] > mx ? v[i] : mx;
-    atomicMax(out, mx);
 }
 // codes (kk*p + c, bit 15 = negative) into the gene's CSR slot range, in arrival order
 __global__ void proj_fill_kernel(const uint32_t *__restrict__ hits, unsigned int cap, const unsigned int *__restrict__ nhits, int k0,
@@ -483,10 +476,6 @@ int dual_neg_base(int ncomp) {
     return (2 * base <= kMaxCompPerGroup && 2 * base * 8 <= 65536) ? base : 0;
 }
 
-bool class_mode_ok(int ncomp, int max_col_sign) {
-    return knobs().rp_class && dual_neg_base(ncomp) > 0 && max_col_sign > 0 && max_col_sign <= 255;
-}
-
 static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, const double *seeds) {
     SHARP_REQUIRE(m >= 2 && p >= 1 && K >= 1, "projector: need m >= 2, p >= 1, K >= 1");
     SHARP_REQUIRE(p <= kMaxCompPerGroup, "projector: reduced dimension p too large for one launch group");
@@ -513,14 +502,7 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
         grp.k0 = k0;
         grp.kcount = std::min(per_group, K - k0);
         grp.ncomp = grp.kcount * p;
-        {   // entries of one sign per column: what bounds a count-class field (projector.hpp)
-            std::vector<int> cc(static_cast<size_t>(grp.ncomp) * 2, 0);
-            for (int kk = 0; kk < grp.kcount; ++kk)
-                for (int32_t e : pr->h_ent[k0 + kk]) { const int c = e >= 0 ? e : ~e; ++cc[(static_cast<size_t>(kk) * p + c) * 2 + (e < 0 ? 1 : 0)]; }
-            for (int v : cc) grp.max_col_sign = std::max(grp.max_col_sign, v);
-        }
-        grp.cls = class_mode_ok(grp.ncomp, grp.max_col_sign) ? 1 : 0;
-        grp.neg_base = grp.cls ? 0 : dual_neg_base(grp.ncomp);
+        grp.neg_base = dual_neg_base(grp.ncomp);
         // gather the group's entries gene-major
         std::vector<uint32_t> rowptr(static_cast<size_t>(m) + 1, 0);
         std::vector<uint16_t> flat;
@@ -644,17 +626,13 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
         grp.k0 = k0;
         grp.kcount = std::min(per_group, K - k0);
         grp.ncomp = grp.kcount * p;
-        DevBuf<unsigned int> d_len, d_fill, d_colsign, d_colmax;
+        DevBuf<unsigned int> d_len, d_fill;
         d_len.alloc_pooled(static_cast<size_t>(m) + 1); d_fill.alloc_pooled(static_cast<size_t>(m) + 1);
-        d_colsign.alloc_pooled(static_cast<size_t>(grp.ncomp) * 2); d_colmax.alloc_pooled(1);
-        d_len.zero(); d_fill.zero(); d_colsign.zero(); d_colmax.zero();
+        d_len.zero(); d_fill.zero();
         hipLaunchKernelGGL(proj_count_kernel, dim3(16, grp.kcount, S), dim3(256), 0, c.stream, pr->d_hits.p, pr->hit_cap, pr->d_nhits.p, k0,
-                           static_cast<uint32_t>(p), d_len.p, d_colsign.p);
-        hipLaunchKernelGGL(proj_max_kernel, dim3(16), dim3(256), 0, c.stream, d_colsign.p, static_cast<size_t>(grp.ncomp) * 2, d_colmax.p);
+                           static_cast<uint32_t>(p), d_len.p);
         launch_check("proj_count_kernel");
         std::vector<unsigned int> len(static_cast<size_t>(m) + 1);
-        unsigned int colmax = 0;
-        SHARP_HIP_CHECK(hipMemcpyAsync(&colmax, d_colmax.p, sizeof(unsigned int), hipMemcpyDeviceToHost, c.stream));
         int err = 0;
         if (first) {                                     // (all three copies behind ONE synchronisation: each one costs a wake-up of the host thread)
             SHARP_HIP_CHECK(hipMemcpyAsync(&err, d_err.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
@@ -665,9 +643,7 @@ static std::shared_ptr<Projector> build_projector_device(int m, int p, int K, co
             SHARP_REQUIRE(err == 0, "projector: hit list overflow in the device build");
             first = false;
         }
-        grp.max_col_sign = static_cast<int>(colmax);
-        grp.cls = class_mode_ok(grp.ncomp, grp.max_col_sign) ? 1 : 0;
-        grp.neg_base = grp.cls ? 0 : dual_neg_base(grp.ncomp);
+        grp.neg_base = dual_neg_base(grp.ncomp);
         const int neg_base = grp.neg_base;
         std::vector<uint32_t> rowptr(static_cast<size_t>(m) + 1, 0);
         int max_len = 0;
@@ -783,8 +759,14 @@ std::shared_ptr<Projector> get_projector(int handle) {
     return it->second;
 }
 void drop_projector(int handle) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_table.erase(handle);
+    std::shared_ptr<Projector> gone;                     // ~Projector drains its device: outside the registry lock, so that the other
+    {                                                    // workers' lookups do not wait behind it
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_table.find(handle);
+        if (it == g_table.end()) return;
+        gone = std::move(it->second);
+        g_table.erase(it);
+    }
 }
 
 }  // namespace sharp

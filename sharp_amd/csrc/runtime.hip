@@ -278,7 +278,6 @@ static Knobs read_knobs() {
     auto env = [](const char *name) { return getenv(name); };                    // (the library's only getenv outside -DSHARP_LAB code)
     auto num = [&](const char *name, int dflt) { const char *e = env(name); return e && *e ? atoi(e) : dflt; };
     v.rp_dual = num("SHARP_RP_DUAL", 1) != 0;
-    v.rp_class = num("SHARP_RP_CLASS", 0) != 0;
     { const int ser = num("SHARP_RP_SERIAL", -1); v.rp_two_streams = ser < 0 ? -1 : (ser == 0 ? 1 : 0); }
     v.rp_chunk = num("SHARP_RP_CHUNK", 0);
     v.rp_ahead = num("SHARP_RP_AHEAD", 2);

@@ -1,3 +1,4 @@
+// rp3_cls_lab.hip (lab copy of sharp_amd/csrc/rp3.hip as of round 4, WITH the count-class mode (MODE 2: process_cls, class_scatter; SHARP_RP_CLASS=1) that round 5 took out of the product source: built, bit-identical, measured 24 % slower -- cfg3 block 1.65 against 1.33 ms.  tools/build_variant.sh NAME "" ../../tools/lab/rp3_cls_lab.hip; needs ProjectorGroup::cls, which the product's projector no longer sets: restore class_mode_ok() from git history (commit 10ae574) to run it)
 // rp3.hip -- the RP matmul (R/RPmat.R:32, R/SHARP.R:343-345,569-585) as ONE persistent kernel with
 // specialised waves.  A workgroup of eight waves owns one cell at a time:
 //   * its NP producer waves stream the NEXT cell's column of X (1024-gene units, D units in flight per wave, non-temporal 16-byte
@@ -14,7 +15,7 @@
 // launch and one tail per chunk -- and the two instruction streams (HBM stream + compaction, L2 gathers + LDS atomics) interleave
 // inside every CU instead of two grids competing for it.  The sum is the same integer sum: E is bit for bit what rp2.hip / rp.hip
 // produce (tests/test_rp_gpu.py).
-#include "rp_shared.hpp"
+#include "../../sharp_amd/csrc/rp_shared.hpp"
 
 #include <cmath>
 #include <cstdlib>
@@ -32,6 +33,13 @@ namespace sharp {
 constexpr int PC_TAB = 1024;
 constexpr uint32_t kPcGeneMask = 0xfffffu, kPcFull = 0x80000000u, kPcOne = 0x3F800000u;
 constexpr uint32_t kPcBadMask = 0xFC00FFFFu;      // (bits - kPcOne) & this != 0: not a table value
+// Count classes (ProjectorGroup::cls): the table values 1, 1.5, 2 and 3 -- (bits - kPcOne) & kPcClsMask == 0, class = table index >> 6 --
+// are not added as 64-bit terms: an entry of class f adds 1 << 8 f to the 32-bit counter of (component, sign of the projector entry),
+// four 8-bit fields per counter (no column of the projector holds more than 255 entries of one sign: checked at its build), and the
+// epilogue adds field x term of the class.  A ds_add_u32 moves two source dwords to the LDS where a ds_add_u64 moves three (4 against
+// 6 cycles per wave instruction, MI355X_MICROARCH.md), needs one broadcast where the term needs two, and 78 % of the synthetic
+// counts' non-zeros (more of a UMI matrix) are such values.  Class entries and the others are kept in two lists per cell.
+constexpr uint32_t kPcClsMask = 0xFF3FFFFFu;
 // An entry word lives in LDS (the first lcap of a cell) or in the scratch block: accessed through pointers of an explicit address
 // space, so that the compiler forms a DS and a GLOBAL operation under the two halves of the test -- left to itself it selects
 // between the two generic pointers and emits one FLAT operation, and a pending FLAT operation makes its wait-count pass drain
@@ -76,8 +84,9 @@ struct PcParams {
     int comp0;
     const int *row_map;
     int lcap;                 // entries per LDS list (a multiple of 64)
+    int lc;                   // class mode: the first lc entries of a list hold the class entries, the other lcap - lc the general ones (else lcap)
     int cap;                  // entries per scratch list (>= m)
-    uint32_t *sw;             // scratch per workgroup: [2 buffers][cap] entry words (those beyond the LDS room of their list) ...
+    uint32_t *sw;             // scratch per workgroup: [2 buffers][2 kinds][cap] entry words (those beyond the LDS room of their list) ...
     long long *st;            // ... and [2][cap] 64-bit terms (first the value as a double, then its term)
 };
 
@@ -127,20 +136,23 @@ __device__ __forceinline__ void pc_wait(PcUnit<double> &u) {
 }
 
 // PC_THREADS / 64 waves: NP producer waves with D units in flight each; the other waves consume.
-// MODE: 0 signed codes, 1 dual accumulators (ProjectorGroup::neg_base).  (The count-class mode of round 4, measured slower, lives in tools/lab/rp3_cls_lab.hip.)
+// MODE: 0 signed codes, 1 dual accumulators, 2 signed codes + count-class counters (ProjectorGroup::neg_base / cls).
 template <typename T, int GW, int SLOTS, int MODE, int PC_THREADS, int NP, int D>
 __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_kernel(const PcParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool DUAL = MODE == 1;
+    constexpr bool DUAL = MODE == 1, CLS = MODE == 2;
     constexpr int PC_NW = PC_THREADS / 64;
     constexpr int NC = PC_NW - NP, SPAN = SLOTS * GW, U = GW;
     typedef RowWord<SLOTS> Row;
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // 64-bit slots in front of the control words: the accumulators and their dump slots
-    const int nslots = (DUAL ? 2 * P.neg_base : P.ncomp) + kDumpSlots;
-    uint32_t *ctl = reinterpret_cast<uint32_t *>(acc + nslots);     // [0], [1]: entries in list 0 / 1; [2] E row; [3] producers done
+    // 64-bit slots in front of the control words: the accumulators and their dump slots; class mode: the same number again for the
+    // counters (component c: positive entries at 8 c, negative at 8 c + 4, from byte cls_base on)
+    const int nacc = (DUAL ? 2 * P.neg_base : P.ncomp) + kDumpSlots;
+    const int nslots = CLS ? 2 * nacc : nacc;
+    const uint32_t cls_base = static_cast<uint32_t>(nacc) * 8u;
+    uint32_t *ctl = reinterpret_cast<uint32_t *>(acc + nslots);     // [0], [1]: (class) entries in list 0 / 1; [2] E row; [3] producers done; [4], [5]: general entries
     uint32_t *lists = ctl + 8;
     for (int c = tid; c < nslots; c += PC_THREADS) acc[c] = 0ull;
     if (tid < 8) ctl[tid] = 0u;
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
     const int G = static_cast<int>(gridDim.x);
     const int nmine = (P.ncell - static_cast<int>(blockIdx.x) + G - 1) / G;
     auto cell_of = [&](int j) __attribute__((always_inline)) -> long long { return P.cell0 + static_cast<long long>(blockIdx.x) + static_cast<long long>(j) * G; };
-    uint32_t *const sw = P.sw + static_cast<size_t>(blockIdx.x) * 2 * P.cap;
+    uint32_t *const sw = P.sw + static_cast<size_t>(blockIdx.x) * 4 * P.cap;
     long long *const st = P.st + static_cast<size_t>(blockIdx.x) * 2 * P.cap;
 
     // End of a cell for EVERY wave: behind the first barrier all atomics of cell `it` have landed and the list of cell it + 1 is
@@ -165,9 +177,16 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
             for (int c = tid - NP * 64; c < P.ncomp; c += PC_THREADS - NP * 64) {
                 long long a = static_cast<long long>(atomicExch(&acc[c], 0ull));
                 if constexpr (DUAL) a -= static_cast<long long>(atomicExch(&acc[P.neg_base + c], 0ull));
+                if constexpr (CLS) {                    // + sum over the classes of (entries of the class: positive - negative) x the class's term
+                    const unsigned long long cw = atomicExch(&acc[nacc + c], 0ull);
+                    const uint32_t pos = static_cast<uint32_t>(cw), neg = static_cast<uint32_t>(cw >> 32);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        a += static_cast<long long>(static_cast<int>((pos >> (8 * f)) & 255u) - static_cast<int>((neg >> (8 * f)) & 255u)) * P.fixtab[64 * f];
+                }
                 __builtin_nontemporal_store(P.out_scale * (P.val * (static_cast<double>(a) * P.inv_fix)), &erow[c]);
             }
-            if (tid == NP * 64) ctl[it & 1] = 0u;     // that list has been consumed: the cell after next appends to it
+            if (tid == NP * 64) { ctl[it & 1] = 0u; ctl[4 + (it & 1)] = 0u; }   // those lists have been consumed: the cell after next appends to them
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
@@ -183,28 +202,53 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
         // flight).  A cell's first batches are set up BEFORE the previous cell's barriers and epilogue whenever the producers have
         // that cell's list complete by then (ctl[3] counts their completions; they normally run a cell ahead): the dependent round
         // trips -- entry word, term, row list -- then travel under the barriers and the epilogue instead of behind them.
+        // class mode: the cell's batches are its class batches [0, nbC) followed by its general batches [nbC, nb); else nbC = 0
         const uint32_t *lst = lists;
-        const uint32_t *swb = sw;                         // scratch words of this cell's list
+        const uint32_t *swc = sw, *swb = sw;             // scratch words of the class / the general list of this cell
         const long long *stb = st;
-        int nnz = 0, nb = 0;
-        const int gcap = P.lcap;
+        int nnzC = 0, nbC = 0, nnz = 0, nb = 0;           // (nnz: the general list's entries; nb: all batches)
+        const int lc = CLS ? P.lc : 0, gcap = P.lcap - lc;
         uint32_t gC = 0u, gL = 0u, wR = 0u;   // genes of the batch being added / of the one after the next; entry words of the one after that
-        long long fC = 0ll, fL = 0ll;         // their terms
+        long long fC = 0ll, fL = 0ll;         // their terms (a class batch: the counter increment 1 << 8 class)
         Row cd[U], cdn[U];
         auto load_word = [&](int bt) __attribute__((always_inline)) -> uint32_t {                 // lane = entry of batch bt; unconditional, clamped
-            const int e = (bt << 6) + lane;
+            if (CLS && bt < nbC) {
+                const int e = (bt << 6) + lane;
+                const int ec = e < nnzC ? e : 0;
+                if ((bt << 6) + 64 <= lc) return *(const pc_lds_u32 *)(lst + ec);
+                return pc_get_word(lst, swc, static_cast<uint32_t>(lc), static_cast<uint32_t>(ec));
+            }
+            const int bk = bt - nbC;
+            const int e = (bk << 6) + lane;
             const int ec = e < nnz ? e : 0;
-            if ((bt << 6) + 64 <= gcap) return *(const pc_lds_u32 *)(lst + ec);
-            return pc_get_word(lst, swb, static_cast<uint32_t>(gcap), static_cast<uint32_t>(ec));
+            if ((bk << 6) + 64 <= gcap) return *(const pc_lds_u32 *)(lst + lc + ec);
+            return pc_get_word(lst + lc, swb, static_cast<uint32_t>(gcap), static_cast<uint32_t>(ec));
         };
         auto decode = [&](int bt, uint32_t w, uint32_t &g, long long &f) __attribute__((always_inline)) {
-            const int e = (bt << 6) + lane;
+            if (CLS && bt < nbC) {
+                const int e = (bt << 6) + lane;
+                g = e < nnzC ? (w & kPcGeneMask) : P.dummy_seg;
+                f = e < nnzC ? static_cast<long long>(1u << ((w >> 23) & 0x18u)) : 0ll;         // class = table index >> 6 = bits 27..26 of the word
+                return;
+            }
+            const int e = ((bt - nbC) << 6) + lane;
             long long ff = P.fixtab[(w >> 20) & 0x3ffu];            // 8 KB, cache resident
             if (__ballot((w & kPcFull) != 0u) != 0ull) {           // rare, wave-uniform test: a value outside the table
                 if (w & kPcFull) ff = __builtin_nontemporal_load((const pc_glb_i64 *)(stb + (e < nnz ? e : 0)));
             }
             g = e < nnz ? (w & kPcGeneMask) : P.dummy_seg;
             f = e < nnz ? ff : 0ll;
+        };
+        // the counter increments of a lane's codes (class batches): 32-bit adds at cls_base + (code & 0xfffc)
+        auto class_scatter = [&](const Row &c, uint32_t inc) __attribute__((always_inline)) {
+            if (lane_live(c.x)) {
+                __hip_atomic_fetch_add(reinterpret_cast<pc_lds_u32 *>(static_cast<uintptr_t>(cls_base + (c.x & 0xfffcu))), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(reinterpret_cast<pc_lds_u32 *>(static_cast<uintptr_t>(cls_base + ((c.x >> 16) & 0xfffcu))), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if constexpr (SLOTS == 4) {
+                    __hip_atomic_fetch_add(reinterpret_cast<pc_lds_u32 *>(static_cast<uintptr_t>(cls_base + (c.y & 0xfffcu))), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(reinterpret_cast<pc_lds_u32 *>(static_cast<uintptr_t>(cls_base + ((c.y >> 16) & 0xfffcu))), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         };
         auto load_lists = [&](uint32_t g, Row (&dst)[U]) __attribute__((always_inline)) {
             const uint32_t gofs = g * static_cast<uint32_t>(SPAN * 2);
@@ -222,7 +266,14 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
             wR = load_word(bt + 3 * NC);
             const uint32_t plo = static_cast<uint32_t>(fC), phi = static_cast<uint32_t>(static_cast<unsigned long long>(fC) >> 32);
             uint32_t more = 0u;
-            if constexpr (DUAL) {
+            const bool cls_batch = CLS && bt < nbC;
+            if (cls_batch) {
+                static_for<U>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    class_scatter(cur[u], group_bcast<GW, u>(plo));
+                    more |= cur[u].x;
+                });
+            } else if constexpr (DUAL) {
                 static_for<U>([&](auto uc) {
                     constexpr int u = decltype(uc)::value;
                     const uint32_t lo = group_bcast<GW, u>(plo), hi = group_bcast<GW, u>(phi);
@@ -254,7 +305,8 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
                         const uint2 oi = P.ovf_slot[g];
                         for (uint32_t sg = 0; sg < oi.y; ++sg) {
                             const Row c2 = load_row_word<SLOTS>(P.ent + (static_cast<size_t>(oi.x) + sg) * SPAN + SLOTS * lg);
-                            if constexpr (DUAL) scatter_row_word<0, SLOTS, false>(c2, static_cast<unsigned long long>(f));
+                            if (cls_batch) class_scatter(c2, bpl);
+                            else if constexpr (DUAL) scatter_row_word<0, SLOTS, false>(c2, static_cast<unsigned long long>(f));
                             else scatter_row_word<0, SLOTS, true>(c2, static_cast<unsigned long long>((c2.x & kCodeNeg) ? -f : f));
                         }
                     }
@@ -266,10 +318,17 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
         auto begin_cell = [&](int it2) __attribute__((always_inline)) {     // the list of cell it2 is complete
             const int b2 = it2 & 1;
             lst = lists + b2 * P.lcap;
-            swb = sw + static_cast<size_t>(b2) * P.cap;
+            swc = sw + static_cast<size_t>(2 * b2) * P.cap;
+            swb = sw + static_cast<size_t>(2 * b2 + (CLS ? 1 : 0)) * P.cap;
             stb = st + static_cast<size_t>(b2) * P.cap;
-            nnz = __builtin_amdgcn_readfirstlane(static_cast<int>(ctl[b2]));
-            nb = (nnz + 63) >> 6;
+            if constexpr (CLS) {
+                nnzC = __builtin_amdgcn_readfirstlane(static_cast<int>(ctl[b2]));
+                nnz = __builtin_amdgcn_readfirstlane(static_cast<int>(ctl[4 + b2]));
+                nbC = (nnzC + 63) >> 6;
+            } else {
+                nnz = __builtin_amdgcn_readfirstlane(static_cast<int>(ctl[b2]));
+            }
+            nb = nbC + ((nnz + 63) >> 6);
             if (cw < nb) {
                 const uint32_t w0 = load_word(cw), w1 = load_word(cw + NC);
                 wR = load_word(cw + 2 * NC);
@@ -360,7 +419,7 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
             // The general path (a value outside the table somewhere in the unit, an fp64 block, or a list beyond the LDS room): every
             // non-zero again -- table values as above, the others flagged kPcFull with the value parked as a double in the scratch
             // block -- then one lane per entry turns the parked value into its term.
-            uint32_t *swb = sw + static_cast<size_t>(b01) * P.cap;
+            uint32_t *swb = sw + static_cast<size_t>(2 * b01) * P.cap;
             long long *stb = st + static_cast<size_t>(b01) * P.cap;
             {
                 uint32_t run = base;
@@ -392,6 +451,106 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
             __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0): the scratch block is complete before this wave reaches the barrier
             asm volatile("" ::: "memory");                      // (a builtin, not inline assembly: the wait-count pass sees it and forgets the stores)
         };
+        // The same for a group with count-class counters: a unit's non-zeros go to TWO lists -- the class values (1, 1.5, 2, 3) to the cell's
+        // class list (the first lc words of the cell's list space in LDS), all others to its general list (the rest) -- each with a
+        // reservation of its own (two returning LDS atomics, waited for together).
+        auto is_class = [&](T x, uint32_t &t) __attribute__((always_inline)) -> bool {
+            const float xf = static_cast<float>(x);
+            t = __float_as_uint(xf) - kPcOne;
+            if constexpr (std::is_same<T, float>::value) return (t & kPcClsMask) == 0u;       // (zero: t = 0xC0800000, never a class)
+            else return static_cast<T>(xf) == x && (t & kPcClsMask) == 0u;
+        };
+        auto process_cls = [&](PcUnit<T> &u, int j, int k, bool live) __attribute__((always_inline)) {
+            pc_wait<(D - 1) * CpLayout<T>::LOADS>(u);
+            CpVals<T> b;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) b.v[q] = pc_val(u, q);
+            const int unit = wave + k * NP;
+            const int ubase = unit * CP_UNIT;
+            const int glim = (live && unit < units) ? P.m - ubase : 0;
+            if (glim < CP_UNIT) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (CpLayout<T>::gene_of(lane, q) >= glim) b.v[q] = T(0);
+            }
+            int totN = 0, totC = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                uint32_t t;
+                totN += __popcll(__ballot(b.v[q] != T(0)));
+                totC += __popcll(__ballot(is_class(b.v[q], t)));
+            }
+            if (totN == 0) return;
+            const int totG = totN - totC;
+            const int b01 = j & 1;
+            uint32_t baseC = 0u, baseG = 0u;
+            if (lane == 0) {
+                if (totC) baseC = atomicAdd(&ctl[b01], static_cast<uint32_t>(totC));
+                if (totG) baseG = atomicAdd(&ctl[4 + b01], static_cast<uint32_t>(totG));
+            }
+            baseC = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(baseC)));
+            baseG = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(baseG)));
+            uint32_t *lst = lists + b01 * P.lcap;
+            const uint32_t lc = static_cast<uint32_t>(P.lc), gcap = static_cast<uint32_t>(P.lcap - P.lc);
+            if constexpr (std::is_same<T, float>::value) {
+                if (baseC + static_cast<uint32_t>(totC) <= lc && baseG + static_cast<uint32_t>(totG) <= gcap) {
+                    // the usual path: every value a table value, every entry in LDS
+                    uint32_t runC = baseC, runG = lc + baseG, bad = 0u;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        uint32_t t;
+                        const bool ic = is_class(b.v[q], t), og = b.v[q] != 0.0f && !ic;
+                        const unsigned long long mC = __ballot(ic), mG = __ballot(og);
+                        const uint32_t word = (t << 4) + static_cast<uint32_t>(ubase + CpLayout<T>::gene_of(lane, q));
+                        if (ic) *(pc_lds_u32 *)(lst + runC + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mC >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mC), 0u))) = word;
+                        if (mG != 0ull) {
+                            if (og) {
+                                *(pc_lds_u32 *)(lst + runG + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mG >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mG), 0u))) = word;
+                                bad |= t & kPcBadMask;
+                            }
+                            runG += static_cast<uint32_t>(__popcll(mG));
+                        }
+                        runC += static_cast<uint32_t>(__popcll(mC));
+                    }
+                    if (__ballot(bad != 0u) == 0ull) return;
+                }
+            }
+            // the general path, as in process(): the same positions of the two lists, entries beyond a list's LDS room in its scratch words,
+            // a value outside the table flagged kPcFull with its term in the scratch block
+            uint32_t *swc = sw + static_cast<size_t>(2 * b01) * P.cap, *swg = sw + static_cast<size_t>(2 * b01 + 1) * P.cap;
+            long long *stb = st + static_cast<size_t>(b01) * P.cap;
+            {
+                uint32_t runC = baseC, runG = baseG;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    uint32_t t;
+                    const bool ic = is_class(b.v[q], t), og = b.v[q] != T(0) && !ic;
+                    const unsigned long long mC = __ballot(ic), mG = __ballot(og);
+                    const uint32_t gene = static_cast<uint32_t>(ubase + CpLayout<T>::gene_of(lane, q));
+                    if (ic) pc_put_word(lst, swc, lc, runC + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mC >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mC), 0u)), (t << 4) + gene);
+                    if (og) {
+                        const uint32_t pos = runG + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mG >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mG), 0u));
+                        const bool tab = static_cast<T>(static_cast<float>(b.v[q])) == b.v[q] && (t & kPcBadMask) == 0u;
+                        pc_put_word(lst + lc, swg, gcap, pos, tab ? (t << 4) + gene : (gene | kPcFull));
+                        if (!tab) *(pc_glb_i64 *)(stb + pos) = __double_as_longlong(static_cast<double>(b.v[q]));
+                    }
+                    runC += static_cast<uint32_t>(__popcll(mC));
+                    runG += static_cast<uint32_t>(__popcll(mG));
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0070);                 // vmcnt(0) lgkmcnt(0): this wave's own stores, before it reads them back
+            asm volatile("" ::: "memory");
+            for (uint32_t e = baseG + static_cast<uint32_t>(lane); e < baseG + static_cast<uint32_t>(totG); e += 64u) {
+                const uint32_t word = pc_get_word(lst + lc, swg, gcap, e);
+                if (word & kPcFull) {
+                    const double x = __longlong_as_double(__builtin_nontemporal_load((const pc_glb_i64 *)(stb + e)));
+                    const double f = P.log_flag == 2 ? log10(1.0 + x) : (P.log_flag ? log2(1.0 + x) : x);
+                    *(pc_glb_i64 *)(stb + e) = __double2ll_rn(f * P.fix_scale);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0): the scratch block is complete before this wave reaches the barrier
+            asm volatile("" ::: "memory");
+        };
         PcUnit<T> buf[D];
         static_for<D>([&](auto ic) { fetch(buf[decltype(ic)::value]); });
         int pj = 0, pk = 0;                               // the item being worked on
@@ -399,7 +558,8 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
             static_for<D>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 const bool live = t + i < total;
-                process(buf[i], pj, pk, live);
+                if constexpr (CLS) process_cls(buf[i], pj, pk, live);
+                else process(buf[i], pj, pk, live);
                 fetch(buf[i]);                            // (unconditional: the loads in flight are the same on every path)
                 if (live && ++pk == upp) {
                     pk = 0;
@@ -446,13 +606,18 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
     if constexpr (std::is_same<T, double>::value) kern = reinterpret_cast<const void *>(rp_pc_kernel<T, GW, SLOTS, MODE, 512, 2, 2>);
     else kern = shape_b ? reinterpret_cast<const void *>(rp_pc_kernel<T, GW, SLOTS, MODE, SHARP_PC_B_THREADS, SHARP_PC_B_NP, 2>)
                         : reinterpret_cast<const void *>(rp_pc_kernel<T, GW, SLOTS, MODE, 512, SHARP_PC_A_NP, SHARP_PC_A_D>);
-    // LDS per workgroup: accumulators + dump slots, eight control words, two entry lists; two workgroups per CU
-    const size_t acc_bytes = static_cast<size_t>(g.acc_slots() + kDumpSlots) * 8 + 32;
+    // LDS per workgroup: accumulators + dump slots (class mode: the same again for the counters), eight control words, two entry lists;
+    // two workgroups per CU
+    const size_t acc_bytes = static_cast<size_t>(g.acc_slots() + kDumpSlots) * 8 * (MODE == 2 ? 2 : 1) + 32;
     const size_t budget = 80 * 1024;
     SHARP_REQUIRE(acc_bytes + 2 * 64 * 4 <= budget, "rp_pc_kernel: the accumulators leave no LDS for the entry lists");
     int lcap = static_cast<int>((budget - acc_bytes) / 8 / 64 * 64);
-    lcap = std::min(lcap, (P.m + 63) / 64 * 64);
+    lcap = std::min(lcap, (P.m + 63) / 64 * 64 + (MODE == 2 ? 64 : 0));
     P.lcap = lcap;
+    // class mode: three quarters of a list's room for the class entries (78 % of the synthetic counts' non-zeros are class values, more
+    // of a UMI matrix; what does not fit a part goes through the scratch words)
+    P.lc = MODE == 2 ? std::max(64, lcap * 3 / 4 / 64 * 64) : lcap;
+    if (MODE == 2 && P.lc >= lcap) P.lc = lcap - 64;
     const size_t lds = acc_bytes + static_cast<size_t>(lcap) * 8;
     SHARP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     {   // scatter_row_word<0, ...>: the accumulators sit at LDS address 0, i.e. the kernel must not have static LDS in front of the dynamic block
@@ -466,7 +631,7 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
     per_cu = std::min(per_cu, std::max(1, knobs().rp_pc_wgs));
     const int grid = c.num_cu * per_cu;
     P.cap = (P.m + 3) / 4 * 4;
-    W.sw.ensure(static_cast<size_t>(c.num_cu) * 2 * 2 * P.cap);       // per workgroup: [2 buffers][cap] words, [2][cap] terms
+    W.sw.ensure(static_cast<size_t>(c.num_cu) * 2 * 4 * P.cap);       // per workgroup: [2 buffers][2 kinds][cap] words, [2][cap] terms
     W.st.ensure(static_cast<size_t>(c.num_cu) * 2 * 2 * P.cap);
     P.sw = W.sw.p;
     P.st = W.st.p;
@@ -511,12 +676,12 @@ void project_dev_pc(const Projector &pr, const ProjectorGroup &g, XRef dX, int m
     P.ent = g.ent.p; P.dummy_seg = static_cast<unsigned int>(g.nseg); P.ovf_slot = g.ovf_slot.p; P.ncomp = g.ncomp; P.neg_base = g.neg_base;
     P.inv_fix = inv_fix; P.val = pr.val; P.out_scale = 1.0 / std::sqrt(static_cast<double>(pr.p));
     P.E = dE; P.ldE = ldE; P.comp0 = g.k0 * pr.p; P.row_map = d_row_map;
-    P.lcap = 0; P.cap = 0; P.sw = nullptr; P.st = nullptr;
+    P.lcap = 0; P.lc = 0; P.cap = 0; P.sw = nullptr; P.st = nullptr;
     KernelTimer t("rp_stage");
     KernelTimer t2("rp_pc");
-    const int mode = g.neg_base > 0 ? 1 : 0;
+    const int mode = g.cls ? 2 : (g.neg_base > 0 ? 1 : 0);
 #define SHARP_PCL(TT, GWV, SL, MD) launch_pc<TT, GWV, SL, MD>(g, pr, P, n, c.stream)
-#define SHARP_PCM(TT, GWV, SL) { if (mode == 1) SHARP_PCL(TT, GWV, SL, 1); else SHARP_PCL(TT, GWV, SL, 0); }
+#define SHARP_PCM(TT, GWV, SL) { if (mode == 2) SHARP_PCL(TT, GWV, SL, 2); else if (mode == 1) SHARP_PCL(TT, GWV, SL, 1); else SHARP_PCL(TT, GWV, SL, 0); }
 #define SHARP_PCT(TT)                                        \
     if (g.gw == 16 && g.slots == 4) SHARP_PCM(TT, 16, 4)     \
     else if (g.gw == 16) SHARP_PCM(TT, 16, 2)                \

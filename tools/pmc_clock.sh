@@ -1,10 +1,12 @@
 #!/bin/bash
+# the interpreter itself goes after `--`: a shim script (pyenv, a conda wrapper) would be an exec hop under the profiler's preloaded GPU runtime
+PY=$(python3 -c 'import os,sys;print(os.path.realpath(sys.executable))')
 # ON THE GPU BOX: the shader clock each kernel actually ran at = GRBM_GUI_ACTIVE (cycles the GPU was busy during the dispatch,
 # kernels run one at a time under counter collection; the counter is summed over the 8 XCDs) / 8 / the dispatch's duration from the
 # kernel trace of the same run.  Short kernels read high: the busy window includes the dispatch overhead, the duration does not.
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-SHARP_HC_PIPE=0 timeout -k 10 400 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_clock -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra > $OUT/pmc_clock.log 2>&1
+SHARP_HC_PIPE=0 timeout -k 10 400 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_clock -- "$PY" $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra > $OUT/pmc_clock.log 2>&1
 cd $REPO
 python3 - <<'PY'
 import csv, glob, collections

@@ -1,10 +1,12 @@
 #!/bin/bash
+# the interpreter itself goes after `--`: a shim script (pyenv, a conda wrapper) would be an exec hop under the profiler's preloaded GPU runtime
+PY=$(python3 -c 'import os,sys;print(os.path.realpath(sys.executable))')
 # ON THE GPU BOX: SQ counters of the correlation-distance GEMM (one chunk at a time, so that it has the chip to itself)
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  SHARP_HC_PIPE=0 timeout 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_gemm_$tag -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_gemm_$tag.log 2>&1
+  SHARP_HC_PIPE=0 timeout 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_gemm_$tag -- "$PY" $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_gemm_$tag.log 2>&1
 done
 cd $REPO
 python3 - <<'PY'

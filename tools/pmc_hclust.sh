@@ -1,10 +1,12 @@
 #!/bin/bash
+# the interpreter itself goes after `--`: a shim script (pyenv, a conda wrapper) would be an exec hop under the profiler's preloaded GPU runtime
+PY=$(python3 -c 'import os,sys;print(os.path.realpath(sys.executable))')
 # ON THE GPU BOX: SQ counters of the agglomeration kernel at 25 tasks (one pass per counter group)
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  SHARP_HC_RANGES=1 timeout 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_hc_$tag -- python3 $REPO/tools/bench_hc.py ${HC_K:-1} > $OUT/pmc_hc_$tag.log 2>&1
+  SHARP_HC_RANGES=1 timeout 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_hc_$tag -- "$PY" $REPO/tools/bench_hc.py ${HC_K:-1} > $OUT/pmc_hc_$tag.log 2>&1
 done
 cd $REPO
 python3 - <<'PY'

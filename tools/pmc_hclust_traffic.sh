@@ -1,9 +1,11 @@
 #!/bin/bash
+# the interpreter itself goes after `--`: a shim script (pyenv, a conda wrapper) would be an exec hop under the profiler's preloaded GPU runtime
+PY=$(python3 -c 'import os,sys;print(os.path.realpath(sys.executable))')
 # ON THE GPU BOX: HBM bytes of the agglomeration kernel (FETCH_SIZE doubled on gfx950, see tools/pmc_calib.sh) at 375 tasks
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  SHARP_HC_RANGES=1 timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_hct_$c -- python3 $REPO/tools/bench_hc.py 15 > $OUT/pmc_hct_$c.log 2>&1
+  SHARP_HC_RANGES=1 timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_hct_$c -- "$PY" $REPO/tools/bench_hc.py 15 > $OUT/pmc_hct_$c.log 2>&1
 done
 cd $REPO
 python3 - <<'PY'

@@ -1,11 +1,13 @@
 #!/bin/bash
+# the interpreter itself goes after `--`: a shim script (pyenv, a conda wrapper) would be an exec hop under the profiler's preloaded GPU runtime
+PY=$(python3 -c 'import os,sys;print(os.path.realpath(sys.executable))')
 # ON THE GPU BOX: exact HBM-side read bytes from the L2's request-size counters (32 / 64 / 128 B), calibrated on known-size streams
 # and applied to the agglomeration kernel at 375 tasks.
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 C="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
 timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_rq_calib -- $REPO/tools/micro/fetch_calib 1024 > $OUT/pmc_rq_calib.log 2>&1
-SHARP_HC_RANGES=1 timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_rq_hc -- python3 $REPO/tools/bench_hc.py 15 > $OUT/pmc_rq_hc.log 2>&1
+SHARP_HC_RANGES=1 timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_rq_hc -- "$PY" $REPO/tools/bench_hc.py 15 > $OUT/pmc_rq_hc.log 2>&1
 cd $REPO
 python3 - <<'PY'
 import csv, glob, collections

@@ -8,7 +8,8 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-traffic"
+PY=$(python3 -c 'import os,sys;print(os.path.realpath(sys.executable))')   # the interpreter itself after `--`, never a shim script
+CMD="$PY $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-traffic"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -- $CMD > $OUT/${TAG}_kt.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- $CMD > $OUT/${TAG}_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- $CMD > $OUT/${TAG}_pmc_write.log 2>&1
