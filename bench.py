@@ -7,26 +7,30 @@ steps, then exactly K timed steps bracketed by barrier + device synchronisation 
 ranks, rank 0 prints ONE JSON line.
 
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
-  N = 1 (default, --config cfg2): BASELINE.json configs[1]: one SHARP() call on 50 000 cells x 20 000 genes,
-          ensize.K = 15 (SHARP_large: projectors, RP matmul, 375 base-clustering tasks, 25 wMetaC, sMetaC).
-  N = 1, --config cfg3: BASELINE.json configs[2]: SHARP_unlimited on 500 000 cells x 20 000 genes as 10 blocks, K = 5.
-          (The default run also times cfg3 once, after the timed region, and reports it under "other_configs".)
+  N = 1 (default, --config cfg3): BASELINE.json configs[2], the largest single-GPU configuration: SHARP_unlimited on 500 000 cells x
+          20 000 genes as 10 blocks of 50 000, ensize.K = 5, p = 474 (per block: projection, 125 base-clustering tasks, 25 wMetaC, sMetaC;
+          then the cross-block sMetaC on the blocks' centroid tables).
+  N = 1, --config cfg2: BASELINE.json configs[1]: one SHARP() call on 50 000 cells x 20 000 genes, ensize.K = 15 (SHARP_large: projectors,
+          RP matmul, 375 base-clustering tasks, 25 wMetaC, sMetaC).  (The default run times it too: "other_configs.cfg2".)
   N > 1, and N = 1 with --config cfg4: BASELINE.json configs[3]: SHARP_unlimited on 1.3 M cells x 27 000 genes, ensize.K = 5, as
           its EIGHT blocks of 162 500 cells whatever N is, block b on GPU b mod N (one per GPU at N = 8; all eight one after the other
           on the one GPU at N = 1: 140 GB of X), p = 508 from the global count: the total problem and its labels are the same for
           every N ("scaling": "strong"), so `--gpus 1 --config cfg4` is the N = 1 point of the curve the N > 1 runs draw (the default
           run reports it under "other_configs.cfg4_one_gpu").  The only data-path collective is the all-gather of the per-block
           centroid table before the final sMetaC (sharp_amd/dist.py).
-The JSON carries `roofline` for the RP matmul stage (rp_pc_kernel, rp3.hip; HBM-bound: X is read once for
-all K projectors) from HIP events on the library's streams inside the timed region, the same stage at the
-K = 5 shapes of cfg3 and of cfg4's per-GPU share (`roofline.by_config`), and `cpu_baseline`: the fp64 CPU oracle (a
-port of the reference's R path, not R itself) timed on the host cores on a bounded sample."""
+`ms_per_step` is the step WITHOUT the view outputs; `ms_per_step_forview` the same step with the reference's default `forview = TRUE` /
+`viewflag = TRUE` outputs requested (viE and x0: R/SHARP.R:46,717-731,844; R/SHARP_unlimited.R:214-232) and brought to the host.
+The JSON carries `roofline` for the RP matmul stage (rp_pc_kernel, rp3.hip; HBM-bound: X is read once for all K projectors)
+from HIP events on the library's streams inside the timed region, `roofline.traffic` from two rocprofv3 --pmc child passes over the same
+stage, the same stage at the other shapes and on other value kinds (`roofline.by_config`), and `cpu_baseline`: the fp64 CPU oracle (a
+port of the reference's R path, not R itself) timed on the host cores on a bounded sample, with its per-stage seconds."""
 import argparse
 import ctypes as C
 import json
 import os
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -35,29 +39,31 @@ if ROOT not in sys.path:
 DATA_SEED = 20261003
 RN_SEED = 2103
 G_TRUE, N_MARK = 12, 1000
+N_MARK_CH = 400          # the "CH-decided" data set of SURVEY.md 8d: base max median silhouette 0.26-0.30 <= sil.thre, so which.max(CHind) and the
+                         # height-gap rule choose k (R/get_opt_hclust.R:194-210); N_MARK = 1000 gives 0.46-0.55 (silhouette-decided)
 CFG2 = dict(cells=50000, genes=20000, K=15)
 CFG3 = dict(cells=500000, genes=20000, K=5, blocks=10)
 CFG4 = dict(cells=1300000, genes=27000, K=5, blocks=8)     # configs[3]: one block per GPU of an 8-GPU node
 METRIC = "cells/sec end-to-end SHARP (fixed genes, n.RP); ARI vs reference labels"
+SHAPES = {"cfg2": (50000, 20000, 15, 391), "cfg3": (50000, 20000, 5, 474), "cfg4": (162500, 27000, 5, 508)}    # one block: cells, genes, K, p
 
 
-def rp_stage_numbers(prof, n, m, K, p, steps_of):
-    """Roofline numbers of the RP matmul stage from the library's HIP-event table: per SHARP() call the stage reads
-    n*m*4 B of X (once for all K projectors) and writes n*K*p*4 B of E (SURVEY.md 8d's algorithmic bytes)."""
+def rp_stage_numbers(prof, n, m, K, p, width=4):
+    """Roofline numbers of the RP matmul stage from the library's HIP-event table: per SHARP() call (per block) the stage reads
+    n*m*width B of X (once for all K projectors; width = the stored width, 4 or 8) and writes n*K*p*4 B of E."""
     cms, ccalls = prof.get("rp_compact", (0.0, 0))
     ams, acalls = prof.get("rp_apply", (0.0, 0))
     sms, scalls = prof.get("rp_stage", (0.0, 0))
     pms, pcalls = prof.get("rp_pc", (0.0, 0))            # the stage as ONE producer / consumer kernel (rp3.hip): the default form
     if not scalls:
         return None
-    # chunks compacted beside the projector build (rp_compact_ahead, second stream) are the stage's work too: their time is ADDED, as if
-    # they had run where they used to, behind the build
+    # chunks compacted beside the projector build (rp_compact_ahead, second stream) are the stage's work too: their time is ADDED
     ahead_ms = prof.get("rp_stage_ahead", (0.0, 0))[0]
     main_ms = sms
     sms += ahead_ms
     t_stage = sms / scalls * 1e-3
-    read_b, write_b = n * m * 4, n * K * p * 4
-    out = {"ms": round(t_stage * 1e3, 4), "cells": n, "genes": m, "n_RP": K, "reduced_dim": p,
+    read_b, write_b = n * m * width, n * K * p * 4
+    out = {"ms": round(t_stage * 1e3, 4), "cells": n, "genes": m, "n_RP": K, "reduced_dim": p, "stored_width_bytes": width,
            "algorithmic_read_bytes": read_b, "algorithmic_write_bytes": write_b,
            "achieved_read": round(read_b / t_stage / 1e9, 1), "frac_read": round(read_b / t_stage / 8e12, 4),
            "frac_read_write": round((read_b + write_b) / t_stage / 8e12, 4), "launches_per_stage": round((ccalls + acalls + pcalls) / scalls, 2)}
@@ -79,21 +85,95 @@ def rp_stage_numbers(prof, n, m, K, p, steps_of):
     return out
 
 
+class Bench:
+    """The pieces every workload shares: the library, synthetic blocks, the entry points as ctypes calls."""
+
+    def __init__(self, np, torch, local_rank):
+        import sharp_amd
+        from sharp_amd import device as dev
+        from sharp_amd import dist as sdist
+        from sharp_amd.api import ARI
+
+        self.np, self.torch, self.sa, self.dev, self.sdist, self.ARI = np, torch, sharp_amd, dev, sdist, ARI
+        sharp_amd.init(local_rank)
+        self.lib = sharp_amd.lib()
+
+    def synth_block(self, cell0, n, m, nmark=N_MARK):
+        x = self.torch.empty((n, m), dtype=self.torch.float32, device="cuda")
+        self.dev.synth_fill(x, DATA_SEED, cell0, G_TRUE, nmark)
+        return x
+
+    def labels(self, cell0, n):
+        return self.dev.synth_labels(DATA_SEED, cell0, n, G_TRUE)
+
+    def unlimited_call(self, blocks, K, view=False):
+        """SHARP_unlimited on resident blocks -> (pred, n_pred, p, viE or None).  view: viewflag = TRUE (R/SHARP_unlimited.R:214-232): above
+        1e5 cells viE is E1 reduced to 50 columns by one more sparse projection, taken per block on the device, so only ncells x 50 doubles
+        leave the GPU; x0 is the sparse one-hot matrix of the labels."""
+        n = sum(int(b.shape[0]) for b in blocks)
+        if view and (self._vbuf is None or self._vbuf.shape[0] != n):
+            # (an R session allocates the result anew per call; first-touch page faults of a fresh numpy array are host noise, so it is kept)
+            self._vbuf = self.np.zeros((n, 50 if n > 1e5 else int(self.np.ceil(self.np.log2(n) / 0.04))))
+        pred, npred, p, viE = self.dev.unlimited_dev(blocks, ensize_K=K, rN_seed=RN_SEED, viewflag=view, viE_out=self._vbuf if view else None)
+        if view:
+            from sharp_amd.api import _one_hot
+
+            self.last_x0 = _one_hot(pred, npred)
+        return pred, npred, p, viE
+
+    _vbuf = None
+
+    def rp_stage_alone(self, x, K, p, reps=10):
+        """The RP matmul stage by itself on a resident block (sharp_project_dev / _dev64, as tools/bench_rp.py): HIP-event time of the stage."""
+        torch, lib, dev = self.torch, self.lib, self.dev
+        n, m = x.shape
+        f64 = x.dtype == torch.float64
+        proj = self.sa.Projector(m, p, [50 + RN_SEED + k for k in range(1, K + 1)])
+        dE = torch.empty((n, K * p), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        entry = lib.sharp_project_dev64 if f64 else lib.sharp_project_dev
+
+        def call():
+            rc = entry(proj.handle, C.c_void_p(x.data_ptr()), m, n, C.c_longlong(x.stride(0)), 1, C.c_void_p(dE.data_ptr()), C.c_longlong(K * p))
+            if rc:
+                raise RuntimeError(lib.sharp_last_error().decode())
+        for _ in range(3):
+            call()
+        dev.profile(True)
+        for _ in range(reps):
+            call()
+        lib.sharp_synchronize()
+        prof = dev.profile_table()
+        dev.profile(False)
+        proj.close()
+        del dE
+        return rp_stage_numbers(prof, n, m, K, p, 8 if f64 else 4)
+
+
+def guarded(out, key, fn):
+    """one failing side measurement must not cost the run its line"""
+    try:
+        out[key] = fn()
+    except Exception as e:  # noqa: BLE001
+        out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4"], default="cfg2", help="N = 1 workload (N > 1 always runs cfg4)")
+    ap.add_argument("--config", choices=["cfg2", "cfg2_ch", "cfg3", "cfg4"], default="cfg3", help="N = 1 workload (N > 1 always runs cfg4)")
     ap.add_argument("--cells", type=int, default=0, help="override the TOTAL number of cells of the workload (tests)")
     ap.add_argument("--genes", type=int, default=0, help="override the number of genes (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the cfg3 / cfg4-share measurements after the timed region")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other configurations / shapes after the timed region")
     ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic under rocprofv3 (two child processes after the timed region)")
-    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-forview", action="store_true", help="skip ms_per_step_forview")
+    ap.add_argument("--traffic-child", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.traffic_child:
-        return traffic_child()
+        return traffic_child(args.traffic_child)
 
     import numpy as np
     import torch
@@ -108,6 +188,12 @@ def main():
     backend = os.environ.get("SHARP_BENCH_BACKEND", "nccl")
     if share_gpu:
         local_rank = 0
+    if world > 1 and "SHARP_HOST_THREADS" not in os.environ:
+        # one process per GPU on ONE host: every rank's upload / tail-helper / host-loop pools are sized from its share of the cores
+        try:
+            os.environ["SHARP_HOST_THREADS"] = str(max(4, len(os.sched_getaffinity(0)) // world))
+        except AttributeError:
+            pass
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
@@ -119,13 +205,8 @@ def main():
             dist.init_process_group(backend)
     xdev = "cuda" if backend == "nccl" else "cpu"      # where the centroid tables are exchanged
 
-    import sharp_amd
-    from sharp_amd import device as dev
-    from sharp_amd import dist as sdist
-    from sharp_amd.api import ARI
-
-    sharp_amd.init(local_rank)
-    lib = sharp_amd.lib()
+    Bn = Bench(np, torch, local_rank)
+    sharp_amd, dev, sdist, lib, ARI = Bn.sa, Bn.dev, Bn.sdist, Bn.lib, Bn.ARI
 
     def barrier():
         torch.cuda.synchronize()
@@ -133,38 +214,20 @@ def main():
             dist.barrier()
         lib.sharp_synchronize()
 
-    def synth_block(cell0, n, m):
-        x = torch.empty((n, m), dtype=torch.float32, device="cuda")
-        dev.synth_fill(x, DATA_SEED, cell0, G_TRUE, N_MARK)
-        return x
-
-    def unlimited_call(blocks, K):
-        """sharp_SHARP_unlimited_dev on resident blocks -> (pred, n_pred, p)"""
-        B = len(blocks)
-        ptrs = (C.c_void_p * B)(*[b.data_ptr() for b in blocks])
-        ncb = np.array([b.shape[0] for b in blocks], np.int64)
-        ldb = np.array([b.stride(0) for b in blocks], np.int64)
-        pred = np.zeros(int(ncb.sum()), np.int32)
-        npred, pu = C.c_int(), C.c_int()
-        rc = lib.sharp_SHARP_unlimited_dev(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), ldb.ctypes.data_as(C.POINTER(C.c_longlong)),
-                                           B, blocks[0].shape[1], K, 0, 0, 0, C.c_double(RN_SEED), pred.ctypes.data_as(C.POINTER(C.c_int)),
-                                           C.byref(npred), C.byref(pu))
-        if rc not in (0, 16, 32, 48):
-            raise RuntimeError(lib.sharp_last_error().decode())
-        return pred, npred.value, pu.value
-
     # ---- workload of this run: synthetic blocks generated on the device (counter-based: identical on CPU and GPU)
     state = {}
     if world > 1 or args.config == "cfg4":
         cfg, tag = dict(CFG4), "cfg4"
     else:
-        cfg, tag = (dict(CFG2), "cfg2") if args.config == "cfg2" else (dict(CFG3), "cfg3")
+        cfg, tag = {"cfg2": (dict(CFG2), "cfg2"), "cfg2_ch": (dict(CFG2), "cfg2_ch"), "cfg3": (dict(CFG3), "cfg3")}[args.config]
     sharded = tag == "cfg4"                                  # blocks dealt to the ranks (all of them to the one rank at N = 1)
+    nmark = N_MARK_CH if tag == "cfg2_ch" else N_MARK
     if args.cells:
         cfg["cells"] = args.cells
     if args.genes:
         cfg["genes"] = args.genes
     n_total, m, K = cfg["cells"], cfg["genes"], cfg["K"]
+    full_size = not args.cells and not args.genes
     if sharded:
         # The data set is cut into the EIGHT blocks of configs[3] whatever N is (one block per GPU at N = 8; at N = 2 / 4 a rank runs 4 / 2
         # blocks one after the other, block b on rank b mod N), so every N clusters the same blocks and finds the same labels: strong
@@ -173,42 +236,53 @@ def main():
         bounds = [n_total * b // B for b in range(B + 1)]
         ncb = [bounds[b + 1] - bounds[b] for b in range(B)]
         mine = [b for b in range(B) if sdist.block_owner(b, world) == rank]
-        blocks = [synth_block(bounds[b], ncb[b], m) for b in mine]
-        truth = np.concatenate([dev.synth_labels(DATA_SEED, bounds[b], ncb[b], G_TRUE) for b in mine])
-        dX = blocks[0]
+        blocks = [Bn.synth_block(bounds[b], ncb[b], m) for b in mine]
+        truth = np.concatenate([Bn.labels(bounds[b], ncb[b]) for b in mine])
+        n_local = ncb[0]
 
-        def step():
+        def step(view=False):
             p = sdist.global_reduced_dim(n_total)                    # R/SHARP_unlimited.R:65-66: from the GLOBAL cell count
             proj = sharp_amd.Projector(m, p, [50 + RN_SEED + k for k in range(1, K + 1)])   # :97-104, regenerated on every rank
+            vi = state.setdefault("view_bufs", {})             # (kept between steps: first-touch page faults of fresh arrays are host noise)
 
             def run_block(blk, p_, nxt):                             # (nxt: this rank's next block, prepared under this one's tail)
-                return dev.unlimited_block_dev(blk, p_, proj.handle, K, RN_SEED, next_block=nxt)
+                v, kd = None, 0
+                if view:
+                    kd = 50 if n_total > 1e5 else 0          # R/SHARP_unlimited.R:216-228: above 1e5 cells viE is E1 reduced to 50 columns
+                    v = vi.setdefault(blk.data_ptr(), np.zeros((blk.shape[0], kd if kd else p_)))
+                return dev.unlimited_block_dev(blk, p_, proj.handle, K, RN_SEED, next_block=nxt, viE=v, view_dim=kd)
 
             out, nfin, p = sdist.unlimited_sharded(blocks, mine, ncb, run_block, dev.unlimited_merge, device=xdev)
             proj.close()
             state["p"], state["pred"], state["n_clusters"] = p, np.concatenate([out[b] for b in mine]), nfin
+            state["crc"] = {int(b): zlib.crc32(np.ascontiguousarray(out[b], np.int32).tobytes()) for b in mine}
         workload = ("SHARP_unlimited on synthetic %d cells x %d genes as %d blocks of %d cells, block b on GPU b mod %d, ensize.K=%d, rN.seed=%d"
                     % (n_total, m, B, ncb[0], world, K, RN_SEED))
-    elif tag == "cfg2":
-        dX = synth_block(0, n_total, m)
-        truth = dev.synth_labels(DATA_SEED, 0, n_total, G_TRUE)
+    elif tag in ("cfg2", "cfg2_ch"):
+        dX = Bn.synth_block(0, n_total, m, nmark)
+        blocks = [dX]
+        truth = Bn.labels(0, n_total)
+        n_local = n_total
 
-        def step():
-            pred, info = dev.SHARP_dev(dX, ensize_K=K, rN_seed=RN_SEED)
+        def step(view=False):
+            pred, info = dev.SHARP_dev(dX, ensize_K=K, rN_seed=RN_SEED, forview=view)
             state["p"], state["pred"], state["n_clusters"] = info["reduced.dim"], pred, info["N.pred_cluster"]
-        workload = "SHARP() on synthetic %d cells x %d genes, ensize.K=%d, SHARP_large path, rN.seed=%d" % (n_total, m, K, RN_SEED)
+        workload = "SHARP() on synthetic %d cells x %d genes%s, ensize.K=%d, SHARP_large path, rN.seed=%d" % (
+            n_total, m, " (%d marker genes per planted cluster: the CH-decided data set)" % nmark if tag == "cfg2_ch" else "", K, RN_SEED)
     else:
         B = cfg["blocks"]
         nb = n_total // B
-        blocks = [synth_block(b * nb, nb, m) for b in range(B)]
-        truth = np.concatenate([dev.synth_labels(DATA_SEED, b * nb, nb, G_TRUE) for b in range(B)])
+        blocks = [Bn.synth_block(b * nb, nb, m) for b in range(B)]
+        truth = np.concatenate([Bn.labels(b * nb, nb) for b in range(B)])
+        n_local = nb
 
-        def step():
-            pred, npred, p = unlimited_call(blocks, K)
+        def step(view=False):
+            pred, npred, p, _ = Bn.unlimited_call(blocks, K, view=view)
             state["p"], state["pred"], state["n_clusters"] = p, pred, npred
         workload = ("SHARP_unlimited on synthetic %d cells x %d genes as %d blocks of %d, ensize.K=%d, rN.seed=%d"
                     % (n_total, m, B, nb, K, RN_SEED))
     torch.cuda.synchronize()
+    cells_per_gpu = sum(int(b.shape[0]) for b in blocks)
 
     for _ in range(args.warmup):
         step()
@@ -220,115 +294,184 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof_timed = dev.profile_table()
-    # Attribution pass, outside the timed region: in the timed steps the two chunks of base-clustering tasks are in flight together
-    # (SHARP_HC_PIPE) and a chunk of 194 tasks or more runs as two ranges on two streams, so the per-kernel event times overlap and
-    # kernels sharing the chip run slower than alone; one more step with one chunk and one range at a time gives each kernel's own time.
-    os.environ["SHARP_HC_RANGES"] = "1"
-    os.environ["SHARP_HC_PIPE"] = "0"
-    sharp_amd.reload_options()                           # (the library reads its switches once; this asks it to read them again)
-    dev.profile(True)
-    step()
-    barrier()
-    prof = dev.profile_table()
-    del os.environ["SHARP_HC_RANGES"]
-    del os.environ["SHARP_HC_PIPE"]
-    sharp_amd.reload_options()
     dev.profile(False)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-
     ms_per_step = dt / args.steps * 1e3
     cells_per_s = n_total * args.steps / dt
+    crc_by_block = None
+    if sharded:
+        # a checksum of every block's final labels, in global block order: equal for every N (the same eight blocks, the same global p)
+        parts = [state["crc"]]
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, state["crc"])
+        merged = {}
+        for d in parts:
+            merged.update(d)
+        crc_by_block = [merged[b] for b in sorted(merged)]
+
+    # ---- the same step with the reference's default view outputs requested (outside the headline's timed region, same contract)
+    ms_forview = None
+    if not args.no_forview:
+        fsteps = max(2, min(args.steps, 3))
+        step(view=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(fsteps):
+            step(view=True)
+        barrier()
+        dtv = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dtv], dtype=torch.float64, device=xdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dtv = float(tmax.item())
+        ms_forview = dtv / fsteps * 1e3
+        Bn._vbuf = None
+
+    prof = prof_timed
+    attribution_note = ("per-kernel HIP-event times summed over the timed steps / steps; the blocks' kernels overlap (pipelined chunks, tail helpers), "
+                        "so these add up to more than ms_per_step")
+    if tag in ("cfg2", "cfg2_ch") and world == 1:
+        # Attribution pass, outside the timed region: in the timed steps the two chunks of base-clustering tasks are in flight together
+        # (SHARP_HC_PIPE) and a chunk of 194 tasks or more runs as two ranges on two streams, so the per-kernel event times overlap and
+        # kernels sharing the chip run slower than alone; one more step with one chunk and one range at a time gives each kernel's own time.
+        os.environ["SHARP_HC_RANGES"] = "1"
+        os.environ["SHARP_HC_PIPE"] = "0"
+        sharp_amd.reload_options()                           # (the library reads its switches once; this asks it to read them again)
+        dev.profile(True)
+        step()
+        barrier()
+        prof = dev.profile_table()
+        del os.environ["SHARP_HC_RANGES"]
+        del os.environ["SHARP_HC_PIPE"]
+        sharp_amd.reload_options()
+        dev.profile(False)
+        attribution_note = ("per-kernel times from one extra step outside the timed region with one chunk of base-clustering tasks and one task range at a "
+                            "time (SHARP_HC_PIPE=0, SHARP_HC_RANGES=1); the timed steps keep two chunks in flight, so these add up to more than ms_per_step")
 
     if rank == 0:
         p = state["p"]
-        n_local = int(dX.shape[0]) if tag != "cfg3" else n_total // cfg["blocks"]     # cells per SHARP() call (per block)
-        # the RP matmul as BASELINE.json's north_star defines it: the whole stage (the compaction kernel streams X, the apply kernel does
-        # the sparse-ternary accumulation and writes E), timed inside the timed region by HIP events on the library's streams
-        st = rp_stage_numbers(prof_timed, n_local, m, K, p, args.steps)
+        # the RP matmul as BASELINE.json's north_star defines it: the whole stage (X streamed once, the sparse-ternary accumulation, E written),
+        # timed inside the timed region by HIP events on the library's streams; per block
+        st = rp_stage_numbers(prof_timed, n_local, m, K, p)
         roof = None
         if st:
             traffic, tsrc = None, None
+            shape_key = {"cfg2": "cfg2", "cfg2_ch": "cfg2", "cfg3": "cfg3", "cfg4": "cfg4"}[tag]
+            if full_size and world == 1 and not args.no_traffic:
+                del blocks                                       # (the child processes need the HBM; the extras regenerate what they use)
+                if tag in ("cfg2", "cfg2_ch"):
+                    del dX
+                blocks = None
+                torch.cuda.empty_cache()
+                traffic, tsrc = measure_traffic(shape_key)      # two rocprofv3 --pmc child processes, this process idle meanwhile
             tf = os.path.join(ROOT, "profiles", "rp_traffic.json")
-            if tag == "cfg2" and n_total == CFG2["cells"] and m == CFG2["genes"]:
-                if world == 1 and not args.no_traffic:
-                    traffic, tsrc = measure_traffic()           # two rocprofv3 --pmc child processes, this process idle meanwhile
-                if traffic is None and os.path.exists(tf):
-                    tj = json.load(open(tf))
+            if traffic is None and os.path.exists(tf):
+                tj = json.load(open(tf)).get(shape_key)
+                if tj:
                     traffic = tj.get("hbm_bytes_per_launch")
                     tsrc = "profiles/rp_traffic.json: rocprofv3 --pmc passes of this command on the builder's box (not measured in this run)"
-            roof = {"kernel": ("RP matmul stage = rp_pc_kernel (one persistent producer / consumer kernel), per SHARP() call (per block)" if "rp_pc_kernel" in st
-                               else "RP matmul stage = rp_compact_kernel + rp_apply_kernel, per SHARP() call (per block)"), "bound": "hbm",
+            roof = {"kernel": ("RP matmul stage = rp_pc_kernel (one persistent producer / consumer kernel), one launch per block of %d cells" % n_local
+                               if "rp_pc_kernel" in st else "RP matmul stage = rp_compact_kernel + rp_apply_kernel, per block"), "bound": "hbm",
                     "achieved": st["achieved_read"], "peak": 8000.0, "unit": "GB/s", "frac": st["frac_read"],
                     "traffic": traffic, "traffic_source": tsrc,
-                    "what": "algorithmic bytes = X read once for all K projectors (cells x genes x 4 B, SURVEY.md 8d: the HBM-read roofline "
-                            "north_star names) / stage time from HIP events in the timed region",
+                    "what": "algorithmic bytes per launch = the block's X read once for all K projectors (cells x genes x 4 B, SURVEY.md 8d: the HBM-read "
+                            "roofline north_star names) / average launch time from HIP events in the timed region",
                     "stage": st}
-        stages = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-        # the two other heavy kernels, for context (from the single-range attribution step)
-        others = []
-        if tag == "cfg2":
-            T_tasks = K * len(range(0, n_total, 2000))
-            gms, gcalls = prof.get("corr_dist_gemm", (0.0, 0))
-            if gcalls:
-                fl = T_tasks * 2000.0 * 2000.0 * p                   # upper triangle of n_t^2 * p * 2 flop per task
-                tg = gms * 1e-3
-                others.append({"kernel": "gemm_tn_f64_fast_kernel", "bound": "mfma", "achieved": round(fl / tg / 1e12, 1), "peak": 78.6,
-                               "unit": "TFLOP/s", "frac": round(fl / tg / 78.6e12, 3), "ms_per_step": round(tg * 1e3, 2),
-                               "work": "%d tasks x n_t^2 x p flop (upper triangle), f64 MFMA" % T_tasks})
-            hms, hcalls = prof.get("hclust", (0.0, 0))
-            if hcalls:
-                by = T_tasks * 2000.0 * 2000.0 * 8 * 10.1            # rounds of (read n_a^2 + write n_a'^2) + the round-0 scan
-                th = hms * 1e-3
-                others.append({"kernel": "hclust_rnn_kernel", "bound": "hbm", "achieved": round(by / th / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                               "frac": round(by / th / 8e12, 3), "ms_per_step": round(th * 1e3, 2),
-                               "work": "%d tasks x 10.1 n_t^2 x 8 B as the kernel streams it (every round rewrites the distance matrix "
-                                       "compacted); the distance matrices themselves are %d x n_t^2 x 8 B = %.1f GB"
-                                       % (T_tasks, T_tasks, T_tasks * 2000.0 * 2000.0 * 8 / 1e9)})
+        stages = {k: round(v[0] / (args.steps if prof is prof_timed else 1), 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         result = {
             "metric": METRIC,
             "value": round(cells_per_s, 1), "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong" if sharded else "weak",
+            "ms_per_step": round(ms_per_step, 2),
+            "ms_per_step_forview": None if ms_forview is None else round(ms_forview, 2),
+            "forview_note": "ms_per_step: labels only; ms_per_step_forview: the same step returning the reference's default view outputs to the host "
+                            "(SHARP(): viE n x p and the soft matrix x0, R/SHARP.R:717-731,844; SHARP_unlimited(): viE reduced to 50 columns above 1e5 "
+                            "cells and the one-hot x0, R/SHARP_unlimited.R:214-232)",
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "baseline_config": {"cfg2": "configs[1]", "cfg3": "configs[2]", "cfg4": "configs[3]"}[tag],
-                       "cells_total": n_total, "cells_per_gpu": (sum(int(b.shape[0]) for b in blocks) if sharded else int(dX.shape[0])) if tag != "cfg3" else n_total, "cells_per_block": n_local, "genes": m, "n_RP": K,
-                       "reduced_dim": p, "x_storage": "fp32 in HBM (synthetic counts are fp32-exact)",
+            "config": {"workload": workload, "baseline_config": {"cfg2": "configs[1]", "cfg2_ch": "configs[1] shape, CH-decided data set (SURVEY.md 8d)",
+                                                                 "cfg3": "configs[2]", "cfg4": "configs[3]"}[tag],
+                       "cells_total": n_total, "cells_per_gpu": cells_per_gpu, "cells_per_block": n_local, "genes": m, "n_RP": K, "reduced_dim": p,
+                       "x_storage": "fp32 in HBM (synthetic counts are fp32-exact)",
                        "parallelism": ("%d blocks, block b on GPU b mod %d; one all-gather of the per-block centroid tables" % (len(ncb), world)) if sharded else "single GPU"},
+            "consistency": {"ms_per_step_x_steps_s": round(ms_per_step * args.steps / 1e3, 3), "timed_region_s": round(dt, 3)},
             "roofline": roof,
-            "other_kernels": others,
             "kernel_ms_per_step": stages,
-            "kernel_ms_note": "per-kernel times from one extra step outside the timed region with one chunk of base-clustering tasks and one task range at a time (SHARP_HC_PIPE=0, SHARP_HC_RANGES=1); the timed steps keep two chunks in flight, so these add up to more than ms_per_step",
+            "kernel_ms_note": attribution_note,
             "clusters_found": int(state["n_clusters"]),
             "ari_vs_planted_truth": round(float(ARI(truth, state["pred"])["HA"]), 4),
         }
-        if world == 1 and tag == "cfg2" and not args.no_extra and not args.cells and not args.genes:
-            del dX
+        if crc_by_block is not None:
+            result["labels_crc32_by_block"] = crc_by_block
+        lv = level_rules(prof_timed, args.steps)
+        if lv:
+            result["level_rule_per_step"] = lv
+        if tag in ("cfg2", "cfg2_ch"):
+            result["other_kernels"] = other_kernels(prof, n_total, K, p)
+        if world == 1 and full_size:
+            if blocks is not None:
+                del blocks
+                if tag in ("cfg2", "cfg2_ch"):
+                    del dX
             torch.cuda.empty_cache()
-            result["other_configs"], by_cfg = extra_configs(np, torch, sharp_amd, dev, lib, synth_block, unlimited_call, ARI)
-            if roof:
-                roof["by_config"] = by_cfg
-                if by_cfg.get("cfg2_alone"):
-                    # `frac` above prices the stage's kernels as they run in the step, a third of them beside the projector draw (slower each,
-                    # faster step); the same kernels with the chip to themselves:
-                    roof["frac_alone"] = by_cfg["cfg2_alone"]["frac_read"]
-                    roof["note"] = ("frac: stage time = main-stream stage + the second stream's compaction beside the projector build (roofline.stage.ms_*); "
-                                    "frac_alone: the same stage enqueued alone on an idle chip (by_config.cfg2_alone); SHARP_RP_AHEAD=0 gives the latter in the step, 2.5 ms slower")
-            dX = synth_block(0, n_total, m)
-        if world == 1 and tag == "cfg2" and not args.no_cpu_baseline:
-            result["cpu_baseline"], result["parity"] = cpu_baseline(np, dX, m, K)
+            if not args.no_extra:
+                result["other_configs"], by_cfg = extra_configs(Bn, tag)
+                if roof:
+                    roof["by_config"] = by_cfg
+            if not args.no_cpu_baseline:
+                cb = {}
+                guarded(cb, "r", lambda: cpu_baseline(Bn, tag))
+                if isinstance(cb["r"], tuple):
+                    result["cpu_baseline"], result["parity"] = cb["r"]
+                else:
+                    result["cpu_baseline"] = cb["r"]
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def level_rules(prof, steps):
+    """which rule of R/get_opt_hclust.R:162-229 chose the level, per step: base tasks (cells) and meta tasks (wMetaC / sMetaC similarity trees)"""
+    out = {}
+    for kind in ("base", "meta"):
+        d = {r: prof.get("host:level_%s_by_%s" % (kind, r), (0.0, 0))[1] / steps for r in ("silhouette", "CH", "height")}
+        if sum(d.values()):
+            out[kind] = {k: round(v, 2) for k, v in d.items()}
+    return out
+
+
+def other_kernels(prof, n_total, K, p):
+    """the two other heavy kernels of a SHARP_large call, for context (from the single-range attribution step)"""
+    others = []
+    T_tasks = K * len(range(0, n_total, 2000))
+    gms, gcalls = prof.get("corr_dist_gemm", (0.0, 0))
+    if gcalls:
+        fl = T_tasks * 2000.0 * 2000.0 * p                   # upper triangle of n_t^2 * p * 2 flop per task
+        tg = gms * 1e-3
+        others.append({"kernel": "gemm_tn_f64_fast_kernel", "bound": "mfma", "achieved": round(fl / tg / 1e12, 1), "peak": 78.6,
+                       "unit": "TFLOP/s", "frac": round(fl / tg / 78.6e12, 3), "ms_per_step": round(tg * 1e3, 2),
+                       "work": "%d tasks x n_t^2 x p flop (upper triangle), f64 MFMA" % T_tasks})
+    hms, hcalls = prof.get("hclust", (0.0, 0))
+    if hcalls:
+        by = T_tasks * 2000.0 * 2000.0 * 8 * 10.1            # rounds of (read n_a^2 + write n_a'^2) + the round-0 scan
+        th = hms * 1e-3
+        others.append({"kernel": "hclust_rnn_kernel", "bound": "hbm", "achieved": round(by / th / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                       "frac": round(by / th / 8e12, 3), "ms_per_step": round(th * 1e3, 2),
+                       "work": "%d tasks x 10.1 n_t^2 x 8 B as the kernel streams it (every round rewrites the distance matrix "
+                               "compacted); the distance matrices themselves are %d x n_t^2 x 8 B = %.1f GB"
+                               % (T_tasks, T_tasks, T_tasks * 2000.0 * 2000.0 * 8 / 1e9)})
+    return others
+
+
 TRAFFIC_CALLS = 8
 
 
-def traffic_child():
-    """The RP matmul stage of the cfg2 workload alone (the same sharp_project_dev calls as rp_stage_alone), as the program
+def traffic_child(shape_key):
+    """The RP matmul stage of one block shape alone (the same sharp_project_dev calls as rp_stage_alone), as the program
     `rocprofv3 --pmc ...` runs: nothing but the stage's kernels touches the L2 counters."""
     import numpy as np
     import torch
@@ -339,8 +482,7 @@ def traffic_child():
     torch.cuda.set_device(0)
     sharp_amd.init(0)
     lib = sharp_amd.lib()
-    n, m, K = CFG2["cells"], CFG2["genes"], CFG2["K"]
-    p = int(np.ceil(np.log2(n) / 0.04))
+    n, m, K, p = SHAPES[shape_key]
     x = torch.empty((n, m), dtype=torch.float32, device="cuda")
     dev.synth_fill(x, DATA_SEED, 0, G_TRUE, N_MARK)
     proj = sharp_amd.Projector(m, p, [50 + RN_SEED + k for k in range(1, K + 1)])
@@ -355,8 +497,8 @@ def traffic_child():
     return 0
 
 
-def measure_traffic():
-    """roofline.traffic measured in THIS run: HBM bytes of the RP stage's kernels per stage (= per SHARP() call) from the L2's
+def measure_traffic(shape_key):
+    """roofline.traffic measured in THIS run: HBM bytes of the RP stage's kernel per launch (= per block) from the L2's
     memory-side counters, FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes (they do not fit one pass), each pass a child process
     that runs the stage alone (`--traffic-child`); FETCH_SIZE (KiB of 64-byte requests) doubled, as MI355X_MICROARCH.md prescribes for
     wide coalesced reads on gfx950.  None if rocprofv3 is not on the box or a pass fails."""
@@ -375,8 +517,8 @@ def measure_traffic():
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             with tempfile.TemporaryDirectory(dir="/tmp") as td:
                 env = dict(os.environ, TMPDIR="/tmp")
-                r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", td, "--", sys.executable,
-                                    os.path.abspath(__file__), "--traffic-child"], cwd="/tmp", env=env, timeout=240,
+                r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", td, "--", os.path.realpath(sys.executable),
+                                    os.path.abspath(__file__), "--traffic-child", shape_key], cwd="/tmp", env=env, timeout=240,
                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 if r.returncode != 0:
                     return None, None
@@ -391,159 +533,246 @@ def measure_traffic():
                     return None, None
                 tot[counter] = val * 1024.0 / TRAFFIC_CALLS
         traffic = int(2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"])
-        return traffic, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one child process each running the stage alone "
-                         "%d times; FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 B); read %.2f GB + write %.2f GB per stage"
-                         % (TRAFFIC_CALLS, 2.0 * tot["FETCH_SIZE"] / 1e9, tot["WRITE_SIZE"] / 1e9))
+        return traffic, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one child process each running the stage alone on one %s "
+                         "block %d times; FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 B); read %.2f GB + write %.2f GB per launch"
+                         % (shape_key, TRAFFIC_CALLS, 2.0 * tot["FETCH_SIZE"] / 1e9, tot["WRITE_SIZE"] / 1e9))
     except Exception:
         return None, None
 
 
-def rp_stage_alone(torch, sharp_amd, dev, lib, x, K, p):
-    """The RP matmul stage by itself on a resident block (sharp_project_dev, as tools/bench_rp.py): HIP-event time of the stage."""
-    n, m = x.shape
-    proj = sharp_amd.Projector(m, p, [50 + RN_SEED + k for k in range(1, K + 1)])
-    dE = torch.empty((n, K * p), dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-
-    def call():
-        rc = lib.sharp_project_dev(proj.handle, C.c_void_p(x.data_ptr()), m, n, C.c_longlong(x.stride(0)), 1, C.c_void_p(dE.data_ptr()),
-                                   C.c_longlong(K * p))
-        if rc:
-            raise RuntimeError(lib.sharp_last_error().decode())
-    for _ in range(3):
-        call()
-    dev.profile(True)
-    reps = 10
-    for _ in range(reps):
-        call()
-    lib.sharp_synchronize()
-    prof = dev.profile_table()
-    dev.profile(False)
-    proj.close()
-    del dE
-    return rp_stage_numbers(prof, n, m, K, p, reps)
+def timed_calls(Bn, fn, calls, warm=1):
+    for _ in range(warm):
+        fn()
+    Bn.lib.sharp_synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        r = fn()
+    Bn.lib.sharp_synchronize()
+    return (time.perf_counter() - t0) / calls, r
 
 
-def extra_configs(np, torch, sharp_amd, dev, lib, synth_block, unlimited_call, ARI):
-    """After the timed region of the default run: BASELINE.json's largest single-GPU configuration (cfg3) end to end, and the RP matmul
-    stage at the K = 5 shapes (a block of cfg3; one GPU's share of cfg4), so that the driver's box produces these numbers too."""
+def extra_configs(Bn, headline_tag):
+    """After the timed region of the default run: the other BASELINE.json configurations a single GPU holds, each under its own warm-up + timed
+    calls, and the RP matmul stage at every block shape and on other kinds of values, so that the driver's box produces these numbers too."""
+    np, torch, dev, lib, sa, ARI = Bn.np, Bn.torch, Bn.dev, Bn.lib, Bn.sa, Bn.ARI
     out, by_cfg = {}, {}
-    # ---- cfg3: 500 000 x 20 000 as 10 blocks, SHARP_unlimited, K = 5
-    m, K, B = CFG3["genes"], CFG3["K"], CFG3["blocks"]
-    nb = CFG3["cells"] // B
-    blocks = [synth_block(b * nb, nb, m) for b in range(B)]
-    truth = np.concatenate([dev.synth_labels(DATA_SEED, b * nb, nb, G_TRUE) for b in range(B)])
-    torch.cuda.synchronize()
-    unlimited_call(blocks, K)                                            # warm-up (workspaces)
-    reps = 2
-    lib.sharp_synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        pred, npred, p = unlimited_call(blocks, K)
-    lib.sharp_synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    out["cfg3"] = {"workload": "SHARP_unlimited on synthetic %d cells x %d genes as %d blocks, ensize.K=%d (BASELINE.json configs[2])"
-                               % (CFG3["cells"], m, B, K),
-                   "value": round(CFG3["cells"] / dt, 1), "unit": "cells/s", "seconds_per_call": round(dt, 4), "calls_timed": reps,
-                   "reduced_dim": p, "clusters_found": int(npred), "ari_vs_planted_truth": round(float(ARI(truth, pred)["HA"]), 4)}
-    # the cfg2 shape (K = 15, p = 391) the same way: the stage alone on an idle chip, projectors resident -- the kernels' own number, beside the
-    # in-step one of `roofline.stage`, where the chunks compacted ahead share the chip with the projector draw and take 1.4x as long
-    by_cfg["cfg2_alone"] = rp_stage_alone(torch, sharp_amd, dev, lib, blocks[0], CFG2["K"], int(np.ceil(np.log2(CFG2["cells"]) / 0.04)))
-    by_cfg["cfg3_block"] = rp_stage_alone(torch, sharp_amd, dev, lib, blocks[0], K, p)   # (inside the call above the next block's RP stage runs
-    del blocks                                                                             #  on a low-priority stream beside the current block's tail)
+
+    # ---- cfg2 (configs[1]) and the CH-decided data set of the same shape: SHARP(), 50 000 x 20 000, K = 15
+    def cfg2_like(nmark, calls):
+        n, m, K = CFG2["cells"], CFG2["genes"], CFG2["K"]
+        x = Bn.synth_block(0, n, m, nmark)
+        truth = Bn.labels(0, n)
+        dev.profile(True)
+        dt, (pred, info) = timed_calls(Bn, lambda: dev.SHARP_dev(x, ensize_K=K, rN_seed=RN_SEED), calls)
+        prof = dev.profile_table()
+        dev.profile(False)
+        dtv, _ = timed_calls(Bn, lambda: dev.SHARP_dev(x, ensize_K=K, rN_seed=RN_SEED, forview=True), 3)
+        r = {"workload": "SHARP() on synthetic %d cells x %d genes, %d marker genes per planted cluster, ensize.K=%d, SHARP_large (BASELINE.json configs[1]%s)"
+                         % (n, m, nmark, K, "" if nmark == N_MARK else " shape; the CH-decided data set of SURVEY.md 8d"),
+             "value": round(n / dt, 1), "unit": "cells/s", "ms_per_step": round(dt * 1e3, 2), "ms_per_step_forview": round(dtv * 1e3, 2), "steps": calls, "warmup": 1,
+             "reduced_dim": info["reduced.dim"], "clusters_found": int(info["N.pred_cluster"]),
+             "ari_vs_planted_truth": round(float(ARI(truth, pred)["HA"]), 4),
+             "level_rule_per_step": level_rules(prof, calls + 1),
+             "rp_stage_in_step": rp_stage_numbers(prof, n, m, K, info["reduced.dim"])}
+        return r, x
+
+    if headline_tag != "cfg2":
+        def run_cfg2():
+            r, x = cfg2_like(N_MARK, 10)
+            by_cfg["cfg2_alone"] = Bn.rp_stage_alone(x, CFG2["K"], SHAPES["cfg2"][3])
+            return r
+        guarded(out, "cfg2", run_cfg2)
+        torch.cuda.empty_cache()
+    if headline_tag != "cfg2_ch":
+        guarded(out, "cfg2_ch", lambda: cfg2_like(N_MARK_CH, 5)[0])
+        torch.cuda.empty_cache()
+
+    # ---- cfg3 when it is not the headline
+    if headline_tag != "cfg3":
+        def run_cfg3():
+            m, K, B = CFG3["genes"], CFG3["K"], CFG3["blocks"]
+            nb = CFG3["cells"] // B
+            blocks = [Bn.synth_block(b * nb, nb, m) for b in range(B)]
+            truth = np.concatenate([Bn.labels(b * nb, nb) for b in range(B)])
+            dt, (pred, npred, p, _) = timed_calls(Bn, lambda: Bn.unlimited_call(blocks, K), 3)
+            return {"workload": "SHARP_unlimited on synthetic %d cells x %d genes as %d blocks, ensize.K=%d (BASELINE.json configs[2])" % (CFG3["cells"], m, B, K),
+                    "value": round(CFG3["cells"] / dt, 1), "unit": "cells/s", "ms_per_step": round(dt * 1e3, 2), "steps": 3, "warmup": 1,
+                    "reduced_dim": p, "clusters_found": int(npred), "ari_vs_planted_truth": round(float(ARI(truth, pred)["HA"]), 4)}
+        guarded(out, "cfg3", run_cfg3)
+        torch.cuda.empty_cache()
+
+    # ---- the RP stage alone on one cfg3 block: counts (the table path), and the other kinds of values the reference meets (R/SHARP.R:110-114:
+    #      exp.type = "count" is CPM-normalised to doubles; the README example is TPM): fp64 blocks and the general path of the kernel
+    def rp_value_kinds():
+        n, m, K, p = SHAPES["cfg3"]
+        x = Bn.synth_block(0, n, m)
+        by_cfg["cfg3_block"] = Bn.rp_stage_alone(x, K, p)
+        by_cfg["cfg2_shape_on_counts"] = by_cfg.get("cfg2_alone") or Bn.rp_stage_alone(x, CFG2["K"], SHAPES["cfg2"][3])
+        # (ii) fp32 counts with a UMI-like heavy tail: 0.1 % of the non-zeros raised to 256 .. 4095 (outside the 1024-entry term table)
+        xt = x.clone()
+        nzmask = xt != 0
+        g = torch.Generator(device="cuda"); g.manual_seed(7)
+        hit = (torch.rand(xt.shape, device="cuda", generator=g) < 1e-3) & nzmask
+        xt[hit] = torch.randint(256, 4096, (int(hit.sum().item()),), device="cuda", generator=g).float()
+        r = Bn.rp_stage_alone(xt, K, p)
+        r["values"] = "counts, 0.1 % of the non-zeros in 256 .. 4095 (not table values)"
+        by_cfg["cfg3_block_heavy_tail"] = r
+        del xt, hit
+        # (iii) CPM-normalised counts (what SHARP() makes of exp.type = "count"): doubles that do not survive fp32 -> an fp64 block
+        xd = x.double()
+        xd = xd / xd.sum(1, keepdim=True).clamp_min(1.0) * 1e6
+        r = Bn.rp_stage_alone(xd, K, p)
+        r["values"] = "CPM-normalised counts as doubles (fp64 block, every non-zero through the general path)"
+        by_cfg["cfg3_block_f64"] = r
+        r = Bn.rp_stage_alone(xd, CFG2["K"], SHAPES["cfg2"][3])
+        r["values"] = "the same fp64 block at the cfg2 shape (K = 15, p = 391)"
+        by_cfg["cfg2_shape_f64"] = r
+        # (i) TPM-like: the same with per-gene length factors (another set of doubles, same sparsity)
+        gl = 0.5 + torch.rand((1, m), device="cuda", generator=g, dtype=torch.float64) * 4.0
+        xd = x.double() / gl
+        xd = xd / xd.sum(1, keepdim=True).clamp_min(1e-300) * 1e6
+        r = Bn.rp_stage_alone(xd, K, p)
+        r["values"] = "TPM-like doubles (counts / gene length, scaled to 1e6 per cell; fp64 block)"
+        by_cfg["cfg3_block_tpm"] = r
+        return True
+    g0 = {}
+    guarded(g0, "rp_value_kinds", rp_value_kinds)
+    if isinstance(g0["rp_value_kinds"], dict):
+        by_cfg["rp_value_kinds_error"] = g0["rp_value_kinds"]
     torch.cuda.empty_cache()
-    # ---- cfg4's per-GPU share at N = 8: one 162 500 x 27 000 block, K = 5, p = 508: the RP stage alone, and the block step
-    m, K = CFG4["genes"], CFG4["K"]
-    nb, p = CFG4["cells"] // 8, 508
-    x = synth_block(0, nb, m)
-    proj = sharp_amd.Projector(m, p, [50 + RN_SEED + k for k in range(1, K + 1)])
-    dev.unlimited_block_dev(x, p, proj.handle, K, RN_SEED)              # warm-up
-    lib.sharp_synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        pr, mn, cn = dev.unlimited_block_dev(x, p, proj.handle, K, RN_SEED)
-    lib.sharp_synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    proj.close()
-    out["cfg4_share"] = {"workload": "one GPU's block of BASELINE.json configs[3] at N = 8: %d cells x %d genes, ensize.K=%d, p=%d, "
-                                     "sharp_unlimited_block_dev (projectors resident)" % (nb, m, K, p),
-                         "value": round(nb / dt, 1), "unit": "cells/s", "seconds_per_call": round(dt, 4), "calls_timed": reps,
-                         "clusters_found": int(mn.shape[0])}
-    by_cfg["cfg4_share"] = rp_stage_alone(torch, sharp_amd, dev, lib, x, K, p)
-    # ---- cfg4 whole on ONE GPU: the same eight 162 500-cell blocks the N > 1 runs deal out, one after the other here (140 GB of X
-    # resident): the N = 1 point of the strong-scaling curve (`--gpus 1 --config cfg4` times it as the headline value)
-    from sharp_amd import dist as sdist
 
-    B = CFG4["blocks"]
-    blocks = [x] + [synth_block(b * nb, nb, m) for b in range(1, B)]
-    truth = np.concatenate([dev.synth_labels(DATA_SEED, b * nb, nb, G_TRUE) for b in range(B)])
-    torch.cuda.synchronize()
+    # ---- cfg4's per-GPU share at N = 8: one 162 500 x 27 000 block, K = 5, p = 508: the RP stage alone, the block step, then cfg4 whole on ONE GPU
+    def run_cfg4():
+        from sharp_amd import dist as sdist
 
-    def cfg4_step():
-        pg = sdist.global_reduced_dim(nb * B)
-        pj = sharp_amd.Projector(m, pg, [50 + RN_SEED + k for k in range(1, K + 1)])
-        res, nfin, _ = sdist.unlimited_sharded(blocks, list(range(B)), [nb] * B,
-                                               lambda blk, p_, nxt: dev.unlimited_block_dev(blk, p_, pj.handle, K, RN_SEED, next_block=nxt),
-                                               dev.unlimited_merge, device="cuda")
-        pj.close()
-        return np.concatenate([res[b] for b in range(B)]), nfin, pg
-    cfg4_step()                                                          # warm-up
-    lib.sharp_synchronize()
-    t0 = time.perf_counter()
-    pred, nfin, pg = cfg4_step()
-    lib.sharp_synchronize()
-    dt = time.perf_counter() - t0
-    out["cfg4_one_gpu"] = {"workload": "SHARP_unlimited on synthetic %d cells x %d genes as %d blocks of %d cells, block b on GPU b mod 1, ensize.K=%d, "
-                                       "rN.seed=%d (BASELINE.json configs[3] on one GPU: the N = 1 point of the curve `--gpus N` draws)"
-                                       % (nb * B, m, B, nb, K, RN_SEED),
-                           "value": round(nb * B / dt, 1), "unit": "cells/s", "seconds_per_call": round(dt, 4), "calls_timed": 1, "scaling": "strong",
-                           "reduced_dim": pg, "clusters_found": int(nfin), "ari_vs_planted_truth": round(float(ARI(truth, pred)["HA"]), 4)}
-    del x, blocks
+        m, K, B = CFG4["genes"], CFG4["K"], CFG4["blocks"]
+        nb, p = CFG4["cells"] // B, 508
+        x = Bn.synth_block(0, nb, m)
+        proj = sa.Projector(m, p, [50 + RN_SEED + k for k in range(1, K + 1)])
+        dt, (pr, mn, cn) = timed_calls(Bn, lambda: dev.unlimited_block_dev(x, p, proj.handle, K, RN_SEED), 3)
+        proj.close()
+        out["cfg4_share"] = {"workload": "one GPU's block of BASELINE.json configs[3] at N = 8: %d cells x %d genes, ensize.K=%d, p=%d, "
+                                         "sharp_unlimited_block_dev (projectors resident)" % (nb, m, K, p),
+                             "value": round(nb / dt, 1), "unit": "cells/s", "ms_per_step": round(dt * 1e3, 2), "steps": 3, "warmup": 1,
+                             "clusters_found": int(mn.shape[0])}
+        by_cfg["cfg4_share"] = Bn.rp_stage_alone(x, K, p)
+        # the same eight 162 500-cell blocks the N > 1 runs deal out, one after the other here (140 GB of X resident): the N = 1 point of the
+        # strong-scaling curve (`--gpus 1 --config cfg4` times it as the headline value)
+        blocks = [x] + [Bn.synth_block(b * nb, nb, m) for b in range(1, B)]
+        truth = np.concatenate([Bn.labels(b * nb, nb) for b in range(B)])
+        torch.cuda.synchronize()
+
+        def cfg4_step():
+            pg = sdist.global_reduced_dim(nb * B)
+            pj = sa.Projector(m, pg, [50 + RN_SEED + k for k in range(1, K + 1)])
+            res, nfin, _ = sdist.unlimited_sharded(blocks, list(range(B)), [nb] * B,
+                                                   lambda blk, p_, nxt: dev.unlimited_block_dev(blk, p_, pj.handle, K, RN_SEED, next_block=nxt),
+                                                   dev.unlimited_merge, device="cuda")
+            pj.close()
+            return np.concatenate([res[b] for b in range(B)]), nfin, pg
+        dt, (pred, nfin, pg) = timed_calls(Bn, cfg4_step, 3)
+        return {"workload": "SHARP_unlimited on synthetic %d cells x %d genes as %d blocks of %d cells, block b on GPU b mod 1, ensize.K=%d, "
+                            "rN.seed=%d (BASELINE.json configs[3] on one GPU: the N = 1 point of the curve `--gpus N` draws)" % (nb * B, m, B, nb, K, RN_SEED),
+                "value": round(nb * B / dt, 1), "unit": "cells/s", "ms_per_step": round(dt * 1e3, 2), "steps": 3, "warmup": 1, "scaling": "strong",
+                "reduced_dim": pg, "clusters_found": int(nfin), "ari_vs_planted_truth": round(float(ARI(truth, pred)["HA"]), 4)}
+    guarded(out, "cfg4_one_gpu", run_cfg4)
+    torch.cuda.empty_cache()
+
+    # ---- host-inclusive: the blocks start on the HOST as an R session holds them (dense fp64 matrices / dgCMatrix-like sparse blocks); never `value`
+    guarded(out, "host_inclusive", lambda: host_inclusive(Bn))
     torch.cuda.empty_cache()
     return out, by_cfg
 
 
-def cpu_baseline(np, dX, m, K):
-    """The oracle (CPU port of the reference path) on a bounded sample of the same workload, on the host
-    cores of this box; plus the GPU-vs-oracle label agreement on that sample."""
-    from oracle import pyoracle as orc
-    from sharp_amd import device as dev
-    from sharp_amd.api import ARI
+def host_inclusive(Bn, B=2):
+    """SHARP_unlimited on a LIST OF HOST BLOCKS (PCIe inside the time; tools/bench_host_blocks.py is the longer form): B blocks of cfg3's shape as
+    dense fp64 matrices and as CSC blocks (what Matrix::dgCMatrix holds), block b + 1 uploaded while block b is clustered."""
+    np, torch, sa = Bn.np, Bn.torch, Bn.sa
+    import scipy.sparse as sps
 
+    nb, m, K, _ = SHAPES["cfg3"]
+    dense, sparse = [], []
+    for b in range(B):
+        x = Bn.synth_block(b * nb, nb, m)
+        nz = x.nonzero()                                              # (cell, gene), sorted by cell then gene = CSC order of genes x cells
+        indptr = np.concatenate([[0], np.cumsum(torch.bincount(nz[:, 0], minlength=nb).cpu().numpy())]).astype(np.int32)
+        sparse.append(sps.csc_matrix((x[nz[:, 0], nz[:, 1]].double().cpu().numpy(), nz[:, 1].int().cpu().numpy(), indptr), shape=(m, nb)))
+        dense.append(x.double().cpu().numpy().T)                      # (genes, cells) column-major view: R's layout, no copy
+        del x, nz
+    torch.cuda.empty_cache()
+    out = {"workload": "SHARP_unlimited on %d host blocks of %d cells x %d genes, ensize.K=%d, viewflag=FALSE; PCIe-inclusive, never `value`" % (B, nb, m, K),
+           "dense_host_gb": round(sum(d.nbytes for d in dense) / 1e9, 2), "sparse_host_gb": round(sum(s.data.nbytes + s.indices.nbytes + s.indptr.nbytes for s in sparse) / 1e9, 3)}
+    ref = None
+    for name, blocks in (("dense_fp64", dense), ("sparse_csc", sparse)):
+        dt, res = timed_calls(Bn, lambda: sa.SHARP_unlimited(blocks, ensize_K=K, rN_seed=RN_SEED, viewflag=False, devices=[0]), 2)
+        ref = res["pred_clusters"] if ref is None else ref
+        out[name] = {"seconds_per_call": round(dt, 4), "cells_per_s": round(B * nb / dt, 1), "labels_equal_dense": bool(np.array_equal(ref, res["pred_clusters"]))}
+    return out
+
+
+def cpu_baseline(Bn, tag):
+    """The oracle (CPU port of the reference path) on a bounded sample of the same workload, on the host cores of this box, with its
+    per-stage seconds; plus the GPU-vs-oracle label agreement (ARI, Hubert-Arabie) on the sample of EVERY configuration."""
+    from oracle import pyoracle as orc
+
+    np, dev, ARI = Bn.np, Bn.dev, Bn.ARI
     orc.build()
     present = os.cpu_count() or 1
     try:
         avail = len(os.sched_getaffinity(0))           # the cores this process may run on (a GPU box hands out a share of the host)
     except AttributeError:
         avail = present
-    # a sample with at least as many base-clustering tasks as cores (the oracle parallelises over the K*T task grid, one task
-    # per thread): 2000-cell folds x K projections, between 4 000 and 16 000 cells
-    folds = max(2, min(8, -(-avail // K)))
-    ns = 2000 * folds
-    Xs = dX[:ns].cpu().numpy().T.astype(np.float64)    # (genes, cells)
-    # The oracle parallelises over the K*T task grid and every thread holds a copy of its fold: it is memory-bound, and more threads
-    # are not always faster (round 3: 672 cells/s on 120 threads, 947 on 30).  The baseline is the BEST of a few thread counts.
-    tried = {}
-    ref = None
-    for cores in sorted({min(avail, c) for c in (32, 64, 128)}):
-        cores = max(1, min(cores, folds * K))
-        if cores in tried:
-            continue
+    # The oracle parallelises over the K*T task grid of a block and every thread holds a copy of its fold: it is memory-bound, and more
+    # threads are not always faster (round 3: 672 cells/s on 120 threads, 947 on 30).
+    threads = max(1, min(avail, 32))
+
+    def unlimited_sample(m, K, nblk, ncell, nmark=N_MARK):
+        xs = [Bn.synth_block(b * 50000, ncell, m, nmark) for b in range(nblk)]     # the first cells of the configuration's first blocks
+        hs = [x.cpu().numpy().T.astype(np.float64) for x in xs]
+        orc.stage_seconds()
         t0 = time.perf_counter()
-        r = orc.SHARP(Xs, K=K, base_ncells=1, rN_seed=RN_SEED, nthreads=cores, want_view=False)
-        tried[cores] = time.perf_counter() - t0
-        ref = ref or r
-    cores = min(tried, key=tried.get)
-    t = tried[cores]
-    pred, _ = dev.SHARP_dev(dX[:ns], ensize_K=K, base_ncells=1, rN_seed=RN_SEED)
-    ari = float(ARI(ref["pred_clusters"], pred)["HA"])
-    base = {"value": round(ns / t, 2), "unit": "cells/s", "cores": cores, "cores_available": avail, "cores_present": present, "kind": "port",
-            "threads_tried": {str(c): round(ns / v, 1) for c, v in sorted(tried.items())},
-            "sample": "oracle SHARP_large on the first %d cells x %d genes of the same data (%d folds x %d RPs = %d tasks, OpenMP over "
-                      "the K*T task grid; best of %s threads = %d, of the %d cores this process may use), %.1f s"
-                      % (ns, m, folds, K, folds * K, "/".join(str(c) for c in sorted(tried)), cores, avail, t)}
-    return base, {"ari_gpu_vs_oracle_on_sample": round(ari, 4), "sample_cells": ns,
-                  "full_size": "tests/test_configs_gpu.py::test_cfg2_full_size_matches_oracle: this workload whole (50 000 x 20 000, K = 15, 375 base tasks), labels identical to the oracle's; ::test_full_size_block_matches_oracle: the same block at K = 5"}
+        ref = orc.SHARP_unlimited(hs, K=K, rN_seed=RN_SEED, nthreads=threads)
+        t = time.perf_counter() - t0
+        stages = orc.stage_seconds()
+        pred, npred, p, _ = Bn.unlimited_call(xs, K)
+        return t, stages, float(ARI(ref["pred_clusters"], pred)["HA"]), bool(np.array_equal(ref["pred_clusters"], pred)), p
+
+    def large_sample(m, K, ncell, nmark):
+        x = Bn.synth_block(0, ncell, m, nmark)
+        h = x.cpu().numpy().T.astype(np.float64)
+        orc.stage_seconds()
+        t0 = time.perf_counter()
+        ref = orc.SHARP(h, K=K, base_ncells=1, rN_seed=RN_SEED, nthreads=threads, want_view=False)
+        t = time.perf_counter() - t0
+        stages = orc.stage_seconds()
+        pred, _ = dev.SHARP_dev(x, ensize_K=K, base_ncells=1, rN_seed=RN_SEED)
+        return t, stages, float(ARI(ref["pred_clusters"], pred)["HA"]), bool(np.array_equal(ref["pred_clusters"], pred))
+
+    parity = {}
+    # cfg3: two blocks of 8000 cells (4 folds x 5 RPs = 20 tasks per block)
+    t3, st3, ari3, eq3, p3 = unlimited_sample(CFG3["genes"], CFG3["K"], 2, 8000)
+    parity["cfg3"] = {"ari_gpu_vs_oracle_on_sample": round(ari3, 4), "labels_identical": eq3, "sample": "2 blocks x 8000 cells x 20000 genes, K = 5"}
+    # cfg2: 8000 cells, K = 15 (60 tasks); and the same on the CH-decided data set
+    t2, st2, ari2, eq2 = large_sample(CFG2["genes"], CFG2["K"], 8000, N_MARK)
+    parity["cfg2"] = {"ari_gpu_vs_oracle_on_sample": round(ari2, 4), "labels_identical": eq2, "sample": "8000 cells x 20000 genes, K = 15"}
+    t2c, st2c, ari2c, eq2c = large_sample(CFG2["genes"], CFG2["K"], 8000, N_MARK_CH)
+    parity["cfg2_ch"] = {"ari_gpu_vs_oracle_on_sample": round(ari2c, 4), "labels_identical": eq2c, "sample": "8000 cells x 20000 genes, K = 15, %d marker genes" % N_MARK_CH}
+    # cfg4: two blocks of 6000 cells x 27000 genes
+    t4, st4, ari4, eq4, _ = unlimited_sample(CFG4["genes"], CFG4["K"], 2, 6000)
+    parity["cfg4"] = {"ari_gpu_vs_oracle_on_sample": round(ari4, 4), "labels_identical": eq4, "sample": "2 blocks x 6000 cells x 27000 genes, K = 5"}
+    parity["ari_gpu_vs_oracle_on_sample"] = parity[{"cfg2": "cfg2", "cfg2_ch": "cfg2_ch", "cfg3": "cfg3", "cfg4": "cfg4"}[tag]]["ari_gpu_vs_oracle_on_sample"]
+    parity["full_size"] = ("tests/test_configs_gpu.py: ::test_cfg2_full_size_matches_oracle (50 000 x 20 000, K = 15, 375 base tasks), ::test_full_size_block_matches_oracle "
+                           "(a cfg3 block, K = 5), ::test_block_of_1e5_cells_no_reshuffle_branch_matches_oracle (cfg4's n >= 1e5 branch): labels identical to the oracle's; "
+                           "profiles/r05_cfg4_share_parity.txt, r05_cfg2_ch_parity.txt: one true cfg4 share and the CH-decided data set at full size")
+    per = {"cfg3": (16000, t3, st3), "cfg2": (8000, t2, st2), "cfg2_ch": (8000, t2c, st2c), "cfg4": (12000, t4, st4)}
+    ns, t, st = per[tag]
+    base = {"value": round(ns / t, 2), "unit": "cells/s", "cores": threads, "cores_available": avail, "cores_present": present, "kind": "port",
+            "sample": "the oracle (CPU restatement of the reference's R path, not R) on a sample of this workload: %s; OpenMP over the K*T task grid of a block, "
+                      "%d threads of the %d cores this process may use; %.1f s" % (parity[tag]["sample"], threads, avail, t),
+            "stage_seconds": st,
+            "stage_seconds_note": "rp_matmul / base_clustering are THREAD-seconds summed over the task grid's threads (task_loop_wall is their wall time); the others wall seconds",
+            "by_config": {k: {"value": round(v[0] / v[1], 2), "unit": "cells/s", "seconds": round(v[1], 2), "sample_cells": v[0], "stage_seconds": v[2]} for k, v in per.items()}}
+    return base, parity
 
 
 if __name__ == "__main__":

@@ -250,6 +250,16 @@ int sharp_SHARP_unlimited_view(const double *const *X_blocks, const long long *n
 int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
                                    int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred,
                                    int *p_used, double *viE);
+/* viewflag above 1e5 cells (R/SHARP_unlimited.R:216-228): enresults$viE is not E1 but 1/sqrt(kdim) * E1 %*% ranM2(p, kdim, seed), kdim = 50.
+ * sharp_unlimited_view_dim(kdim) arms that for the NEXT SHARP_unlimited call of the process (any of the entries above that takes a viE
+ * buffer; one-shot, like sharp_unlimited_next_block_dev): every block's product is taken on its GPU as soon as the block's viE exists and
+ * the caller's viE receives ncells x kdim doubles (row-major) instead of ncells x p.  kdim = 0 disarms.  The seed expression of :222 reads an
+ * undefined `k` (an R error whenever rN.seed is given): taken as ensize.K + 1, the next seed of the projector sequence.
+ * sharp_SHARP_unlimited_viewk_dev = sharp_unlimited_view_dim(view_dim) + sharp_SHARP_unlimited_view_dev. */
+int sharp_unlimited_view_dim(int kdim);
+int sharp_SHARP_unlimited_viewk_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                                    int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred,
+                                    int *p_used, int view_dim, double *viE /* ncells x (view_dim > 0 ? view_dim : p) row-major */);
 /* The same split for one-block-per-GPU sharding: every rank runs its blocks through
  * sharp_unlimited_block_dev (block labels 1..*n_clusters by first appearance, the cluster means of viE,
  * n_clusters x p row-major into `means` with room for cap_rows rows, and the cluster sizes), the

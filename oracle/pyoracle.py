@@ -293,6 +293,16 @@ def SHARP_unlimited2(blocks, K=0, reduced_ndim=0, partition_ncells=0, hmethod="w
     return dict(rc=rc, pred_clusters=pred, viE=viE, p=po.value)
 
 
+STAGES = ("projector_build", "rp_matmul_thread_s", "base_clustering_thread_s", "wMetaC", "sMetaC_in_block", "cross_block_merge", "task_loop_wall")
+
+
+def stage_seconds(reset=True):
+    """Seconds per stage of the SHARP_large / SHARP_unlimited calls since the last reset (oracle_stage_seconds): bench.py's cpu_baseline."""
+    out = np.zeros(7)
+    lib().oracle_stage_seconds(_dp(out), int(bool(reset)))
+    return dict(zip(STAGES, [round(float(v), 3) for v in out]))
+
+
 def marker_genes(X, label, G, theta=1e-4, ng=1):
     """Per-gene (auc, icluster, pvalue, sparsity, FC) of R/get_marker_genes.R:120-152; X genes x cells."""
     X = np.asfortranarray(X, dtype=np.float64)

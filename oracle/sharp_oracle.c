@@ -931,6 +931,21 @@ int oracle_make_folds(int ncells, int ng, int *folds) {
 /* ------------------------------------------------------------------------- */
 /* R's round(x, 1): nmath/fround.c of R >= 4.0.0 restated (R core: unpinned third-party dependency of the reference):  */
 /* the closer of floor(10x)/10 and ceil(10x)/10, the even multiple on a tie.  Used by R/SHARP_unlimited2.R:410.        */
+/* Stage clocks for bench.py's cpu_baseline leg (per-stage seconds beside the GPU's): seconds spent in each stage of  */
+/* SHARP_large / SHARP_unlimited since the last reset.  [0] projector build (ranM), [1] RP matmul (log2 + projection; THREAD-seconds:  */
+/* summed over the OpenMP threads of the task grid), [2] base clustering (getrowColor; thread-seconds), [3] per-fold wMetaC (wall),   */
+/* [4] sMetaC within blocks (wall), [5] cross-block sMetaC + relabel of SHARP_unlimited (wall), [6] wall of the K*T task loop.        */
+#include <omp.h>
+static double oracle_stage_s[7];
+void oracle_stage_seconds(double *out, int reset) {
+    if (out) for (int q = 0; q < 7; q++) out[q] = oracle_stage_s[q];
+    if (reset) for (int q = 0; q < 7; q++) oracle_stage_s[q] = 0.0;
+}
+static void stage_add(int q, double dt) {
+    #pragma omp atomic
+    oracle_stage_s[q] += dt;
+}
+
 double oracle_round1(double x) {
     if (x != x || x == 0.0 || x - x != 0.0) return x;
     double sgn = x < 0.0 ? -1.0 : 1.0;
@@ -960,9 +975,11 @@ static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng,
     int T = oracle_make_folds(n, ng, folds);
     int8_t *tern = NULL; const int8_t *tn = tern_in;
     if (!tn) {                                                               /* :539-549 */
+        double ts = omp_get_wtime();
         tern = (int8_t *)xmalloc((size_t)K * (size_t)m * (size_t)p);
         for (int k = 1; k <= K; k++) oracle_ranM(m, p, (rN_seed == 0.5) ? 0.5 : 50 + rN_seed + k, tern + (size_t)(k - 1) * m * p);
         tn = tern;
+        stage_add(0, omp_get_wtime() - ts);
     }
     /* fold start offsets (folds are contiguous) */
     int *fstart = (int *)xcalloc((size_t)T + 2, sizeof(int));
@@ -972,8 +989,10 @@ static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng,
     double *enE = (double *)xcalloc((size_t)n * (size_t)p, sizeof(double));
     double *Eall = (double *)xmalloc(sizeof(double) * (size_t)K * (size_t)n * (size_t)p);
     int ntask = K * T;
+    double t_loop = omp_get_wtime();
     #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
     for (int task = 0; task < ntask; task++) {                               /* :554-618 */
+        double ts0 = omp_get_wtime();
         int k = task / T, t = task % T + 1;
         int c0 = fstart[t], nt = fstart[t + 1] - fstart[t];
         double *Xt = (double *)xmalloc(sizeof(double) * (size_t)m * (size_t)nt);
@@ -984,6 +1003,8 @@ static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng,
         double *Et = Eall + ((size_t)k * n + c0) * p;
         oracle_project(Xt, m, nt, tn + (size_t)k * m * p, p, flag, Et);
         if (fpart) for (size_t q = 0; q < (size_t)nt * (size_t)p; q++) Et[q] = oracle_round1(Et[q]);
+        double ts1 = omp_get_wtime();
+        stage_add(1, ts1 - ts0);
         double maxsil;
         int r = oracle_getrowColor(Et, nt, p, hmethod, indN, minN, fpart ? 40 : maxN, sil_thre, height_Ntimes,
                                    enrp + (size_t)k * n + c0, &maxsil);
@@ -992,7 +1013,9 @@ static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng,
             rc |= r;
         }
         free(Xt);
+        stage_add(2, omp_get_wtime() - ts1);
     }
+    stage_add(6, omp_get_wtime() - t_loop);
     for (int k = 0; k < K; k++)                                              /* :629-635, k ascending */
         for (size_t q = 0; q < (size_t)n * (size_t)p; q++) enE[q] += Eall[(size_t)k * n * p + q];
     free(Eall);
@@ -1000,6 +1023,7 @@ static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng,
     int *fColor = (int *)xmalloc(sizeof(int) * (size_t)n);
     double **fx0 = (double **)xcalloc((size_t)T + 1, sizeof(double *));      /* per fold: wres$x0 (nt x nwC, column-major), wres$nwC (:703-707) */
     int *fncl = (int *)xcalloc((size_t)T + 1, sizeof(int));
+    double t_wm = omp_get_wtime();
     #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
     for (int t = 1; t <= T; t++) {
         int c0 = fstart[t], nt = fstart[t + 1] - fstart[t];
@@ -1017,6 +1041,7 @@ static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng,
         for (int j = 0; j < nt; j++) fColor[c0 + j] = t * 65536 + fc[j];
         free(sub); free(fc);
     }
+    stage_add(3, omp_get_wtime() - t_wm);
     int *S = (int *)xmalloc(sizeof(int) * (size_t)n);
     double *E1 = (double *)xmalloc(sizeof(double) * (size_t)n * (size_t)p);
     for (size_t q = 0; q < (size_t)n * (size_t)p; q++) E1[q] = enE[q] / K;   /* :750 */
@@ -1042,7 +1067,9 @@ static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng,
         ncol = lenuC;
     } else {
         int *tf = (int *)xmalloc(sizeof(int) * (size_t)n); int nCu;
+        double t_sm = omp_get_wtime();
         rc |= oracle_sMetaC(fColor, E1, n, p, hmethod, N_cluster, minN, maxN, sil_thre, height_Ntimes, S, tf, &nCu);  /* :754 */
+        stage_add(4, omp_get_wtime() - t_sm);
         /* :761-773: sn = length(unique(stf)); x0[, i] = rowSums(sx0[, which(stf == i)]).  (nCu == lenuC: both count unique(fColor).) */
         for (int q = 0; q < lenuC && q < nCu; q++) { colmap[q] = tf[q] - 1; if (tf[q] > ncol) ncol = tf[q]; }
         free(tf);
@@ -1151,8 +1178,10 @@ int oracle_SHARP_unlimited(const double *Xcat, int m, int nb, const int *ncb, in
     if (minN <= 0) minN = 2;
     if (maxN <= 0) { int c = (ncells + 4999) / 5000; maxN = c > 40 ? c : 40; }
     if (K <= 0) K = 5;
+    double t_pr = omp_get_wtime();
     int8_t *tern = (int8_t *)xmalloc((size_t)K * (size_t)m * (size_t)p);     /* :97-104 */
     for (int k = 1; k <= K; k++) oracle_ranM(m, p, (rN_seed == 0.5) ? 0.5 : 50 + rN_seed + k, tern + (size_t)(k - 1) * m * p);
+    stage_add(0, omp_get_wtime() - t_pr);
     int *fColor = (int *)xmalloc(sizeof(int) * (size_t)ncells);
     double *E1 = (double *)xmalloc(sizeof(double) * (size_t)ncells * (size_t)p);
     size_t off = 0;
@@ -1168,6 +1197,7 @@ int oracle_SHARP_unlimited(const double *Xcat, int m, int nb, const int *ncb, in
         off += (size_t)nbk;
     }
     int *tf = (int *)xmalloc(sizeof(int) * (size_t)ncells); int nCu;
+    double t_mg = omp_get_wtime();
     /* sMetaC(fColor, E1, folds, hmethod, N.cluster, minN, maxN, sil.thre, height.Ntimes) (:163);
        hmethod/sil.thre/height.Ntimes come from block 1's paras = the defaults */
     rc |= oracle_sMetaC(fColor, E1, ncells, p, 1, N_cluster, minN, maxN, 0.35, 2.0, pred, tf, &nCu);
@@ -1185,6 +1215,7 @@ int oracle_SHARP_unlimited(const double *Xcat, int m, int nb, const int *ncb, in
         for (int i = 0; i < ncells; i++) pred[i] = map[pred[i]];
         free(cnt); free(pairs); free(map);
     }
+    stage_add(5, omp_get_wtime() - t_mg);
     if (viE_out) memcpy(viE_out, E1, sizeof(double) * (size_t)ncells * (size_t)p);
     if (p_out) *p_out = p;
     free(tern); free(fColor); free(E1);

@@ -481,7 +481,12 @@ def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster
     pred = np.zeros(n, np.int32)
     npred, pu = C.c_int(), C.c_int()
     p = int(np.ceil(np.log2(n) / 0.04))                                   # :65-66, from the TOTAL number of cells
-    viE = np.zeros((n, p)) if viewflag else None
+    # :215-232: above 1e5 cells enresults$viE is E1 reduced to 50 columns by one more sparse projection; the library takes that product per
+    # block on the GPU (sharp_unlimited_view_dim), so that ncells x 50 doubles come back instead of ncells x p
+    kdim = 50 if (viewflag and n > 1e5) else 0
+    viE = np.zeros((n, kdim if kdim else p)) if viewflag else None
+    if kdim:
+        check(lib().sharp_unlimited_view_dim(kdim))
     if sparse:
         # only the non-zeros of a block cross PCIe, block b + W while block b is clustered (sharp_SHARP_unlimited_csc_multi)
         cps, ris = _csc_int_slots(blocks)
@@ -498,7 +503,7 @@ def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster
         K = int(ensize_K or 5)
         out = _enresults(pred, None, None, n, m, pu.value, K, t0, {}, False, key="N.pred_clusters")
         if viewflag:                                                      # :215-232
-            out["viE"] = _view_reduce(viE, rN_seed, K) if n > 1e5 else viE
+            out["viE"] = viE
             out["x0"] = _one_hot(pred, npred.value)
         return out
     ptrs = (C.POINTER(C.c_double) * len(blocks))(*[_dp(b) for b in blocks])
@@ -515,7 +520,7 @@ def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster
     K = int(ensize_K or 5)
     out = _enresults(pred, None, None, n, m, pu.value, K, t0, {}, False, key="N.pred_clusters")
     if viewflag:                                                          # :215-232
-        out["viE"] = _view_reduce(viE, rN_seed, K) if n > 1e5 else viE
+        out["viE"] = viE
         out["x0"] = _one_hot(pred, npred.value)
     return out
 

@@ -98,6 +98,7 @@ struct Knobs {
     bool mean_early = false;    // SHARP_MEAN_EARLY=1: the ensemble mean of SHARP_large behind the LAST agglomeration, beside the last statistics, instead of behind them (measured: 53.2 against 51.7 ms per cfg2 step, four interleaved pairs: the statistics slow down by more than the mean takes)
     int gemm_slice = 8;         // SHARP_GEMM_SLICE: workgroups per CU per slice of a distance GEMM prepared under another block's tail
     bool proj_host = false;     // SHARP_PROJ_HOST=1 (cross-check): the host build of the projectors
+    int host_threads = 0;       // SHARP_HOST_THREADS: cap on the host cores this process sizes its pools from (0: its affinity mask); host_cores()
     int upload_threads = 0;     // SHARP_UPLOAD_THREADS: host threads narrowing / copying an uploaded block (0: up to 32)
     std::vector<int> devices;   // SHARP_DEVICES=0,1,2,...: the GPUs sharp_SHARP_unlimited deals a list of blocks to (empty / one: the caller's device)
     int rp_shape = 0;           // SHARP_RP_SHAPE=1: 8 lanes x 4 slots per gene where the default is 16 x 2 (A/B runs)
@@ -240,6 +241,7 @@ inline void stream_sync() { SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream));
 // fn(0) .. fn(n-1) on the calling thread plus up to max_threads - 1 workers of a persistent pool (items handed out dynamically).
 // For the short host loops between kernels (per-fold relabelling and votes): starting std::threads anew cost more than the loops.
 // fn must not call HIP and must not throw.
+int host_cores();                   // cores this process may use (affinity mask), capped by SHARP_HOST_THREADS
 void host_pool_threads_hint(int n);   // the calling thread's slot gets a pool of n workers if its pool does not exist yet (tail helpers: several run side by side)
 void host_parallel_for(int n, int max_threads, const std::function<void(int)> &fn);
 inline void launch_check(const char *what) {

@@ -595,6 +595,35 @@ void unlimited_block_dev(XRef dX, int m, long long nb, long long ld, int p, int 
     unlimited_block_summary(o, nb, p, pred, means, counts, viE_host);
 }
 
+// viewflag above 1e5 cells (R/SHARP_unlimited.R:216-228): enresults$viE = 1/sqrt(kdim) * E1 %*% ranM2(p, kdim, seed), kdim = 50.  E1 (ncells x p) exists
+// only to be multiplied: the product is taken PER BLOCK on the device, by the RP kernels themselves (the block's viE as an fp64 "expression"
+// block of p genes, raw mode), as soon as the block's tail has its viE, and ncells x kdim doubles leave the GPU instead of ncells x p
+// (cfg3: 0.2 GB instead of 1.9 GB).  Armed for ONE SHARP_unlimited call by sharp_unlimited_view_dim(); every pointer into the caller's viE
+// is then taken with view_cols(p) columns per cell.
+struct ViewReduce {
+    std::mutex mu;
+    int pending = 0;         // set by sharp_unlimited_view_dim(): the next SHARP_unlimited call takes it
+    int kdim = 0;            // > 0 while that call runs
+    double seed = 0.5;
+};
+ViewReduce &view_reduce() { static ViewReduce v; return v; }
+int view_cols(int p) { const int k = view_reduce().kdim; return k > 0 ? k : p; }
+struct ViewGuard {           // at the top of a SHARP_unlimited run: pending -> active, cleared when the run ends (however it ends)
+    bool own = false;
+    ViewGuard(double rN_seed, int K) {
+        ViewReduce &v = view_reduce();
+        std::lock_guard<std::mutex> lk(v.mu);
+        if (v.pending <= 0) return;                      // (not armed, or an outer run of this call holds it)
+        own = true;
+        v.kdim = v.pending; v.pending = 0;
+        // `50 + rN.seed + k` at :222 reads a `k` that only exists inside the foreach at :96 (an R error whenever a seed
+        // is given); fixed as the next seed of that sequence, k = ensize.K + 1
+        v.seed = rN_seed == 0.5 ? 0.5 : 50 + rN_seed + K + 1;
+    }
+    ~ViewGuard() { if (!own) return; ViewReduce &v = view_reduce(); std::lock_guard<std::mutex> lk(v.mu); v.kdim = 0; }
+};
+struct ViewProj { std::shared_ptr<Projector> pr; int p = 0, kdim = 0; double seed = 0; DevBuf<double> out; };
+
 // labels, per-cluster means of viE and cluster sizes of one finished block (what the cross-block sMetaC needs, :153-163)
 void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector<int> &pred, std::vector<double> &means,
                              std::vector<long long> &counts, double *viE_host) {
@@ -608,7 +637,19 @@ void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector
     cluster_means_dev(o.viE.p, p, static_cast<int>(nb), p, uid, G, dm.p);
     means.resize(static_cast<size_t>(G) * p);
     dm.download(means.data(), means.size());
-    if (viE_host) o.viE.download(viE_host, static_cast<size_t>(nb) * p);        // E1 rows of this block (:153), viewflag only
+    if (!viE_host) return;
+    const int kdim = view_reduce().kdim;
+    if (kdim <= 0) { o.viE.download(viE_host, static_cast<size_t>(nb) * p); return; }   // E1 rows of this block (:153), viewflag only
+    ViewProj &V = per_slot<ViewProj>();                                         // (a tail helper's slot builds its own, once)
+    const double seed = view_reduce().seed;
+    if (!V.pr || V.p != p || V.kdim != kdim || V.seed != seed || seed == 0.5) {
+        V.pr = build_projector(p, kdim, 1, &seed);                              // ranM2(p, kdim, seed): the same draw as ranM (R/ranM2.R:11-35)
+        V.p = p; V.kdim = kdim; V.seed = seed;
+    }
+    V.out.ensure(static_cast<size_t>(nb) * kdim);
+    HostTimer ht("tail_view_reduce");
+    project_dev(*V.pr, dev64_ref(o.viE.p, p, nb, p), p, static_cast<int>(nb), p, 0, V.out.p, kdim, nullptr);
+    V.out.download(viE_host, static_cast<size_t>(nb) * kdim);
 }
 
 // Blocks [b0, b1) of a SHARP_unlimited call whose base-clustering tasks run as ONE pipelined batch (get_opt_hclust_batch: chunks of
@@ -690,7 +731,7 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
     Ctx &mc = ctx();
     const int dev = mc.device, owner = cur_slot();
     const bool prof = mc.profiling;
-    const int H = std::max(1, std::min({knobs().tail_threads, nbk, 4}));
+    const int H = std::max(1, std::min({knobs().tail_threads, nbk, 4, std::max(1, host_cores() / 4)}));   // (a helper brings a five-thread host pool)
     std::vector<int> tslot(H);
     for (int h = 0; h < H; ++h) tslot[h] = acquire_slot(dev, owner * 4 + h, 2);
     std::vector<std::thread> helpers;
@@ -975,6 +1016,7 @@ int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long lo
                                    double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
                                    long long *counts, double *viE) {
     SHARP_API_BEGIN
+    ViewGuard vg(rN_seed, ensize_K > 0 ? ensize_K : 5);     // (a rank of the sharded run arms sharp_unlimited_view_dim per block: its E1 rows come back reduced)
     ctx();
     SHARP_REQUIRE(pred && n_clusters && means && counts, "sharp_unlimited_block_view_dev: null output");
     std::vector<int> pr;
@@ -1094,6 +1136,7 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
                          int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used,
                          double *viE) {
     SHARP_API_BEGIN
+    ViewGuard vg(rN_seed, ensize_K > 0 ? ensize_K : 5);     // (first: a call that fails its argument checks disarms the view dimension too)
     ctx();
     SHARP_REQUIRE(dX_blocks && ncb && ldb && pred, "The input should be a LIST of partitioned scRNA-seq expression matrices!");
     SHARP_REQUIRE(nblocks >= 2, "SHARP is used instead of SHARP_unlimited because the length of the input is 1!");
@@ -1119,7 +1162,7 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
         };
         std::vector<double *> viE_of(nblocks, nullptr);
         long long at = 0;
-        for (int b = 0; b < nblocks; ++b) { if (viE) viE_of[b] = viE + static_cast<size_t>(at) * p; at += ncb[b]; }
+        for (int b = 0; b < nblocks; ++b) { if (viE) viE_of[b] = viE + static_cast<size_t>(at) * view_cols(p); at += ncb[b]; }
         unlimited_blocks_loop(dX_blocks, ncb, ldb, nblocks, m, p, proj, K, rN_seed, viE ? viE_of.data() : nullptr, take);
     } catch (...) { drop_projector(proj); throw; }
     drop_projector(proj);
@@ -1286,6 +1329,7 @@ double wall_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv
 int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K, int N_cluster, int minN, int maxN, double rN_seed,
                         const int *devices, int ndev, int *pred, int *n_pred, int *p_used, double *viE) {
     SHARP_API_BEGIN
+    ViewGuard vg(rN_seed, ensize_K > 0 ? ensize_K : 5);
     const int nblocks = static_cast<int>(blocks.size());
     SHARP_REQUIRE(pred, "The input should be a LIST of partitioned scRNA-seq expression matrices!");
     SHARP_REQUIRE(nblocks >= 2, "SHARP is used instead of SHARP_unlimited because the length of the input is 1!");
@@ -1410,7 +1454,7 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
                     for (size_t i = 0; i < my.size(); ++i) {
                         block_ref(i, true, refs[i], ll[i]);
                         nn[i] = blocks[my[i]].n;
-                        if (viE) vo[i] = viE + static_cast<size_t>(cell0[my[i]]) * p;
+                        if (viE) vo[i] = viE + static_cast<size_t>(cell0[my[i]]) * view_cols(p);
                     }
                     const double t_go = wall_s() - t_begin;
                     unlimited_blocks_loop(refs.data(), nn.data(), ll.data(), static_cast<int>(my.size()), m, p, proj, K, rN_seed, viE ? vo.data() : nullptr,
@@ -1431,7 +1475,7 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
                     const bool more = i + 1 < my.size() && block_ref(i + 1, false, nref, nld);
                     tl[static_cast<size_t>(b) * 6 + 4] = wall_s() - t_begin;
                     unlimited_block_dev(ref, m, blocks[b].n, ld, p, proj, K, rN_seed, pb[b], mb[b], cb[b],
-                                        viE ? viE + static_cast<size_t>(cell0[b]) * p : nullptr,   // E1 rows of this block (:153), viewflag only
+                                        viE ? viE + static_cast<size_t>(cell0[b]) * view_cols(p) : nullptr,   // E1 rows of this block (:153), viewflag only
                                         1, nullptr, more ? nref : XRef(), more ? blocks[my[i + 1]].n : 0, more ? nld : 0);
                     tl[static_cast<size_t>(b) * 6 + 5] = wall_s() - t_begin;
                     tl[static_cast<size_t>(b) * 6 + 0] = w; tl[static_cast<size_t>(b) * 6 + 1] = b;
@@ -1531,6 +1575,22 @@ int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long lon
                                    double *viE) {
     const std::vector<XRef> refs = f32_refs(dX_blocks, nblocks);
     return unlimited_run(dX_blocks ? refs.data() : nullptr, ncb, ldb, nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred, p_used, viE);
+}
+
+int sharp_unlimited_view_dim(int kdim) {
+    SHARP_API_BEGIN
+    SHARP_REQUIRE(kdim >= 0 && kdim <= 4096, "sharp_unlimited_view_dim: the view dimension must lie in 0 .. 4096");
+    ViewReduce &v = view_reduce();
+    std::lock_guard<std::mutex> lk(v.mu);
+    v.pending = kdim;
+    SHARP_API_END
+}
+
+int sharp_SHARP_unlimited_viewk_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
+                                    int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used,
+                                    int view_dim, double *viE) {
+    if (const int rc = sharp_unlimited_view_dim(viE ? view_dim : 0)) return rc;
+    return sharp_SHARP_unlimited_view_dev(dX_blocks, ncb, ldb, nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred, p_used, viE);
 }
 
 int sharp_SHARP_unlimited2_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,

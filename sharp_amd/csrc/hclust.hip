@@ -2184,6 +2184,14 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
         }
         chosen[t] = oind - 1;
     });
+    if (c.profiling) {      // which rule of R/get_opt_hclust.R:162-229 decided each task's level (bench.py reports the split per data set)
+        static const char *const rule[3] = {"silhouette", "CH", "height"};
+        for (int t = 0; t < T; ++t) {
+            if (tasks[i0 + t].prm.N_cluster > 0) continue;
+            const std::string key = std::string(tasks[i0 + t].symmetric ? "host:level_meta_by_" : "host:level_base_by_") + rule[std::min(2, std::max(0, out[i0 + t].branch))];
+            c.stats[key].launches += 1;
+        }
+    }
     W.chosen.ensure(T); W.packoff.ensure(T); W.packed.ensure(ptot);
     W.chosen.upload(chosen.data(), T);
     W.packoff.upload(poff.data(), T);

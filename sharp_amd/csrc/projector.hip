@@ -485,8 +485,7 @@ static std::shared_ptr<Projector> build_projector_host(int m, int p, int K, cons
     pr->h_rowptr.resize(K);
     pr->h_ent.resize(K);
     {
-        unsigned hw = std::thread::hardware_concurrency();
-        if (hw == 0) hw = 4;
+        const unsigned hw = static_cast<unsigned>(host_cores());
         const int nthr = static_cast<int>(std::min<unsigned>(hw, K));
         std::vector<std::thread> pool;
         for (int t = 0; t < nthr; ++t)

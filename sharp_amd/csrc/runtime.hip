@@ -178,13 +178,27 @@ void pool_atfork_child() {
 }
 }  // namespace
 
+// The cores this process may run on (its affinity mask: a GPU box hands a rank a share of the host; hardware_concurrency() counts the
+// whole machine), capped by SHARP_HOST_THREADS -- bench.py sets that to cores / world size when it runs one process per GPU, so that eight
+// ranks' upload pools, tail helpers and host loops together ask for the host's cores once, not eight times.
+int host_cores() {
+    static const int present = [] {
+        cpu_set_t set;
+        int c = 0;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) c = CPU_COUNT(&set);
+        if (c <= 0) c = static_cast<int>(std::thread::hardware_concurrency());
+        return c > 0 ? c : 4;
+    }();
+    const int cap = knobs().host_threads;
+    return cap > 0 ? std::max(1, std::min(present, cap)) : present;
+}
+
 static thread_local int g_pool_threads_hint = 0;
 void host_pool_threads_hint(int n) { g_pool_threads_hint = n; }
 
 void host_parallel_for(int n, int max_threads, const std::function<void(int)> &fn) {
     if (n <= 0) return;
-    unsigned hw = std::thread::hardware_concurrency();
-    if (hw == 0) hw = 4;
+    const unsigned hw = static_cast<unsigned>(host_cores());
     if (n == 1 || max_threads <= 1 || hw <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
     PoolTable &T = pool_table();
     PoolState *S = nullptr;
@@ -306,6 +320,7 @@ static Knobs read_knobs() {
     v.stats_sums = num("SHARP_STATS_SUMS", 1) != 0;
     v.dist_i8 = num("SHARP_DIST_I8", 0) != 0;
     v.tail_threads = num("SHARP_TAIL_THREADS", 4);
+    v.host_threads = num("SHARP_HOST_THREADS", 0);
     v.tail_priority = num("SHARP_TAIL_PRIORITY", 1) != 0;
     v.gemm_slice = num("SHARP_GEMM_SLICE", 8);
     v.proj_host = num("SHARP_PROJ_HOST", 0) == 1;

@@ -31,7 +31,7 @@ UploadStage &upload_stage() { return per_slot<UploadStage>(); }
 int &last_storage() { static int s = 0; return s; }
 
 int upload_threads() {
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = static_cast<unsigned>(host_cores());
     if (knobs().upload_threads > 0) hw = static_cast<unsigned>(knobs().upload_threads);
     return static_cast<int>(std::max(1u, std::min(hw ? hw : 4u, 32u)));
 }

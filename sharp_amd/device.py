@@ -57,34 +57,50 @@ def csc_to_dev(sp):
 
 def SHARP_dev(dX, ensize_K=0, reduced_ndim=0, base_ncells=0, partition_ncells=0, hmethod=1, N_cluster=0, enpN_cluster=0,
               indN_cluster=0, minN_cluster=0, maxN_cluster=0, sil_thre=-1.0, height_Ntimes=0.0, flag=True, projector=0,
-              rN_seed=0.5):
+              rN_seed=0.5, forview=False):
     """SHARP() (R/SHARP.R:44-318) on a resident block (float32, or float64 for TPM / CPM-like values: sharp_SHARP_dev64);
-    returns (pred_clusters, info)."""
+    returns (pred_clusters, info).  forview (the reference's default, R/SHARP.R:46,844): info also carries "viE" (n x p, the
+    ensemble-mean projection) and "x0" (n x G, the soft cluster matrix of :717-731,763-783)."""
     _lib.ensure_init()
     n, m = dX.shape
     pred = np.zeros(n, np.int32)
-    npred, pu, Ku, path = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    npred, pu, Ku, path, x0c = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    viE = x0 = None
+    cap = 0
+    if forview:
+        pmax = reduced_ndim if reduced_ndim > 0 else int(np.ceil(np.log2(n) / 0.04))
+        cap = max(maxN_cluster, 40, -(-n // 5000)) + 2
+        viE = np.empty((n, pmax))
+        x0 = np.empty(n * cap)
     entry = lib().sharp_SHARP_dev64 if str(dX.dtype) == "torch.float64" else lib().sharp_SHARP_dev
     rc = check(entry(C.c_void_p(dX.data_ptr()), m, C.c_longlong(n), C.c_longlong(dX.stride(0)), ensize_K,
                                      reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
                                      indN_cluster, minN_cluster, maxN_cluster, C.c_double(sil_thre), C.c_double(height_Ntimes),
-                                     int(bool(flag)), projector, C.c_double(rN_seed), _ip(pred), C.byref(npred), None, None, 0,
-                                     None, C.byref(pu), C.byref(Ku), C.byref(path)), allow=48)
-    return pred, {"N.pred_cluster": npred.value, "reduced.dim": pu.value, "ensize.K": Ku.value,
-                  "path": "SHARP_large" if path.value else "SHARP_small", "warn": rc}
+                                     int(bool(flag)), projector, C.c_double(rN_seed), _ip(pred), C.byref(npred), _dp(viE), _dp(x0), cap,
+                                     C.byref(x0c), C.byref(pu), C.byref(Ku), C.byref(path)), allow=48)
+    info = {"N.pred_cluster": npred.value, "reduced.dim": pu.value, "ensize.K": Ku.value,
+            "path": "SHARP_large" if path.value else "SHARP_small", "warn": rc}
+    if forview:
+        info["viE"] = viE[:, :pu.value] if pu.value != viE.shape[1] else viE
+        info["x0"] = x0[: n * x0c.value].reshape(x0c.value, n).T
+    return pred, info
 
 
-def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag=True, viE=None, next_block=None):
+def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag=True, viE=None, next_block=None, view_dim=0):
     """One block of SHARP_unlimited: labels, per-cluster means of viE (G x p) and cluster sizes.
 
     flag: the log flag of the block's SHARP() call; viE: optional (nb, p) float64 host array that receives the block's
-    ensemble-mean projection (viewflag); next_block: the resident block of the NEXT call (same genes / projector / parameters):
-    its projection and distance matrices are prepared under this call's tail (sharp_unlimited_next_block_dev)."""
+    ensemble-mean projection (viewflag) -- or, with view_dim > 0, an (nb, view_dim) array that receives those rows reduced on the device
+    (sharp_unlimited_view_dim: what SHARP_unlimited returns as viE above 1e5 cells, R/SHARP_unlimited.R:216-228); next_block: the resident
+    block of the NEXT call (same genes / projector / parameters): its projection and distance matrices are prepared under this call's tail
+    (sharp_unlimited_next_block_dev)."""
     _lib.ensure_init()
     nb, m = dX.shape
     if next_block is not None:
         check(lib().sharp_unlimited_next_block_dev(C.c_void_p(next_block.data_ptr()), C.c_longlong(next_block.shape[0]),
                                                    C.c_longlong(next_block.stride(0))))
+    if viE is not None and view_dim > 0:
+        check(lib().sharp_unlimited_view_dim(int(view_dim)))
     pred = np.zeros(nb, np.int32)
     means = np.empty((cap_rows, p))                 # only the first G rows are written and returned
     counts = np.empty(cap_rows, np.int64)
@@ -121,6 +137,29 @@ def unlimited_blocks_dev(blocks, p, projector, ensize_K, rN_seed, cap_rows=4096)
         out.append((pred[o:o + int(ncb[b])].copy(), means[r:r + g].copy(), counts[r:r + g].copy()))
         o += int(ncb[b]); r += g
     return out
+
+
+def unlimited_dev(blocks, ensize_K=0, N_cluster=0, minN_cluster=0, maxN_cluster=0, rN_seed=0.5, viewflag=False, view_dim=None, viE_out=None):
+    """SHARP_unlimited (R/SHARP_unlimited.R:29-242) on float32 blocks resident on the current GPU -> (pred, n_pred, p, viE or None).
+    viewflag: viE as the reference returns it (:214-228): E1 (ncells x p) up to 1e5 cells, above that E1 reduced to 50 columns by one
+    more sparse projection -- taken per block on the device (sharp_SHARP_unlimited_viewk_dev).  view_dim forces the reduction (tests)."""
+    _lib.ensure_init()
+    B = len(blocks)
+    ptrs = (C.c_void_p * B)(*[b.data_ptr() for b in blocks])
+    ncb = np.array([b.shape[0] for b in blocks], np.int64)
+    ldb = np.array([b.stride(0) for b in blocks], np.int64)
+    n = int(ncb.sum())
+    pred = np.zeros(n, np.int32)
+    npred, pu = C.c_int(), C.c_int()
+    viE, kdim = None, 0
+    if viewflag:
+        kdim = int(view_dim) if view_dim is not None else (50 if n > 1e5 else 0)
+        cols = kdim if kdim else int(np.ceil(np.log2(n) / 0.04))
+        viE = viE_out if viE_out is not None and viE_out.shape == (n, cols) else np.zeros((n, cols))
+    check(lib().sharp_SHARP_unlimited_viewk_dev(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), ldb.ctypes.data_as(C.POINTER(C.c_longlong)), B,
+                                                int(blocks[0].shape[1]), int(ensize_K), int(N_cluster), int(minN_cluster), int(maxN_cluster),
+                                                C.c_double(rN_seed), _ip(pred), C.byref(npred), C.byref(pu), kdim, _dp(viE)), allow=48)
+    return pred, npred.value, pu.value, viE
 
 
 def unlimited_multi_dev(blocks, device_of_block, devices, ensize_K=0, N_cluster=0, minN_cluster=0, maxN_cluster=0, rN_seed=0.5,

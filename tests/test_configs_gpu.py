@@ -241,6 +241,46 @@ def test_cfg2_full_size_matches_oracle(env, oracle):
     assert np.array_equal(pred, ref["pred_clusters"])
 
 
+def test_block_of_1e5_cells_no_reshuffle_branch_matches_oracle(env, oracle):
+    """The branch a block of BASELINE.json configs[3] takes (162 500 cells per GPU): n >= 1e5, so SHARP_large keeps the cells in their
+    original order (no `scExp[, reind]`, R/SHARP.R:504-507) and skips the un-shuffle of labels, viE and x0 (:777-783); 51 folds whose
+    last two are re-balanced (:513-536); a within-block sMetaC over ~ 500 fold clusters with minN = min(max(n / 1e4, 2), 10) = 10
+    (R/sMetaC.R:103-109).  One block of 100 200 cells x 1500 genes, K = 3, through SHARP() on a resident block -- labels, viE and x0 --
+    and through the per-block entry of SHARP_unlimited (R/SHARP_unlimited.R:135-143): identical to the oracle, cell for cell."""
+    sa, dev, torch = env
+    n, m, K = 100200, 1500, 3
+    p = int(np.ceil(np.log2(n) / 0.04))
+    assert n >= 100000 and p == 416
+    dX = torch.empty((n, m), dtype=torch.float32, device="cuda")
+    dev.synth_fill(dX, SEED + 5, 0, 8, 150)
+    pred, info = dev.SHARP_dev(dX, ensize_K=K, rN_seed=RN, forview=True)
+    assert info["path"] == "SHARP_large" and info["reduced.dim"] == p
+    proj = sa.Projector(m, p, [50 + RN + k for k in range(1, K + 1)])
+    viE_b = np.empty((n, p))
+    pred_b, means_b, counts_b = dev.unlimited_block_dev(dX, p, proj.handle, K, RN, viE=viE_b)
+    proj.close()
+    X = dX.cpu().numpy().T.astype(np.float64)                             # (genes, cells)
+    del dX
+    torch.cuda.empty_cache()
+    cores = min(len(os.sched_getaffinity(0)), 32)
+    t0 = time.perf_counter()
+    ref = oracle.SHARP_large(X, K=K, p=p, rN_seed=RN, nthreads=cores)
+    print("oracle: %.1f s on %d threads" % (time.perf_counter() - t0, cores))
+    assert ref["rc"] in (0, 16)
+    assert len(set(ref["pred_clusters"])) >= 6                               # (the planted clusters were found: a real comparison)
+    assert np.array_equal(pred, ref["pred_clusters"])
+    assert np.array_equal(pred_b, ref["pred_clusters"])
+    tol = 2e-12 * np.abs(ref["viE"]).max()
+    np.testing.assert_allclose(info["viE"], ref["viE"], rtol=0, atol=tol)   # rows in the ORIGINAL cell order, never shuffled
+    np.testing.assert_allclose(viE_b, ref["viE"], rtol=0, atol=tol)
+    assert info["x0"].shape == ref["x0"].shape
+    np.testing.assert_allclose(info["x0"], ref["x0"], rtol=0, atol=1e-15)
+    # the per-block summary the cross-block merge consumes: centroids = colMeans(viE[cluster, ]) (R/sMetaC.R:58-63)
+    for g in (1, int(pred_b.max())):
+        np.testing.assert_allclose(means_b[g - 1], ref["viE"][ref["pred_clusters"] == g].mean(0), rtol=0, atol=1e-10)
+    assert np.array_equal(counts_b, np.bincount(ref["pred_clusters"])[1:])
+
+
 def test_cfg1_shaped_call_matches_oracle(env, oracle):
     """BASELINE.json configs[0] is the reference's own example (479 cells of TPM values, default ensize.K = 15, rN.seed = 2103,
     README.md:88-114); its data blob is not in the repository, so the SHAPE is run: 479 cells x 20 000 genes of TPM-like doubles,

@@ -59,12 +59,14 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path, cells, genes, nblocks):
     assert d["ari_vs_planted_truth"] > 0.85                        # (what the algorithm finds on this data; parity is tested elsewhere)
 
 
-def test_bench_default_line_names_cfg2_and_carries_the_other_configs():
-    """`python bench.py` (N = 1): the headline is BASELINE.json configs[1]; the same line carries cfg3 end to end and the RP-stage roofline
-    at the K = 5 shapes (cfg3's block, cfg4's per-GPU share), and the CPU baseline."""
+def test_bench_default_line_names_cfg3_with_forview_roofline_and_cpu_baseline():
+    """`python bench.py` (N = 1): the headline is BASELINE.json configs[2], the largest single-GPU configuration, under the steps / warm-up
+    contract, with the forview step, the RP-stage roofline of its block shape (traffic measured in the run), the CPU baseline with its
+    per-stage seconds and the GPU-vs-oracle ARI of every configuration's sample.  (--no-extra: the other configurations' timings are the
+    driver's bench run; tools/dryrun_8ranks.sh and the two-rank test above cover N > 1.)"""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     # the bench is a process of its own on the same GPU: this one gives back what earlier tests left in its worker / helper slots and in
-    # torch's cache first (cfg4 whole on one GPU needs ~150 GB)
+    # torch's cache first
     import sharp_amd
     import torch
 
@@ -72,31 +74,30 @@ def test_bench_default_line_names_cfg2_and_carries_the_other_configs():
         sharp_amd.init(0)
         assert sharp_amd.lib().sharp_trim() == 0
         torch.cuda.empty_cache()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"], env=env, timeout=1200,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extra"], env=env, timeout=1200,
                        capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["baseline_config"] == "configs[1]"
-    assert d["config"]["workload"].startswith("SHARP() on synthetic 50000 cells x 20000 genes, ensize.K=15")
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["baseline_config"] == "configs[2]" and d["steps"] == 3
+    assert d["config"]["workload"].startswith("SHARP_unlimited on synthetic 500000 cells x 20000 genes as 10 blocks of 50000, ensize.K=5")
+    assert d["config"]["reduced_dim"] == 474 and d["ari_vs_planted_truth"] > 0.9
+    assert d["value"] == pytest.approx(500000 / (d["ms_per_step"] * 1e-3), rel=1e-3)
+    assert d["consistency"]["ms_per_step_x_steps_s"] == pytest.approx(d["consistency"]["timed_region_s"], rel=1e-2)
+    assert d["ms_per_step_forview"] >= 0.9 * d["ms_per_step"]
     rf = d["roofline"]
-    assert rf["kernel"].startswith("RP matmul stage") and rf["peak"] == 8000.0
+    assert rf["kernel"].startswith("RP matmul stage") and rf["peak"] == 8000.0 and rf["bound"] == "hbm"
     assert rf["frac"] == pytest.approx(50000 * 20000 * 4 / (rf["stage"]["ms"] * 1e-3) / 8e12, rel=2e-3)
-    assert set(rf["by_config"]) == {"cfg2_alone", "cfg3_block", "cfg4_share"} and rf["by_config"]["cfg4_share"]["reduced_dim"] == 508
-    assert rf["by_config"]["cfg2_alone"]["reduced_dim"] == d["config"]["reduced_dim"] == 391
-    # the stage is ONE launch of the producer / consumer kernel: its HIP-event launch time is the stage's time
+    # the stage is ONE launch of the producer / consumer kernel per block: its HIP-event launch time is the stage's time
     assert rf["stage"]["launches_per_stage"] == 1.0 and "rp_pc_kernel" in rf["kernel"]
     assert rf["stage"]["rp_pc_kernel"]["launch_ms"] == pytest.approx(rf["stage"]["ms"], rel=0.03)
-    # roofline.traffic: HBM bytes of the stage, measured in the run when rocprofv3 is on the box (else the committed figure, labelled):
+    # roofline.traffic: HBM bytes of one launch, measured in the run when rocprofv3 is on the box (else the committed figure, labelled):
     # X once plus E once -- between 1.0 and 2.0 times the algorithmic read
     assert 4.0e9 <= rf["traffic"] <= 8.0e9 and ("measured in this run" in rf["traffic_source"] or "not measured in this run" in rf["traffic_source"])
-    assert d["other_configs"]["cfg3"]["reduced_dim"] == 474 and d["other_configs"]["cfg3"]["ari_vs_planted_truth"] > 0.9
-    # cfg4 whole on the one GPU: the N = 1 point of the strong-scaling curve, same workload string as the N > 1 runs up to the GPU count
-    c4 = d["other_configs"]["cfg4_one_gpu"]
-    assert c4["scaling"] == "strong" and c4["reduced_dim"] == 508 and c4["ari_vs_planted_truth"] > 0.9
-    assert c4["workload"].startswith("SHARP_unlimited on synthetic 1300000 cells x 27000 genes as 8 blocks of 162500 cells, block b on GPU b mod 1")
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and d["parity"]["ari_gpu_vs_oracle_on_sample"] >= 0.99
-    assert cb["cores"] <= cb["cores_available"] <= cb["cores_present"] and "tasks" in cb["sample"]
-    assert str(cb["cores"]) in cb["threads_tried"] and cb["value"] == max(cb["threads_tried"].values()) or abs(cb["value"] - max(cb["threads_tried"].values())) < 0.1
+    assert cb["kind"] == "port" and cb["cores"] <= cb["cores_available"] <= cb["cores_present"]
+    assert set(cb["by_config"]) == {"cfg2", "cfg2_ch", "cfg3", "cfg4"} and cb["stage_seconds"]["base_clustering_thread_s"] > 0
+    for k in ("cfg2", "cfg2_ch", "cfg3", "cfg4"):
+        assert d["parity"][k]["ari_gpu_vs_oracle_on_sample"] >= 0.99, (k, d["parity"][k])
+    assert d["parity"]["ari_gpu_vs_oracle_on_sample"] == d["parity"]["cfg3"]["ari_gpu_vs_oracle_on_sample"]

@@ -295,6 +295,52 @@ def test_view_reduction_above_1e5_cells(sa, oracle):
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-12 * np.abs(ref).max())
 
 
+def test_view_reduction_on_the_device_per_block(sa, oracle):
+    """The same reduction taken per block on the GPU (sharp_unlimited_view_dim / sharp_SHARP_unlimited_viewk_dev: what SHARP_unlimited does above
+    1e5 cells, so that ncells x 50 doubles leave the GPU instead of ncells x p), forced here on a small list of ragged blocks: resident blocks in
+    one call, the in-process multi-device entry, the per-block entry of a sharded rank -- against the oracle's E1 put through the oracle's
+    projection, block by block."""
+    import torch
+    from sharp_amd import device as dev
+
+    m, K, seed = 1400, 3, 2103
+    sizes = [5300, 640, 5050]
+    host, c0 = [], 0
+    for nb in sizes:
+        host.append(oracle.synth_fill(77, m, c0, nb, 5, 140))
+        c0 += nb
+    n = sum(sizes)
+    ref = oracle.SHARP_unlimited(host, K=K, rN_seed=seed, nthreads=8, want_view=True)
+    p = ref["p"]
+    z0 = oracle.ranM(p, 50, 50 + seed + K + 1)
+    want = np.concatenate([oracle.project(ref["viE"][a:b].T, z0, False) for a, b in zip(np.cumsum([0] + sizes[:-1]), np.cumsum(sizes))])
+    tol = 4e-12 * np.abs(want).max()
+    blocks = [torch.from_numpy(np.ascontiguousarray(h.T.astype(np.float32))).cuda() for h in host]
+    torch.cuda.synchronize()
+    pred, npred, pu, viE = dev.unlimited_dev(blocks, ensize_K=K, rN_seed=seed, viewflag=True, view_dim=50)
+    assert pu == p and viE.shape == (n, 50) and np.array_equal(pred, ref["pred_clusters"])
+    np.testing.assert_allclose(viE, want, rtol=0, atol=tol)
+    # not armed: the plain view (E1 itself), and the armed state does not leak into the next call
+    pred2, _, _, viE2 = dev.unlimited_dev(blocks, ensize_K=K, rN_seed=seed, viewflag=True)
+    assert viE2.shape == (n, p) and np.array_equal(pred2, pred)
+    np.testing.assert_allclose(viE2, ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
+    # the host-list entries of the API arm it themselves above 1e5 cells only; armed by hand here through the one-shot switch
+    from sharp_amd._lib import check, lib
+    check(lib().sharp_unlimited_view_dim(50))
+    pm, nm, _, vm = dev.unlimited_multi_dev(blocks, [0, 1, 0], [0, 0], ensize_K=K, rN_seed=seed, viewflag=True)
+    assert np.array_equal(pm, pred)
+    np.testing.assert_allclose(vm.reshape(-1)[: n * 50].reshape(n, 50), want, rtol=0, atol=tol)
+    # a rank of the sharded run, block by block
+    proj = sa.Projector(m, p, [50 + seed + k for k in range(1, K + 1)])
+    at = 0
+    for b, nb in enumerate(sizes):
+        v = np.zeros((nb, 50))
+        dev.unlimited_block_dev(blocks[b], p, proj.handle, K, seed, viE=v, view_dim=50)
+        np.testing.assert_allclose(v, want[at:at + nb], rtol=0, atol=tol)
+        at += nb
+    proj.close()
+
+
 def test_ARI_five_indices_match_oracle(sa, oracle):
     """R/ARI.R:20-42 -> clues::adjustedRand(label, res$pred_clusters): Rand, HA, MA, FM, Jaccard; labels may be strings."""
     rng = np.random.default_rng(21)
