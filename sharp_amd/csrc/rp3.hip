@@ -26,7 +26,13 @@ namespace sharp {
 //   B = 12 waves: 4 producers with 2 units in flight + 8 consumers (80 registers per lane: the K = 5 shapes -- 24 waves per CU keep
 //       the LDS and the vector memory path busier: cfg3 block 1.44 -> 1.35 ms, cfg4 share 5.71 -> 5.29 ms on one box).
 // The producers run at a raised wave priority: the consumers wait for them at the cell's first barrier, never the other way round.
-// Entry word: bits 19..0 gene, bits 29..20 table index, bit 31: the term is in the scratch block (value outside the table).
+// Entry word: bits 19..0 gene, bits 29..20 table index, bit 31: the value is outside the table and the entry has a 64-bit term of its own.
+// fp32 blocks (counts: such entries are rare) keep those terms in a per-workgroup scratch block in global memory.  fp64 blocks (TPM / CPM-like
+// doubles: EVERY entry is one) have a 64-bit term slot per LDS list entry beside the word (round 5): the lane that holds a value parks its
+// bits there, then one lane per entry turns them into log2(1 + x) in fixed point in place, and the consumers read the term where they read the
+// word -- no global store, no global load, and above all none of the two s_waitcnt vmcnt(0) per unit that the scratch round trip costs (a
+// producer's own stores must have landed before it reads them back, and that wait drains the units it has in flight: 40 stalls of a memory
+// latency per cell made the fp64 stage 3.8 x as long as the fp32 one for twice the bytes).  Entries beyond the LDS room still go through scratch.
 // The table holds fix(f(x)) for every float x in [1, 256) whose low 16 bits are zero -- every integer count below 256 is one --
 // indexed by (bits(x) - bits(1.0f)) >> 16: the index IS the high half of the value's bits, no conversion on either side.
 constexpr int PC_TAB = 1024;
@@ -39,6 +45,7 @@ constexpr uint32_t kPcBadMask = 0xFC00FFFFu;      // (bits - kPcOne) & this != 0
 typedef __attribute__((address_space(3))) uint32_t pc_lds_u32;
 typedef __attribute__((address_space(1))) uint32_t pc_glb_u32;
 typedef __attribute__((address_space(1))) long long pc_glb_i64;
+typedef __attribute__((address_space(3))) long long pc_lds_i64;
 __device__ __forceinline__ void pc_put_word(uint32_t *lst, uint32_t *swb, uint32_t lcap, uint32_t pos, uint32_t word) {
     if (pos < lcap) *(pc_lds_u32 *)(lst + pos) = word;
     else *(pc_glb_u32 *)(swb + pos) = word;
@@ -132,6 +139,7 @@ template <typename T, int GW, int SLOTS, int MODE, int PC_THREADS, int NP, int D
 __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_kernel(const PcParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool DUAL = MODE == 1;
+    constexpr bool WIDE = std::is_same<T, double>::value;      // a 64-bit term slot per LDS list entry (layout: [2 lists][lcap words], then [2 lists][lcap terms])
     constexpr int PC_NW = PC_THREADS / 64;
     constexpr int NC = PC_NW - NP, SPAN = SLOTS * GW, U = GW;
     typedef RowWord<SLOTS> Row;
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
     const int nslots = (DUAL ? 2 * P.neg_base : P.ncomp) + kDumpSlots;
     uint32_t *ctl = reinterpret_cast<uint32_t *>(acc + nslots);     // [0], [1]: entries in list 0 / 1; [2] E row; [3] producers done
     uint32_t *lists = ctl + 8;
+    long long *lterms = reinterpret_cast<long long *>(lists + 2 * P.lcap);       // (WIDE only; 8-byte aligned: everything before it is a multiple of 8 bytes)
     for (int c = tid; c < nslots; c += PC_THREADS) acc[c] = 0ull;
     if (tid < 8) ctl[tid] = 0u;
     __syncthreads();
@@ -186,6 +195,7 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
         const uint32_t *lst = lists;
         const uint32_t *swb = sw;                         // scratch words of this cell's list
         const long long *stb = st;
+        const long long *ltm = lterms;                    // (WIDE) the LDS term slots of this cell's list
         int nnz = 0, nb = 0;
         const int gcap = P.lcap;
         uint32_t gC = 0u, gL = 0u, wR = 0u;   // genes of the batch being added / of the one after the next; entry words of the one after that
@@ -200,8 +210,12 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
         auto decode = [&](int bt, uint32_t w, uint32_t &g, long long &f) __attribute__((always_inline)) {
             const int e = (bt << 6) + lane;
             long long ff = P.fixtab[(w >> 20) & 0x3ffu];            // 8 KB, cache resident
-            if (__ballot((w & kPcFull) != 0u) != 0ull) {           // rare, wave-uniform test: a value outside the table
-                if (w & kPcFull) ff = __builtin_nontemporal_load((const pc_glb_i64 *)(stb + (e < nnz ? e : 0)));
+            if (__ballot((w & kPcFull) != 0u) != 0ull) {           // wave-uniform test: a value outside the table (rare in an fp32 block)
+                if (w & kPcFull) {
+                    const int ec = e < nnz ? e : 0;
+                    if (WIDE && ec < gcap) ff = *(const pc_lds_i64 *)(ltm + ec);
+                    else ff = __builtin_nontemporal_load((const pc_glb_i64 *)(stb + ec));
+                }
             }
             g = e < nnz ? (w & kPcGeneMask) : P.dummy_seg;
             f = e < nnz ? ff : 0ll;
@@ -268,6 +282,7 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
             lst = lists + b2 * P.lcap;
             swb = sw + static_cast<size_t>(b2) * P.cap;
             stb = st + static_cast<size_t>(b2) * P.cap;
+            ltm = lterms + b2 * P.lcap;
             nnz = __builtin_amdgcn_readfirstlane(static_cast<int>(ctl[b2]));
             nb = (nnz + 63) >> 6;
             if (cw < nb) {
@@ -358,10 +373,14 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
                 }
             }
             // The general path (a value outside the table somewhere in the unit, an fp64 block, or a list beyond the LDS room): every
-            // non-zero again -- table values as above, the others flagged kPcFull with the value parked as a double in the scratch
-            // block -- then one lane per entry turns the parked value into its term.
+            // non-zero again -- table values as above, the others flagged kPcFull with the value parked as a double where the entry's
+            // term belongs (fp64 blocks: the entry's LDS term slot; fp32 blocks, and entries beyond the LDS room: the scratch block) --
+            // then one lane per entry turns the parked value into its term, in place.
             uint32_t *swb = sw + static_cast<size_t>(b01) * P.cap;
             long long *stb = st + static_cast<size_t>(b01) * P.cap;
+            long long *ltm = lterms + b01 * P.lcap;
+            const uint32_t lcap = static_cast<uint32_t>(P.lcap);
+            const bool spill = !WIDE || base + static_cast<uint32_t>(tot) > lcap;      // (wave-uniform) some of this unit's terms live in global memory
             {
                 uint32_t run = base;
 #pragma unroll
@@ -373,24 +392,47 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
                         const bool tab = static_cast<T>(xf) == b.v[q] && (t & kPcBadMask) == 0u;
                         const uint32_t gene = static_cast<uint32_t>(ubase + CpLayout<T>::gene_of(lane, q));
                         const uint32_t word = tab ? (t << 4) + gene : (gene | kPcFull);
-                        pc_put_word(lst, swb, static_cast<uint32_t>(P.lcap), pos, word);
-                        if (!tab) *(pc_glb_i64 *)(stb + pos) = __double_as_longlong(static_cast<double>(b.v[q]));
+                        pc_put_word(lst, swb, lcap, pos, word);
+                        if (!tab) {
+                            const long long bits = __double_as_longlong(static_cast<double>(b.v[q]));
+                            if (WIDE && pos < lcap) *(pc_lds_i64 *)(ltm + pos) = bits;
+                            else *(pc_glb_i64 *)(stb + pos) = bits;
+                        }
                     }
                     run += static_cast<uint32_t>(__popcll(mk[q]));
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0x0070);                 // vmcnt(0) lgkmcnt(0): this wave's own stores, before it reads them back
-            asm volatile("" ::: "memory");
-            for (uint32_t e = base + static_cast<uint32_t>(lane); e < base + static_cast<uint32_t>(tot); e += 64u) {
-                const uint32_t word = pc_get_word(lst, swb, static_cast<uint32_t>(P.lcap), e);
-                if (word & kPcFull) {
-                    const double x = __longlong_as_double(__builtin_nontemporal_load((const pc_glb_i64 *)(stb + e)));
-                    const double f = P.log_flag == 2 ? log10(1.0 + x) : (P.log_flag ? log2(1.0 + x) : x);
-                    *(pc_glb_i64 *)(stb + e) = __double2ll_rn(f * P.fix_scale);
+            // Two loops, one per address space, so that no value is ever selected between an LDS read and a global load: the compiler
+            // would wait for the (possibly pending) global load where the two paths join, i.e. on the LDS path too, and a vmcnt wait
+            // there drains the units in flight.
+            const uint32_t e_end = base + static_cast<uint32_t>(tot);
+            const uint32_t e_lds = WIDE ? (e_end < lcap ? e_end : (base < lcap ? lcap : base)) : base;     // [base, e_lds): term slots in LDS; [e_lds, e_end): in scratch
+            if constexpr (WIDE) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): this wave's own LDS stores (the units in flight stay in flight)
+                asm volatile("" ::: "memory");
+                for (uint32_t e = base + static_cast<uint32_t>(lane); e < e_lds; e += 64u) {
+                    const uint32_t word = *(const pc_lds_u32 *)(lst + e);
+                    if (word & kPcFull) {
+                        const double x = __longlong_as_double(*(const pc_lds_i64 *)(ltm + e));
+                        const double f = P.log_flag == 2 ? log10(1.0 + x) : (P.log_flag ? log2(1.0 + x) : x);
+                        *(pc_lds_i64 *)(ltm + e) = __double2ll_rn(f * P.fix_scale);
+                    }
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0): the scratch block is complete before this wave reaches the barrier
-            asm volatile("" ::: "memory");                      // (a builtin, not inline assembly: the wait-count pass sees it and forgets the stores)
+            if (spill) {
+                __builtin_amdgcn_s_waitcnt(0x0070);             // vmcnt(0) lgkmcnt(0): this wave's own stores, before it reads them back
+                asm volatile("" ::: "memory");
+                for (uint32_t e = e_lds + static_cast<uint32_t>(lane); e < e_end; e += 64u) {
+                    const uint32_t word = pc_get_word(lst, swb, lcap, e);        // (fp32 blocks: the word may be in LDS, its term never is)
+                    if (word & kPcFull) {
+                        const double x = __longlong_as_double(__builtin_nontemporal_load((const pc_glb_i64 *)(stb + e)));
+                        const double f = P.log_flag == 2 ? log10(1.0 + x) : (P.log_flag ? log2(1.0 + x) : x);
+                        *(pc_glb_i64 *)(stb + e) = __double2ll_rn(f * P.fix_scale);
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0x0f70);             // vmcnt(0): the scratch block is complete before this wave reaches the barrier
+                asm volatile("" ::: "memory");                  // (a builtin, not inline assembly: the wait-count pass sees it and forgets the stores)
+            }
         };
         PcUnit<T> buf[D];
         static_for<D>([&](auto ic) { fetch(buf[decltype(ic)::value]); });
@@ -431,8 +473,8 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
     PcParams P = P0;
     // the workgroup shape (above rp_pc_kernel): B for the narrow row lists (K = 5), A for 16 lanes x 4 slots (K = 15) and fp64 blocks
     // (an fp64 unit is 32 registers per lane); SHARP_RP_PC_SHAPE=a / b forces one for fp32 blocks
-    const bool wide = g.gw == 16 && g.slots == 4;
-    const bool shape_b = !std::is_same<T, double>::value && (knobs().rp_pc_shape == 2 || (knobs().rp_pc_shape == 0 && !wide));
+    const bool wide_rows = g.gw == 16 && g.slots == 4;
+    const bool shape_b = !std::is_same<T, double>::value && (knobs().rp_pc_shape == 2 || (knobs().rp_pc_shape == 0 && !wide_rows));
 #ifndef SHARP_PC_B_THREADS      // (tools/build_variant.sh: other splits of shape B)
 #define SHARP_PC_B_THREADS 768
 #define SHARP_PC_B_NP 4
@@ -449,11 +491,13 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
     // LDS per workgroup: accumulators + dump slots, eight control words, two entry lists; two workgroups per CU
     const size_t acc_bytes = static_cast<size_t>(g.acc_slots() + kDumpSlots) * 8 + 32;
     const size_t budget = 80 * 1024;
-    SHARP_REQUIRE(acc_bytes + 2 * 64 * 4 <= budget, "rp_pc_kernel: the accumulators leave no LDS for the entry lists");
-    int lcap = static_cast<int>((budget - acc_bytes) / 8 / 64 * 64);
+    SHARP_REQUIRE(acc_bytes + 2 * 64 * 12 <= budget, "rp_pc_kernel: the accumulators leave no LDS for the entry lists");
+    constexpr bool wide = std::is_same<T, double>::value;     // fp64 blocks: a word and a 64-bit term slot per list entry (rp_pc_kernel: WIDE)
+    const size_t per_entry = wide ? 12 : 4;
+    int lcap = static_cast<int>((budget - acc_bytes) / (2 * per_entry) / 64 * 64);
     lcap = std::min(lcap, (P.m + 63) / 64 * 64);
     P.lcap = lcap;
-    const size_t lds = acc_bytes + static_cast<size_t>(lcap) * 8;
+    const size_t lds = acc_bytes + static_cast<size_t>(lcap) * 2 * per_entry;
     SHARP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     {   // scatter_row_word<0, ...>: the accumulators sit at LDS address 0, i.e. the kernel must not have static LDS in front of the dynamic block
         hipFuncAttributes fa;

@@ -76,11 +76,17 @@ def test_pc_kernel_value_kinds_and_list_overflow(sa, oracle, monkeypatch):
         assert np.all(E3[0] == 0) and np.all(E3[20] == 0)
         ref = oracle.project(X, oracle.ranM(m, p, 2154), logflag)
         np.testing.assert_allclose(E3[:, :p], ref, rtol=0, atol=2e-12 * np.abs(ref).max())
-    Xt = X / np.maximum(X.sum(0, keepdims=True), 1.0) * 1e6           # non-fp32-exact doubles: the block is stored as fp64
-    E2, E3 = both(sa, monkeypatch, pr, Xt, True)
-    assert np.array_equal(E2, E3)
-    ref = oracle.project(Xt, oracle.ranM(m, p, 2154), True)
-    np.testing.assert_allclose(E3[:, :p], ref, rtol=0, atol=2e-12 * np.abs(ref).max())
+    # non-fp32-exact doubles: the block is stored as fp64, and every entry of the producer / consumer kernel's lists has a 64-bit term slot in
+    # LDS (round 5); dense cells overflow it into the scratch block, a cell of exact small counts takes the term table inside the fp64 block
+    Xt = X / np.maximum(X.sum(0, keepdims=True), 1.0) * 1e6
+    Xt[:, 1] = X[:, 1]
+    Xt[:, 9] = np.where(np.arange(m) % 3 == 0, 2.0, 0.1234567891234)
+    for logflag in (True, False):
+        E2, E3 = both(sa, monkeypatch, pr, Xt, logflag)
+        assert sa.lib().sharp_x_storage() == 64
+        assert np.array_equal(E2, E3)
+        ref = oracle.project(Xt, oracle.ranM(m, p, 2154), logflag)
+        np.testing.assert_allclose(E3[:, :p], ref, rtol=0, atol=2e-12 * np.abs(ref).max())
 
 
 def test_pc_kernel_resident_block_bit_identical_at_cfg3_shape(sa):
