@@ -27,12 +27,15 @@ namespace sharp {
 //       the LDS and the vector memory path busier: cfg3 block 1.44 -> 1.35 ms, cfg4 share 5.71 -> 5.29 ms on one box).
 // The producers run at a raised wave priority: the consumers wait for them at the cell's first barrier, never the other way round.
 // Entry word: bits 19..0 gene, bits 29..20 table index, bit 31: the value is outside the table and the entry has a 64-bit term of its own.
-// fp32 blocks (counts: such entries are rare) keep those terms in a per-workgroup scratch block in global memory.  fp64 blocks (TPM / CPM-like
-// doubles: EVERY entry is one) have a 64-bit term slot per LDS list entry beside the word (round 5): the lane that holds a value parks its
-// bits there, then one lane per entry turns them into log2(1 + x) in fixed point in place, and the consumers read the term where they read the
-// word -- no global store, no global load, and above all none of the two s_waitcnt vmcnt(0) per unit that the scratch round trip costs (a
-// producer's own stores must have landed before it reads them back, and that wait drains the units it has in flight: 40 stalls of a memory
-// latency per cell made the fp64 stage 3.8 x as long as the fp32 one for twice the bytes).  Entries beyond the LDS room still go through scratch.
+// fp32 blocks (counts: such entries are rare): the producer wave parks the values in a per-workgroup scratch block in global memory, reads
+// them back one lane per entry and stores the terms there (two drained waits per such unit).  fp64 blocks (TPM / CPM-like doubles: EVERY entry is one): the entry travels with its VALUE (the bits of
+// the double) in a 64-bit slot per LDS list entry beside the word -- only entries beyond the LDS room go through scratch -- and the CONSUMER
+// lane that decodes the entry turns it into the term log2(1 + x) in fixed point (round 5).  Round 4 had the producer wave read its parked values back and convert them itself: two
+// s_waitcnt vmcnt(0) per unit (its own stores had to land first, which drained the units it had in flight) and all of an fp64 block's
+// log2 evaluations -- ~250 fp64 instructions per 64 entries -- on the two producer waves while six consumer waves waited for them: the fp64
+// stage took 3.8 x as long as the fp32 one for twice the bytes, and the two-kernel form was faster.  Now a producer stores and moves on
+// (one wait per CELL, and only if something of the cell went to global memory), and the conversions run 64 lanes wide on the waves that
+// were waiting.
 // The table holds fix(f(x)) for every float x in [1, 256) whose low 16 bits are zero -- every integer count below 256 is one --
 // indexed by (bits(x) - bits(1.0f)) >> 16: the index IS the high half of the value's bits, no conversion on either side.
 constexpr int PC_TAB = 1024;
@@ -210,11 +213,19 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
         auto decode = [&](int bt, uint32_t w, uint32_t &g, long long &f) __attribute__((always_inline)) {
             const int e = (bt << 6) + lane;
             long long ff = P.fixtab[(w >> 20) & 0x3ffu];            // 8 KB, cache resident
-            if (__ballot((w & kPcFull) != 0u) != 0ull) {           // wave-uniform test: a value outside the table (rare in an fp32 block)
+            if (__ballot((w & kPcFull) != 0u) != 0ull) {           // wave-uniform test: a value outside the table (rare in an fp32 block, all of an fp64 block)
                 if (w & kPcFull) {
                     const int ec = e < nnz ? e : 0;
-                    if (WIDE && ec < gcap) ff = *(const pc_lds_i64 *)(ltm + ec);
-                    else ff = __builtin_nontemporal_load((const pc_glb_i64 *)(stb + ec));
+                    if constexpr (WIDE) {                          // the entry carries its VALUE: the expressions of the general path, one lane per entry
+                        long long bits;
+                        if (ec < gcap) bits = *(const pc_lds_i64 *)(ltm + ec);
+                        else bits = __builtin_nontemporal_load((const pc_glb_i64 *)(stb + ec));
+                        const double x = __longlong_as_double(bits);
+                        const double fv = P.log_flag == 2 ? log10(1.0 + x) : (P.log_flag ? log2(1.0 + x) : x);
+                        ff = __double2ll_rn(fv * P.fix_scale);
+                    } else {                                       // (fp32 blocks: the producer stored the term)
+                        ff = __builtin_nontemporal_load((const pc_glb_i64 *)(stb + ec));
+                    }
                 }
             }
             g = e < nnz ? (w & kPcGeneMask) : P.dummy_seg;
@@ -332,6 +343,7 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
         // last unit).  Every path through here READS all sixteen values before it returns: a value nobody waited for would still be
         // in flight when the next fetch overwrites its register, and the compiler protects that write with a wait that drains
         // the other units in flight as well.
+        bool spilled = false;      // this wave stored words / values of the current cell to the scratch block: they have to land before the cell is handed over
         auto process = [&](PcUnit<T> &u, int j, int k, bool live) __attribute__((always_inline)) {
             pc_wait<(D - 1) * CpLayout<T>::LOADS>(u);      // the unit has arrived; the D - 1 units fetched after it stay in flight
             CpVals<T> b;
@@ -373,14 +385,12 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
                 }
             }
             // The general path (a value outside the table somewhere in the unit, an fp64 block, or a list beyond the LDS room): every
-            // non-zero again -- table values as above, the others flagged kPcFull with the value parked as a double where the entry's
-            // term belongs (fp64 blocks: the entry's LDS term slot; fp32 blocks, and entries beyond the LDS room: the scratch block) --
-            // then one lane per entry turns the parked value into its term, in place.
+            // non-zero again -- table values as above, the others flagged kPcFull with the value's bits as a double parked where the
+            // consumer will look for them: the entry's 64-bit LDS slot (fp64 blocks), else the scratch block.  Nothing is read back here.
             uint32_t *swb = sw + static_cast<size_t>(b01) * P.cap;
             long long *stb = st + static_cast<size_t>(b01) * P.cap;
             long long *ltm = lterms + b01 * P.lcap;
             const uint32_t lcap = static_cast<uint32_t>(P.lcap);
-            const bool spill = !WIDE || base + static_cast<uint32_t>(tot) > lcap;      // (wave-uniform) some of this unit's terms live in global memory
             {
                 uint32_t run = base;
 #pragma unroll
@@ -402,28 +412,15 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
                     run += static_cast<uint32_t>(__popcll(mk[q]));
                 }
             }
-            // Two loops, one per address space, so that no value is ever selected between an LDS read and a global load: the compiler
-            // would wait for the (possibly pending) global load where the two paths join, i.e. on the LDS path too, and a vmcnt wait
-            // there drains the units in flight.
-            const uint32_t e_end = base + static_cast<uint32_t>(tot);
-            const uint32_t e_lds = WIDE ? (e_end < lcap ? e_end : (base < lcap ? lcap : base)) : base;     // [base, e_lds): term slots in LDS; [e_lds, e_end): in scratch
             if constexpr (WIDE) {
-                __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): this wave's own LDS stores (the units in flight stay in flight)
+                if (base + static_cast<uint32_t>(tot) > lcap) spilled = true;          // (wave-uniform) something of this cell is in global memory
+            } else {
+                // fp32 blocks (rare: a count of 256 or more, a non-integer): this wave turns the values it parked into their terms itself, one lane
+                // per entry -- its own stores have to land first, and that wait drains the units it has in flight: twice per such unit
+                __builtin_amdgcn_s_waitcnt(0x0070);             // vmcnt(0) lgkmcnt(0)
                 asm volatile("" ::: "memory");
-                for (uint32_t e = base + static_cast<uint32_t>(lane); e < e_lds; e += 64u) {
-                    const uint32_t word = *(const pc_lds_u32 *)(lst + e);
-                    if (word & kPcFull) {
-                        const double x = __longlong_as_double(*(const pc_lds_i64 *)(ltm + e));
-                        const double f = P.log_flag == 2 ? log10(1.0 + x) : (P.log_flag ? log2(1.0 + x) : x);
-                        *(pc_lds_i64 *)(ltm + e) = __double2ll_rn(f * P.fix_scale);
-                    }
-                }
-            }
-            if (spill) {
-                __builtin_amdgcn_s_waitcnt(0x0070);             // vmcnt(0) lgkmcnt(0): this wave's own stores, before it reads them back
-                asm volatile("" ::: "memory");
-                for (uint32_t e = e_lds + static_cast<uint32_t>(lane); e < e_end; e += 64u) {
-                    const uint32_t word = pc_get_word(lst, swb, lcap, e);        // (fp32 blocks: the word may be in LDS, its term never is)
+                for (uint32_t e = base + static_cast<uint32_t>(lane); e < base + static_cast<uint32_t>(tot); e += 64u) {
+                    const uint32_t word = pc_get_word(lst, swb, lcap, e);
                     if (word & kPcFull) {
                         const double x = __longlong_as_double(__builtin_nontemporal_load((const pc_glb_i64 *)(stb + e)));
                         const double f = P.log_flag == 2 ? log10(1.0 + x) : (P.log_flag ? log2(1.0 + x) : x);
@@ -445,6 +442,11 @@ __global__ __launch_bounds__(PC_THREADS, 2 * (PC_THREADS / 64) / 4) void rp_pc_k
                 fetch(buf[i]);                            // (unconditional: the loads in flight are the same on every path)
                 if (live && ++pk == upp) {
                     pk = 0;
+                    if (spilled) {                            // once per cell, and only for a cell that spilled: vmcnt(0), the scratch block is complete
+                        __builtin_amdgcn_s_waitcnt(0x0f70);   // (a builtin, not inline assembly: the wait-count pass sees it and forgets the stores)
+                        asm volatile("" ::: "memory");
+                        spilled = false;
+                    }
                     if (lane == 0) atomicAdd(&ctl[3], 1u);    // this wave's entries of cell pj are in the list (LDS operations of a wave execute in order)
                     cell_end(pj - 1);
                     ++pj;
