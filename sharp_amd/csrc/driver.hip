@@ -622,7 +622,7 @@ struct ViewGuard {           // at the top of a SHARP_unlimited run: pending -> 
     }
     ~ViewGuard() { if (!own) return; ViewReduce &v = view_reduce(); std::lock_guard<std::mutex> lk(v.mu); v.kdim = 0; }
 };
-struct ViewProj { std::shared_ptr<Projector> pr; int p = 0, kdim = 0; double seed = 0; DevBuf<double> out; };
+struct ViewProj { std::shared_ptr<Projector> pr; int p = 0, kdim = 0; double seed = 0; DevBuf<double> out, pad; };
 
 // labels, per-cluster means of viE and cluster sizes of one finished block (what the cross-block sMetaC needs, :153-163)
 void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector<int> &pred, std::vector<double> &means,
@@ -648,7 +648,18 @@ void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector
     }
     V.out.ensure(static_cast<size_t>(nb) * kdim);
     HostTimer ht("tail_view_reduce");
-    project_dev(*V.pr, dev64_ref(o.viE.p, p, nb, p), p, static_cast<int>(nb), p, 0, V.out.p, kdim, nullptr);
+    // (the block's viE is the library's own: finite, 16-byte aligned, |x| far below FLT_MAX -- no validation pass as for a caller's fp64 block;
+    // an odd p gets a padded copy: the RP kernels read an fp64 block with 16-byte loads, i.e. an even leading dimension)
+    const double *src = o.viE.p;
+    long long ldv = p;
+    if (p % 2) {
+        ldv = p + 1;
+        V.pad.ensure(static_cast<size_t>(nb) * ldv);
+        SHARP_HIP_CHECK(hipMemcpy2DAsync(V.pad.p, static_cast<size_t>(ldv) * 8, o.viE.p, static_cast<size_t>(p) * 8, static_cast<size_t>(p) * 8, static_cast<size_t>(nb),
+                                         hipMemcpyDeviceToDevice, ctx().stream));
+        src = V.pad.p;
+    }
+    project_dev(*V.pr, XRef(src), p, static_cast<int>(nb), ldv, 0, V.out.p, kdim, nullptr);
     V.out.download(viE_host, static_cast<size_t>(nb) * kdim);
 }
 

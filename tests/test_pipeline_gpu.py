@@ -295,7 +295,8 @@ def test_view_reduction_above_1e5_cells(sa, oracle):
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-12 * np.abs(ref).max())
 
 
-def test_view_reduction_on_the_device_per_block(sa, oracle):
+@pytest.mark.parametrize("sizes", [[5300, 640, 5050], [5300, 1650, 5050]])      # p = 336, and p = 339: an odd p goes through a padded copy
+def test_view_reduction_on_the_device_per_block(sa, oracle, sizes):
     """The same reduction taken per block on the GPU (sharp_unlimited_view_dim / sharp_SHARP_unlimited_viewk_dev: what SHARP_unlimited does above
     1e5 cells, so that ncells x 50 doubles leave the GPU instead of ncells x p), forced here on a small list of ragged blocks: resident blocks in
     one call, the in-process multi-device entry, the per-block entry of a sharded rank -- against the oracle's E1 put through the oracle's
@@ -304,7 +305,6 @@ def test_view_reduction_on_the_device_per_block(sa, oracle):
     from sharp_amd import device as dev
 
     m, K, seed = 1400, 3, 2103
-    sizes = [5300, 640, 5050]
     host, c0 = [], 0
     for nb in sizes:
         host.append(oracle.synth_fill(77, m, c0, nb, 5, 140))
