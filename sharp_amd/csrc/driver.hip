@@ -34,6 +34,9 @@ struct SharpArgs {
     int projector = 0;       // handle of a shared rM list, 0 = draw from rN_seed
     double rN_seed = 0.5;    // 0.5 = the reference's "unseeded" sentinel
     bool want_viE = false, want_x0 = false;
+    // the caller wants viE on the HOST (forview = TRUE, R/SHARP.R:46,844): SHARP_large then sends it on its way -- un-shuffle, copy into a pinned
+    // staging block on the mean stream -- as soon as the ensemble mean exists, under the per-fold wMetaC and the sMetaC, instead of behind them
+    bool view_to_host = false;
     // SHARP_fpart (R/SHARP_unlimited2.R:297-544): the large path with log10 (flag = 2), E1 rounded to one decimal before
     // clustering, maxN.cluster = 40 for the base tasks, and NO sMetaC: the per-fold ensemble labels go up to the caller
     bool fpart = false;
@@ -48,7 +51,19 @@ struct SharpOut {
     // n x p, ORIGINAL cell order, on the device: a view of a workspace kept between calls (valid until the next call)
     struct View {
         double *p = nullptr;
+        const double *staged = nullptr;      // pinned host copy on its way (SharpArgs::view_to_host), complete when `staged_done` has happened
+        hipEvent_t staged_done = nullptr;
         void download(double *h, size_t count) const {
+            if (staged) {
+                SHARP_HIP_CHECK(hipEventSynchronize(staged_done));
+                const size_t piece = (count + 15) / 16;
+                const double *src = staged;
+                host_parallel_for(16, 16, [&](int t) {       // (one thread copies ~10 GB/s out of pinned memory)
+                    const size_t lo = std::min(count, piece * static_cast<size_t>(t)), hi = std::min(count, lo + piece);
+                    if (hi > lo) memcpy(h + lo, src + lo, (hi - lo) * sizeof(double));
+                });
+                return;
+            }
             SHARP_HIP_CHECK(hipMemcpyAsync(h, p, count * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
             SHARP_HIP_CHECK(hipStreamSynchronize(ctx().stream));
         }
@@ -69,6 +84,9 @@ struct DriverWs {
     DevBuf<double> Ebatch;                       // Ebatch / posbatch: all blocks of a batched SHARP_unlimited window
     DevBuf<int> posbatch;
     DevBuf<double> fold_means, block_means;      // grow-only: a hipFree in a block's tail would wait for every stream
+    double *view_pinned = nullptr;               // staging block of the early viE download (SharpArgs::view_to_host)
+    size_t view_pinned_n = 0;
+    hipEvent_t view_done = nullptr;
 };
 DriverWs &dws() { return per_slot<DriverWs>(); }
 
@@ -318,6 +336,33 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
     // behind the last chunk's agglomeration (enqueue_ensemble_mean from the base clustering's hook: beside the last statistics).
     hipEvent_t &mean_done = dws().mean_done;
     if (!hc_after_last_agglomeration_fired()) enqueue_ensemble_mean(E.p, ldE, n, p, K, viE_sh.p, nullptr);
+    bool view_sent = false;
+    if (a.view_to_host && !a.fpart) {
+        // viE (:776-783) is final as soon as the mean is: back to the original cell order and off to the host on the mean stream, under the tail
+        DriverWs &W = dws();
+        const size_t cnt = static_cast<size_t>(n) * p;
+        if (W.view_pinned_n < cnt) {
+            if (W.view_pinned) (void)hipHostFree(W.view_pinned);
+            W.view_pinned = nullptr; W.view_pinned_n = 0;
+            SHARP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&W.view_pinned), cnt * sizeof(double), hipHostMallocDefault));
+            W.view_pinned_n = cnt;
+        }
+        if (!W.view_done) SHARP_HIP_CHECK(hipEventCreateWithFlags(&W.view_done, hipEventDisableTiming));
+        W.viE_out.ensure(cnt);
+        {
+            StreamScope scope(W.mean_stream);
+            if (shuffle) {
+                hipLaunchKernelGGL(gather_rows_kernel, dim3(ctx().num_cu * 8), dim3(256), 0, W.mean_stream, viE_sh.p, dpos.p, static_cast<long long>(n), p, W.viE_out.p);
+                launch_check("gather_rows_kernel");
+            } else {
+                SHARP_HIP_CHECK(hipMemcpyAsync(W.viE_out.p, viE_sh.p, cnt * 8, hipMemcpyDeviceToDevice, W.mean_stream));
+            }
+            SHARP_HIP_CHECK(hipMemcpyAsync(W.view_pinned, W.viE_out.p, cnt * 8, hipMemcpyDeviceToHost, W.mean_stream));
+        }
+        SHARP_HIP_CHECK(hipEventRecord(W.view_done, W.mean_stream));
+        out.viE.p = W.viE_out.p; out.viE.staged = W.view_pinned; out.viE.staged_done = W.view_done;
+        view_sent = true;
+    }
     // enrp per fold (:627-635); labels "<colour>p<t>" only need to be distinct per (k, t): the colour id does
     std::vector<std::vector<int>> enrp(T);
     for (int q = 0; q < K * T; ++q) out.rc |= hr[q].rc;
@@ -409,14 +454,16 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
             }
         }
     }
-    // viE back to the original cell order (:776-783)
-    dws().viE_out.ensure(static_cast<size_t>(n) * p); out.viE.p = dws().viE_out.p;
-    if (shuffle) {
-        Ctx &c = ctx();
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(c.num_cu * 8), dim3(256), 0, c.stream, viE_sh.p, dpos.p, static_cast<long long>(n), p, out.viE.p);
-        launch_check("gather_rows_kernel");
-    } else {
-        SHARP_HIP_CHECK(hipMemcpyAsync(out.viE.p, viE_sh.p, static_cast<size_t>(n) * p * 8, hipMemcpyDeviceToDevice, ctx().stream));
+    // viE back to the original cell order (:776-783) -- unless that went out with the early download above
+    if (!view_sent) {
+        dws().viE_out.ensure(static_cast<size_t>(n) * p); out.viE.p = dws().viE_out.p;
+        if (shuffle) {
+            Ctx &c = ctx();
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(c.num_cu * 8), dim3(256), 0, c.stream, viE_sh.p, dpos.p, static_cast<long long>(n), p, out.viE.p);
+            launch_check("gather_rows_kernel");
+        } else {
+            SHARP_HIP_CHECK(hipMemcpyAsync(out.viE.p, viE_sh.p, static_cast<size_t>(n) * p * 8, hipMemcpyDeviceToDevice, ctx().stream));
+        }
     }
     if (a.N_cluster <= 0 && n > 10000) merge_small(out.pred);                   // :816-825
     out.n_pred = relabel_first(out.pred);                                       // :828-843
@@ -877,6 +924,7 @@ int sharp_run_block(XRef dX, int m, long long n, long long ld, int ensize_K, int
     a.hmethod = hmethod; a.N_cluster = N_cluster; a.enpN = enpN_cluster; a.indN = indN_cluster; a.minN = minN; a.maxN = maxN;
     a.sil_thre = sil_thre; a.height_Ntimes = height_Ntimes; a.flag = log_flag; a.projector = projector; a.rN_seed = rN_seed;
     a.want_viE = viE != nullptr; a.want_x0 = x0 != nullptr;
+    a.view_to_host = viE != nullptr;
     SharpOut o;
     sharp_front_dev(dX, m, n, ld, a, o);
     warn = o.rc;
@@ -977,6 +1025,7 @@ int sharp_trim(void) {
         upload_release_staging();
         dws().Ebatch.release();                          // a batched SHARP_unlimited window's projections (up to 16 GB)
         dws().posbatch.release();
+        if (dws().view_pinned) { (void)hipHostFree(dws().view_pinned); dws().view_pinned = nullptr; dws().view_pinned_n = 0; }   // staging of the early viE download
         rp_pc_trim();
         rp_trim();                                       // the per-chunk entry buffers of a block compacted ahead (up to 16 GB)
         // worker and helper slots (in-process multi-GPU runs, tail helpers) also give back their clustering workspaces -- tens of GB per

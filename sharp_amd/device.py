@@ -57,7 +57,7 @@ def csc_to_dev(sp):
 
 def SHARP_dev(dX, ensize_K=0, reduced_ndim=0, base_ncells=0, partition_ncells=0, hmethod=1, N_cluster=0, enpN_cluster=0,
               indN_cluster=0, minN_cluster=0, maxN_cluster=0, sil_thre=-1.0, height_Ntimes=0.0, flag=True, projector=0,
-              rN_seed=0.5, forview=False):
+              rN_seed=0.5, forview=False, view_out=None):
     """SHARP() (R/SHARP.R:44-318) on a resident block (float32, or float64 for TPM / CPM-like values: sharp_SHARP_dev64);
     returns (pred_clusters, info).  forview (the reference's default, R/SHARP.R:46,844): info also carries "viE" (n x p, the
     ensemble-mean projection) and "x0" (n x G, the soft cluster matrix of :717-731,763-783)."""
@@ -70,8 +70,11 @@ def SHARP_dev(dX, ensize_K=0, reduced_ndim=0, base_ncells=0, partition_ncells=0,
     if forview:
         pmax = reduced_ndim if reduced_ndim > 0 else int(np.ceil(np.log2(n) / 0.04))
         cap = max(maxN_cluster, 40, -(-n // 5000)) + 2
-        viE = np.empty((n, pmax))
-        x0 = np.empty(n * cap)
+        if view_out is not None and view_out[0].shape == (n, pmax) and view_out[1].size == n * cap:
+            viE, x0 = view_out                        # (a caller that keeps its result buffers between calls: no first-touch page faults)
+        else:
+            viE = np.empty((n, pmax))
+            x0 = np.empty(n * cap)
     entry = lib().sharp_SHARP_dev64 if str(dX.dtype) == "torch.float64" else lib().sharp_SHARP_dev
     rc = check(entry(C.c_void_p(dX.data_ptr()), m, C.c_longlong(n), C.c_longlong(dX.stride(0)), ensize_K,
                                      reduced_ndim, base_ncells, partition_ncells, hmethod, N_cluster, enpN_cluster,
@@ -81,6 +84,7 @@ def SHARP_dev(dX, ensize_K=0, reduced_ndim=0, base_ncells=0, partition_ncells=0,
     info = {"N.pred_cluster": npred.value, "reduced.dim": pu.value, "ensize.K": Ku.value,
             "path": "SHARP_large" if path.value else "SHARP_small", "warn": rc}
     if forview:
+        info["view_out"] = (viE, x0)
         info["viE"] = viE[:, :pu.value] if pu.value != viE.shape[1] else viE
         info["x0"] = x0[: n * x0c.value].reshape(x0c.value, n).T
     return pred, info

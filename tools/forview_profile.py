@@ -37,7 +37,16 @@ def diff(a, b, top=14):
 
 x = Bn.synth_block(0, 50000, 20000)
 _, a = run("cfg2 labels only", lambda: dev.SHARP_dev(x, ensize_K=15, rN_seed=2103))
-_, b = run("cfg2 forview", lambda: dev.SHARP_dev(x, ensize_K=15, rN_seed=2103, forview=True))
+keep = {}
+
+
+def view_call():
+    r = dev.SHARP_dev(x, ensize_K=15, rN_seed=2103, forview=True, view_out=keep.get("b"))
+    keep["b"] = r[1]["view_out"]
+
+
+_, b0 = run("cfg2 forview, fresh buffers", lambda: dev.SHARP_dev(x, ensize_K=15, rN_seed=2103, forview=True))
+_, b = run("cfg2 forview, kept buffers", view_call)
 diff(a, b)
 del x
 blocks = [Bn.synth_block(b * 50000, 50000, 20000) for b in range(10)]
