@@ -2003,7 +2003,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                                                         static_cast<int>(ldsl)));
                     hipLaunchKernelGGL(hclust_tri_kernel, dim3(Ts), dim3(HT_THREADS), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p,
                                        W.height.p, W.status.p + R.t0, static_cast<int>(ldsl));
-                } else if (Ts <= c.num_cu) {
+                } else if (Ts <= c.num_cu && !knobs().hc_half) {
                     auto k0 = hclust_rnn_kernel<1024, 0>;
                     // one workgroup per CU: everything the CU has beyond the state stages the pair members' entries
                     const size_t ldsl = std::max(lds, HR_LDS_CU);
@@ -2012,6 +2012,8 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                     hipLaunchKernelGGL(k0, dim3(Ts), dim3(1024), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p,
                                        W.height.p, W.status.p + R.t0, nullptr, 0LL, static_cast<int>(lds), 0, nullptr, static_cast<int>(ldsl));
                 } else {
+                    // (also SHARP_HC_HALF=1 with at most one task per CU: the eight-wave form then leaves half of every CU's registers and LDS to a
+                    // workgroup of the next chunk's distance GEMM -- an experiment)
                     auto k0 = hclust_rnn_kernel<512, 0>;
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         static_cast<int>(lds)));

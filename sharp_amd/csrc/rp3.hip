@@ -481,6 +481,9 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
 #define SHARP_PC_B_THREADS 768
 #define SHARP_PC_B_NP 4
 #endif
+#ifndef SHARP_PC_B_D
+#define SHARP_PC_B_D 2
+#endif
 #ifndef SHARP_PC_A_NP                     // shape A (512 threads): producer waves and ring depth (variant builds sweep them)
 #define SHARP_PC_A_NP 2
 #define SHARP_PC_A_D 3
@@ -488,7 +491,7 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
     const int threads = shape_b ? SHARP_PC_B_THREADS : 512;
     const void *kern = nullptr;
     if constexpr (std::is_same<T, double>::value) kern = reinterpret_cast<const void *>(rp_pc_kernel<T, GW, SLOTS, MODE, 512, 2, 2>);
-    else kern = shape_b ? reinterpret_cast<const void *>(rp_pc_kernel<T, GW, SLOTS, MODE, SHARP_PC_B_THREADS, SHARP_PC_B_NP, 2>)
+    else kern = shape_b ? reinterpret_cast<const void *>(rp_pc_kernel<T, GW, SLOTS, MODE, SHARP_PC_B_THREADS, SHARP_PC_B_NP, SHARP_PC_B_D>)
                         : reinterpret_cast<const void *>(rp_pc_kernel<T, GW, SLOTS, MODE, 512, SHARP_PC_A_NP, SHARP_PC_A_D>);
     // LDS per workgroup: accumulators + dump slots, eight control words, two entry lists; two workgroups per CU
     const size_t acc_bytes = static_cast<size_t>(g.acc_slots() + kDumpSlots) * 8 + 32;

@@ -13,6 +13,11 @@ import sys
 from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+# round 5 on: the profiled command is the default bench (cfg3: 1 warm-up + 3 timed SHARP_unlimited calls = 4 calls of 10 blocks), or cfg2
+# (1 warm-up + 3 timed + 1 attribution step = 5 SHARP() calls): `profile_collect.py TAG CALLS SHAPE`
+CALLS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+SHAPE = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
+LAUNCHES_PER_CALL = {"cfg2": 1, "cfg3": 10, "cfg4": 8}[SHAPE]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 prof = os.path.join(root, "profiles")
@@ -47,28 +52,24 @@ for counter, sub in (("FETCH_SIZE", "_pmc_fetch"), ("WRITE_SIZE", "_pmc_write"))
             agg[k][counter] += float(row["Counter_Value"])
             if counter == "FETCH_SIZE":
                 agg[k]["launches"] += 1
-steps = 5  # bench.py --steps 3 --warmup 1: 1 warm-up + 3 timed + 1 attribution step = 5 SHARP() calls
+steps = CALLS
 rows = []
 for k, v in sorted(agg.items(), key=lambda kv: -(2 * kv[1]["FETCH_SIZE"] + kv[1]["WRITE_SIZE"])):
     hbm = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
     rows.append((k, v["launches"], round(v["FETCH_SIZE"], 1), round(v["WRITE_SIZE"], 1), int(hbm), int(hbm / steps)))
 with open(os.path.join(prof, tag + "_pmc_hbm_traffic.csv"), "w") as fh:
-    fh.write("kernel,launches(%d SHARP calls: 1 warm-up + 3 timed + 1 attribution),FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum,"
-             "hbm_bytes_total(2xFETCH gfx950 correction + WRITE),hbm_bytes_per_SHARP_call\n" % steps)
+    fh.write("kernel,launches(%d calls of the %s workload),FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum,"
+             "hbm_bytes_total(2xFETCH gfx950 correction + WRITE),hbm_bytes_per_call\n" % (steps, SHAPE))
     for r in rows:
         fh.write(",".join(str(x) for x in r) + "\n")
 rp = [r for r in rows if "rp_compact_kernel" in r[0] or "rp_apply_kernel" in r[0] or "rp_pc_kernel" in r[0]]
 if rp:
-    per_call = sum(r[5] for r in rp)
-    launches = {r[0]: r[1] // steps for r in rp}
-    json.dump({"kernels": [r[0] for r in rp], "launches_per_SHARP_call": launches, "hbm_bytes_per_launch": per_call,
-               "hbm_bytes_per_kernel_per_SHARP_call": {r[0]: r[5] for r in rp},
-               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python3 bench.py --steps 3 --warmup 1 "
-                         "--no-cpu-baseline` (tools/profile_round.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports "
-                         "half of wide coalesced reads); summed over the RP stage's launches of one SHARP() call (rp_pc_kernel: one launch; the two-kernel form: compact + apply launches)",
-               "workload": "bench.py default (50000 cells x 20000 genes, K=15, p=391)"},
-              open(os.path.join(prof, "rp_traffic.json"), "w"), indent=1)
-    print("rp traffic per SHARP call: %.3f GB" % (per_call / 1e9))
+    per_launch = sum(r[4] for r in rp) / max(1, sum(r[1] for r in rp if "rp_pc_kernel" in r[0] or "rp_compact_kernel" in r[0]))
+    tf = os.path.join(prof, "rp_traffic.json")
+    tj = json.load(open(tf)) if os.path.exists(tf) else {}
+    tj[SHAPE] = {"hbm_bytes_per_launch": int(per_launch), "kernel": rp[0][0], "source": "profiles/%s_pmc_hbm_traffic.csv (rocprofv3 --pmc passes over bench.py --config %s)" % (tag, SHAPE)}
+    json.dump(tj, open(tf, "w"), indent=1)
+    print("rp traffic per launch (%s): %.3f GB" % (SHAPE, per_launch / 1e9))
 b = os.path.join(out, tag + "_bench_n1.json")
 if os.path.exists(b) and os.path.getsize(b) > 10:
     shutil.copy(b, os.path.join(prof, tag + "_bench_n1.json"))
