@@ -1,11 +1,11 @@
 #!/bin/bash
-# ON A ONE-GPU BOX: rehearse `bench.py --gpus N` with N ranks (default 6: the box's process guard allows at most six processes on the card) --
+# ON A ONE-GPU BOX: rehearse `bench.py --gpus N` with N ranks (default 5: the box's process guard allows at most six processes on the card, and the launcher counts as one) --
 # gloo instead of RCCL, every rank on GPU 0 (SHARP_BENCH_SHARE_GPU=1) -- at reduced size, and check the labels' summary against the N = 1 run
 # of the same reduced problem (same eight blocks, same global p: every block's final labels must be identical, compared by checksum).
 # No scaling number comes out of this (the ranks share one GPU); it exercises the rank bookkeeping, the all-gather of the centroid tables
 # with N ranks, and the per-rank host-thread cap (SHARP_HOST_THREADS = cores / N, set by bench.py).
 # usage: tools/dryrun_8ranks.sh [ranks=6] [cells=96000] [genes=6000]
-N=${1:-6}; CELLS=${2:-96000}; GENES=${3:-6000}
+N=${1:-5}; CELLS=${2:-96000}; GENES=${3:-6000}
 REPO=$(cd "$(dirname "$0")/.." && pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT
 cd $REPO
 export HSA_ENABLE_IPC_MODE_LEGACY=0
