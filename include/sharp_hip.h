@@ -396,6 +396,7 @@ void sharp_C_last_rpinfo(int *dims, int *enrp, double *indE, int *want, int *sta
 void sharp_C_SHARP_unlimited(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *N_cluster, int *minN, int *maxN,
                              double *rN_seed, int *pred, double *viE, int *info, int *want, int *status);
 /* sharp_SHARP_unlimited_multi: devices = integer vector of GPU indices (block b on devices[b mod *ndevices]) */
+void sharp_C_unlimited_view_dim(int *kdim, int *status);      /* sharp_unlimited_view_dim: the next sharp_C_SHARP_unlimited* call's viE is ncells x *kdim */
 void sharp_C_SHARP_unlimited_multi(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *N_cluster, int *minN, int *maxN,
                                    double *rN_seed, int *devices, int *ndevices, int *pred, double *viE, int *info, int *want, int *status);
 /* sharp_SHARP_unlimited_csc_multi for a list of dgCMatrix blocks: pcat / icat / xcat = the blocks' @p / @i / @x one after the other;

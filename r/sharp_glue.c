@@ -152,8 +152,10 @@ static SEXP list_elt(SEXP lst, const char *name) {
         if (nm != R_NilValue && strcmp(CHAR(STRING_ELT(nm, q)), name) == 0) return VECTOR_ELT(lst, q);
     return R_NilValue;
 }
-SEXP R_sharp_unlimited_multi(SEXP blocks, SEXP ipar, SEXP seed, SEXP viewflag_, SEXP devices) {
-    const int nb = LENGTH(blocks), *ip = INTEGER(ipar), viewflag = asLogical(viewflag_), ndev = LENGTH(devices);
+SEXP R_sharp_unlimited_multi(SEXP blocks, SEXP ipar, SEXP seed, SEXP viewflag_, SEXP devices, SEXP view_dim_) {
+    /* view_dim > 0 (r/sharp_hip.R passes 50 above 1e5 cells): viE comes back as ncells x view_dim, E1 reduced per block on its GPU by one
+     * more sparse projection -- what R/SHARP_unlimited.R:216-228 computes from E1 on the host (sharp_unlimited_view_dim) */
+    const int nb = LENGTH(blocks), *ip = INTEGER(ipar), viewflag = asLogical(viewflag_), ndev = LENGTH(devices), view_dim = viewflag ? asInteger(view_dim_) : 0;
     if (nb < 1) error("No expression data is provided!");
     const int sparse = isNewList(VECTOR_ELT(blocks, 0));
     long long *ncb = (long long *)R_alloc((size_t)nb, sizeof(long long));
@@ -193,9 +195,12 @@ SEXP R_sharp_unlimited_multi(SEXP blocks, SEXP ipar, SEXP seed, SEXP viewflag_, 
         ncells += ncb[b];
     }
     const int p = (int)ceil(log2((double)ncells) / 0.04);
+    if (view_dim < 0 || view_dim > 4096) error("view.dim must lie in 0 .. 4096");
+    const int vcols = view_dim > 0 ? view_dim : p;
     SEXP pred = PROTECT(allocVector(INTSXP, (R_xlen_t)ncells));
-    SEXP viE = PROTECT(allocVector(REALSXP, viewflag ? (R_xlen_t)ncells * p : 1));
+    SEXP viE = PROTECT(allocVector(REALSXP, viewflag ? (R_xlen_t)ncells * vcols : 1));
     int npred = 0, pu = 0;
+    if (view_dim > 0) chk(sharp_unlimited_view_dim(view_dim));      /* one-shot: the call below takes it */
     if (sparse)
         chk(sharp_SHARP_unlimited_csc_multi(cp, ri, ptrs, ncb, nb, m, ip[0], ip[1], ip[2], ip[3], asReal(seed), ndev ? INTEGER(devices) : NULL,
                                             ndev, INTEGER(pred), &npred, &pu, viewflag ? REAL(viE) : NULL));
@@ -209,10 +214,10 @@ SEXP R_sharp_unlimited_multi(SEXP blocks, SEXP ipar, SEXP seed, SEXP viewflag_, 
     SEXP out = PROTECT(mkNamed(VECSXP, names));
     SET_VECTOR_ELT(out, 0, pred);
     if (viewflag) {
-        SEXP v = PROTECT(allocMatrix(REALSXP, (int)ncells, pu));
+        SEXP v = PROTECT(allocMatrix(REALSXP, (int)ncells, vcols));
         const double *s = REAL(viE);
         double *d = REAL(v);
-        for (long long i = 0; i < ncells; ++i) for (int c = 0; c < pu; ++c) d[(size_t)c * (size_t)ncells + (size_t)i] = s[(size_t)i * pu + c];
+        for (long long i = 0; i < ncells; ++i) for (int c = 0; c < vcols; ++c) d[(size_t)c * (size_t)ncells + (size_t)i] = s[(size_t)i * vcols + c];
         SET_VECTOR_ELT(out, 1, v);
         UNPROTECT(1);
     }
@@ -227,7 +232,7 @@ static const R_CallMethodDef call_methods[] = {
     {"R_sharp_SHARP", (DL_FUNC)&R_sharp_SHARP, 4},
     {"R_sharp_SHARP_csc", (DL_FUNC)&R_sharp_SHARP_csc, 7},
     {"R_sharp_unlimited", (DL_FUNC)&R_sharp_unlimited, 4},
-    {"R_sharp_unlimited_multi", (DL_FUNC)&R_sharp_unlimited_multi, 5},
+    {"R_sharp_unlimited_multi", (DL_FUNC)&R_sharp_unlimited_multi, 6},
     {NULL, NULL, 0}};
 
 void R_init_sharp_glue(DllInfo *dll) {

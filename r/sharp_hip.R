@@ -217,37 +217,46 @@ sMetaC <- function(rerowColor, sE1, folds, hmethod, finalN.cluster, minN.cluster
     else .sharp_dmat(b)
 }
 .sharp_unlimited_run <- function(scExp, ensize.K, N.cluster, minN.cluster, maxN.cluster, rN.seed, viewflag,
-                                 devices = getOption("sharp.devices")) {
+                                 devices = getOption("sharp.devices"), view.reduce = TRUE) {
     nb <- length(scExp); m <- nrow(scExp[[1]])
     ncb <- vapply(scExp, ncol, 1)
     ncells <- sum(ncb)
     p <- ceiling(log2(ncells)/(0.2^2))
+    # R/SHARP_unlimited.R:216-228: above 1e5 cells enresults$viE is 1/sqrt(50) * E1 %*% ranM2(p, 50, seed), never E1.  With view.reduce the
+    # library takes that product per block on the GPU (sharp_unlimited_view_dim) and r$viE comes back ncells x 50: the caller then sets
+    # enresults$viE = r$viE instead of running lines 216-228 on a ncells x p matrix it no longer has.
+    kdim <- if (isTRUE(view.reduce) && viewflag && ncells > 1e5) 50L else 0L
+    vcols <- if (kdim > 0L) kdim else p
+    arm <- function() if (kdim > 0L) .sharp_check(.C("sharp_C_unlimited_view_dim", kdim, status = integer(1))$status)
     ipar <- c(.sharp_int(ensize.K), .sharp_int(N.cluster), .sharp_int(minN.cluster), .sharp_int(maxN.cluster))
     sparse <- all(vapply(scExp, function(b) inherits(b, "sparseMatrix"), TRUE))
     if (.sharp_has_glue()) {
         blocks <- if (sparse) lapply(scExp, .sharp_block) else lapply(scExp, .sharp_dmat)
-        r <- .Call("R_sharp_unlimited_multi", blocks, ipar, as.double(rN.seed), as.logical(viewflag), as.integer(devices))
+        r <- .Call("R_sharp_unlimited_multi", blocks, ipar, as.double(rN.seed), as.logical(viewflag), as.integer(devices), kdim)
     } else if (sparse) {
         cs <- lapply(scExp, .sharp_block)
         if (sum(as.numeric(vapply(cs, function(b) length(b$x), 1))) >= 2^31) stop("SHARP_unlimited: this input needs the .Call glue (r/sharp_glue.c): .C() carries at most 2^31 - 1 values")
+        arm()
         r <- .C("sharp_C_SHARP_unlimited_csc", unlist(lapply(cs, `[[`, "p")), unlist(lapply(cs, `[[`, "i")), unlist(lapply(cs, `[[`, "x")), nb,
                 as.double(ncb), m, ipar[1], ipar[2], ipar[3], ipar[4], as.double(rN.seed), as.integer(c(devices, 0L)), length(devices),
-                pred = integer(ncells), viE = double(if (viewflag) ncells * p else 1), info = integer(2), as.integer(viewflag), status = integer(1))
+                pred = integer(ncells), viE = double(if (viewflag) ncells * vcols else 1), info = integer(2), as.integer(viewflag), status = integer(1))
         .sharp_check(r$status)
-        r <- list(pred = r$pred, viE = if (viewflag) t(matrix(r$viE, nrow = p)) else NULL, p = r$info[2])
+        r <- list(pred = r$pred, viE = if (viewflag) t(matrix(r$viE, nrow = vcols)) else NULL, p = r$info[2])
     } else {
         if (as.numeric(m) * ncells >= 2^31) stop("SHARP_unlimited: this input needs the .Call glue (r/sharp_glue.c): .C() carries at most 2^31 - 1 values")
         xcat <- unlist(lapply(scExp, function(b) as.double(data.matrix(b))))
+        arm()
         if (length(devices) >= 2)
             r <- .C("sharp_C_SHARP_unlimited_multi", xcat, nb, as.double(ncb), m, ipar[1], ipar[2], ipar[3], ipar[4], as.double(rN.seed),
-                    as.integer(devices), length(devices), pred = integer(ncells), viE = double(if (viewflag) ncells * p else 1),
+                    as.integer(devices), length(devices), pred = integer(ncells), viE = double(if (viewflag) ncells * vcols else 1),
                     info = integer(2), as.integer(viewflag), status = integer(1))
         else
             r <- .C("sharp_C_SHARP_unlimited", xcat, nb, as.double(ncb), m, ipar[1], ipar[2], ipar[3], ipar[4], as.double(rN.seed),
-                    pred = integer(ncells), viE = double(if (viewflag) ncells * p else 1), info = integer(2), as.integer(viewflag),
+                    pred = integer(ncells), viE = double(if (viewflag) ncells * vcols else 1), info = integer(2), as.integer(viewflag),
                     status = integer(1))
         .sharp_check(r$status)
-        r <- list(pred = r$pred, viE = if (viewflag) t(matrix(r$viE, nrow = p)) else NULL, p = r$info[2])
+        r <- list(pred = r$pred, viE = if (viewflag) t(matrix(r$viE, nrow = vcols)) else NULL, p = r$info[2])
     }
-    r                                                                         # finalrowColor = r$pred (ids by decreasing size), E1 = r$viE
+    r$view.dim <- kdim                                                        # > 0: r$viE IS enresults$viE (ncells x 50); 0: r$viE is E1
+    r                                                                         # finalrowColor = r$pred (ids by decreasing size)
 }

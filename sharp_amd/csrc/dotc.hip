@@ -159,6 +159,9 @@ void sharp_C_SHARP_unlimited(double *Xcat, int *nblocks, double *ncb, int *m, in
     *status = sharp_SHARP_unlimited_view(ptrs.data(), nc.data(), B, *m, *ensize_K, *N_cluster, *minN, *maxN, *rN_seed, pred, &info[0],
                                          &info[1], (*want & 1) ? viE : nullptr);
 }
+/* arms the device-side view reduction for the NEXT sharp_C_SHARP_unlimited* call (sharp_unlimited_view_dim; R/SHARP_unlimited.R:216-228): its viE
+ * buffer is then ncells x *kdim */
+void sharp_C_unlimited_view_dim(int *kdim, int *status) { *status = sharp_unlimited_view_dim(*kdim); }
 /* the same on several GPUs (sharp_SHARP_unlimited_multi): devices = integer vector of device indices, block b on devices[b mod ndev] */
 void sharp_C_SHARP_unlimited_multi(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *N_cluster, int *minN, int *maxN,
                                    double *rN_seed, int *devices, int *ndevices, int *pred, double *viE, int *info, int *want, int *status) {

@@ -119,6 +119,7 @@ SEXP rmock_list_get(SEXP lst, const char *name) {
     return R_NilValue;
 }
 typedef SEXP (*f0)(void); typedef SEXP (*f1)(SEXP); typedef SEXP (*f4)(SEXP, SEXP, SEXP, SEXP); typedef SEXP (*f5)(SEXP, SEXP, SEXP, SEXP, SEXP);
+typedef SEXP (*f6)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
 typedef SEXP (*f7)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
 SEXP rmock_call(DL_FUNC f, int nargs, SEXP *a) {
     SEXP r = NULL;
@@ -131,6 +132,7 @@ SEXP rmock_call(DL_FUNC f, int nargs, SEXP *a) {
         case 1: r = ((f1)f)(a[0]); break;
         case 4: r = ((f4)f)(a[0], a[1], a[2], a[3]); break;
         case 5: r = ((f5)f)(a[0], a[1], a[2], a[3], a[4]); break;
+        case 6: r = ((f6)f)(a[0], a[1], a[2], a[3], a[4], a[5]); break;
         case 7: r = ((f7)f)(a[0], a[1], a[2], a[3], a[4], a[5], a[6]); break;
         default: snprintf(err_msg, sizeof err_msg, "rmock_call: %d arguments not supported", nargs);
         }

@@ -165,6 +165,15 @@ def test_dotc_unlimited_and_merge(lib, oracle):
     assert st[0] in (0, 16, 32, 48) and info[1] == p == ref["p"] and info[0] == pred.max()
     assert np.array_equal(pred, ref["pred_clusters"])
     np.testing.assert_allclose(viE.reshape(ncells, p), ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
+    # the view dimension armed the way r/sharp_hip.R arms it above 1e5 cells: viE comes back ncells x 50, E1 reduced per block on the GPU
+    v50 = np.zeros(ncells * 50)
+    dotc(lib, "sharp_C_unlimited_view_dim", I(50), st)
+    assert st[0] == 0
+    dotc(lib, "sharp_C_SHARP_unlimited", Xcat, I(2), D(*sizes), I(m), I(3), I(0), I(0), I(0), D(2103.0), pred, v50, info, I(1), st)
+    assert st[0] in (0, 16, 32, 48) and np.array_equal(pred, ref["pred_clusters"])
+    z0 = oracle.ranM(p, 50, 50 + 2103 + 3 + 1)
+    want = np.concatenate([oracle.project(ref["viE"][a:b].T, z0, False) for a, b in ((0, 5200), (5200, ncells))])
+    np.testing.assert_allclose(v50.reshape(ncells, 50), want, rtol=0, atol=4e-12 * np.abs(want).max())
     rng = np.random.default_rng(2)
     M = rng.standard_normal((60, 16)) + np.repeat(rng.standard_normal((6, 16)) * 3, 10, 0)
     cnt = rng.integers(20, 900, 60).astype(np.float64)

@@ -15,14 +15,14 @@ def glue():
 
 def test_registration_table(glue):
     for name, nargs in [("R_sharp_init", 1), ("R_sharp_trim", 0), ("R_sharp_SHARP", 4), ("R_sharp_SHARP_csc", 7), ("R_sharp_unlimited", 4),
-                        ("R_sharp_unlimited_multi", 5)]:
+                        ("R_sharp_unlimited_multi", 6)]:
         assert glue.L.rmock_registered(name.encode()) == nargs
         assert hasattr(glue.L, name)
 
 
 def test_empty_list_is_the_reference_error(glue):
     """R/SHARP_unlimited.R:33-35"""
-    for fn, extra in (("R_sharp_unlimited", ()), ("R_sharp_unlimited_multi", (glue.int(),))):
+    for fn, extra in (("R_sharp_unlimited", ()), ("R_sharp_unlimited_multi", (glue.int(), glue.int(0)))):
         with pytest.raises(RuntimeError, match="No expression data is provided!"):
             glue.call(fn, glue.list([]), glue.int(5, 0, 0, 0), glue.real(2103), glue.lgl(False), *extra)
     glue.reset()
@@ -31,7 +31,7 @@ def test_empty_list_is_the_reference_error(glue):
 def test_blocks_must_share_the_gene_axis(glue):
     a, b = np.zeros((30, 8)), np.zeros((31, 8))
     with pytest.raises(RuntimeError, match="LIST of partitioned"):
-        glue.call("R_sharp_unlimited_multi", glue.list([glue.matrix(a), glue.matrix(b)]), glue.int(5, 0, 0, 0), glue.real(2103), glue.lgl(False), glue.int())
+        glue.call("R_sharp_unlimited_multi", glue.list([glue.matrix(a), glue.matrix(b)]), glue.int(5, 0, 0, 0), glue.real(2103), glue.lgl(False), glue.int(), glue.int(0))
     with pytest.raises(RuntimeError, match="LIST of partitioned"):
         glue.call("R_sharp_unlimited", glue.list([glue.matrix(a), glue.int(1, 2, 3)]), glue.int(5, 0, 0, 0), glue.real(2103), glue.lgl(False))
     glue.reset()
@@ -47,7 +47,7 @@ def test_malformed_sparse_blocks_are_refused_before_any_pointer_is_used(glue):
         return glue.list([glue.int(d["p"]), glue.int(d["i"]), glue.real(d["x"]), glue.int(d["dim"])], ["p", "i", "x", "dim"])
 
     def run(b):
-        return glue.call("R_sharp_unlimited_multi", glue.list([b]), glue.int(5, 0, 0, 0), glue.real(2103), glue.lgl(False), glue.int())
+        return glue.call("R_sharp_unlimited_multi", glue.list([b]), glue.int(5, 0, 0, 0), glue.real(2103), glue.lgl(False), glue.int(), glue.int(0))
 
     p_bad0 = good["p"].copy(); p_bad0[0] = 1
     p_dec = good["p"].copy(); p_dec[3] = p_dec[2] - 1 if p_dec[2] > 0 else p_dec[4] + 1

@@ -72,12 +72,21 @@ def test_call_unlimited_multi_dense_and_sparse(glue, oracle, devices):
     n = sum(sizes)
     for make in (lambda b: glue.matrix(b), lambda b: glue.csc_block(sps.csc_matrix(b))):
         r = glue.call("R_sharp_unlimited_multi", glue.list([make(b) for b in blocks]), glue.int(K, 0, 0, 0), glue.real(2103), glue.lgl(True),
-                      glue.int(*devices))
+                      glue.int(*devices), glue.int(0))
         assert glue.get(r, "p")[0] == ref["p"]
         assert np.array_equal(glue.get(r, "pred"), ref["pred_clusters"])
         viE = glue.get(r, "viE")
         assert viE.shape == (n, ref["p"])
         np.testing.assert_allclose(viE, ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
+        glue.reset()
+        # view.dim = 50: what r/sharp_hip.R passes above 1e5 cells -- E1 reduced per block on the GPU (R/SHARP_unlimited.R:216-228)
+        r = glue.call("R_sharp_unlimited_multi", glue.list([make(b) for b in blocks]), glue.int(K, 0, 0, 0), glue.real(2103), glue.lgl(True),
+                      glue.int(*devices), glue.int(50))
+        v50 = glue.get(r, "viE")
+        assert v50.shape == (n, 50) and np.array_equal(glue.get(r, "pred"), ref["pred_clusters"])
+        z0 = oracle.ranM(ref["p"], 50, 50 + 2103 + K + 1)
+        want = np.concatenate([oracle.project(ref["viE"][a:b].T, z0, False) for a, b in zip(np.cumsum([0] + sizes[:-1]), np.cumsum(sizes))])
+        np.testing.assert_allclose(v50, want, rtol=0, atol=4e-12 * np.abs(want).max())
         glue.reset()
     # the plain list entry (no devices argument) and viewflag = FALSE
     r = glue.call("R_sharp_unlimited", glue.list([glue.matrix(b) for b in blocks]), glue.int(K, 0, 0, 0), glue.real(2103), glue.lgl(False))
