@@ -408,6 +408,10 @@ def main():
         }
         if crc_by_block is not None:
             result["labels_crc32_by_block"] = crc_by_block
+        if sharded:
+            # the N > 1 lines (and --config cfg4) run configs[3], a fixed problem ("strong"); the default --gpus 1 line runs configs[2]: the N = 1
+            # point of the curve the N > 1 lines draw is that line's other_configs.cfg4_one_gpu (or `--gpus 1 --config cfg4`), not its headline
+            result["scaling_curve"] = {"workload": "configs[3], 1.3 M cells x 27 000 genes as eight blocks, whatever N", "n1_point": "the `--gpus 1` line's other_configs.cfg4_one_gpu.value (same blocks on one GPU), or `--gpus 1 --config cfg4`"}
         lv = level_rules(prof_timed, args.steps)
         if lv:
             result["level_rule_per_step"] = lv
@@ -423,6 +427,10 @@ def main():
                 result["other_configs"], by_cfg = extra_configs(Bn, tag)
                 if roof:
                     roof["by_config"] = by_cfg
+                c4 = result["other_configs"].get("cfg4_one_gpu", {})
+                if "value" in c4:
+                    # what `--gpus N` (N > 1) is to be compared with: the same eight blocks of configs[3] on this one GPU
+                    result["scaling_curve"] = {"workload": "configs[3] (what --gpus N > 1 runs)", "n1_point_cells_per_s": c4["value"], "n1_point_ms_per_step": c4["ms_per_step"]}
             if not args.no_cpu_baseline:
                 cb = {}
                 guarded(cb, "r", lambda: cpu_baseline(Bn, tag))

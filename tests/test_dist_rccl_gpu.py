@@ -57,6 +57,7 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path, cells, genes, nblocks):
     assert d["config"]["cells_per_block"] == cells // nblocks
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["ari_vs_planted_truth"] > 0.85                        # (what the algorithm finds on this data; parity is tested elsewhere)
+    assert len(d["labels_crc32_by_block"]) == nblocks and "cfg4_one_gpu" in d["scaling_curve"]["n1_point"]
 
 
 def test_bench_default_line_names_cfg3_with_forview_roofline_and_cpu_baseline():
