@@ -984,6 +984,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
 }
 
 #include "hclust_tri.inc"
+#include "hclust_front.inc"
 
 #ifdef SHARP_LAB       // the lazy agglomeration (an experiment kept for reference): lab builds only
 #include "../../tools/lab/hclust_lazy.inc"
@@ -2003,6 +2004,22 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                                                         static_cast<int>(ldsl)));
                     hipLaunchKernelGGL(hclust_tri_kernel, dim3(Ts), dim3(HT_THREADS), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p,
                                        W.height.p, W.status.p + R.t0, static_cast<int>(ldsl));
+                } else if (Ts <= c.num_cu && knobs().hc_front > 0 && max_n <= 2400) {
+                    // SHARP_HC_FRONT=c (an experiment, hclust_front.inc): the first c rounds without rewriting the matrix -- new rows and the
+                    // survivors' tails appended beside the pristine D -- then one compaction into S0 and hclust_rnn_kernel's MODE 3 for the rest
+                    const size_t ldsf = (static_cast<size_t>(max_n) * 3 / 2 + 8) * 34 + 96;
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(hclust_front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        static_cast<int>(ldsf)));
+                    W0.img.ensure(static_cast<size_t>(Ts) * lds);
+                    W0.remaining.ensure(1);
+                    hipLaunchKernelGGL(hclust_front_kernel, dim3(Ts), dim3(HF_THREADS), ldsf, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p, W.height.p,
+                                       W.status.p + R.t0, W0.img.p, static_cast<long long>(lds), knobs().hc_front);
+                    launch_check("hclust_front_kernel");
+                    auto kc = hclust_rnn_kernel<1024, 3, false>;
+                    const size_t ldsl = std::max(lds, HR_LDS_CU);
+                    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsl)));
+                    hipLaunchKernelGGL(kc, dim3(Ts), dim3(1024), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p, W.height.p,
+                                       W.status.p + R.t0, W0.img.p, static_cast<long long>(lds), static_cast<int>(lds), 1, W0.remaining.p, static_cast<int>(ldsl));
                 } else if (Ts <= c.num_cu && !knobs().hc_half) {
                     auto k0 = hclust_rnn_kernel<1024, 0>;
                     // one workgroup per CU: everything the CU has beyond the state stages the pair members' entries

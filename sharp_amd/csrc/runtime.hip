@@ -322,6 +322,7 @@ static Knobs read_knobs() {
     v.tail_threads = num("SHARP_TAIL_THREADS", 4);
     v.host_threads = num("SHARP_HOST_THREADS", 0);
     v.hc_half = num("SHARP_HC_HALF", 0) != 0;
+    v.hc_front = num("SHARP_HC_FRONT", 0);
     v.tail_priority = num("SHARP_TAIL_PRIORITY", 1) != 0;
     v.gemm_slice = num("SHARP_GEMM_SLICE", 8);
     v.proj_host = num("SHARP_PROJ_HOST", 0) == 1;
