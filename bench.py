@@ -319,7 +319,8 @@ def main():
     ms_forview = None
     if not args.no_forview:
         fsteps = max(2, min(args.steps, 3))
-        step(view=True)
+        step(view=True)                                    # two warm-up calls: the view projector and its buffers exist once per tail-helper slot,
+        step(view=True)                                    # and which helper takes which block's tail is decided at run time
         barrier()
         t0 = time.perf_counter()
         for _ in range(fsteps):
