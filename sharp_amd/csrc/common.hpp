@@ -91,6 +91,7 @@ struct Knobs {
     bool tail_priority = true;  // SHARP_TAIL_PRIORITY=0: the helpers' streams in the normal priority class
     bool dist_i8 = false;       // SHARP_DIST_I8=1: the correlation-distance GEMM on the integer matrix cores (gemm_i8.hip) instead of the fp64 MFMA
     bool stats_sums = true;     // SHARP_STATS_SUMS=0: the finest level's cluster sums as a skinny GEMM over a one-hot matrix
+    bool stats_lane = true;     // SHARP_STATS_LANE=0: stats_kernel (the walk re-read from LDS per cell, bitonic median) where stats_lane_kernel runs by default (cross-check)
     bool hc_tri = false;        // SHARP_HC_TRI=1: the upper-triangle agglomeration kernel (hclust_tri.inc: 44 % of the HBM bytes, the same time alone,
                                 // 8 % slower inside the batched SHARP_unlimited pipeline) where the full-matrix one runs by default
     bool hc_prep_early = true;  // SHARP_HC_PREP_EARLY=0: a chunk's row preparation behind the previous chunk's distance GEMM instead of beside it

@@ -1283,6 +1283,8 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const HcMeta *__restr
     }
 }
 
+#include "hclust_stats.inc"
+
 // ---------------------------------------------------------------------------------------------
 // a5b for MANY candidate levels (the cross-block sMetaC of a run of >= 1e6 cells tries k = n/50000 .. n/5000: 1801 levels at 1e7
 // cells, R/sMetaC.R:110-119).  stats_kernel recomputes every level from the finest-level quantities, O(n kf) per level and a
@@ -2138,12 +2140,15 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         // a5b: silhouette medians + CH per level
         {
             const int kcap = std::max(J.max_kpad, 64);
-            const size_t lds = stats_lds_bytes(max_n, kcap);
-            SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            // at most 64 finest clusters (every call of the reference's defaults: maxN = 40): the walk over them fits one register per lane
+            const bool lane_form = knobs().stats_lane && J.max_kpad <= 64;
+            const size_t lds = lane_form ? stats_lane_lds_bytes(max_n, kcap) : stats_lds_bytes(max_n, kcap);
+            const auto kern = lane_form ? stats_lane_kernel : stats_kernel;
+            SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 static_cast<int>(lds)));
             KernelTimer tm("sil_ch_stats");
             const long long blocks = static_cast<long long>((Ts + 7) / 8) * 8 * max_nk;
-            hipLaunchKernelGGL(stats_kernel, dim3(static_cast<unsigned>(blocks)), dim3(ST_THREADS), lds, st, dmeta, W.lab.p, W.T.p,
+            hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(ST_THREADS), lds, st, dmeta, W.lab.p, W.T.p,
                                W.G.p, W.Q.p, W.nrm.p, W.out.p, Ts, max_nk, kcap);
             launch_check("stats_kernel");
         }

@@ -318,6 +318,7 @@ static Knobs read_knobs() {
     v.hc_prep_early = num("SHARP_HC_PREP_EARLY", 1) != 0;
     v.hc_tri = num("SHARP_HC_TRI", 0) != 0;
     v.stats_sums = num("SHARP_STATS_SUMS", 1) != 0;
+    v.stats_lane = num("SHARP_STATS_LANE", 1) != 0;
     v.dist_i8 = num("SHARP_DIST_I8", 0) != 0;
     v.tail_threads = num("SHARP_TAIL_THREADS", 4);
     v.host_threads = num("SHARP_HOST_THREADS", 0);

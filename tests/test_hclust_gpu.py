@@ -295,3 +295,41 @@ def test_many_levels_statistics_match_the_per_level_kernel_and_the_oracle(sa, or
     c = sa.get_opt_hclust(mat, minN_cluster=5, maxN_cluster=300, sil_thre=2.0)
     refc = oracle.get_opt_hclust(mat, minN=5, maxN=300, sil_thre=2.0)
     assert c["branch"] == refc["branch"] and np.array_equal(c["f"], refc["f"])
+
+
+@pytest.mark.parametrize("kind,n,maxN", [("features", 2000, 40), ("features", 701, 40), ("features", 96, 20), ("similarity", 180, 40),
+                                         ("similarity", 333, 64), ("features", 1200, 60), ("features", 900, 70)])
+def test_lane_program_statistics_equal_the_per_cell_walk(sa, oracle, kind, n, maxN, monkeypatch):
+    """stats_lane_kernel (the default up to 64 finest clusters: the walk over the finest clusters as a program in registers read with
+    v_readlane, the median by radix selection, the clusters' Gram sums by rows) against stats_kernel (SHARP_STATS_LANE=0: the walk
+    re-read from LDS per cell, bitonic sort): the same sums in the same order per cell, so the median silhouettes are EQUAL, for odd
+    and even n, feature and similarity tasks, with runs of exactly-zero silhouettes (singleton clusters); CH agrees to rounding (the
+    two Gram sums of a cluster are associated by rows); both equal the oracle.  maxN = 70: more than 64 finest clusters, both runs
+    take stats_kernel."""
+    rng = np.random.default_rng(100 + n)
+    p, G = 60, 7
+    E = rng.standard_normal((n, p)) * 0.9 + rng.standard_normal((G, p))[rng.integers(0, G, n)] * 1.6
+    E[: min(12, n // 8)] += rng.standard_normal((min(12, n // 8), p)) * 6.0      # outliers: singleton clusters at the finer levels
+    if kind == "similarity":
+        mat = np.corrcoef(E)
+        np.fill_diagonal(mat, 1.0)
+        mat = (mat + mat.T) / 2
+    else:
+        mat = E
+    kw = dict(maxN_cluster=maxN, sil_thre=0.35)
+    monkeypatch.setenv("SHARP_STATS_LANE", "0")
+    a = sa.get_opt_hclust(mat, **kw)
+    monkeypatch.delenv("SHARP_STATS_LANE")
+    b = sa.get_opt_hclust(mat, **kw)
+    assert a["msil"].size == maxN - 1
+    assert np.array_equal(a["msil"], b["msil"])
+    np.testing.assert_allclose(b["CHind"], a["CHind"], rtol=1e-12)
+    assert np.array_equal(a["f"], b["f"]) and a["branch"] == b["branch"] and np.array_equal(a["v"], b["v"])
+    ref = oracle.get_opt_hclust(mat, maxN=maxN, sil_thre=0.35)
+    np.testing.assert_allclose(b["msil"], ref["msil"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(b["CHind"], ref["CHind"], rtol=1e-8)
+    assert np.array_equal(b["f"], ref["f"]) and b["branch"] == ref["branch"]
+    # the CH rule (every median below the threshold) on the same statistics
+    c = sa.get_opt_hclust(mat, maxN_cluster=maxN, sil_thre=2.0)
+    refc = oracle.get_opt_hclust(mat, maxN=maxN, sil_thre=2.0)
+    assert c["branch"] == refc["branch"] and np.array_equal(c["f"], refc["f"])
