@@ -104,10 +104,14 @@ struct Knobs {
     int host_threads = 0;       // SHARP_HOST_THREADS: cap on the host cores this process sizes its pools from (0: its affinity mask); host_cores()
     int upload_threads = 0;     // SHARP_UPLOAD_THREADS: host threads narrowing / copying an uploaded block (0: up to 32)
     std::vector<int> devices;   // SHARP_DEVICES=0,1,2,...: the GPUs sharp_SHARP_unlimited deals a list of blocks to (empty / one: the caller's device)
+    bool step_marks = false;    // SHARP_STEP_MARKS=1: host timestamps of a SHARP_unlimited call's milestones (chunks fetched, blocks' tails, merge) on stderr at its end
     int rp_shape = 0;           // SHARP_RP_SHAPE=1: 8 lanes x 4 slots per gene where the default is 16 x 2 (A/B runs)
 };
 const Knobs &knobs();
 void reload_knobs();
+// SHARP_STEP_MARKS=1: (label, id, time) marks of the running call, from any of its threads; step_marks_dump() prints them, in ms from the first one, and clears them
+void step_mark(const char *label, int id = -1);
+void step_marks_dump();
 #ifdef SHARP_LAB
 inline const char *lab_env(const char *name) { return getenv(name); }   // lab builds (tools/build_variant.sh) only: ablation / timing switches
 #endif
@@ -146,7 +150,7 @@ Ctx &ctx_unchecked();
 // sharp_init() sets up, which is all a single-GPU host ever sees).  The multi-GPU entry points (sharp_SHARP_unlimited_multi) start one
 // host thread per device and bind each to a slot of its own, so several GPUs -- or, in the tests, several slots on ONE GPU -- run
 // side by side in one process.
-constexpr int kMaxSlots = 132;       // the caller's slot and its 4 tail helpers' + (compute, upload, 4 tail helpers) of up to 16 GPUs, with room for repeated devices
+constexpr int kMaxSlots = 200;       // the caller's slot and its tail helpers' (up to 8) + (compute, upload, up to 8 tail helpers) of up to 16 GPUs, with room for repeated devices
 int cur_slot();
 void bind_slot(int slot);                   // the calling thread works on this slot from now on
 void init_slot(int slot, int device, bool high_priority = false);   // (high_priority: the slot's main stream in the high class, tail helpers)
@@ -203,13 +207,23 @@ struct DevBuf {
         release();
         n = count;
         if (count) SHARP_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        if (count) step_mark("        hipMalloc (after a hipFree if the buffer grew), KB", static_cast<int>(count * sizeof(T) >> 10));
     }
     void alloc_pooled(size_t count) {    // (see pool_take)
         release();
         n = count;
         if (count) p = static_cast<T *>(pool_take(count * sizeof(T), &pooled_cap));
     }
-    void ensure(size_t count) { if (count > n) alloc(count); }
+    // A buffer that has to grow is freed and allocated anew, and hipFree drains the WHOLE device: from a tail helper of a batched
+    // SHARP_unlimited window that wait lasts until the pipeline's last agglomeration is over (a 524 KB label buffer kept block 2's tail,
+    // and its helper thread, for 62 of a call's 172 ms: SHARP_STEP_MARKS).  Sizes that follow the data (clusters per fold, columns of
+    // a soft matrix) differ by a few per cent from block to block, so a buffer below 64 MB grows by half again and stops growing.
+    void ensure(size_t count) {
+        if (count <= n) return;
+        size_t want = count;
+        if (n && count * sizeof(T) <= (64ull << 20)) want = count + count / 2;
+        alloc(want);
+    }
     void release() {
         if (!p) return;
         if (pooled_cap) pool_give(p, pooled_cap); else (void)hipFree(p);

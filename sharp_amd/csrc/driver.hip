@@ -385,6 +385,7 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
     }
     std::vector<WmResult> wr;
     { HostTimer ht("wmetac_total"); wmetac_batch(wts, a.want_x0, false, wr); }
+    step_mark("  tail: per-fold wMetaC done, folds", T);
     SHARP_HIP_CHECK(hipStreamWaitEvent(ctx().stream, mean_done, 0));           // every use of viE_sh is below
     std::vector<int> Slab(n);                                                   // SrowColor in shuffled order
     std::vector<int> stf;                                                       // meta id per (fold, cluster) column of sx0
@@ -429,7 +430,9 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
         { HostTimer ht("tail_fold_means"); cluster_means_dev(viE_sh.p, p, n, p, uid, nCu, means.p); }   // sMetaC :58-63 on E1 = enE/K
         HcParams sp = base; sp.N_cluster = a.N_cluster;
         SmResult sr;
+        step_mark("  tail: fold means done, clusters", nCu);
         { HostTimer ht("smetac_total"); sr = smetac_from_means(means.p, nCu, p, n, sp); }   // :754
+        step_mark("  tail: sMetaC done", sr.optN);
         out.rc |= sr.rc;
         stf = sr.tf;
         for (int i = 0; i < n; ++i) Slab[i] = stf[uid[i]];
@@ -755,9 +758,12 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
     const auto tail_of = [&](int q) {
         SharpOut o;
         o.path = 1;
+        step_mark("tail begins, block", b0 + q);
         large_tail(*F[q], A[q], K, p, base[q], hr.data() + first[q], o);
         o.p = p; o.K = K;
+        step_mark("tail's labels ready, block", b0 + q);
         deliver(b0 + q, o);
+        step_mark("tail delivered, block", b0 + q);
         F[q].reset();
     };
     int next = 0;
@@ -789,9 +795,9 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
     Ctx &mc = ctx();
     const int dev = mc.device, owner = cur_slot();
     const bool prof = mc.profiling;
-    const int H = std::max(1, std::min({knobs().tail_threads, nbk, 4, std::max(1, host_cores() / 4)}));   // (a helper brings a five-thread host pool)
+    const int H = std::max(1, std::min({knobs().tail_threads, nbk, 8, std::max(1, host_cores() / 4)}));   // (a helper brings a five-thread host pool)
     std::vector<int> tslot(H);
-    for (int h = 0; h < H; ++h) tslot[h] = acquire_slot(dev, owner * 4 + h, 2);
+    for (int h = 0; h < H; ++h) tslot[h] = acquire_slot(dev, owner * 8 + h, 2);
     std::vector<std::thread> helpers;
     helpers.reserve(H);
     auto helper_body = [&](int h) {
@@ -832,6 +838,7 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
     }
     const std::function<void(size_t)> progress = [&](size_t done) {
         int r = next;
+        step_mark("base tasks reported done", static_cast<int>(done));
         while (r < nbk && first[r + 1] <= done) ++r;
         if (r == next) return;
         next = r;
@@ -870,7 +877,8 @@ void unlimited_merge(const double *means, const long long *counts, int nC, int p
     prm.minN = minN > 0 ? minN : 2;                                             // :70-72
     prm.maxN = maxN > 0 ? maxN : static_cast<int>(std::max<long long>(40, (ncells + 4999) / 5000));   // :75-77
     prm.sil_thre = sil_thre; prm.height_Ntimes = height_Ntimes;
-    DevBuf<double> dm(static_cast<size_t>(nC) * p);
+    DevBuf<double> dm;                                                          // (from the block cache: no hipMalloc / hipFree per call; smetac_from_means
+    dm.alloc_pooled(static_cast<size_t>(nC) * p);                               //  returns with its stream drained, so the block may go back)
     dm.upload(means, static_cast<size_t>(nC) * p);
     SmResult sr = smetac_from_means(dm.p, nC, p, ncells, prm);
     final_id = sr.tf;
@@ -1207,6 +1215,7 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
     const int K = ensize_K > 0 ? ensize_K : 5;                                                                 // :92-94
     std::vector<double> seeds(K);
     for (int k = 0; k < K; ++k) seeds[k] = (rN_seed == 0.5) ? 0.5 : 50 + rN_seed + (k + 1);                    // :97-104
+    step_mark("SHARP_unlimited begins, blocks", nblocks);
     const int proj = register_projector(build_projector(m, p, K, seeds.data()));
     std::vector<double> means;
     std::vector<long long> counts;
@@ -1225,10 +1234,12 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
         for (int b = 0; b < nblocks; ++b) { if (viE) viE_of[b] = viE + static_cast<size_t>(at) * view_cols(p); at += ncb[b]; }
         unlimited_blocks_loop(dX_blocks, ncb, ldb, nblocks, m, p, proj, K, rN_seed, viE ? viE_of.data() : nullptr, take);
     } catch (...) { drop_projector(proj); throw; }
+    step_mark("blocks done, projector dropped: merge of centroids", first[nblocks]);
     drop_projector(proj);
     std::vector<int> fid;
     int nf = 0;
     unlimited_merge(means.data(), counts.data(), first[nblocks], p, ncells, N_cluster, minN, maxN, fid, nf);
+    step_mark("merge done, clusters", nf);
     off = 0;
     for (int b = 0; b < nblocks; ++b) {
         for (long long i = 0; i < ncb[b]; ++i) pred[off + i] = fid[first[b] + pred[off + i] - 1];
@@ -1236,6 +1247,8 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
     }
     if (n_pred) *n_pred = nf;
     if (p_used) *p_used = p;
+    step_mark("SHARP_unlimited returns", 0);
+    step_marks_dump();
     SHARP_API_END
 }
 
@@ -1261,6 +1274,7 @@ static int unlimited2_run(const XRef *dX_blocks, const long long *ncb, const lon
     fa.N_cluster = 0;                                                                                          // fpart does not cut; the final sMetaC does
     std::vector<double> seeds(K);
     for (int k = 0; k < K; ++k) seeds[k] = (rN_seed == 0.5) ? 0.5 : 50 + rN_seed + (k + 1);                    // :130-137
+    step_mark("SHARP_unlimited begins, blocks", nblocks);
     const int proj = register_projector(build_projector(m, p, K, seeds.data()));
     std::vector<double> means;
     std::vector<long long> counts;

@@ -2051,6 +2051,8 @@ void enqueue_chunk(ChunkJob &J, int phases) {
             else J.seq_pending = true;
         }
         if (J.pipe) SHARP_HIP_CHECK(hipEventRecord(EV.hc[J.slot], st));
+        if (J.pipe && knobs().step_marks)
+            SHARP_HIP_CHECK(hipLaunchHostFunc(st, [](void *) { step_mark("    (device) an agglomeration ends"); }, nullptr));
         }
         if (!(phases & PH_STATS)) continue;
         // pipelined: the next chunk's distance GEMM (already enqueued) is on the critical path -- its agglomeration cannot start
@@ -2159,6 +2161,8 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         }
     }
     if (J.pipe && (phases & PH_STATS)) SHARP_HIP_CHECK(hipEventRecord(EV.done[J.slot], chunk_stream));
+    if (J.pipe && (phases & PH_STATS) && knobs().step_marks)
+        SHARP_HIP_CHECK(hipLaunchHostFunc(chunk_stream, [](void *) { step_mark("    (device) a chunk's statistics end"); }, nullptr));
 }
 
 void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, std::vector<HcResult> &out) {
@@ -2334,7 +2338,7 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
     ChunkJob jobs[3];
     size_t fetched = 0;                                                     // chunks 0 .. fetched - 1 are finished
     auto fetch_upto = [&](size_t upto) {                                    // finish chunks in order, report
-        for (; fetched < upto; ++fetched) finish_chunk(tasks, jobs[fetched % R], want_v, out);
+        for (; fetched < upto; ++fetched) { finish_chunk(tasks, jobs[fetched % R], want_v, out); step_mark("chunk fetched", static_cast<int>(fetched)); }
     };
     auto start_chunk = [&](size_t j) {                                      // descriptors, uploads, rows and distance matrices of chunk j
         ChunkJob &J = jobs[j % R];
@@ -2351,6 +2355,7 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
     for (size_t j = 0; j < nb; ++j) {
         if (j >= 1 && !stats_last) enqueue_chunk(jobs[(j - 1) % R], PH_STATS);
         enqueue_chunk(jobs[j % R], PH_AGGLO);
+        step_mark("agglomeration enqueued, chunk", static_cast<int>(j));
         if (j + 1 == nb && after_agglo().fn && g_batch_depth == 0) {        // the caller's side work behind the last agglomeration
             std::function<void(hipEvent_t)> fn = std::move(after_agglo().fn);
             after_agglo().fn = nullptr;

@@ -9,6 +9,9 @@
 #include <thread>
 #include <unistd.h>
 #include <sstream>
+#include <tuple>
+#include <vector>
+#include <cstdio>
 
 #include "common.hpp"
 
@@ -323,6 +326,7 @@ static Knobs read_knobs() {
     v.tail_threads = num("SHARP_TAIL_THREADS", 4);
     v.host_threads = num("SHARP_HOST_THREADS", 0);
     v.hc_half = num("SHARP_HC_HALF", 0) != 0;
+    v.step_marks = num("SHARP_STEP_MARKS", 0) != 0;
     v.hc_front = num("SHARP_HC_FRONT", 0);
     v.tail_priority = num("SHARP_TAIL_PRIORITY", 1) != 0;
     v.gemm_slice = num("SHARP_GEMM_SLICE", 8);
@@ -342,6 +346,27 @@ static Knobs read_knobs() {
 static Knobs &knobs_storage() { static Knobs k = read_knobs(); return k; }
 const Knobs &knobs() { return knobs_storage(); }
 void reload_knobs() { knobs_storage() = read_knobs(); }
+
+namespace {
+struct StepMarks { std::mutex mu; std::vector<std::tuple<const char *, int, double>> v; };
+StepMarks &step_marks() { static StepMarks *M = new StepMarks; return *M; }
+}  // namespace
+void step_mark(const char *label, int id) {
+    if (!knobs().step_marks) return;
+    const double t = now_s();
+    StepMarks &M = step_marks();
+    std::lock_guard<std::mutex> lk(M.mu);
+    M.v.emplace_back(label, id, t);
+}
+void step_marks_dump() {
+    if (!knobs().step_marks) return;
+    StepMarks &M = step_marks();
+    std::lock_guard<std::mutex> lk(M.mu);
+    if (M.v.empty()) return;
+    const double t0 = std::get<2>(M.v.front());
+    for (const auto &m : M.v) fprintf(stderr, "[step] %9.3f ms  %s %d\n", (std::get<2>(m) - t0) * 1e3, std::get<0>(m), std::get<1>(m));
+    M.v.clear();
+}
 }  // namespace sharp
 
 namespace sharp {
