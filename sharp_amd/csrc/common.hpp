@@ -104,6 +104,9 @@ struct Knobs {
     int host_threads = 0;       // SHARP_HOST_THREADS: cap on the host cores this process sizes its pools from (0: its affinity mask); host_cores()
     int upload_threads = 0;     // SHARP_UPLOAD_THREADS: host threads narrowing / copying an uploaded block (0: up to 32)
     std::vector<int> devices;   // SHARP_DEVICES=0,1,2,...: the GPUs sharp_SHARP_unlimited deals a list of blocks to (empty / one: the caller's device)
+    int front_overlap = 0;      // SHARP_FRONT_OVERLAP=b (an experiment): in a batched SHARP_unlimited window the blocks from the b-th on are projected with ONE workgroup per CU and
+                                // the chunks of base tasks wait for their own blocks' projections only, so that the first distance GEMM runs beside the later blocks' RP kernels
+    int hc_first_chunk = 0;     // SHARP_HC_FIRST_CHUNK=n: tasks in the first chunk of a pipelined batch (0: by the library, -1: equal chunks)
     bool step_marks = false;    // SHARP_STEP_MARKS=1: host timestamps of a SHARP_unlimited call's milestones (chunks fetched, blocks' tails, merge) on stderr at its end
     int rp_shape = 0;           // SHARP_RP_SHAPE=1: 8 lanes x 4 slots per gene where the default is 16 x 2 (A/B runs)
 };
@@ -126,6 +129,7 @@ struct Ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t main_stream = nullptr;   // `stream` outside every StreamScope
+    int rp_wgs_cap = 0;                  // > 0: the producer / consumer RP kernel with at most this many workgroups per CU (a block projected beside the first chunk's distance GEMM)
     bool polite = false;                 // work enqueued now is a block prepared ahead of time under another block's tail (SHARP_unlimited):
                                          // long launches go out in slices, nothing goes to the high-priority second stream
     hipStream_t stream2 = nullptr;   // side stream: producer kernels that overlap with consumers on `stream`

@@ -87,6 +87,7 @@ struct DriverWs {
     double *view_pinned = nullptr;               // staging block of the early viE download (SharpArgs::view_to_host)
     size_t view_pinned_n = 0;
     hipEvent_t view_done = nullptr;
+    std::vector<hipEvent_t> front_ev;            // SHARP_FRONT_OVERLAP: one event per block of a batched window (block q's projection is complete)
 };
 DriverWs &dws() { return per_slot<DriverWs>(); }
 
@@ -737,7 +738,8 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
     last_small().valid = false;
     std::vector<HcTask> tasks;
     std::vector<size_t> first(nbk + 1, 0);
-    long long r0 = 0;
+    std::vector<long long> row0(nbk + 1, 0);
+    const int fo = knobs().front_overlap;
     for (int q = 0; q < nbk; ++q) {
         const int n = static_cast<int>(ncb[b0 + q]);
         SharpArgs &a = A[q];
@@ -749,10 +751,51 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
         LargeFront &f = *F[q];
         f.dX = dX[b0 + q]; f.m = m; f.n = n; f.ld = ldb[b0 + q]; f.K = K; f.p = p; f.ng = 2000; f.flag = a.flag; f.projector = proj;
         f.rN_seed = rN_seed; f.fpart = false; f.bp = bp;
-        large_front(f, a, false, W.Ebatch.p + r0 * ldE, W.posbatch.p + r0);
-        tasks.insert(tasks.end(), f.tasks.begin(), f.tasks.end());
-        first[q + 1] = tasks.size();
-        r0 += n;
+        row0[q + 1] = row0[q] + n;
+    }
+    // A block's front: its shuffle, its projection into its rows of the batch's E (the RP kernel), its K x T task descriptors.
+    int fronts_done = 0;
+    const auto front_of = [&](int q) {
+        if (fo >= 2 && q >= 2) ctx().rp_wgs_cap = 1;
+        large_front(*F[q], A[q], false, W.Ebatch.p + row0[q] * ldE, W.posbatch.p + row0[q]);
+        ctx().rp_wgs_cap = 0;
+    };
+    std::function<hipEvent_t(size_t)> prepare;
+    if (fo <= 0) {
+        for (int q = 0; q < nbk; ++q) {
+            front_of(q);
+            tasks.insert(tasks.end(), F[q]->tasks.begin(), F[q]->tasks.end());
+            first[q + 1] = tasks.size();
+        }
+        fronts_done = nbk;
+    } else {
+        // SHARP_FRONT_OVERLAP (an experiment): the fronts go out just in time -- a chunk of base tasks asks for the blocks it reads before its
+        // own work is enqueued, so the first distance GEMM starts behind the first blocks' RP kernels and the later blocks are projected beside the
+        // pipeline.  The task descriptors need no device work: fold boundaries and row offsets only (the same as large_front builds).
+        for (int q = 0; q < nbk; ++q) {
+            const LargeFront &f = *F[q];
+            const std::vector<int> fst = fold_starts(f.n, f.ng);
+            const int T = static_cast<int>(fst.size()) - 1;
+            const double *E0 = W.Ebatch.p + row0[q] * ldE;
+            for (int k = 0; k < K; ++k)
+                for (int t = 0; t < T; ++t) {
+                    HcTask tk;
+                    tk.d_mat = E0 + static_cast<long long>(fst[t]) * ldE + static_cast<long long>(k) * p;
+                    tk.ld = ldE; tk.n = fst[t + 1] - fst[t]; tk.p = p; tk.prm = f.bp;
+                    tasks.push_back(tk);
+                }
+            first[q + 1] = tasks.size();
+        }
+        prepare = [&](size_t upto) -> hipEvent_t {
+            while (fronts_done < nbk && first[fronts_done] < upto) {
+                const int q = fronts_done++;
+                front_of(q);
+                SHARP_REQUIRE(F[q]->tasks.size() == first[q + 1] - first[q] && F[q]->tasks[0].d_mat == tasks[first[q]].d_mat, "SHARP_unlimited: a block's tasks are not where its front put them");
+                while (W.front_ev.size() <= static_cast<size_t>(q)) { hipEvent_t e; SHARP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); W.front_ev.push_back(e); }
+                SHARP_HIP_CHECK(hipEventRecord(W.front_ev[q], ctx().stream));
+            }
+            return W.front_ev[fronts_done - 1];
+        };
     }
     std::vector<HcResult> hr;
     const auto tail_of = [&](int q) {
@@ -773,7 +816,7 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
         };
         {
             HostTimer ht("base_clustering_total");
-            get_opt_hclust_batch(tasks, false, hr, &progress);
+            get_opt_hclust_batch(tasks, false, hr, &progress, fo > 0 ? &prepare : nullptr);
         }
         progress(tasks.size());
         return;
@@ -849,7 +892,7 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
     try {
         {
             HostTimer ht("base_clustering_total");
-            get_opt_hclust_batch(tasks, false, hr, &progress);
+            get_opt_hclust_batch(tasks, false, hr, &progress, fo > 0 ? &prepare : nullptr);
         }
         progress(tasks.size());
     } catch (...) { err = std::current_exception(); }

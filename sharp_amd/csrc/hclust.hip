@@ -1624,6 +1624,7 @@ struct ChunkJob {
     size_t i0 = 0, i1 = 0;
     int T = 0, slot = 0;
     bool pipe = false, first = true;
+    hipEvent_t input_ready = nullptr;          // pipelined: what the chunk's stream waits for before it reads its tasks' inputs (nullptr: EV.in)
     bool i8 = false;          // the distance matrices through the sliced-integer GEMM
     std::vector<HcMeta> metas;
     std::vector<RowPrepTask> prep;
@@ -1678,7 +1679,7 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
     // a pipelined chunk lives on its slot's stream from its first upload on (the slot's buffers are reused by the chunk after next,
     // which is on the same stream); its inputs come from the main stream (EV.in, recorded by the caller)
     hipStream_t chunk_stream = J.pipe ? c.aux_stream(J.slot) : c.stream;
-    if (J.pipe) SHARP_HIP_CHECK(hipStreamWaitEvent(chunk_stream, EV.in, 0));
+    if (J.pipe) SHARP_HIP_CHECK(hipStreamWaitEvent(chunk_stream, J.input_ready ? J.input_ready : EV.in, 0));
     StreamScope chunk_scope(chunk_stream);
     long long oD = 0, oD0 = 0, oCr = 0, oCt = 0, oN = 0, oM = 0, oLab = 0, oK = 0, oCS = 0, oQ = 0, oOut = 0;
     int max_n = 0, max_p = 0, max_nk = 0, max_kpad = 0;
@@ -2251,7 +2252,7 @@ void hc_set_after_last_agglomeration(std::function<void(hipEvent_t)> fn) { after
 bool hc_after_last_agglomeration_fired() { return after_agglo().fired; }
 
 void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::vector<HcResult> &out,
-                          const std::function<void(size_t)> *progress) {
+                          const std::function<void(size_t)> *progress, const std::function<hipEvent_t(size_t)> *prepare) {
     out.assign(tasks.size(), HcResult());
     if (tasks.empty()) return;
     ctx();
@@ -2291,10 +2292,24 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
     }
     std::vector<std::pair<size_t, size_t>> bounds;
     size_t i0 = 0;
+    // SHARP_HC_FIRST_CHUNK=n: a first chunk of n tasks (its distance GEMM has the chip to itself and nothing to run beside: a short one
+    // starts the first agglomeration earlier), the rest in equal chunks as above
+    // (cfg3, 1250 tasks: 140 + 7 x 159 against 7 x 179: 162.2 against 164.4 ms per call, medians of 7 and 8 interleaved runs; a first chunk
+    // of at most kHcSplitMaxTasks tasks takes the round-per-launch agglomeration, which wants the whole chip: 173 ms.)  Default with three
+    // chunks or more: four fifths of a chunk, above that threshold; SHARP_HC_FIRST_CHUNK=-1: equal chunks.
+    size_t first_tasks = 0;
+    int first_knob = knobs().hc_first_chunk;
+    if (first_knob == 0 && knobs().hc_chunk <= 0 && tasks.size() > 2 * max_tasks)
+        first_knob = std::max(kHcSplitMaxTasks + 4, static_cast<int>(max_tasks) * 4 / 5);
+    if (first_knob > 0 && static_cast<size_t>(first_knob) < max_tasks && tasks.size() > max_tasks) {
+        first_tasks = static_cast<size_t>(first_knob);
+        const size_t rest = tasks.size() - first_tasks, nch = (rest + max_tasks - 1) / max_tasks;
+        max_tasks = (rest + nch - 1) / nch;
+    }
     while (i0 < tasks.size()) {
         double bytes = 0;
         size_t i1 = i0;
-        while (i1 < tasks.size() && i1 - i0 < max_tasks) {
+        while (i1 < tasks.size() && i1 - i0 < (i0 == 0 && first_tasks ? first_tasks : max_tasks)) {
             const HcTask &t = tasks[i1];
             const double nld = static_cast<double>(rup(t.n, 128));
             const double p = t.symmetric ? t.n : t.p;
@@ -2312,6 +2327,7 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
     // label download of chunk j under chunk j + 1's device work.  SHARP_HC_PIPE=0: one chunk at a time.
     const bool pipe = bounds.size() > 1 && knobs().hc_pipe;
     if (!pipe) {
+        if (prepare) (void)(*prepare)(tasks.size());                         // (everything on the caller's stream: its order is the dependency)
         for (const auto &b : bounds) {
             ChunkJob J;
             J.i0 = b.first; J.i1 = b.second;
@@ -2346,6 +2362,7 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
         J.i0 = bounds[j].first; J.i1 = bounds[j].second;
         J.slot = slot_of[j % R]; J.prev_slot = slot_of[(j + R - 1) % R]; J.next_slot = slot_of[(j + 1) % R];
         J.pipe = true; J.first = j == 0; J.has_next = j + 1 < nb;
+        if (prepare) J.input_ready = (*prepare)(J.i1);                    // (whatever prepare_ahead has not asked for already)
         setup_chunk(tasks, J);
         enqueue_chunk(J, PH_DIST);
     };
@@ -2356,6 +2373,9 @@ void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::ve
         if (j >= 1 && !stats_last) enqueue_chunk(jobs[(j - 1) % R], PH_STATS);
         enqueue_chunk(jobs[j % R], PH_AGGLO);
         step_mark("agglomeration enqueued, chunk", static_cast<int>(j));
+        // the inputs of the chunk after the next are asked for NOW, behind this agglomeration's launch: start_chunk(j + 1) below has to wait
+        // for chunk j - 2's statistics first (its buffers), and inputs produced only then sat on the critical path in front of that chunk's GEMM
+        if (prepare && j + 2 < nb) (void)(*prepare)(bounds[j + 2].second);
         if (j + 1 == nb && after_agglo().fn && g_batch_depth == 0) {        // the caller's side work behind the last agglomeration
             std::function<void(hipEvent_t)> fn = std::move(after_agglo().fn);
             after_agglo().fn = nullptr;

@@ -46,8 +46,12 @@ constexpr int kHcMaxN = 16384;
 // progress (optional; only used when the batch runs as pipelined chunks): called with the number of leading tasks whose results in
 // `out` are final, at moments when the device has later chunks' agglomeration to work on; it may itself call get_opt_hclust_batch
 // (that nested batch gets buffers and agglomeration scratch of its own).
+// prepare (optional; pipelined chunks only): called on the calling thread before a chunk's work is enqueued, with the number of leading
+// tasks whose inputs that chunk needs; it enqueues whatever still has to produce them (on the caller's stream) and returns the event behind
+// it, which the chunk's stream waits for.  Without it every chunk waits for the caller's stream as it stands at the call.
 void get_opt_hclust_batch(const std::vector<HcTask> &tasks, bool want_v, std::vector<HcResult> &out,
-                          const std::function<void(size_t)> *progress = nullptr);
+                          const std::function<void(size_t)> *progress = nullptr,
+                          const std::function<hipEvent_t(size_t)> *prepare = nullptr);
 
 // One-shot hook for the NEXT get_opt_hclust_batch call of this device slot that runs as pipelined chunks: fn(ev) is called once, on the
 // host, right after the LAST chunk's agglomeration has been enqueued; ev is recorded behind that agglomeration.  For work that needs

@@ -513,6 +513,7 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
     SHARP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
     per_cu = std::max(1, std::min(per_cu, 2));
     per_cu = std::min(per_cu, std::max(1, knobs().rp_pc_wgs));
+    if (c.rp_wgs_cap > 0) per_cu = std::min(per_cu, c.rp_wgs_cap);
     const int grid = c.num_cu * per_cu;
     P.cap = (P.m + 3) / 4 * 4;
     W.sw.ensure(static_cast<size_t>(c.num_cu) * 2 * 2 * P.cap);       // per workgroup: [2 buffers][cap] words, [2][cap] terms

@@ -327,6 +327,8 @@ static Knobs read_knobs() {
     v.host_threads = num("SHARP_HOST_THREADS", 0);
     v.hc_half = num("SHARP_HC_HALF", 0) != 0;
     v.step_marks = num("SHARP_STEP_MARKS", 0) != 0;
+    v.front_overlap = num("SHARP_FRONT_OVERLAP", 0);
+    v.hc_first_chunk = num("SHARP_HC_FIRST_CHUNK", 0);
     v.hc_front = num("SHARP_HC_FRONT", 0);
     v.tail_priority = num("SHARP_TAIL_PRIORITY", 1) != 0;
     v.gemm_slice = num("SHARP_GEMM_SLICE", 8);

@@ -439,11 +439,19 @@ def test_unlimited_batched_base_clustering_equals_block_by_block(env, monkeypatc
         assert nw == n1 and np.array_equal(pw, p1)
     # the blocks' tails of a batched window run on helper threads with their own device slots (four by default; they finish in any
     # order): none (the calling thread, from the batch's progress callback), one and three must give the same call
-    for h in ("0", "1", "3"):
+    for h in ("0", "1", "3", "7"):
         monkeypatch.setenv("SHARP_TAIL_THREADS", h)
         ph, nh, _ = run()
         monkeypatch.delenv("SHARP_TAIL_THREADS")
         assert nh == n1 and np.array_equal(ph, p1), h
+    # the schedule switches of the window: the blocks' fronts (shuffle, RP kernel) enqueued just in time, two chunks ahead of the base
+    # tasks that read them (SHARP_FRONT_OVERLAP=1; =2: the later blocks' RP kernels with one workgroup per CU), and the first chunk's
+    # size (equal chunks / a short first chunk): the same tasks on the same inputs, whatever the order they are enqueued in
+    for var, val in (("SHARP_FRONT_OVERLAP", "1"), ("SHARP_FRONT_OVERLAP", "2"), ("SHARP_HC_FIRST_CHUNK", "-1"), ("SHARP_HC_FIRST_CHUNK", "150")):
+        monkeypatch.setenv(var, val)
+        ps, ns_, _ = run()
+        monkeypatch.delenv(var)
+        assert ns_ == n1 and np.array_equal(ps, p1), (var, val)
 
     def run_view():                                      # the viewflag form: every block's E1 rows, written by whichever helper ran its tail
         ptrs = (C.c_void_p * B)(*[x.data_ptr() for x in blocks])
