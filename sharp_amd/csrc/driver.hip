@@ -16,6 +16,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <ctime>
+#include <future>
 #include <mutex>
 #include <vector>
 
@@ -251,16 +252,42 @@ void drop_pending_front() {
     PF.f.reset();
 }
 
-static void large_front(LargeFront &F, const SharpArgs &a, bool ahead, double *E_into = nullptr, int *pos_into = nullptr) {
+// The shuffle of a block (:493-507): sample(n) after set.seed(50) -- 1 ms of host time for 50 000 cells, a function of n alone unless
+// rN.seed = 0.5.  It is computed on a thread of its own beside whatever the device work of the front needs first (the projector build:
+// 1.4 ms), and a SHARP_unlimited run asks for its first block's shuffle before it builds its projectors (shuffle_ahead).
+struct Shuffle { std::vector<int> reind, pos; };
+static Shuffle make_shuffle(int n, bool random_seed) {
+    Shuffle S;
+    RRng rng(random_seed ? static_cast<uint32_t>(std::random_device{}()) : 50u);   // :493-499
+    S.reind = rng.permutation(n);
+    S.pos.assign(n, 0);
+    for (int i = 0; i < n; ++i) S.pos[S.reind[i] - 1] = i;
+    return S;
+}
+namespace {
+struct ShuffleAhead { int n = 0; std::future<Shuffle> fut; };
+ShuffleAhead &shuffle_ahead_slot() { return per_slot<ShuffleAhead>(); }
+}  // namespace
+static void shuffle_ahead(long long n, double rN_seed) {
+    ShuffleAhead &H = shuffle_ahead_slot();
+    H.n = 0; H.fut = std::future<Shuffle>();
+    if (n >= 100000 || n < 5000 || rN_seed == 0.5) return;
+    H.n = static_cast<int>(n);
+    H.fut = std::async(std::launch::async, make_shuffle, static_cast<int>(n), false);
+}
+
+static void large_front(LargeFront &F, const SharpArgs &a, bool ahead, double *E_into = nullptr, int *pos_into = nullptr,
+                        const Shuffle *same_size = nullptr) {
     const int n = F.n, m = F.m, K = F.K, p = F.p;
     F.shuffle = n < 100000;                                                     // :504-507
     std::vector<int> &pos = F.pos;
-    pos.assign(n, 0);
+    std::future<Shuffle> shuf;
     if (F.shuffle) {
-        RRng rng((a.rN_seed == 0.5) ? static_cast<uint32_t>(std::random_device{}()) : 50u);   // :493-499
-        F.reind = rng.permutation(n);
-        for (int i = 0; i < n; ++i) pos[F.reind[i] - 1] = i;
-    }
+        ShuffleAhead &H = shuffle_ahead_slot();
+        if (same_size && a.rN_seed != 0.5 && static_cast<int>(same_size->pos.size()) == n) { F.reind = same_size->reind; pos = same_size->pos; }
+        else if (H.n == n && H.fut.valid() && a.rN_seed != 0.5) { shuf = std::move(H.fut); H.n = 0; }
+        else shuf = std::async(std::launch::async, make_shuffle, n, a.rN_seed == 0.5);
+    } else pos.assign(n, 0);
     F.fst = fold_starts(n, F.ng);
     F.T = static_cast<int>(F.fst.size()) - 1;
     // projectors drawn for this call: the block's compaction (which needs X only) is enqueued behind the draw kernel, on the second stream,
@@ -272,6 +299,7 @@ static void large_front(LargeFront &F, const SharpArgs &a, bool ahead, double *E
     if (knobs().rp_ahead >= 2) start_compaction();
     { HostTimer ht("projector_build"); F.pr = projector_for(a, m, p, K, &start_compaction); }       // :539-549
     F.ldE = static_cast<long long>(F.pr->K) * p;
+    if (shuf.valid()) { Shuffle S = shuf.get(); F.reind = std::move(S.reind); pos = std::move(S.pos); }
     if (E_into) {                                                               // (a block of a batch: rows of the batch's own buffers)
         F.E = E_into; F.dpos = F.shuffle ? pos_into : nullptr;
         if (F.shuffle) SHARP_HIP_CHECK(hipMemcpyAsync(pos_into, pos.data(), static_cast<size_t>(n) * sizeof(int), hipMemcpyHostToDevice, ctx().stream));
@@ -755,10 +783,12 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
     }
     // A block's front: its shuffle, its projection into its rows of the batch's E (the RP kernel), its K x T task descriptors.
     int fronts_done = 0;
+    Shuffle same_size;                                    // (the shuffle of the latest block: blocks of one size share it)
     const auto front_of = [&](int q) {
         if (fo >= 2 && q >= 2) ctx().rp_wgs_cap = 1;
-        large_front(*F[q], A[q], false, W.Ebatch.p + row0[q] * ldE, W.posbatch.p + row0[q]);
+        large_front(*F[q], A[q], false, W.Ebatch.p + row0[q] * ldE, W.posbatch.p + row0[q], &same_size);
         ctx().rp_wgs_cap = 0;
+        if (F[q]->shuffle && static_cast<int>(same_size.pos.size()) != F[q]->n) { same_size.reind = F[q]->reind; same_size.pos = F[q]->pos; }
     };
     std::function<hipEvent_t(size_t)> prepare;
     if (fo <= 0) {
@@ -1259,6 +1289,7 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
     std::vector<double> seeds(K);
     for (int k = 0; k < K; ++k) seeds[k] = (rN_seed == 0.5) ? 0.5 : 50 + rN_seed + (k + 1);                    // :97-104
     step_mark("SHARP_unlimited begins, blocks", nblocks);
+    shuffle_ahead(ncb[0], rN_seed);                        // (the first block's shuffle beside the projector build)
     const int proj = register_projector(build_projector(m, p, K, seeds.data()));
     std::vector<double> means;
     std::vector<long long> counts;
