@@ -876,7 +876,8 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
     auto helper_body = [&](int h) {
             try {
                 init_slot(tslot[h], dev, knobs().tail_priority);
-                host_pool_threads_hint(5);                 // (up to four helpers per GPU run their tails' host loops side by side)
+                // (several helpers per GPU run their tails' host loops side by side: 25 folds on five threads take five rounds, on thirteen two)
+                host_pool_threads_hint(std::max(5, std::min(12, host_cores() / (2 * (H + 1)))));
                 ctx().profiling = prof;
                 for (;;) {
                     int q;
