@@ -107,6 +107,7 @@ struct Knobs {
     int front_overlap = 0;      // SHARP_FRONT_OVERLAP=b (an experiment): in a batched SHARP_unlimited window the blocks from the b-th on are projected with ONE workgroup per CU and
                                 // the chunks of base tasks wait for their own blocks' projections only, so that the first distance GEMM runs beside the later blocks' RP kernels
     int hc_first_chunk = 0;     // SHARP_HC_FIRST_CHUNK=n: tasks in the first chunk of a pipelined batch (0: by the library, -1: equal chunks)
+    bool free_later = true;     // SHARP_FREE_LATER=0: a buffer that grows inside a batched SHARP_unlimited window is freed at once (hipFree drains the device) instead of when the window ends
     bool step_marks = false;    // SHARP_STEP_MARKS=1: host timestamps of a SHARP_unlimited call's milestones (chunks fetched, blocks' tails, merge) on stderr at its end
     int rp_shape = 0;           // SHARP_RP_SHAPE=1: 8 lanes x 4 slots per gene where the default is 16 x 2 (A/B runs)
 };
@@ -188,6 +189,10 @@ struct HostTimer {
 // (DevBuf::alloc_pooled): a block handed back is handed out again without any synchronisation, so the owner must have synchronised
 // the stream(s) that used it -- which is what every user of these buffers did before releasing them anyway.  Blocks up to 64 MB, at most
 // 512 MB held per process; sharp_trim() / sharp_shutdown() empty it.
+// hipFree drains the whole device.  While a pipelined SHARP_unlimited window runs (FreeLater scope: the device is busy until its last
+// agglomeration ends) a DevBuf that lets go of a block below 64 MB parks it instead; the parked blocks are freed when the last such scope ends.
+struct FreeLater { FreeLater(); ~FreeLater(); FreeLater(const FreeLater &) = delete; FreeLater &operator=(const FreeLater &) = delete; };
+bool free_later(void *p, size_t bytes);                // true: parked (a scope is open and the block is small); false: the caller frees it
 void *pool_take(size_t bytes, size_t *cap_bytes);      // a cached block of the current device with capacity >= bytes (its size class), or a fresh one
 void pool_give(void *p, size_t cap_bytes);
 void pool_clear();
@@ -230,7 +235,7 @@ struct DevBuf {
     }
     void release() {
         if (!p) return;
-        if (pooled_cap) pool_give(p, pooled_cap); else (void)hipFree(p);
+        if (pooled_cap) pool_give(p, pooled_cap); else if (!free_later(p, n * sizeof(T))) (void)hipFree(p);
         p = nullptr; n = 0; pooled_cap = 0;
     }
     void upload(const T *h, size_t count) {

@@ -750,6 +750,7 @@ void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector
 // deliver(b, out): called once per block; with SHARP_TAIL_THREADS > 0 (the default) from helper threads, in no particular order.
 static void unlimited_batch_window(const XRef *dX, const long long *ncb, const long long *ldb, int b0, int b1, int m, int p, int proj, int K,
                                    double rN_seed, const std::function<void(int, const SharpOut &)> &deliver) {
+    FreeLater park_frees;                                 // (a buffer that grows in a tail helper or between chunks: no hipFree, i.e. no drain of the device, before the window is through)
     PendingFront &PF = pending_front();
     hc_set_after_last_agglomeration(nullptr);             // (every block's tail enqueues its own ensemble mean here)
     if (PF.f) { SHARP_HIP_CHECK(hipStreamSynchronize(PF.stream)); PF.f.reset(); }   // (no block-by-block front may be pending)

@@ -240,6 +240,24 @@ size_t pool_class(size_t bytes) {
     return c;
 }
 }  // namespace
+namespace {
+struct Parked { std::mutex mu; int scopes = 0; std::vector<void *> blocks; };
+Parked &parked() { static Parked *P = new Parked; return *P; }
+}  // namespace
+FreeLater::FreeLater() { Parked &P = parked(); std::lock_guard<std::mutex> lk(P.mu); ++P.scopes; }
+FreeLater::~FreeLater() {
+    std::vector<void *> gone;
+    { Parked &P = parked(); std::lock_guard<std::mutex> lk(P.mu); if (--P.scopes == 0) gone.swap(P.blocks); }
+    for (void *p : gone) (void)hipFree(p);
+}
+bool free_later(void *p, size_t bytes) {
+    if (bytes > (64ull << 20) || !knobs().free_later) return false;
+    Parked &P = parked();
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (P.scopes <= 0) return false;
+    P.blocks.push_back(p);
+    return true;
+}
 void *pool_take(size_t bytes, size_t *cap_bytes) {
     int dev = 0;
     SHARP_HIP_CHECK(hipGetDevice(&dev));
@@ -327,6 +345,7 @@ static Knobs read_knobs() {
     v.host_threads = num("SHARP_HOST_THREADS", 0);
     v.hc_half = num("SHARP_HC_HALF", 0) != 0;
     v.step_marks = num("SHARP_STEP_MARKS", 0) != 0;
+    v.free_later = num("SHARP_FREE_LATER", 1) != 0;
     v.front_overlap = num("SHARP_FRONT_OVERLAP", 0);
     v.hc_first_chunk = num("SHARP_HC_FIRST_CHUNK", 0);
     v.hc_front = num("SHARP_HC_FRONT", 0);
