@@ -1316,10 +1316,14 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
     int nf = 0;
     unlimited_merge(means.data(), counts.data(), first[nblocks], p, ncells, N_cluster, minN, maxN, fid, nf);
     step_mark("merge done, clusters", nf);
-    off = 0;
-    for (int b = 0; b < nblocks; ++b) {
-        for (long long i = 0; i < ncb[b]; ++i) pred[off + i] = fid[first[b] + pred[off + i] - 1];
-        off += ncb[b];
+    {
+        std::vector<long long> offs(nblocks + 1, 0);
+        for (int b = 0; b < nblocks; ++b) offs[b + 1] = offs[b] + ncb[b];
+        host_parallel_for(nblocks, 16, [&](int b) {              // (every block's cells through the merge's map: 0.3 ms for 500 000 cells on one thread)
+            int *pb = pred + offs[b];
+            const int *map = fid.data() + first[b];
+            for (long long i = 0; i < ncb[b]; ++i) pb[i] = map[pb[i] - 1];
+        });
     }
     if (n_pred) *n_pred = nf;
     if (p_used) *p_used = p;
