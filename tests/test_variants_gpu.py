@@ -112,3 +112,18 @@ def test_run_via_host_unlimited_with_ragged_blocks(sa, oracle):
     ref = oracle.SHARP_unlimited(blocks, rN_seed=2103, nthreads=8)
     res = sa.SHARP_unlimited(blocks, rN_seed=2103)
     assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
+
+
+def test_unseeded_run_rn_seed_one_half(sa, oracle):
+    """rN.seed missing = 0.5 (R/SHARP.R:493-499, R/SHARP_unlimited.R:97-104): projectors and shuffle from the system's entropy -- nothing to compare
+    label for label, so the large path (whose shuffle now runs on a thread of its own beside the projector build) and SHARP_unlimited
+    are checked against the planted clusters, twice (two different shuffles, the same partition)."""
+    X = _data(oracle, m=2500, n=6100, G=5, nm=300)
+    truth = oracle.synth_cluster(SEED, range(6100), 5)
+    for _ in range(2):
+        res = sa.SHARP(X, logflag=False, prep=False)                     # rN_seed missing: 0.5
+        assert adjusted_rand_score(truth, res["pred_clusters"]) > 0.95
+    blocks = [_data(oracle, n=n, cell0=c0) for n, c0 in [(5300, 0), (5200, 6000)]]
+    tb = np.concatenate([oracle.synth_cluster(SEED, range(c0, c0 + n), 5) for n, c0 in [(5300, 0), (5200, 6000)]])
+    res = sa.SHARP_unlimited(blocks)
+    assert adjusted_rand_score(tb, res["pred_clusters"]) > 0.95
