@@ -251,11 +251,14 @@ int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long lon
                                    int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred,
                                    int *p_used, double *viE);
 /* viewflag above 1e5 cells (R/SHARP_unlimited.R:216-228): enresults$viE is not E1 but 1/sqrt(kdim) * E1 %*% ranM2(p, kdim, seed), kdim = 50.
- * sharp_unlimited_view_dim(kdim) arms that for the NEXT SHARP_unlimited call of the process (any of the entries above that takes a viE
- * buffer; one-shot, like sharp_unlimited_next_block_dev): every block's product is taken on its GPU as soon as the block's viE exists and
- * the caller's viE receives ncells x kdim doubles (row-major) instead of ncells x p.  kdim = 0 disarms.  The seed expression of :222 reads an
- * undefined `k` (an R error whenever rN.seed is given): taken as ensize.K + 1, the next seed of the projector sequence.
- * sharp_SHARP_unlimited_viewk_dev = sharp_unlimited_view_dim(view_dim) + sharp_SHARP_unlimited_view_dev. */
+ * Every block's product is taken on its GPU as soon as the block's viE exists and the caller's viE receives ncells x kdim doubles
+ * (row-major) instead of ncells x p.  sharp_SHARP_unlimited_viewk_dev carries kdim as an argument.  For the other entries that take a viE
+ * buffer sharp_unlimited_view_dim(kdim) arms it for the NEXT SHARP_unlimited call OF THE CALLING THREAD (one-shot and thread-local: a call
+ * made by another thread never takes it; the call that takes it keeps kdim and its seed as state of its own, so overlapping calls of one
+ * process do not see each other).  Arm it immediately before the call; kdim = 0 disarms.  ONE z0 per call: seed 50 + rN.seed + ensize.K + 1
+ * (the expression of :222 reads an undefined `k`, an R error whenever rN.seed is given: taken as the next seed of the projector sequence),
+ * or, for an unseeded call, one random integer seed drawn when the call begins and used for every block, helper thread and device (:219-225
+ * draw z0 once and multiply all of E1 by it). */
 int sharp_unlimited_view_dim(int kdim);
 int sharp_SHARP_unlimited_viewk_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
                                     int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred,
@@ -293,6 +296,12 @@ int sharp_SHARP_unlimited2_dev(const float *const *dX_blocks, const long long *n
 int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
                                    double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
                                    long long *counts, double *viE);
+/* The same with the view reduction as arguments (a caller that runs its blocks one call at a time, e.g. a rank of the sharded run): viE
+ * receives nb x view_dim doubles (view_dim = 0: nb x p); view_seed: the integer seed of the RUN's z0 = ranM2(p, view_dim, view_seed),
+ * the same for every block and rank (50 + rN.seed + ensize.K + 1, or one random integer per run when the run is unseeded). */
+int sharp_unlimited_block_viewk_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
+                                    double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
+                                    long long *counts, int view_dim, double view_seed, double *viE);
 int sharp_unlimited_merge(const double *means, const long long *counts, int nC, int p, long long ncells, int N_cluster,
                           int minN, int maxN, int *final_id, int *n_final);
 /* One-shot hint for a caller that runs its blocks one call at a time (a rank of the sharded run with several blocks per GPU): the block

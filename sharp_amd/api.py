@@ -485,8 +485,18 @@ def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster
     # block on the GPU (sharp_unlimited_view_dim), so that ncells x 50 doubles come back instead of ncells x p
     kdim = 50 if (viewflag and n > 1e5) else 0
     viE = np.zeros((n, kdim if kdim else p)) if viewflag else None
-    if kdim:
-        check(lib().sharp_unlimited_view_dim(kdim))
+
+    def call(entry, *args):
+        # the arm is one-shot and thread-local in the library, taken by the call that follows on this thread; it is set here, after all the
+        # marshalling that can raise, and withdrawn if the call itself is never made
+        try:
+            if kdim:
+                check(lib().sharp_unlimited_view_dim(kdim))
+            return check(entry(*args), allow=48)
+        finally:
+            if kdim:
+                lib().sharp_unlimited_view_dim(0)
+
     if sparse:
         # only the non-zeros of a block cross PCIe, block b + W while block b is clustered (sharp_SHARP_unlimited_csc_multi)
         cps, ris = _csc_int_slots(blocks)
@@ -496,10 +506,9 @@ def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster
         rip = (C.POINTER(C.c_int) * B)(*[_ip(a) if a.size else C.cast(None, C.POINTER(C.c_int)) for a in ris])
         vxp = (C.POINTER(C.c_double) * B)(*[_dp(a) if a.size else C.cast(None, C.POINTER(C.c_double)) for a in vxs])
         dv = np.ascontiguousarray(devices if devices is not None else [], np.int32)
-        check(lib().sharp_SHARP_unlimited_csc_multi(cpp, rip, vxp, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), B, m, int(ensize_K or 0),
-                                                    int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0), C.c_double(rN_seed),
-                                                    _ip(dv) if dv.size else None, int(dv.size), _ip(pred), C.byref(npred), C.byref(pu),
-                                                    _dp(viE)), allow=48)
+        call(lib().sharp_SHARP_unlimited_csc_multi, cpp, rip, vxp, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), B, m, int(ensize_K or 0),
+             int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0), C.c_double(rN_seed),
+             _ip(dv) if dv.size else None, int(dv.size), _ip(pred), C.byref(npred), C.byref(pu), _dp(viE))
         K = int(ensize_K or 5)
         out = _enresults(pred, None, None, n, m, pu.value, K, t0, {}, False, key="N.pred_clusters")
         if viewflag:                                                      # :215-232
@@ -509,14 +518,13 @@ def SHARP_unlimited(scExp, viewflag=True, n_cores=None, ensize_K=None, N_cluster
     ptrs = (C.POINTER(C.c_double) * len(blocks))(*[_dp(b) for b in blocks])
     if devices is not None and len(devices) >= 1:
         dv = np.ascontiguousarray(devices, np.int32)
-        check(lib().sharp_SHARP_unlimited_multi(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), len(blocks), m, int(ensize_K or 0),
-                                                int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0),
-                                                C.c_double(rN_seed), _ip(dv), len(dv), _ip(pred), C.byref(npred), C.byref(pu), _dp(viE)),
-              allow=48)
+        call(lib().sharp_SHARP_unlimited_multi, ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), len(blocks), m, int(ensize_K or 0),
+             int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0),
+             C.c_double(rN_seed), _ip(dv), len(dv), _ip(pred), C.byref(npred), C.byref(pu), _dp(viE))
     else:
-        check(lib().sharp_SHARP_unlimited_view(ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), len(blocks), m, int(ensize_K or 0),
-                                               int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0),
-                                               C.c_double(rN_seed), _ip(pred), C.byref(npred), C.byref(pu), _dp(viE)), allow=48)
+        call(lib().sharp_SHARP_unlimited_view, ptrs, ncb.ctypes.data_as(C.POINTER(C.c_longlong)), len(blocks), m, int(ensize_K or 0),
+             int(N_cluster or 0), int(minN_cluster or 0), int(maxN_cluster or 0),
+             C.c_double(rN_seed), _ip(pred), C.byref(npred), C.byref(pu), _dp(viE))
     K = int(ensize_K or 5)
     out = _enresults(pred, None, None, n, m, pu.value, K, t0, {}, False, key="N.pred_clusters")
     if viewflag:                                                          # :215-232

@@ -190,7 +190,7 @@ struct HostTimer {
 // the stream(s) that used it -- which is what every user of these buffers did before releasing them anyway.  Blocks up to 64 MB, at most
 // 512 MB held per process; sharp_trim() / sharp_shutdown() empty it.
 // hipFree drains the whole device.  While a pipelined SHARP_unlimited window runs (FreeLater scope: the device is busy until its last
-// agglomeration ends) a DevBuf that lets go of a block below 64 MB parks it instead; the parked blocks are freed when the last such scope ends.
+// agglomeration ends) a DevBuf that lets go of a block below 64 MB parks it instead (at most 1 GB parked: beyond that it is freed at once); the parked blocks are freed when the last such scope ends.
 struct FreeLater { FreeLater(); ~FreeLater(); FreeLater(const FreeLater &) = delete; FreeLater &operator=(const FreeLater &) = delete; };
 bool free_later(void *p, size_t bytes);                // true: parked (a scope is open and the block is small); false: the caller frees it
 void *pool_take(size_t bytes, size_t *cap_bytes);      // a cached block of the current device with capacity >= bytes (its size class), or a fresh one

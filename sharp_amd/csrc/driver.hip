@@ -658,11 +658,20 @@ void sharp_front_dev(XRef dX, int m, long long n_, long long ld, SharpArgs a, Sh
 // ---------------------------------------------------------------------------------------------
 // one block: y[[i]] = SHARP(mat, reduced.ndim = p, prep = FALSE, logflag = FALSE, rM = rM, ensize.K, rN.seed)
 // (:135) and the colMeans of its viE per predicted cluster -- all sMetaC ever uses of E1 (:163, R/sMetaC.R:58-63)
+// The view reduction of ONE SHARP_unlimited call (R/SHARP_unlimited.R:216-228), fixed when the call begins and handed down by value to
+// everything that works for it (block loops, tail helpers, device workers): kdim > 0 = the caller's viE takes kdim columns per cell, the
+// product E1 %*% ranM2(p, kdim, seed) taken per block on the device; seed = the ONE seed of that call's z0 (an integer, also for an
+// unseeded run: the reference draws z0 once and multiplies all of E1 by it, :219-225).
+struct ViewCall {
+    int kdim = 0;
+    double seed = 0;
+    int cols(int p) const { return kdim > 0 ? kdim : p; }
+};
 void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector<int> &pred, std::vector<double> &means,
-                             std::vector<long long> &counts, double *viE_host);
+                             std::vector<long long> &counts, double *viE_host, const ViewCall &view);
 void unlimited_block_dev(XRef dX, int m, long long nb, long long ld, int p, int projector, int K, double rN_seed,
                          std::vector<int> &pred, std::vector<double> &means, std::vector<long long> &counts, double *viE_host,
-                         int flag = 1, const SharpArgs *fpart_args = nullptr, XRef next_dX = XRef(), long long next_n = 0,
+                         const ViewCall &view, int flag = 1, const SharpArgs *fpart_args = nullptr, XRef next_dX = XRef(), long long next_n = 0,
                          long long next_ld = 0) {
     SharpArgs a;
     if (fpart_args) a = *fpart_args;                                            // SHARP_unlimited2: every SHARP_fpart parameter
@@ -671,41 +680,39 @@ void unlimited_block_dev(XRef dX, int m, long long nb, long long ld, int p, int 
     a.fpart = fpart_args != nullptr;
     SharpOut o;
     sharp_front_dev(dX, m, nb, ld, a, o);
-    unlimited_block_summary(o, nb, p, pred, means, counts, viE_host);
+    unlimited_block_summary(o, nb, p, pred, means, counts, viE_host, view);
 }
 
 // viewflag above 1e5 cells (R/SHARP_unlimited.R:216-228): enresults$viE = 1/sqrt(kdim) * E1 %*% ranM2(p, kdim, seed), kdim = 50.  E1 (ncells x p) exists
 // only to be multiplied: the product is taken PER BLOCK on the device, by the RP kernels themselves (the block's viE as an fp64 "expression"
 // block of p genes, raw mode), as soon as the block's tail has its viE, and ncells x kdim doubles leave the GPU instead of ncells x p
-// (cfg3: 0.2 GB instead of 1.9 GB).  Armed for ONE SHARP_unlimited call by sharp_unlimited_view_dim(); every pointer into the caller's viE
-// is then taken with view_cols(p) columns per cell.
-struct ViewReduce {
-    std::mutex mu;
-    int pending = 0;         // set by sharp_unlimited_view_dim(): the next SHARP_unlimited call takes it
-    int kdim = 0;            // > 0 while that call runs
-    double seed = 0.5;
-};
-ViewReduce &view_reduce() { static ViewReduce v; return v; }
-int view_cols(int p) { const int k = view_reduce().kdim; return k > 0 ? k : p; }
-struct ViewGuard {           // at the top of a SHARP_unlimited run: pending -> active, cleared when the run ends (however it ends)
-    bool own = false;
-    ViewGuard(double rN_seed, int K) {
-        ViewReduce &v = view_reduce();
-        std::lock_guard<std::mutex> lk(v.mu);
-        if (v.pending <= 0) return;                      // (not armed, or an outer run of this call holds it)
-        own = true;
-        v.kdim = v.pending; v.pending = 0;
-        // `50 + rN.seed + k` at :222 reads a `k` that only exists inside the foreach at :96 (an R error whenever a seed
-        // is given); fixed as the next seed of that sequence, k = ensize.K + 1
-        v.seed = rN_seed == 0.5 ? 0.5 : 50 + rN_seed + K + 1;
-    }
-    ~ViewGuard() { if (!own) return; ViewReduce &v = view_reduce(); std::lock_guard<std::mutex> lk(v.mu); v.kdim = 0; }
-};
+// (cfg3: 0.2 GB instead of 1.9 GB).  The entries that carry a view_dim argument say so themselves; for the others sharp_unlimited_view_dim()
+// arms it for the NEXT SHARP_unlimited call OF THE CALLING THREAD (the arm is thread-local: a call on another thread never takes it, and
+// nothing of a running call is shared).  take_view() at the top of a run turns the arm into that run's ViewCall -- whatever the run then
+// does, the arm is spent.
+thread_local int tl_view_pending = 0;
+static double fresh_view_seed() {                        // an unseeded run: one integer seed for the call's z0 (set.seed() of a random word)
+    std::random_device rd;
+    return static_cast<double>(rd() & 0x7fffffffu);
+}
+static ViewCall make_view(int kdim, double rN_seed, int K) {
+    ViewCall v;
+    v.kdim = kdim > 0 ? kdim : 0;
+    // `50 + rN.seed + k` at :222 reads a `k` that only exists inside the foreach at :96 (an R error whenever a seed
+    // is given); fixed as the next seed of that sequence, k = ensize.K + 1
+    if (v.kdim > 0) v.seed = rN_seed == 0.5 ? fresh_view_seed() : 50 + rN_seed + K + 1;
+    return v;
+}
+static ViewCall take_view(double rN_seed, int K) {
+    const int kdim = tl_view_pending;
+    tl_view_pending = 0;
+    return make_view(kdim, rN_seed, K);
+}
 struct ViewProj { std::shared_ptr<Projector> pr; int p = 0, kdim = 0; double seed = 0; DevBuf<double> out, pad; };
 
 // labels, per-cluster means of viE and cluster sizes of one finished block (what the cross-block sMetaC needs, :153-163)
 void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector<int> &pred, std::vector<double> &means,
-                             std::vector<long long> &counts, double *viE_host) {
+                             std::vector<long long> &counts, double *viE_host, const ViewCall &view) {
     pred = o.pred;
     const int G = o.n_pred;
     std::vector<int> uid(pred.size());
@@ -717,11 +724,11 @@ void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector
     means.resize(static_cast<size_t>(G) * p);
     dm.download(means.data(), means.size());
     if (!viE_host) return;
-    const int kdim = view_reduce().kdim;
+    const int kdim = view.kdim;
     if (kdim <= 0) { o.viE.download(viE_host, static_cast<size_t>(nb) * p); return; }   // E1 rows of this block (:153), viewflag only
     ViewProj &V = per_slot<ViewProj>();                                         // (a tail helper's slot builds its own, once)
-    const double seed = view_reduce().seed;
-    if (!V.pr || V.p != p || V.kdim != kdim || V.seed != seed || seed == 0.5) {
+    const double seed = view.seed;                                              // (one z0 per call: every block, slot and device builds the same one)
+    if (!V.pr || V.p != p || V.kdim != kdim || V.seed != seed) {
         V.pr = build_projector(p, kdim, 1, &seed);                              // ranM2(p, kdim, seed): the same draw as ranM (R/ranM2.R:11-35)
         V.p = p; V.kdim = kdim; V.seed = seed;
     }
@@ -1155,11 +1162,13 @@ int sharp_unlimited_next_block_dev(const float *dX_next, long long nb_next, long
     return SHARP_OK;
 }
 
-int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
-                                   double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
-                                   long long *counts, double *viE) {
+static int unlimited_block_view_entry(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
+                                      double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
+                                      long long *counts, double *viE, const ViewCall *view_in) {
     SHARP_API_BEGIN
-    ViewGuard vg(rN_seed, ensize_K > 0 ? ensize_K : 5);     // (a rank of the sharded run arms sharp_unlimited_view_dim per block: its E1 rows come back reduced)
+    // (a caller that arms sharp_unlimited_view_dim per block gets its E1 rows back reduced; block by block an UNSEEDED run must say which z0
+    // its blocks share: sharp_unlimited_block_viewk_dev)
+    const ViewCall view = view_in ? *view_in : take_view(rN_seed, ensize_K > 0 ? ensize_K : 5);
     ctx();
     SHARP_REQUIRE(pred && n_clusters && means && counts, "sharp_unlimited_block_view_dev: null output");
     std::vector<int> pr;
@@ -1167,7 +1176,7 @@ int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long lo
     std::vector<long long> cn;
     const NextHint h = next_hint();
     next_hint() = NextHint();
-    unlimited_block_dev(dX, m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, viE, flag != 0, nullptr,
+    unlimited_block_dev(dX, m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, viE, view, flag != 0, nullptr,
                         h.dX ? XRef(h.dX) : XRef(), h.nb, h.ld);
     SHARP_REQUIRE(static_cast<int>(cn.size()) <= cap_rows, "sharp_unlimited_block_view_dev: centroid buffer too small");
     std::copy(pr.begin(), pr.end(), pred);
@@ -1175,6 +1184,25 @@ int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long lo
     std::copy(cn.begin(), cn.end(), counts);
     *n_clusters = static_cast<int>(cn.size());
     SHARP_API_END
+}
+
+int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
+                                   double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
+                                   long long *counts, double *viE) {
+    return unlimited_block_view_entry(dX, m, nb, ld, p, projector, ensize_K, rN_seed, flag, pred, n_clusters, means, cap_rows, counts, viE, nullptr);
+}
+
+int sharp_unlimited_block_viewk_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
+                                    double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
+                                    long long *counts, int view_dim, double view_seed, double *viE) {
+    if (view_dim < 0 || view_dim > 4096 || (view_dim > 0 && std::fmod(view_seed, 1.0) != 0.0)) {
+        sharp::set_error("sharp_unlimited_block_viewk_dev: view_dim must lie in 0 .. 4096 and view_seed must be an integer (the seed of the run's z0)");
+        return SHARP_ERR_ARG;
+    }
+    ViewCall v;
+    v.kdim = viE ? view_dim : 0;
+    v.seed = view_seed;
+    return unlimited_block_view_entry(dX, m, nb, ld, p, projector, ensize_K, rN_seed, flag, pred, n_clusters, means, cap_rows, counts, viE, &v);
 }
 
 int sharp_unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K, double rN_seed,
@@ -1185,7 +1213,7 @@ int sharp_unlimited_block_dev(const float *dX, int m, long long nb, long long ld
     std::vector<int> pr;
     std::vector<double> mn;
     std::vector<long long> cn;
-    unlimited_block_dev(dX, m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, nullptr);
+    unlimited_block_dev(dX, m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, nullptr, ViewCall());
     SHARP_REQUIRE(static_cast<int>(cn.size()) <= cap_rows, "sharp_unlimited_block_dev: centroid buffer too small");
     std::copy(pr.begin(), pr.end(), pred);
     std::copy(mn.begin(), mn.end(), means);
@@ -1202,7 +1230,7 @@ int sharp_unlimited_block_dev64(const double *dX, int m, long long nb, long long
     std::vector<int> pr;
     std::vector<double> mn;
     std::vector<long long> cn;
-    unlimited_block_dev(dev64_ref(dX, m, nb, ld), m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, nullptr);
+    unlimited_block_dev(dev64_ref(dX, m, nb, ld), m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, nullptr, ViewCall());
     SHARP_REQUIRE(static_cast<int>(cn.size()) <= cap_rows, "sharp_unlimited_block_dev64: centroid buffer too small");
     std::copy(pr.begin(), pr.end(), pred);
     std::copy(mn.begin(), mn.end(), means);
@@ -1232,6 +1260,7 @@ int sharp_unlimited_merge(const double *means, const long long *counts, int nC, 
 // take(b, labels, cluster means, cluster sizes) is called once per block, in block order.
 static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m, int p, int proj, int K,
                                   double rN_seed, double *const *viE_of,   // NULL, or per block where its E1 rows go (NULL: not wanted)
+                                  const ViewCall &view,
                                   const std::function<void(int, std::vector<int> &, std::vector<double> &, std::vector<long long> &)> &take) {
     {
         int b = 0;
@@ -1255,7 +1284,7 @@ static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, c
                 std::vector<Got> got(e - b);                                    // (the window's tails finish on helper threads, in any order)
                 unlimited_batch_window(dX_blocks, ncb, ldb, b, e, m, p, proj, K, rN_seed, [&](int bb, const SharpOut &o) {
                     Got &g = got[bb - b];
-                    unlimited_block_summary(o, ncb[bb], p, g.pb, g.mb, g.cb, viE_of ? viE_of[bb] : nullptr);
+                    unlimited_block_summary(o, ncb[bb], p, g.pb, g.mb, g.cb, viE_of ? viE_of[bb] : nullptr, view);
                 });
                 for (int q = b; q < e; ++q) take(q, got[q - b].pb, got[q - b].mb, got[q - b].cb);
                 b = e;
@@ -1266,7 +1295,7 @@ static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, c
             std::vector<long long> cb;
             const bool more = b + 1 < nblocks;
             unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb,
-                                viE_of ? viE_of[b] : nullptr, 1, nullptr, more ? dX_blocks[b + 1] : XRef(),
+                                viE_of ? viE_of[b] : nullptr, view, 1, nullptr, more ? dX_blocks[b + 1] : XRef(),
                                 more ? ncb[b + 1] : 0, more ? ldb[b + 1] : 0);
             take(b, pb, mb, cb);
             ++b;
@@ -1277,9 +1306,9 @@ static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, c
 // SHARP_unlimited on resident blocks (fp32 or fp64 each)
 static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
                          int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used,
-                         double *viE) {
+                         double *viE, const ViewCall *view_in = nullptr) {
     SHARP_API_BEGIN
-    ViewGuard vg(rN_seed, ensize_K > 0 ? ensize_K : 5);     // (first: a call that fails its argument checks disarms the view dimension too)
+    const ViewCall view = view_in ? *view_in : take_view(rN_seed, ensize_K > 0 ? ensize_K : 5);   // (first: a call that fails its argument checks spends the arm too)
     ctx();
     SHARP_REQUIRE(dX_blocks && ncb && ldb && pred, "The input should be a LIST of partitioned scRNA-seq expression matrices!");
     SHARP_REQUIRE(nblocks >= 2, "SHARP is used instead of SHARP_unlimited because the length of the input is 1!");
@@ -1307,8 +1336,8 @@ static int unlimited_run(const XRef *dX_blocks, const long long *ncb, const long
         };
         std::vector<double *> viE_of(nblocks, nullptr);
         long long at = 0;
-        for (int b = 0; b < nblocks; ++b) { if (viE) viE_of[b] = viE + static_cast<size_t>(at) * view_cols(p); at += ncb[b]; }
-        unlimited_blocks_loop(dX_blocks, ncb, ldb, nblocks, m, p, proj, K, rN_seed, viE ? viE_of.data() : nullptr, take);
+        for (int b = 0; b < nblocks; ++b) { if (viE) viE_of[b] = viE + static_cast<size_t>(at) * view.cols(p); at += ncb[b]; }
+        unlimited_blocks_loop(dX_blocks, ncb, ldb, nblocks, m, p, proj, K, rN_seed, viE ? viE_of.data() : nullptr, view, take);
     } catch (...) { drop_projector(proj); throw; }
     step_mark("blocks done, projector dropped: merge of centroids", first[nblocks]);
     drop_projector(proj);
@@ -1367,7 +1396,7 @@ static int unlimited2_run(const XRef *dX_blocks, const long long *ncb, const lon
             std::vector<long long> cb;
             const bool more = b + 1 < nblocks;
             unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb,
-                                viE ? viE + static_cast<size_t>(off) * p : nullptr, flag ? 2 : 0, &fa, more ? dX_blocks[b + 1] : XRef(),
+                                viE ? viE + static_cast<size_t>(off) * p : nullptr, ViewCall(), flag ? 2 : 0, &fa, more ? dX_blocks[b + 1] : XRef(),
                                 more ? ncb[b + 1] : 0, more ? ldb[b + 1] : 0);
             std::copy(pb.begin(), pb.end(), pred + off);
             means.insert(means.end(), mb.begin(), mb.end());
@@ -1410,7 +1439,7 @@ int sharp_unlimited_blocks_dev(const void *const *dX_blocks, const int *is_f64, 
     }
     long long off = 0;
     int rows = 0;
-    unlimited_blocks_loop(refs.data(), ncb, ldb, nblocks, m, p, projector, K, rN_seed, nullptr,
+    unlimited_blocks_loop(refs.data(), ncb, ldb, nblocks, m, p, projector, K, rN_seed, nullptr, ViewCall(),
                           [&](int b, std::vector<int> &pb, std::vector<double> &mb, std::vector<long long> &cb) {
         SHARP_REQUIRE(rows + static_cast<int>(cb.size()) <= cap_rows, "sharp_unlimited_blocks_dev: centroid buffer too small");
         std::copy(pb.begin(), pb.end(), pred + off);
@@ -1483,7 +1512,7 @@ double wall_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv
 int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K, int N_cluster, int minN, int maxN, double rN_seed,
                         const int *devices, int ndev, int *pred, int *n_pred, int *p_used, double *viE) {
     SHARP_API_BEGIN
-    ViewGuard vg(rN_seed, ensize_K > 0 ? ensize_K : 5);
+    const ViewCall view = take_view(rN_seed, ensize_K > 0 ? ensize_K : 5);       // (by value into every worker: one z0 on all devices)
     const int nblocks = static_cast<int>(blocks.size());
     SHARP_REQUIRE(pred, "The input should be a LIST of partitioned scRNA-seq expression matrices!");
     SHARP_REQUIRE(nblocks >= 2, "SHARP is used instead of SHARP_unlimited because the length of the input is 1!");
@@ -1608,10 +1637,10 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
                     for (size_t i = 0; i < my.size(); ++i) {
                         block_ref(i, true, refs[i], ll[i]);
                         nn[i] = blocks[my[i]].n;
-                        if (viE) vo[i] = viE + static_cast<size_t>(cell0[my[i]]) * view_cols(p);
+                        if (viE) vo[i] = viE + static_cast<size_t>(cell0[my[i]]) * view.cols(p);
                     }
                     const double t_go = wall_s() - t_begin;
-                    unlimited_blocks_loop(refs.data(), nn.data(), ll.data(), static_cast<int>(my.size()), m, p, proj, K, rN_seed, viE ? vo.data() : nullptr,
+                    unlimited_blocks_loop(refs.data(), nn.data(), ll.data(), static_cast<int>(my.size()), m, p, proj, K, rN_seed, viE ? vo.data() : nullptr, view,
                                           [&](int i, std::vector<int> &a, std::vector<double> &c, std::vector<long long> &d) {
                         const int b = my[i];
                         pb[b].swap(a); mb[b].swap(c); cb[b].swap(d);
@@ -1629,8 +1658,8 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
                     const bool more = i + 1 < my.size() && block_ref(i + 1, false, nref, nld);
                     tl[static_cast<size_t>(b) * 6 + 4] = wall_s() - t_begin;
                     unlimited_block_dev(ref, m, blocks[b].n, ld, p, proj, K, rN_seed, pb[b], mb[b], cb[b],
-                                        viE ? viE + static_cast<size_t>(cell0[b]) * view_cols(p) : nullptr,   // E1 rows of this block (:153), viewflag only
-                                        1, nullptr, more ? nref : XRef(), more ? blocks[my[i + 1]].n : 0, more ? nld : 0);
+                                        viE ? viE + static_cast<size_t>(cell0[b]) * view.cols(p) : nullptr,   // E1 rows of this block (:153), viewflag only
+                                        view, 1, nullptr, more ? nref : XRef(), more ? blocks[my[i + 1]].n : 0, more ? nld : 0);
                     tl[static_cast<size_t>(b) * 6 + 5] = wall_s() - t_begin;
                     tl[static_cast<size_t>(b) * 6 + 0] = w; tl[static_cast<size_t>(b) * 6 + 1] = b;
                     if (blocks[b].on_host()) {
@@ -1734,17 +1763,18 @@ int sharp_SHARP_unlimited_view_dev(const float *const *dX_blocks, const long lon
 int sharp_unlimited_view_dim(int kdim) {
     SHARP_API_BEGIN
     SHARP_REQUIRE(kdim >= 0 && kdim <= 4096, "sharp_unlimited_view_dim: the view dimension must lie in 0 .. 4096");
-    ViewReduce &v = view_reduce();
-    std::lock_guard<std::mutex> lk(v.mu);
-    v.pending = kdim;
+    tl_view_pending = kdim;
     SHARP_API_END
 }
 
 int sharp_SHARP_unlimited_viewk_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,
                                     int ensize_K, int N_cluster, int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used,
                                     int view_dim, double *viE) {
-    if (const int rc = sharp_unlimited_view_dim(viE ? view_dim : 0)) return rc;
-    return sharp_SHARP_unlimited_view_dev(dX_blocks, ncb, ldb, nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred, p_used, viE);
+    if (view_dim < 0 || view_dim > 4096) { sharp::set_error("sharp_SHARP_unlimited_viewk_dev: the view dimension must lie in 0 .. 4096"); return SHARP_ERR_ARG; }
+    tl_view_pending = 0;                                                       // (the explicit argument wins over an earlier arm)
+    const ViewCall view = make_view(viE ? view_dim : 0, rN_seed, ensize_K > 0 ? ensize_K : 5);
+    const std::vector<XRef> refs = f32_refs(dX_blocks, nblocks);
+    return unlimited_run(dX_blocks ? refs.data() : nullptr, ncb, ldb, nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred, p_used, viE, &view);
 }
 
 int sharp_SHARP_unlimited2_dev(const float *const *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m,

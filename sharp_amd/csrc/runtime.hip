@@ -241,21 +241,23 @@ size_t pool_class(size_t bytes) {
 }
 }  // namespace
 namespace {
-struct Parked { std::mutex mu; int scopes = 0; std::vector<void *> blocks; };
+struct Parked { std::mutex mu; int scopes = 0; std::vector<void *> blocks; size_t bytes = 0; };
+constexpr size_t kParkedMaxBytes = 1ull << 30;      // (overlapping windows on several GPUs keep the scope open: beyond 1 GB parked the block is freed at once)
 Parked &parked() { static Parked *P = new Parked; return *P; }
 }  // namespace
 FreeLater::FreeLater() { Parked &P = parked(); std::lock_guard<std::mutex> lk(P.mu); ++P.scopes; }
 FreeLater::~FreeLater() {
     std::vector<void *> gone;
-    { Parked &P = parked(); std::lock_guard<std::mutex> lk(P.mu); if (--P.scopes == 0) gone.swap(P.blocks); }
+    { Parked &P = parked(); std::lock_guard<std::mutex> lk(P.mu); if (--P.scopes == 0) { gone.swap(P.blocks); P.bytes = 0; } }
     for (void *p : gone) (void)hipFree(p);
 }
 bool free_later(void *p, size_t bytes) {
     if (bytes > (64ull << 20) || !knobs().free_later) return false;
     Parked &P = parked();
     std::lock_guard<std::mutex> lk(P.mu);
-    if (P.scopes <= 0) return false;
+    if (P.scopes <= 0 || P.bytes + bytes > kParkedMaxBytes) return false;
     P.blocks.push_back(p);
+    P.bytes += bytes;
     return true;
 }
 void *pool_take(size_t bytes, size_t *cap_bytes) {

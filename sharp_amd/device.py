@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import check, lib
+from ._lib import SharpError, check, lib
 
 
 def _ip(a):
@@ -85,17 +85,19 @@ def SHARP_dev(dX, ensize_K=0, reduced_ndim=0, base_ncells=0, partition_ncells=0,
             "path": "SHARP_large" if path.value else "SHARP_small", "warn": rc}
     if forview:
         info["view_out"] = (viE, x0)
-        info["viE"] = viE[:, :pu.value] if pu.value != viE.shape[1] else viE
+        # (the library writes n x p_used doubles row-major from the start of the buffer)
+        info["viE"] = viE if pu.value == viE.shape[1] else viE.reshape(-1)[: n * pu.value].reshape(n, pu.value)
         info["x0"] = x0[: n * x0c.value].reshape(x0c.value, n).T
     return pred, info
 
 
-def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag=True, viE=None, next_block=None, view_dim=0):
+def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag=True, viE=None, next_block=None, view_dim=0, view_seed=None):
     """One block of SHARP_unlimited: labels, per-cluster means of viE (G x p) and cluster sizes.
 
     flag: the log flag of the block's SHARP() call; viE: optional (nb, p) float64 host array that receives the block's
     ensemble-mean projection (viewflag) -- or, with view_dim > 0, an (nb, view_dim) array that receives those rows reduced on the device
-    (sharp_unlimited_view_dim: what SHARP_unlimited returns as viE above 1e5 cells, R/SHARP_unlimited.R:216-228); next_block: the resident
+    (sharp_unlimited_block_viewk_dev: what SHARP_unlimited returns as viE above 1e5 cells, R/SHARP_unlimited.R:216-228; view_seed: the integer
+    seed of the RUN's z0, the same for all of its blocks -- default 50 + rN_seed + ensize_K + 1; an unseeded run must name one); next_block: the resident
     block of the NEXT call (same genes / projector / parameters): its projection and distance matrices are prepared under this call's tail
     (sharp_unlimited_next_block_dev)."""
     _lib.ensure_init()
@@ -103,15 +105,18 @@ def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag
     if next_block is not None:
         check(lib().sharp_unlimited_next_block_dev(C.c_void_p(next_block.data_ptr()), C.c_longlong(next_block.shape[0]),
                                                    C.c_longlong(next_block.stride(0))))
-    if viE is not None and view_dim > 0:
-        check(lib().sharp_unlimited_view_dim(int(view_dim)))
+    if viE is not None and view_dim > 0 and view_seed is None:
+        if rN_seed == 0.5:
+            raise SharpError("unlimited_block_dev: an unseeded run reduced block by block needs view_seed, the one seed of the run's z0")
+        view_seed = 50 + rN_seed + (ensize_K if ensize_K > 0 else 5) + 1
     pred = np.zeros(nb, np.int32)
     means = np.empty((cap_rows, p))                 # only the first G rows are written and returned
     counts = np.empty(cap_rows, np.int64)
     G = C.c_int()
-    check(lib().sharp_unlimited_block_view_dev(C.c_void_p(dX.data_ptr()), m, C.c_longlong(nb), C.c_longlong(dX.stride(0)), p,
-                                               projector, ensize_K, C.c_double(rN_seed), int(bool(flag)), _ip(pred), C.byref(G),
-                                               _dp(means), cap_rows, counts.ctypes.data_as(C.POINTER(C.c_longlong)), _dp(viE)))
+    check(lib().sharp_unlimited_block_viewk_dev(C.c_void_p(dX.data_ptr()), m, C.c_longlong(nb), C.c_longlong(dX.stride(0)), p,
+                                                projector, ensize_K, C.c_double(rN_seed), int(bool(flag)), _ip(pred), C.byref(G),
+                                                _dp(means), cap_rows, counts.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                                int(view_dim) if viE is not None else 0, C.c_double(view_seed or 0.0), _dp(viE)))
     return pred, means[: G.value].copy(), counts[: G.value].copy()
 
 

@@ -298,7 +298,8 @@ def test_many_levels_statistics_match_the_per_level_kernel_and_the_oracle(sa, or
 
 
 @pytest.mark.parametrize("kind,n,maxN", [("features", 2000, 40), ("features", 701, 40), ("features", 96, 20), ("similarity", 180, 40),
-                                         ("similarity", 333, 64), ("features", 1200, 60), ("features", 900, 70)])
+                                         ("similarity", 333, 64), ("features", 1200, 60), ("features", 900, 70),
+                                         ("duplicates", 400, 40), ("duplicates", 41, 40)])   # every row twice: equal silhouettes in pairs, an even n whose two middle keys are equal; n - 1 = maxN: all-singleton levels
 def test_lane_program_statistics_equal_the_per_cell_walk(sa, oracle, kind, n, maxN, monkeypatch):
     """stats_lane_kernel (the default up to 64 finest clusters: the walk over the finest clusters as a program in registers read with
     v_readlane, the median by radix selection, the clusters' Gram sums by rows) against stats_kernel (SHARP_STATS_LANE=0: the walk
@@ -314,6 +315,9 @@ def test_lane_program_statistics_equal_the_per_cell_walk(sa, oracle, kind, n, ma
         mat = np.corrcoef(E)
         np.fill_diagonal(mat, 1.0)
         mat = (mat + mat.T) / 2
+    elif kind == "duplicates":
+        mat = E.copy()
+        mat[n // 2: 2 * (n // 2)] = mat[: n // 2]
     else:
         mat = E
     kw = dict(maxN_cluster=maxN, sil_thre=0.35)

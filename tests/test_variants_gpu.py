@@ -127,3 +127,61 @@ def test_unseeded_run_rn_seed_one_half(sa, oracle):
     tb = np.concatenate([oracle.synth_cluster(SEED, range(c0, c0 + n), 5) for n, c0 in [(5300, 0), (5200, 6000)]])
     res = sa.SHARP_unlimited(blocks)
     assert adjusted_rand_score(tb, res["pred_clusters"]) > 0.95
+
+
+def test_unseeded_view_reduction_uses_one_z0_for_the_whole_run(sa, oracle):
+    """R/SHARP_unlimited.R:219-225 draws z0 ONCE and multiplies all of E1 by it, seed or no seed.  Two identical blocks in an unseeded run
+    (rN.seed missing): their E1 rows are equal (one projector list for all blocks, :92-105), so their reduced rows must be equal too -- through
+    the resident entry with the reduction as an argument, through the armed host entry, and over two logical devices (one z0 on every
+    device).  Two calls draw two different z0."""
+    import torch
+    from sharp_amd import device as dev
+    from sharp_amd._lib import check, lib
+
+    X = _data(oracle, m=1500, n=5200, G=5, nm=250)
+    dX = torch.from_numpy(np.ascontiguousarray(X.T.astype(np.float32))).cuda()
+    torch.cuda.synchronize()
+    n = 5200
+    _, _, p, plain = dev.unlimited_dev([dX, dX], ensize_K=3, viewflag=True, view_dim=0)          # unseeded, E1 itself
+    assert plain.shape == (2 * n, p)
+    np.testing.assert_array_equal(plain[:n], plain[n:])
+    _, _, _, v1 = dev.unlimited_dev([dX, dX], ensize_K=3, viewflag=True, view_dim=50)
+    assert v1.shape == (2 * n, 50) and np.abs(v1).max() > 0
+    np.testing.assert_array_equal(v1[:n], v1[n:])
+    _, _, _, v2 = dev.unlimited_dev([dX, dX], ensize_K=3, viewflag=True, view_dim=50)
+    np.testing.assert_array_equal(v2[:n], v2[n:])
+    assert not np.array_equal(v1, v2)                                                  # (another run: other projectors, another z0)
+    check(lib().sharp_unlimited_view_dim(50))                                           # two logical devices on the one GPU
+    _, _, _, vm = dev.unlimited_multi_dev([dX, dX], [0, 1], [0, 0], ensize_K=3, viewflag=True)
+    vm = vm.reshape(-1)[: 2 * n * 50].reshape(2 * n, 50)
+    np.testing.assert_array_equal(vm[:n], vm[n:])
+    # the arm is spent by the call that took it: the next call returns E1 itself
+    _, _, _, again = dev.unlimited_multi_dev([dX, dX], [0, 1], [0, 0], ensize_K=3, viewflag=True)
+    assert np.abs(again[:, 50:]).max() > 0
+    # block by block an unseeded run must name the seed of its z0
+    proj = sa.Projector(1500, p, [0.5] * 3)
+    with pytest.raises(sa.SharpError):
+        dev.unlimited_block_dev(dX, p, proj.handle, 3, 0.5, viE=np.zeros((n, 50)), view_dim=50)
+    a, b = np.zeros((n, 50)), np.zeros((n, 50))
+    dev.unlimited_block_dev(dX, p, proj.handle, 3, 0.5, viE=a, view_dim=50, view_seed=12345)
+    dev.unlimited_block_dev(dX, p, proj.handle, 3, 0.5, viE=b, view_dim=50, view_seed=12345)
+    np.testing.assert_array_equal(a, b)
+    proj.close()
+
+
+def test_view_arm_does_not_leak_past_a_failed_call(sa, oracle):
+    """the armed view dimension must not survive a call that raised before (or inside) the library: the next viewflag call with
+    at most 1e5 cells gets its n x p buffer filled with E1, not with n x 50 numbers."""
+    import scipy.sparse as sp
+
+    blocks = [_data(oracle, n=n, cell0=c0) for n, c0 in [(300, 0), (320, 400)]]
+    with pytest.raises(sa.SharpError):
+        sa.SHARP_unlimited(blocks, rN_seed=2103.5)                                     # rejected before the library
+    ref = oracle.SHARP_unlimited(blocks, rN_seed=2103, nthreads=4, want_view=True)
+    res = sa.SHARP_unlimited(blocks, rN_seed=2103)
+    assert res["viE"].shape == ref["viE"].shape
+    np.testing.assert_allclose(res["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
+    from sharp_amd._lib import lib
+    assert lib().sharp_unlimited_view_dim(5000) != 0                                    # rejected: nothing armed
+    res = sa.SHARP_unlimited([sp.csc_matrix(b) for b in blocks], rN_seed=2103)
+    np.testing.assert_allclose(res["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
