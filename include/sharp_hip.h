@@ -113,6 +113,25 @@ int sharp_get_opt_hclust(const double *mat, int n, int p, int hmethod, int N_clu
                          double *maxsil, double *height, int *optN, int *nk, int *branch);
 
 /* ---- a6: getrowColor ----------------------------------------------------------- */
+/* ---- the decision log -------------------------------------------------
+ * Every choice of a number of clusters on the path is an arg-max over doubles compared with `==` (R/get_opt_hclust.R:162-168: the middle one of
+ * the exact ties of the median silhouette; :194-195: which.max(CHind) when max(msil) <= sil.thre; :196-210: the height-gap rule;
+ * R/sMetaC.R:139-148: the two-cluster override).  sharp_decision_log(1) (or SHARP_DECISION_LOG=1 in the environment) makes every
+ * get_opt_hclust call of the process leave one row of SHARP_DECISION_COLS doubles; sharp_decision_log(0) stops and clears.
+ * sharp_last_decisions copies up to cap_rows rows, sorted by (level, block, k, fold), and returns the number held in *n_rows.  Row:
+ *  [0] level: 0 base clustering of one projection of one fold (getrowColor, R/SHARP.R:366,592), 1 a fold's wMetaC (R/wMetaC.R:98-99),
+ *      2 the sMetaC across a block's folds (R/SHARP.R:754), 3 SHARP_unlimited's sMetaC across blocks (R/SHARP_unlimited.R:163), -1 a direct call
+ *  [1] block (index in the SHARP_unlimited list; 0 for SHARP())  [2] k (projection, 0-based)  [3] fold (0-based)  [4] observations
+ *  [5] branch: 0 median silhouette, 1 CH, 2 height gap, 3 N.cluster given   [6] chosen number of clusters
+ *  [7] exact ties at the deciding maximum  [8] that maximum (msil: branch 0 / 3, CH: 1 / 2)  [9] largest value strictly below it (NaN: none)
+ *  [10] max(msil) - sil.thre  [11] height rule, when CH's first level won: gap / ((height.Ntimes - 1) * height) of the deciding step
+ *       (branch 2: > 1) or its maximum over the last ten merges (branch 1: <= 1); NaN otherwise
+ *  [12] sMetaC's two-cluster override: the number of clusters of the column taken instead (0: not applied)  [13] candidate levels
+ * oracle/sharp_oracle.c writes the same rows (oracle_decision_log / oracle_last_decisions): tests compare the two logs entry by entry. */
+#define SHARP_DECISION_COLS 14
+int sharp_decision_log(int enable);
+int sharp_last_decisions(double *rows /* cap_rows x SHARP_DECISION_COLS */, int cap_rows, int *n_rows);
+
 /* R/getrowColor.R:17-121.  rowColor[i] in 1..40 is the index into the reference's colorL table
  * (cluster j > 40 wraps and collides exactly like :59-68); height_Ntimes <= 0 -> 1 (:28-30). */
 int sharp_getrowColor(const double *E, int n, int p, int hmethod, int indN_cluster, int minN, int maxN,
@@ -343,11 +362,6 @@ int sharp_synth_labels(unsigned seed, long long cell0, int ncell, int G, int *la
  * with a zero diagonal (correlation distance), 2 = clamp(v) with a unit diagonal; symmetric: Bt is ignored (C = At^T At, upper
  * triangle computed and mirrored); fast: the 128 x 128-tile kernel on zero-padded copies, else the generic 64 x 64 kernel. */
 int sharp_gemm_tn_f64(const double *At, const double *Bt, double *C, int M, int N, int K, int epilogue, int symmetric, int fast);
-/* Test hook: D = 1 - U U^T (n x n row-major) of n unit rows U (n x p row-major) through the sliced-integer distance GEMM
- * (gemm_i8.hip: seven 7-bit digits per entry, exact int8 products on the matrix cores; R/get_opt_hclust.R:66-74 is what it serves). */
-int sharp_dist_i8(const double *U, int n, int p, double *D);
-/* Bench hook: `count` tasks of n x p unit rows; ms[0] rows -> digits, ms[1] digits -> D, ms[2] the fp64 MFMA kernel on the same tasks. */
-int sharp_dist_i8_bench(int n, int p, int count, int reps, double *ms);
 
 /* ---- device memory helpers for non-torch hosts (R glue, tests) -------------- */
 int sharp_dev_alloc(long long bytes, void **dptr);
@@ -406,6 +420,8 @@ void sharp_C_SHARP_unlimited(double *Xcat, int *nblocks, double *ncb, int *m, in
                              double *rN_seed, int *pred, double *viE, int *info, int *want, int *status);
 /* sharp_SHARP_unlimited_multi: devices = integer vector of GPU indices (block b on devices[b mod *ndevices]) */
 void sharp_C_unlimited_view_dim(int *kdim, int *status);      /* sharp_unlimited_view_dim: the next sharp_C_SHARP_unlimited* call's viE is ncells x *kdim */
+void sharp_C_decision_log(int *enable, int *status);          /* sharp_decision_log */
+void sharp_C_last_decisions(double *rows, int *cap_rows, int *n_rows, int *status);   /* sharp_last_decisions */
 void sharp_C_SHARP_unlimited_multi(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *N_cluster, int *minN, int *maxN,
                                    double *rN_seed, int *devices, int *ndevices, int *pred, double *viE, int *info, int *want, int *status);
 /* sharp_SHARP_unlimited_csc_multi for a list of dgCMatrix blocks: pcat / icat / xcat = the blocks' @p / @i / @x one after the other;

@@ -296,6 +296,24 @@ def SHARP_unlimited2(blocks, K=0, reduced_ndim=0, partition_ncells=0, hmethod="w
 STAGES = ("projector_build", "rp_matmul_thread_s", "base_clustering_thread_s", "wMetaC", "sMetaC_in_block", "cross_block_merge", "task_loop_wall")
 
 
+DECISION_COLS = 14
+DECISION_FIELDS = ("level", "block", "k", "fold", "n", "branch", "chosen_k", "ties", "best", "runner_up", "sil_minus_thre", "height_ratio",
+                   "smetac_override_k", "levels")
+
+
+def decision_log(enable=True):
+    """oracle_decision_log: every get_opt_hclust call leaves a row until switched off; switching clears the log."""
+    lib().oracle_decision_log(int(bool(enable)))
+
+
+def last_decisions():
+    """rows x DECISION_COLS, sorted by (level, block, k, fold): the columns of DECISION_FIELDS (include/sharp_hip.h, sharp_last_decisions)"""
+    n = lib().oracle_last_decisions(None, 0)
+    rows = np.zeros((max(n, 1), DECISION_COLS))
+    n = lib().oracle_last_decisions(_dp(rows), rows.shape[0])
+    return rows[:n]
+
+
 def stage_seconds(reset=True):
     """Seconds per stage of the SHARP_large / SHARP_unlimited calls since the last reset (oracle_stage_seconds): bench.py's cpu_baseline."""
     out = np.zeros(7)

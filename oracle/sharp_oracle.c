@@ -508,6 +508,104 @@ void oracle_cor_dist(const double *mat, int n, int p, double *dcond) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* The decision log ("tests must log the best-vs-     */
+/* second-best margin of every model-selection decision so sub-1e-9 flips are   */
+/* attributable").  While on, every get_opt_hclust call leaves one row of       */
+/* OR_DEC_COLS doubles -- the row include/sharp_hip.h documents for             */
+/* sharp_last_decisions, computed by the same arithmetic: [0] level (0 base     */
+/* clustering, 1 a fold's wMetaC, 2 sMetaC across a block's folds, 3 sMetaC      */
+/* across blocks, -1 a direct call) [1] block [2] k [3] fold [4] n [5] branch    */
+/* (0 msil, 1 CH, 2 height gap, 3 N.cluster given) [6] chosen number of clusters */
+/* [7] exact ties at the deciding maximum (R/get_opt_hclust.R:162-168,194-195)   */
+/* [8] that maximum [9] the largest value strictly below it [10] max(msil) -     */
+/* sil.thre [11] the height rule's ratio (:196-210) [12] sMetaC's two-cluster    */
+/* override (R/sMetaC.R:139-148): clusters of the column taken, 0 = none         */
+/* [13] candidate levels.  Where the call sits in the run is thread-local state  */
+/* set by the drivers below (the task loops are OpenMP loops).                   */
+/* ------------------------------------------------------------------------- */
+#define OR_DEC_COLS 14
+static _Thread_local int dec_level = -1, dec_k = 0, dec_fold = 0;
+static int dec_block = 0;                     /* (the block loop of SHARP_unlimited is serial, R/SHARP_unlimited.R:125) */
+static int dec_on = 0;
+static double *dec_rows = NULL; static size_t dec_n = 0, dec_cap = 0;
+static void dec_set(int level, int k, int fold) { dec_level = level; dec_k = k; dec_fold = fold; }
+void oracle_decision_log(int enable) {
+    #pragma omp critical(or_declog)
+    { dec_on = enable != 0; dec_n = 0; }
+}
+static void dec_add(const double *row) {
+    #pragma omp critical(or_declog)
+    {
+        if (dec_n == dec_cap) { dec_cap = dec_cap ? 2 * dec_cap : 1024; dec_rows = (double *)realloc(dec_rows, sizeof(double) * OR_DEC_COLS * dec_cap); }
+        memcpy(dec_rows + dec_n * OR_DEC_COLS, row, sizeof(double) * OR_DEC_COLS);
+        dec_n++;
+    }
+}
+static void dec_override(int level, int block, int k_taken) {
+    #pragma omp critical(or_declog)
+    {
+        for (size_t r = dec_n; r-- > 0;) {
+            double *row = dec_rows + r * OR_DEC_COLS;
+            if ((int)row[0] == level && (int)row[1] == block) { row[12] = k_taken; break; }
+        }
+    }
+}
+static int dec_cmp(const void *a, const void *b) {
+    const double *x = (const double *)a, *y = (const double *)b;
+    for (int c = 0; c < 4; c++) if (x[c] != y[c]) return x[c] < y[c] ? -1 : 1;
+    return x[OR_DEC_COLS] < y[OR_DEC_COLS] ? -1 : 1;        /* (insertion order: the sort is stable through the extra column) */
+}
+int oracle_last_decisions(double *rows, int cap_rows) {
+    int nr;
+    #pragma omp critical(or_declog)
+    {
+        nr = (int)dec_n;
+        double *tmp = (double *)xmalloc(sizeof(double) * (OR_DEC_COLS + 1) * (size_t)(nr > 0 ? nr : 1));
+        for (int i = 0; i < nr; i++) { memcpy(tmp + (size_t)i * (OR_DEC_COLS + 1), dec_rows + (size_t)i * OR_DEC_COLS, sizeof(double) * OR_DEC_COLS); tmp[(size_t)i * (OR_DEC_COLS + 1) + OR_DEC_COLS] = i; }
+        qsort(tmp, (size_t)nr, sizeof(double) * (OR_DEC_COLS + 1), dec_cmp);
+        for (int i = 0; i < nr && i < cap_rows; i++) memcpy(rows + (size_t)i * OR_DEC_COLS, tmp + (size_t)i * (OR_DEC_COLS + 1), sizeof(double) * OR_DEC_COLS);
+        free(tmp);
+    }
+    return nr;
+}
+static void decision_row(int N_cluster, double sil_thre, double height_Ntimes, int n, int kmin, int nk, const double *msil, const double *CH,
+                         const double *height, int oind, int branch, double *row) {
+    for (int c = 0; c < OR_DEC_COLS; c++) row[c] = NAN;
+    row[0] = dec_level; row[1] = dec_block; row[2] = dec_k; row[3] = dec_fold; row[4] = n;
+    row[5] = branch; row[6] = kmin + oind - 1; row[12] = 0; row[13] = nk;
+    if (N_cluster > 0) { row[5] = 3; row[6] = N_cluster; row[7] = 1; row[8] = msil[0]; row[13] = 1; return; }
+    double mx = msil[0];
+    for (int c = 1; c < nk; c++) if (msil[c] > mx) mx = msil[c];
+    row[10] = mx - sil_thre;
+    const double *val = branch == 0 ? msil : CH;
+    double best = branch == 0 ? mx : val[0];
+    if (branch != 0) for (int c = 1; c < nk; c++) if (val[c] > best) best = val[c];
+    int ties = 0;
+    double second = NAN;
+    for (int c = 0; c < nk; c++) {
+        if (val[c] == best) ties++;
+        else if (val[c] < best && (!(second == second) || val[c] > second)) second = val[c];
+    }
+    row[7] = ties; row[8] = best; row[9] = second;
+    if (branch >= 1 && (branch == 2 || CH[0] == best)) {
+        int first = 1;
+        for (int c = 1; c < nk; c++) if (CH[c] > CH[0]) first = 0;
+        if (first) {
+            int nh = n - 1, t0 = nh > 10 ? nh - 10 : 0, tl = nh - t0;
+            const double *tmp = height + t0;
+            double rmax = NAN;
+            for (int i = 0; i + 1 < tl; i++) {
+                double dif = tmp[i + 1] - tmp[i], den = (height_Ntimes - 1) * tmp[i];
+                double r = den > 0 ? dif / den : (dif > 0 ? INFINITY : 0.0);
+                if (branch == 2) { if (dif > den) { rmax = r; break; } }
+                else if (!(rmax == rmax) || r > rmax) rmax = r;
+            }
+            row[11] = rmax;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* get_opt_hclust  (R/get_opt_hclust.R:33-244).                               */
 /* mat: n x p row-major (features) or n x n symmetric similarity.             */
 /* N_cluster: 0 = NULL.  Outputs: f[n]; v[n*nk] column-major (nk columns for  */
@@ -546,6 +644,7 @@ int oracle_get_opt_hclust(const double *mat_in, int n, int p, int hmethod, int N
         msil[0] = (kk >= 2 && kk <= n - 1) ? oracle_median_silhouette(n, kk, v, d) : NAN;
         CHind[0] = ch_euclid(mat, n, p, v, kk);
         *maxsil = msil[0]; *optN = N_cluster; *nk_out = 1;
+        if (dec_on) { double row[OR_DEC_COLS]; decision_row(N_cluster, sil_thre, height_Ntimes, n, minN, 1, msil, CHind, height, 1, 0, row); dec_add(row); }
         goto done;
     }
     {
@@ -589,6 +688,7 @@ int oracle_get_opt_hclust(const double *mat_in, int n, int p, int hmethod, int N
             }
         }
         if (oind < 1 || oind > nk) { rc = OR_ERR_RANGE; oind = oind < 1 ? 1 : nk; }
+        if (dec_on) { double row[OR_DEC_COLS]; decision_row(0, sil_thre, height_Ntimes, n, minN, nk, msil, CHind, height, oind, branch ? *branch : 0, row); dec_add(row); }
         memcpy(f, v + (size_t)(oind - 1) * n, sizeof(int) * (size_t)n);
         int kk = 0; for (int i = 0; i < n; i++) if (f[i] > kk) kk = f[i];
         *optN = kk; *maxsil = mx;
@@ -804,6 +904,7 @@ static int smetac_core(const double *aG, int nC, int p, long long ncells_ll, int
            take the first. */
         int s2 = 0; for (int c = 0; c < nko; c++) if (msil[c] == s1) { s2 = c; break; }
         tf = v + (size_t)s2 * nC;
+        if (dec_on) dec_override(dec_level, dec_block, minN + s2);
     }
     for (int t = 0; t < nC; t++) tf_out[t] = tf[t];
     free(S); free(f); free(v); free(msil); free(ch); free(height);
@@ -893,13 +994,17 @@ int oracle_SHARP_small(const double *X, int m, int n, int K, int p, int hmethod,
         oracle_ranM(m, p, seedn, tern);
         oracle_project(X, m, n, tern, p, flag, E);
         double maxsil;
+        dec_set(0, k - 1, 0);
         rc |= oracle_getrowColor(E, n, p, hmethod, indN, minN, maxN, sil_thre, height_Ntimes,
                                  enrp + (size_t)(k - 1) * n, &maxsil);
+        dec_set(-1, 0, 0);
         for (size_t q = 0; q < (size_t)n * (size_t)p; q++) enE[q] += E[q];   /* :398 */
     }
     int ncl;
+    dec_set(1, 0, 0);
     rc |= oracle_wMetaC(enrp, n, K, hmethod, N_cluster, minN, maxN, sil_thre, height_Ntimes,
                         pred, x0, &ncl, NULL, NULL, NULL, NULL);             /* :401 */
+    dec_set(-1, 0, 0);
     if (ncl_x0) *ncl_x0 = ncl;
     if (viE) for (size_t q = 0; q < (size_t)n * (size_t)p; q++) viE[q] = enE[q] / K;  /* :416 */
     if (N_cluster <= 0 && n > 10000) merge_small_clusters(pred, n);          /* :418-427 */
@@ -1006,8 +1111,10 @@ static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng,
         double ts1 = omp_get_wtime();
         stage_add(1, ts1 - ts0);
         double maxsil;
+        dec_set(0, k, t - 1);
         int r = oracle_getrowColor(Et, nt, p, hmethod, indN, minN, fpart ? 40 : maxN, sil_thre, height_Ntimes,
                                    enrp + (size_t)k * n + c0, &maxsil);
+        dec_set(-1, 0, 0);
         if (r) {
             #pragma omp atomic
             rc |= r;
@@ -1032,7 +1139,9 @@ static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng,
         int *fc = (int *)xmalloc(sizeof(int) * (size_t)nt); int ncl;
         int capc = K * (maxN > 40 ? maxN : 40) + 2;        /* (the meta-clusters of a fold cannot outnumber its K * maxN base clusters) */
         if (x0_out && !fpart) fx0[t] = (double *)xmalloc(sizeof(double) * (size_t)nt * (size_t)capc);
+        dec_set(1, 0, t - 1);
         int r = oracle_wMetaC(sub, nt, K, hmethod, enpN, minN, maxN, sil_thre, height_Ntimes, fc, fx0[t], &ncl, NULL, NULL, NULL, NULL);
+        dec_set(-1, 0, 0);
         fncl[t] = ncl;
         if (r) {
             #pragma omp atomic
@@ -1068,7 +1177,9 @@ static int sharp_large_core(const double *X, int m, int n, int K, int p, int ng,
     } else {
         int *tf = (int *)xmalloc(sizeof(int) * (size_t)n); int nCu;
         double t_sm = omp_get_wtime();
+        dec_set(2, 0, 0);
         rc |= oracle_sMetaC(fColor, E1, n, p, hmethod, N_cluster, minN, maxN, sil_thre, height_Ntimes, S, tf, &nCu);  /* :754 */
+        dec_set(-1, 0, 0);
         stage_add(4, omp_get_wtime() - t_sm);
         /* :761-773: sn = length(unique(stf)); x0[, i] = rowSums(sx0[, which(stf == i)]).  (nCu == lenuC: both count unique(fColor).) */
         for (int q = 0; q < lenuC && q < nCu; q++) { colmap[q] = tf[q] - 1; if (tf[q] > ncol) ncol = tf[q]; }
@@ -1188,6 +1299,7 @@ int oracle_SHARP_unlimited(const double *Xcat, int m, int nb, const int *ncb, in
     for (int b = 0; b < nb; b++) {                                           /* :125-149 */
         int nbk = ncb[b];
         int *pb = (int *)xmalloc(sizeof(int) * (size_t)nbk);
+        dec_block = b;
         /* SHARP(mat, reduced.ndim=p, prep=FALSE, logflag=FALSE, rM=rM, ensize.K, rN.seed) (:135):
            logflag FALSE -> flag TRUE (log always, R/SHARP.R:225-228); block-level defaults */
         rc |= oracle_SHARP(Xcat + off * (size_t)m, m, nbk, K, p, 0, 0, 0, 0, 0, 0, 0, 0, -1.0, 0, 1, tern,
@@ -1200,7 +1312,10 @@ int oracle_SHARP_unlimited(const double *Xcat, int m, int nb, const int *ncb, in
     double t_mg = omp_get_wtime();
     /* sMetaC(fColor, E1, folds, hmethod, N.cluster, minN, maxN, sil.thre, height.Ntimes) (:163);
        hmethod/sil.thre/height.Ntimes come from block 1's paras = the defaults */
+    dec_block = 0;
+    dec_set(3, 0, 0);
     rc |= oracle_sMetaC(fColor, E1, ncells, p, 1, N_cluster, minN, maxN, 0.35, 2.0, pred, tf, &nCu);
+    dec_set(-1, 0, 0);
     free(tf);
     if (N_cluster <= 0 && ncells > 10000) merge_small_clusters(pred, ncells);       /* :168-177 */
     {   /* x = sort(table(finalrowColor), decreasing=TRUE); map (:180-183) */
@@ -1231,7 +1346,9 @@ int oracle_unlimited_merge(const double *means, const long long *counts, int nC,
                            int minN, int maxN, int *final_id, int *n_final) {
     if (minN <= 0) minN = 2;                                                 /* :70-72 */
     if (maxN <= 0) { long long c = (ncells + 4999) / 5000; maxN = c > 40 ? (int)c : 40; }   /* :75-77 */
+    dec_set(3, 0, 0);
     int rc = smetac_core(means, nC, p, ncells, 1, N_cluster, minN, maxN, 0.35, 2.0, final_id);   /* :163 */
+    dec_set(-1, 0, 0);
     int mx = 0; for (int q = 0; q < nC; q++) if (final_id[q] > mx) mx = final_id[q];
     long long *cnt = (long long *)xcalloc((size_t)mx + 1, sizeof(long long));
     for (int q = 0; q < nC; q++) cnt[final_id[q]] += counts[q];

@@ -13,7 +13,7 @@ from ._lib import SharpError, check, lib
 
 __all__ = ["ranM", "ranM2", "RPmat", "Projector", "SharpError", "get_opt_hclust", "getrowColor", "colorL", "HMETHODS",
            "wMetaC", "sMetaC", "SHARP", "SHARP_small", "SHARP_large", "SHARP_unlimited", "SHARP_unlimited2", "SHARP_unlimited3", "run_Mtimes_SHARP", "get_marker_genes", "get_marker_genes_unlimited",
-           "get_marker_genes_unlimited2", "testlog", "ARI"]
+           "get_marker_genes_unlimited2", "testlog", "ARI", "decision_log", "last_decisions", "decision_margins", "DECISION_FIELDS"]
 
 
 def _dp(a):
@@ -855,6 +855,51 @@ def _p_adjust_holm(p):
     adj = np.minimum(1.0, np.maximum.accumulate((n - np.arange(n)) * p[o]))
     out = np.empty(n)
     out[o] = adj
+    return out
+
+
+DECISION_COLS = 14
+DECISION_FIELDS = ("level", "block", "k", "fold", "n", "branch", "chosen_k", "ties", "best", "runner_up", "sil_minus_thre", "height_ratio",
+                   "smetac_override_k", "levels")
+
+
+def decision_log(enable=True):
+    """sharp_decision_log: while on, every get_opt_hclust call of the process -- base clustering, wMetaC, sMetaC,
+    the cross-block merge -- leaves one row saying which rule of R/get_opt_hclust.R:162-229 chose the number of clusters and by what
+    margin.  Switching it (on or off) clears the log.  SHARP_DECISION_LOG=1 in the environment: on from the start."""
+    _lib.ensure_init()
+    check(lib().sharp_decision_log(int(bool(enable))))
+
+
+def last_decisions():
+    """sharp_last_decisions: rows x DECISION_COLS (the columns of DECISION_FIELDS; include/sharp_hip.h), sorted by (level, block, k, fold)."""
+    n = C.c_int()
+    check(lib().sharp_last_decisions(None, 0, C.byref(n)))
+    rows = np.zeros((max(n.value, 1), DECISION_COLS))
+    check(lib().sharp_last_decisions(_dp(rows), rows.shape[0], C.byref(n)))
+    return rows[: n.value]
+
+
+def decision_margins(rows):
+    """Per level: how close the decisions of a run came to going the other way.  For a decision by the median silhouette with one exact
+    maximum the margin is best - runner-up; with exact ties (R picks the middle one by `==` on doubles, R/get_opt_hclust.R:162-168) the
+    margin is 0 by construction and the ties are counted instead; a decision by CH: the relative margin (best - runner-up) / |best|;
+    every decision also has its distance to the silhouette / CH switch, |max(msil) - sil.thre|.  -> {level: {...}}"""
+    out = {}
+    names = {0: "base", 1: "wMetaC", 2: "sMetaC", 3: "merge", -1: "direct"}
+    for lev in sorted(set(rows[:, 0].astype(int))) if len(rows) else []:
+        r = rows[rows[:, 0] == lev]
+        sil = r[r[:, 5] == 0]
+        ch = r[(r[:, 5] == 1) | (r[:, 5] == 2)]
+        single = sil[sil[:, 7] == 1]
+        d = {"decisions": int(len(r)), "by_silhouette": int(len(sil)), "by_CH": int((r[:, 5] == 1).sum()), "by_height": int((r[:, 5] == 2).sum()),
+             "N_cluster_given": int((r[:, 5] == 3).sum()),
+             "silhouette_decisions_with_exact_ties": int((sil[:, 7] > 1).sum()),
+             "min_silhouette_margin": float(np.nanmin(single[:, 8] - single[:, 9])) if len(single) and np.isfinite(single[:, 9]).any() else None,
+             "min_CH_relative_margin": float(np.nanmin((ch[:, 8] - ch[:, 9]) / np.abs(ch[:, 8]))) if len(ch) and np.isfinite(ch[:, 9]).any() else None,
+             "min_distance_to_sil_thre": float(np.nanmin(np.abs(r[:, 10]))) if np.isfinite(r[:, 10]).any() else None,
+             "smetac_overrides": int((r[:, 12] > 0).sum())}
+        out[names.get(lev, str(lev))] = d
     return out
 
 

@@ -162,6 +162,8 @@ void sharp_C_SHARP_unlimited(double *Xcat, int *nblocks, double *ncb, int *m, in
 /* arms the device-side view reduction for the NEXT sharp_C_SHARP_unlimited* call (sharp_unlimited_view_dim; R/SHARP_unlimited.R:216-228): its viE
  * buffer is then ncells x *kdim */
 void sharp_C_unlimited_view_dim(int *kdim, int *status) { *status = sharp_unlimited_view_dim(*kdim); }
+void sharp_C_decision_log(int *enable, int *status) { *status = sharp_decision_log(*enable); }
+void sharp_C_last_decisions(double *rows, int *cap_rows, int *n_rows, int *status) { *status = sharp_last_decisions(rows, *cap_rows, n_rows); }
 /* the same on several GPUs (sharp_SHARP_unlimited_multi): devices = integer vector of device indices, block b on devices[b mod ndev] */
 void sharp_C_SHARP_unlimited_multi(double *Xcat, int *nblocks, double *ncb, int *m, int *ensize_K, int *N_cluster, int *minN, int *maxN,
                                    double *rN_seed, int *devices, int *ndevices, int *pred, double *viE, int *info, int *want, int *status) {

@@ -41,6 +41,7 @@ struct SharpArgs {
     // SHARP_fpart (R/SHARP_unlimited2.R:297-544): the large path with log10 (flag = 2), E1 rounded to one decimal before
     // clustering, maxN.cluster = 40 for the base tasks, and NO sMetaC: the per-fold ensemble labels go up to the caller
     bool fpart = false;
+    int block = 0;           // the block's index in its SHARP_unlimited call (decision log only)
     // SHARP_unlimited with several blocks on this GPU: the block that comes next (same genes, projector, parameters).  Its projection,
     // row preparation and distance matrices are enqueued on a side stream before this block's agglomeration starts, so that they run
     // under this block's (HBM-bound, then host-bound) tail; the next call finds them done.
@@ -175,13 +176,17 @@ void sharp_small_dev(XRef dX, int m, int n, long long ld, const SharpArgs &a, in
     project_dev(*pr, dX, m, n, ld, a.flag, E.p, ldE, nullptr);                  // :350-363 for all k at once
     std::vector<HcTask> tasks(K);
     HcParams bp = base; bp.N_cluster = a.indN;
-    for (int k = 0; k < K; ++k) { tasks[k].d_mat = E.p + static_cast<long long>(k) * p; tasks[k].ld = ldE; tasks[k].n = n; tasks[k].p = p; tasks[k].prm = bp; }
+    for (int k = 0; k < K; ++k) {
+        tasks[k].d_mat = E.p + static_cast<long long>(k) * p; tasks[k].ld = ldE; tasks[k].n = n; tasks[k].p = p; tasks[k].prm = bp;
+        tasks[k].prm.dec_level = 0; tasks[k].prm.dec_k = k;
+    }
     std::vector<HcResult> hr;
     get_opt_hclust_batch(tasks, false, hr);                                     // :366 getrowColor
     std::vector<int> enrp(static_cast<size_t>(n) * K);
     for (int k = 0; k < K; ++k) { out.rc |= hr[k].rc; for (int i = 0; i < n; ++i) enrp[static_cast<size_t>(k) * n + i] = colour_of(hr[k].f[i]); }
     { LastSmall &L = last_small(); L.n = n; L.K = K; L.p = p; L.ldE = ldE; L.enrp = enrp; }
     WmTask wt; wt.nC = enrp.data(); wt.N = n; wt.C = K; wt.prm = base; wt.prm.N_cluster = a.N_cluster;   // :401
+    wt.prm.dec_level = 1;
     std::vector<WmTask> wts{wt};
     std::vector<WmResult> wr;
     wmetac_batch(wts, a.want_x0, false, wr);
@@ -324,6 +329,7 @@ static void large_front(LargeFront &F, const SharpArgs &a, bool ahead, double *E
             HcTask &tk = F.tasks[static_cast<size_t>(k) * F.T + t];
             tk.d_mat = F.E + static_cast<long long>(F.fst[t]) * F.ldE + static_cast<long long>(k) * p;
             tk.ld = F.ldE; tk.n = F.fst[t + 1] - F.fst[t]; tk.p = p; tk.prm = F.bp;
+            tk.prm.dec_level = 0; tk.prm.dec_k = k; tk.prm.dec_fold = t;           // (decision log; the block is stamped by the call that uses the front)
         }
 }
 
@@ -411,6 +417,7 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
     for (int t = 0; t < T; ++t) {
         wts[t].nC = enrp[t].data(); wts[t].N = fst[t + 1] - fst[t]; wts[t].C = K;
         wts[t].prm = base; wts[t].prm.N_cluster = a.enpN;
+        wts[t].prm.dec_level = 1; wts[t].prm.dec_fold = t;
     }
     std::vector<WmResult> wr;
     { HostTimer ht("wmetac_total"); wmetac_batch(wts, a.want_x0, false, wr); }
@@ -458,6 +465,7 @@ static void large_tail(const LargeFront &F, const SharpArgs &a, int K, int p, co
         means.ensure(static_cast<size_t>(nCu) * p);                             // batched SHARP_unlimited later chunks' agglomeration is in flight)
         { HostTimer ht("tail_fold_means"); cluster_means_dev(viE_sh.p, p, n, p, uid, nCu, means.p); }   // sMetaC :58-63 on E1 = enE/K
         HcParams sp = base; sp.N_cluster = a.N_cluster;
+        sp.dec_level = 2;
         SmResult sr;
         step_mark("  tail: fold means done, clusters", nCu);
         { HostTimer ht("smetac_total"); sr = smetac_from_means(means.p, nCu, p, n, sp); }   // :754
@@ -593,7 +601,7 @@ static void sharp_large_dev_body(XRef dX, int m, int n, long long ld, const Shar
     std::vector<HcResult> hr;
     {
         HostTimer ht("base_clustering_total");
-        if (F.hc) { hc_set_after_last_agglomeration(nullptr); hc_prefetch_finish(*F.hc, false, hr); }
+        if (F.hc) { hc_set_after_last_agglomeration(nullptr); hc_prefetch_stamp_block(*F.hc, a.block); hc_prefetch_finish(*F.hc, false, hr); }
         else {
             // the ensemble mean needs E only: it goes out behind the LAST chunk's agglomeration, beside that chunk's statistics
             // (latency-bound), instead of behind them in the serial tail (-0.5 ms per cfg2 step)
@@ -603,6 +611,7 @@ static void sharp_large_dev_body(XRef dX, int m, int n, long long ld, const Shar
             double *vsh = dws().viE_sh.p;
             if (knobs().mean_early) hc_set_after_last_agglomeration([=](hipEvent_t ev) { enqueue_ensemble_mean(Ep, ldEp, n, p, K, vsh, ev); });
             else hc_set_after_last_agglomeration(nullptr);
+            for (HcTask &tk : F.tasks) tk.prm.dec_block = a.block;
             try { get_opt_hclust_batch(F.tasks, false, hr); } catch (...) { hc_set_after_last_agglomeration(nullptr); throw; }
         }
     }
@@ -627,6 +636,7 @@ void sharp_front_dev(XRef dX, int m, long long n_, long long ld, SharpArgs a, Sh
     base.maxN = a.maxN > 0 ? a.maxN : std::max(40, (n + 4999) / 5000);          // :144-146
     base.sil_thre = a.sil_thre >= 0 ? a.sil_thre : 0.35;                        // :149-151
     base.height_Ntimes = a.height_Ntimes > 0 ? a.height_Ntimes : 2.0;           // :154-156
+    base.dec_block = a.block;
     int K = a.K;
     if (a.N_cluster > 0 && n < base_ncells) {                                   // :181-191
         a.indN = a.N_cluster;
@@ -672,9 +682,10 @@ void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector
 void unlimited_block_dev(XRef dX, int m, long long nb, long long ld, int p, int projector, int K, double rN_seed,
                          std::vector<int> &pred, std::vector<double> &means, std::vector<long long> &counts, double *viE_host,
                          const ViewCall &view, int flag = 1, const SharpArgs *fpart_args = nullptr, XRef next_dX = XRef(), long long next_n = 0,
-                         long long next_ld = 0) {
+                         long long next_ld = 0, int block = 0) {
     SharpArgs a;
-    if (fpart_args) a = *fpart_args;                                            // SHARP_unlimited2: every SHARP_fpart parameter
+    if (fpart_args) a = *fpart_args;
+    a.block = block;                                            // SHARP_unlimited2: every SHARP_fpart parameter
     a.next_dX = next_dX; a.next_n = next_n; a.next_ld = next_ld;                // the block after this one (prepared under this one's tail)
     a.K = K; a.reduced_ndim = p; a.flag = flag; a.projector = projector; a.rN_seed = rN_seed; a.want_viE = true;
     a.fpart = fpart_args != nullptr;
@@ -756,7 +767,7 @@ void unlimited_block_summary(const SharpOut &o, long long nb, int p, std::vector
 // the HBM busy.  Every block is the same SHARP() call as in the block-by-block form (same shuffle, folds, parameters): same labels.
 // deliver(b, out): called once per block; with SHARP_TAIL_THREADS > 0 (the default) from helper threads, in no particular order.
 static void unlimited_batch_window(const XRef *dX, const long long *ncb, const long long *ldb, int b0, int b1, int m, int p, int proj, int K,
-                                   double rN_seed, const std::function<void(int, const SharpOut &)> &deliver) {
+                                   double rN_seed, const std::function<void(int, const SharpOut &)> &deliver, const int *gids = nullptr) {
     FreeLater park_frees;                                 // (a buffer that grows in a tail helper or between chunks: no hipFree, i.e. no drain of the device, before the window is through)
     PendingFront &PF = pending_front();
     hc_set_after_last_agglomeration(nullptr);             // (every block's tail enqueues its own ensemble mean here)
@@ -775,13 +786,18 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
     std::vector<HcTask> tasks;
     std::vector<size_t> first(nbk + 1, 0);
     std::vector<long long> row0(nbk + 1, 0);
-    const int fo = knobs().front_overlap;
+#ifdef SHARP_LAB
+    const int fo = knobs().front_overlap;                 // (SHARP_FRONT_OVERLAP, an experiment: lab builds only)
+#else
+    constexpr int fo = 0;
+#endif
     for (int q = 0; q < nbk; ++q) {
         const int n = static_cast<int>(ncb[b0 + q]);
         SharpArgs &a = A[q];
         a.K = K; a.reduced_ndim = p; a.flag = 1; a.projector = proj; a.rN_seed = rN_seed; a.want_viE = true;   // as unlimited_block_dev
         HcParams &bs = base[q];                                                 // as sharp_front_dev for the large path
         bs.hmethod = 1; bs.minN = 2; bs.maxN = std::max(40, (n + 4999) / 5000); bs.sil_thre = 0.35; bs.height_Ntimes = 2.0;
+        a.block = gids ? gids[b0 + q] : b0 + q; bs.dec_block = a.block;
         HcParams bp = bs; bp.N_cluster = a.indN;
         F[q].reset(new LargeFront);
         LargeFront &f = *F[q];
@@ -804,6 +820,7 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
             front_of(q);
             tasks.insert(tasks.end(), F[q]->tasks.begin(), F[q]->tasks.end());
             first[q + 1] = tasks.size();
+            for (size_t i = first[q]; i < first[q + 1]; ++i) tasks[i].prm.dec_block = A[q].block;
         }
         fronts_done = nbk;
     } else {
@@ -820,6 +837,7 @@ static void unlimited_batch_window(const XRef *dX, const long long *ncb, const l
                     HcTask tk;
                     tk.d_mat = E0 + static_cast<long long>(fst[t]) * ldE + static_cast<long long>(k) * p;
                     tk.ld = ldE; tk.n = fst[t + 1] - fst[t]; tk.p = p; tk.prm = f.bp;
+                    tk.prm.dec_level = 0; tk.prm.dec_k = k; tk.prm.dec_fold = t; tk.prm.dec_block = A[q].block;
                     tasks.push_back(tk);
                 }
             first[q + 1] = tasks.size();
@@ -959,6 +977,7 @@ void unlimited_merge(const double *means, const long long *counts, int nC, int p
     prm.minN = minN > 0 ? minN : 2;                                             // :70-72
     prm.maxN = maxN > 0 ? maxN : static_cast<int>(std::max<long long>(40, (ncells + 4999) / 5000));   // :75-77
     prm.sil_thre = sil_thre; prm.height_Ntimes = height_Ntimes;
+    prm.dec_level = 3;
     DevBuf<double> dm;                                                          // (from the block cache: no hipMalloc / hipFree per call; smetac_from_means
     dm.alloc_pooled(static_cast<size_t>(nC) * p);                               //  returns with its stream drained, so the block may go back)
     dm.upload(means, static_cast<size_t>(nC) * p);
@@ -1261,7 +1280,8 @@ int sharp_unlimited_merge(const double *means, const long long *counts, int nC, 
 static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, const long long *ldb, int nblocks, int m, int p, int proj, int K,
                                   double rN_seed, double *const *viE_of,   // NULL, or per block where its E1 rows go (NULL: not wanted)
                                   const ViewCall &view,
-                                  const std::function<void(int, std::vector<int> &, std::vector<double> &, std::vector<long long> &)> &take) {
+                                  const std::function<void(int, std::vector<int> &, std::vector<double> &, std::vector<long long> &)> &take,
+                                  const int *gids = nullptr) {   // (decision log: the blocks' indices in the caller's list; NULL: 0, 1, ...)
     {
         int b = 0;
         while (b < nblocks) {                                                                                  // :125-149
@@ -1285,7 +1305,7 @@ static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, c
                 unlimited_batch_window(dX_blocks, ncb, ldb, b, e, m, p, proj, K, rN_seed, [&](int bb, const SharpOut &o) {
                     Got &g = got[bb - b];
                     unlimited_block_summary(o, ncb[bb], p, g.pb, g.mb, g.cb, viE_of ? viE_of[bb] : nullptr, view);
-                });
+                }, gids);
                 for (int q = b; q < e; ++q) take(q, got[q - b].pb, got[q - b].mb, got[q - b].cb);
                 b = e;
                 continue;
@@ -1296,7 +1316,7 @@ static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, c
             const bool more = b + 1 < nblocks;
             unlimited_block_dev(dX_blocks[b], m, ncb[b], ldb[b], p, proj, K, rN_seed, pb, mb, cb,
                                 viE_of ? viE_of[b] : nullptr, view, 1, nullptr, more ? dX_blocks[b + 1] : XRef(),
-                                more ? ncb[b + 1] : 0, more ? ldb[b + 1] : 0);
+                                more ? ncb[b + 1] : 0, more ? ldb[b + 1] : 0, gids ? gids[b] : b);
             take(b, pb, mb, cb);
             ++b;
         }
@@ -1646,7 +1666,7 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
                         pb[b].swap(a); mb[b].swap(c); cb[b].swap(d);
                         tl[static_cast<size_t>(b) * 6 + 0] = w; tl[static_cast<size_t>(b) * 6 + 1] = b;
                         tl[static_cast<size_t>(b) * 6 + 4] = t_go; tl[static_cast<size_t>(b) * 6 + 5] = wall_s() - t_begin;
-                    });
+                    }, my.data());
                 }
                 for (size_t i = hostpos.empty() && my.size() >= 2 ? my.size() : 0; i < my.size(); ++i) {
                     if (failed.load()) break;
@@ -1659,7 +1679,7 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
                     tl[static_cast<size_t>(b) * 6 + 4] = wall_s() - t_begin;
                     unlimited_block_dev(ref, m, blocks[b].n, ld, p, proj, K, rN_seed, pb[b], mb[b], cb[b],
                                         viE ? viE + static_cast<size_t>(cell0[b]) * view.cols(p) : nullptr,   // E1 rows of this block (:153), viewflag only
-                                        view, 1, nullptr, more ? nref : XRef(), more ? blocks[my[i + 1]].n : 0, more ? nld : 0);
+                                        view, 1, nullptr, more ? nref : XRef(), more ? blocks[my[i + 1]].n : 0, more ? nld : 0, b);
                     tl[static_cast<size_t>(b) * 6 + 5] = wall_s() - t_begin;
                     tl[static_cast<size_t>(b) * 6 + 0] = w; tl[static_cast<size_t>(b) * 6 + 1] = b;
                     if (blocks[b].on_host()) {

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <type_traits>
 
 #include "linalg.hpp"
@@ -983,10 +984,9 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     }
 }
 
-#include "hclust_tri.inc"
-#include "hclust_front.inc"
-
-#ifdef SHARP_LAB       // the lazy agglomeration (an experiment kept for reference): lab builds only
+#ifdef SHARP_LAB       // lab builds only (make LAB=1 -> sharp_amd/variants/libsharp_hip_lab.so; LAB_NOTES.md): the agglomeration forms that were
+#include "../../tools/lab/hclust_tri.inc"      // measured and not adopted -- on the upper triangle, append-only first rounds, lazy rows
+#include "../../tools/lab/hclust_front.inc"
 #include "../../tools/lab/hclust_lazy.inc"
 #endif
 
@@ -1551,7 +1551,9 @@ struct Workspace {
     DevBuf<HcMeta> meta;
     DevBuf<RowPrepTask> prep;
     DevBuf<GemmTask> gemm;
-    DevBuf<DistI8Task> i8;              // the sliced-integer form of the distance GEMM (gemm_i8.hip): descriptors, digits, row scales
+#ifdef SHARP_LAB
+    DevBuf<DistI8Task> i8;              // the sliced-integer form of the distance GEMM (tools/lab/gemm_i8.hip): descriptors, digits, row scales
+#endif
     DevBuf<signed char> sl;
     DevBuf<double> slscale;
 };
@@ -1616,6 +1618,81 @@ void select_level(const HcParams &prm, int n, int kmin, int nk, const double *ms
     (void)kmin;
     if (oind < 1 || oind > nk) { rc |= SHARP_WARN_RANGE; oind = oind < 1 ? 1 : nk; }
 }
+
+}  // namespace
+
+// ---- the decision log (hclust.hpp) -------------------------------------------------------------------------------------------------
+namespace {
+struct DecisionLog { std::mutex mu; bool on = false; std::vector<double> rows; };
+DecisionLog &dlog() { static DecisionLog *L = new DecisionLog; return *L; }
+inline double dnan() { return std::numeric_limits<double>::quiet_NaN(); }
+}  // namespace
+bool decision_log_on() { return dlog().on || knobs().decision_log; }
+void decision_log_set(bool on) { DecisionLog &L = dlog(); std::lock_guard<std::mutex> lk(L.mu); L.on = on; L.rows.clear(); }
+void decision_log_add(const double *row) { DecisionLog &L = dlog(); std::lock_guard<std::mutex> lk(L.mu); L.rows.insert(L.rows.end(), row, row + kDecisionCols); }
+void decision_log_override(int level, int block, int k_taken) {
+    DecisionLog &L = dlog();
+    std::lock_guard<std::mutex> lk(L.mu);
+    for (size_t r = L.rows.size() / kDecisionCols; r-- > 0;) {        // (the latest row of that call)
+        double *row = L.rows.data() + r * kDecisionCols;
+        if (static_cast<int>(row[0]) == level && static_cast<int>(row[1]) == block) { row[12] = k_taken; return; }
+    }
+}
+int decision_log_fetch(double *rows, int cap_rows) {
+    DecisionLog &L = dlog();
+    std::lock_guard<std::mutex> lk(L.mu);
+    const int nr = static_cast<int>(L.rows.size() / kDecisionCols);
+    std::vector<int> ord(nr);
+    for (int i = 0; i < nr; ++i) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+        const double *x = L.rows.data() + static_cast<size_t>(a) * kDecisionCols, *y = L.rows.data() + static_cast<size_t>(b) * kDecisionCols;
+        for (int c = 0; c < 4; ++c) if (x[c] != y[c]) return x[c] < y[c];
+        return false;
+    });
+    for (int i = 0; i < nr && i < cap_rows; ++i)
+        std::copy(L.rows.data() + static_cast<size_t>(ord[i]) * kDecisionCols, L.rows.data() + static_cast<size_t>(ord[i] + 1) * kDecisionCols,
+                  rows + static_cast<size_t>(i) * kDecisionCols);
+    return nr;
+}
+// the row of one decision: the same arithmetic, line for line, as the CPU checker's decision_row (the two logs are compared entry by entry)
+void decision_row(const HcParams &prm, int n, int kmin, int nk, const double *msil, const double *CH, const double *height, int oind,
+                  int branch, double *row) {
+    for (int c = 0; c < kDecisionCols; ++c) row[c] = dnan();
+    row[0] = prm.dec_level; row[1] = prm.dec_block; row[2] = prm.dec_k; row[3] = prm.dec_fold; row[4] = n;
+    row[5] = branch; row[6] = kmin + oind - 1; row[12] = 0; row[13] = nk;
+    if (prm.N_cluster > 0) { row[5] = 3; row[6] = prm.N_cluster; row[7] = 1; row[8] = msil[0]; row[13] = 1; return; }
+    double mx = msil[0];
+    for (int c = 1; c < nk; ++c) if (msil[c] > mx) mx = msil[c];
+    row[10] = mx - prm.sil_thre;
+    const double *val = branch == 0 ? msil : CH;
+    double best = branch == 0 ? mx : val[0];
+    if (branch != 0) for (int c = 1; c < nk; ++c) if (val[c] > best) best = val[c];
+    int ties = 0;
+    double second = dnan();
+    for (int c = 0; c < nk; ++c) {
+        if (val[c] == best) ++ties;
+        else if (val[c] < best && (!(second == second) || val[c] > second)) second = val[c];
+    }
+    row[7] = ties; row[8] = best; row[9] = second;
+    if (branch >= 1 && (branch == 2 || CH[0] == best)) {                    // which.max(CHind) == 1: the height rule was consulted (:196-210)
+        bool first = true;
+        for (int c = 1; c < nk; ++c) if (CH[c] > CH[0]) first = false;
+        if (first) {
+            const int nh = n - 1, t0 = nh > 10 ? nh - 10 : 0, tl = nh - t0;
+            const double *tmp = height + t0;
+            double rmax = dnan();
+            for (int i = 0; i + 1 < tl; ++i) {
+                const double dif = tmp[i + 1] - tmp[i], den = (prm.height_Ntimes - 1) * tmp[i];
+                const double r = den > 0 ? dif / den : (dif > 0 ? std::numeric_limits<double>::infinity() : 0.0);
+                if (branch == 2) { if (dif > den) { rmax = r; break; } }
+                else if (!(rmax == rmax) || r > rmax) rmax = r;
+            }
+            row[11] = rmax;
+        }
+    }
+}
+
+namespace {
 
 // One chunk of tasks: enqueue_chunk() puts all its device work on streams, finish_chunk() fetches the statistics, selects the
 // levels on the host and fetches the labels.  `pipe` = the chunk is one of several in flight (run on its slot's own stream, ordered
@@ -1794,6 +1871,7 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
             R.cnt[kind] = static_cast<int>(g.size()) - R.off[kind];
         }
     }
+#ifdef SHARP_LAB
     J.i8 = knobs().dist_i8 && max_p <= 8192;
     if (J.i8) {
         std::vector<DistI8Task> d8;
@@ -1813,6 +1891,7 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
         W.i8.ensure(std::max<size_t>(d8.size(), 1));
         if (!d8.empty()) W.i8.upload(d8.data(), d8.size());
     }
+#endif
     // many candidate levels (> kMlMinLevels; SHARP_ML_MIN_LEVELS for tests): G and T of the whole chunk row-major (n x kpad)
     {
         J.ml = max_nk > ml_min_levels();
@@ -1916,8 +1995,11 @@ void enqueue_chunk(ChunkJob &J, int phases) {
         // this chunk's distance GEMM starts when the previous chunk's has finished, i.e. together with the previous chunk's
         // agglomeration, and fills the CUs that one leaves free (it holds a whole CU per task)
         if (J.pipe && !J.first) SHARP_HIP_CHECK(hipStreamWaitEvent(st, EV.gemm[J.prev_slot], 0));
+#ifdef SHARP_LAB
         if (R.cnt[0] && J.i8) dist_i8_batched(W.i8.p + R.off8, R.cnt[0], max_n);
-        else if (R.cnt[0]) gemm_tn_f64_batched(W.gemm.p + R.off[0], R.cnt[0], max_n, max_n, "corr_dist_gemm", true, true);
+        else
+#endif
+        if (R.cnt[0]) gemm_tn_f64_batched(W.gemm.p + R.off[0], R.cnt[0], max_n, max_n, "corr_dist_gemm", true, true);
         if (J.pipe) SHARP_HIP_CHECK(hipEventRecord(EV.gemm[J.slot], st));
         if (R.any_sym) {
             KernelTimer tm("copy_d");
@@ -1998,7 +2080,6 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                     if (const char *e = lab_env("SHARP_HC_LAZY_THETA")) theta = std::max(10, std::min(95, atoi(e)));
                     hipLaunchKernelGGL(hclust_lazy_kernel, dim3(Ts), dim3(HL_THREADS), ldsz, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p,
                                        W.height.p, W.status.p + R.t0, theta);
-#endif
                 } else if (Ts <= c.num_cu && max_n <= HT_MAXN && knobs().hc_tri) {
                     // one workgroup per CU on the upper triangle of the matrix (hclust_tri.inc): half the bytes of hclust_rnn_kernel
                     const size_t tstate = (static_cast<size_t>(nal) * (16 + 8 + 4 + 4 + 2 * 7 + 1) + 16 * 4 + (1024 / 64 + 1) * 4 + 64 + 15) / 16 * 16;
@@ -2023,6 +2104,7 @@ void enqueue_chunk(ChunkJob &J, int phases) {
                     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsl)));
                     hipLaunchKernelGGL(kc, dim3(Ts), dim3(1024), ldsl, st, dmeta, W.D.p, W0.S0.p, W0.S1.p, W.ia.p, W.ib.p, W.height.p,
                                        W.status.p + R.t0, W0.img.p, static_cast<long long>(lds), static_cast<int>(lds), 1, W0.remaining.p, static_cast<int>(ldsl));
+#endif
                 } else if (Ts <= c.num_cu && !knobs().hc_half) {
                     auto k0 = hclust_rnn_kernel<1024, 0>;
                     // one workgroup per CU: everything the CU has beyond the state stages the pair members' entries
@@ -2210,6 +2292,11 @@ void finish_chunk(const std::vector<HcTask> &tasks, ChunkJob &J, bool want_v, st
         } else {
             select_level(tk.prm, M.n, M.kmin, M.nk, R.msil.data(), R.CHind.data(), R.height.data(), oind, R.branch, R.rc);
             R.maxsil = *std::max_element(R.msil.begin(), R.msil.end());
+        }
+        if (decision_log_on()) {
+            double row[kDecisionCols];
+            decision_row(tk.prm, M.n, M.kmin, M.nk, R.msil.data(), R.CHind.data(), R.height.data(), oind, R.branch, row);
+            decision_log_add(row);
         }
         chosen[t] = oind - 1;
     });
@@ -2452,6 +2539,7 @@ hipEvent_t hc_prefetch_agglomerate(HcPrefetch &P) {
     return P.agglo_done;
 }
 
+void hc_prefetch_stamp_block(HcPrefetch &P, int block) { for (HcTask &t : P.tasks) t.prm.dec_block = block; }   // (decision log: the call that uses the batch names its block)
 void hc_prefetch_finish(HcPrefetch &P, bool want_v, std::vector<HcResult> &out) {
     out.assign(P.tasks.size(), HcResult());
     if (!P.agglo_enqueued) hc_prefetch_agglomerate(P);
@@ -2559,6 +2647,19 @@ int sharp_get_opt_hclust(const double *mat, int n, int p, int hmethod, int N_clu
     catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
     catch (const std::exception &e) { sharp::set_error(e.what()); return SHARP_ERR; }
     return warn;
+}
+
+/* the decision log (hclust.hpp says what a row holds) */
+int sharp_decision_log(int enable) {
+    SHARP_API_BEGIN
+    decision_log_set(enable != 0);
+    SHARP_API_END
+}
+int sharp_last_decisions(double *rows, int cap_rows, int *n_rows) {
+    SHARP_API_BEGIN
+    SHARP_REQUIRE(n_rows && (rows || cap_rows == 0) && cap_rows >= 0, "sharp_last_decisions: null argument");
+    *n_rows = decision_log_fetch(rows, cap_rows);
+    SHARP_API_END
 }
 
 int sharp_getrowColor(const double *E, int n, int p, int hmethod, int indN_cluster, int minN, int maxN, double sil_thre,

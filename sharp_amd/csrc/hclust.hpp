@@ -15,7 +15,30 @@ struct HcParams {
     int minN = 2, maxN = 40;
     double sil_thre = 0.35;
     double height_Ntimes = 2.0;
+    // where the call sits in the run, for the decision log only (sharp_decision_log): level 0 = base clustering of one random projection of
+    // one fold (getrowColor), 1 = a fold's wMetaC, 2 = the sMetaC across a block's folds, 3 = SHARP_unlimited's sMetaC across blocks,
+    // -1 = a direct call of the entry point
+    int dec_level = -1, dec_block = 0, dec_k = 0, dec_fold = 0;
 };
+
+// The decision log ("tests must log the best-vs-second-best margin of every model-selection decision"): one row per
+// get_opt_hclust call while it is on (sharp_decision_log(1) or SHARP_DECISION_LOG=1), the same row the CPU checker of tests/ writes:
+//  0 level  1 block  2 k (projection)  3 fold  4 n  5 branch (0 median silhouette, 1 CH, 2 height gap, 3 N.cluster given)  6 chosen number of
+//  clusters  7 exact ties at the deciding maximum (R/get_opt_hclust.R:162-168 picks the middle one; which.max the first, :194-195)
+//  8 the deciding maximum (msil for branch 0 / 3, CH for 1 / 2)  9 the largest value strictly below it (NaN: none)
+//  10 max(msil) - sil.thre: the distance to the silhouette / CH switch (:194)
+//  11 height rule (:196-210), when CH's first level won: (gap / ((height.Ntimes - 1) * height)) of the deciding step (branch 2: > 1) or its
+//     maximum over the last ten merges (branch 1: <= 1); NaN otherwise
+//  12 sMetaC's two-cluster override (R/sMetaC.R:139-148): the number of clusters of the column taken instead, 0 = not applied
+//  13 number of candidate levels
+constexpr int kDecisionCols = 14;
+bool decision_log_on();
+void decision_log_set(bool on);                 // (clears the log)
+void decision_log_add(const double *row);
+void decision_log_override(int level, int block, int k_taken);
+int decision_log_fetch(double *rows, int cap_rows);     // rows sorted by (level, block, k, fold); returns the number of rows held
+void decision_row(const HcParams &prm, int n, int kmin, int nk, const double *msil, const double *CH, const double *height, int oind,
+                  int branch, double *row);
 
 // One clustering problem of a batch.  d_mat is DEVICE memory: n x p row-major with leading dimension
 // ld (feature rows), or an n x n symmetric similarity (symmetric = true, p = n).
@@ -73,6 +96,7 @@ std::shared_ptr<HcPrefetch> hc_prefetch_begin(std::vector<HcTask> tasks, int slo
 // what the caller makes the NEXT block's front wait for, so that it runs under the statistics and the host-bound tail, not beside
 // the HBM-bound agglomeration
 hipEvent_t hc_prefetch_agglomerate(HcPrefetch &P);
+void hc_prefetch_stamp_block(HcPrefetch &P, int block);
 void hc_prefetch_finish(HcPrefetch &P, bool want_v, std::vector<HcResult> &out);
 
 }  // namespace sharp

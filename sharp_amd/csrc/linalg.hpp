@@ -46,7 +46,8 @@ struct RowPrepTask {
 void row_prep_batched(const RowPrepTask *d_tasks, int count, int max_n, int max_p, bool all_feature_rows = false);
 
 
-// The correlation-distance matrix of one task on the integer matrix cores (gemm_i8.hip): D = 1 - clamp(U U^T), zero diagonal, from the
+#ifdef SHARP_LAB
+// (lab builds only) The correlation-distance matrix of one task on the integer matrix cores (tools/lab/gemm_i8.hip): D = 1 - clamp(U U^T), zero diagonal, from the
 // unit rows Cr (n x p row-major, ld p) cut into kDistI8Slices 7-bit digits per entry.
 constexpr int kDistI8Slices = 7;
 struct DistI8Task {
@@ -60,5 +61,6 @@ size_t dist_i8_slice_bytes(int nld, int p);
 void dist_i8_batched(const DistI8Task *d_tasks, int count, int max_n);
 void dist_i8_slices(const DistI8Task *d_tasks, int count, int max_n);     // rows -> digits
 void dist_i8_products(const DistI8Task *d_tasks, int count, int max_n);   // digits -> D
+#endif
 
 }  // namespace sharp

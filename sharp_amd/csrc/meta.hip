@@ -454,6 +454,7 @@ SmResult smetac_from_means(const double *d_means, int nC, int p, long long ncell
         int s2 = 0;
         for (int q = 0; q < H.nk; ++q) if (H.msil[q] == s1) { s2 = q; break; }   // quirk 9: first of tied columns
         R.tf.assign(H.v.begin() + static_cast<size_t>(s2) * nC, H.v.begin() + static_cast<size_t>(s2 + 1) * nC);
+        if (decision_log_on()) decision_log_override(prm.dec_level, prm.dec_block, prm.minN + s2);
     }
     R.optN = *std::max_element(R.tf.begin(), R.tf.end());
     return R;

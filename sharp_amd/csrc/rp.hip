@@ -308,8 +308,16 @@ static void launch_rp(const ProjectorGroup &g, const Projector &pr, const float 
     launch_check("rp_scatter_kernel");
 }
 
+#ifdef SHARP_LAB
 void project_dev_split(const Projector &pr, const ProjectorGroup &g, XRef dX, int m, int n, long long ld, int log_flag,
-                       int fix_bits, double *dE, long long ldE, const int *d_row_map, unsigned ahead_token);   // rp2.hip
+                       int fix_bits, double *dE, long long ldE, const int *d_row_map, unsigned ahead_token);   // tools/lab/rp2.hip
+#else
+// (the two-kernel form -- compaction + apply, tools/lab/rp2.hip -- and its compaction ahead of the projector build are lab code: the
+// producer / consumer kernel of rp3.hip takes every input they took)
+unsigned rp_compact_ahead(XRef, int, int, long long, int) { return 0; }
+void rp_compact_ahead_drop() {}
+void rp_trim() {}
+#endif
 
 void project_dev(const Projector &pr, XRef X, int m, int n, long long ld, int log_flag, double *dE, long long ldE,
                  const int *d_row_map, unsigned ahead_token) {
@@ -347,10 +355,15 @@ void project_dev(const Projector &pr, XRef X, int m, int n, long long ld, int lo
             project_dev_pc(pr, g, X, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map);
             continue;
         }
+#ifdef SHARP_LAB
         if (vec && m >= 8 && m <= (1 << 20) && (X.f64 || !fused)) {   // (20-bit gene index in the compacted entries)
             project_dev_split(pr, g, X, m, n, ld, log_flag, fix_bits, dE, ldE, d_row_map, ahead_token);
             continue;
         }
+#else
+        (void)fused; (void)ahead_token;
+#endif
+        SHARP_REQUIRE(!X.f64, "project: an fp64 block needs at least 17 genes (the producer / consumer kernel) or the dense form");
         if (gw == 16 && g.slots == 4) { SHARP_RP_CASE(16, 4); }
         else if (gw == 16) { SHARP_RP_CASE(16, 2); }
         else if (gw == 8) { SHARP_RP_CASE(8, 4); }

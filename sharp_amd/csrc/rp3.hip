@@ -536,11 +536,11 @@ void launch_pc(const ProjectorGroup &g, const Projector &pr, const PcParams &P0,
 }  // namespace
 
 // The default form of the RP matmul (SHARP_RP_KERNEL unset or "pc") wherever X can be read with 16-byte loads and a gene index fits
-// the entry word; "split" / "fused" / "dense" name the other forms.
+// the entry word; "fused" / "dense" name the other forms (lab builds: "split", the two-kernel form of tools/lab/rp2.hip).
 bool rp_pc_eligible(XRef X, int m, long long ld) {
     const bool vec = (ld % (X.f64 ? 2 : 4) == 0) && ((reinterpret_cast<uintptr_t>(X.p) & 15u) == 0);
     const int k = knobs().rp_kernel;
-    return (k == 0 || k == 3 || k == 4) && vec && m > 16 && m <= (1 << 20);
+    return (k == 0 || k == 3 || k == 4 || (X.f64 && k != 2)) && vec && m > 16 && m <= (1 << 20);   // (an fp64 block has no other sparse form)
 }
 
 // One projector group per call; X 16-byte aligned with ld % 4 == 0 (fp32) / ld % 2 == 0 (fp64).

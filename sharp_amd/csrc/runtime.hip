@@ -312,8 +312,35 @@ namespace sharp {
 // The one place the library reads its environment: at the first use (sharp_init) and again only when sharp_reload_options() asks for it.
 static Knobs read_knobs() {
     Knobs v;
-    auto env = [](const char *name) { return getenv(name); };                    // (the library's only getenv outside -DSHARP_LAB code)
+    auto env = [](const char *name) { return getenv(name); };                    // (the library's only getenv outside lab_env())
     auto num = [&](const char *name, int dflt) { const char *e = env(name); return e && *e ? atoi(e) : dflt; };
+    // what a user or a test of the product may want to set
+    if (const char *kv = env("SHARP_RP_KERNEL")) v.rp_kernel = !strcmp(kv, "fused") ? 1 : !strcmp(kv, "dense") ? 2 : !strcmp(kv, "pc") ? 4 : 0;
+    if (const char *xs = env("SHARP_X_STORAGE")) v.x_storage = !strcmp(xs, "fp32") ? 32 : !strcmp(xs, "fp64") ? 64 : 0;
+    v.host_threads = num("SHARP_HOST_THREADS", 0);
+    v.upload_threads = num("SHARP_UPLOAD_THREADS", 0);
+    v.tail_threads = num("SHARP_TAIL_THREADS", 4);
+    v.unlimited_batch = num("SHARP_UNLIMITED_BATCH", 1) != 0;
+    v.unlimited_window_mb = num("SHARP_UNLIMITED_WINDOW_MB", 0);
+    v.block_prefetch = num("SHARP_NO_BLOCK_PREFETCH", 0) == 0;
+    v.decision_log = num("SHARP_DECISION_LOG", 0) != 0;
+    v.step_marks = num("SHARP_STEP_MARKS", 0) != 0;
+    // cross-checks between the forms the library itself chooses from (tests/): sequential / one-launch / round-per-launch agglomeration, chunking,
+    // the two statistics kernels, the incremental statistics, the host build of the projectors
+    v.hc_seq = num("SHARP_HC_SEQ", 0) == 1;
+    v.hc_mono = num("SHARP_HC_MONO", 0) == 1;
+    v.hc_split = num("SHARP_HC_SPLIT", -1);
+    v.hc_pipe = num("SHARP_HC_PIPE", 1) != 0;
+    v.hc_chunk = num("SHARP_HC_CHUNK", 0);
+    v.hc_first_chunk = num("SHARP_HC_FIRST_CHUNK", 0);
+    v.hc_ranges = num("SHARP_HC_RANGES", 0);
+    v.stats_lane = num("SHARP_STATS_LANE", 1) != 0;
+    v.ml_min_levels = num("SHARP_ML_MIN_LEVELS", 0);
+    v.proj_host = num("SHARP_PROJ_HOST", 0) == 1;
+    v.rp_pc_wgs = std::max(1, num("SHARP_RP_PC_WGS", 2));
+#ifdef SHARP_LAB
+    // lab builds (make LAB=1) only: alternative kernels and schedule experiments that were measured and not adopted (LAB_NOTES.md)
+    if (const char *kv = env("SHARP_RP_KERNEL")) { if (!strcmp(kv, "sparse")) v.rp_kernel = 3; else if (!strcmp(kv, "split")) v.rp_kernel = 5; }
     v.rp_dual = num("SHARP_RP_DUAL", 1) != 0;
     { const int ser = num("SHARP_RP_SERIAL", -1); v.rp_two_streams = ser < 0 ? -1 : (ser == 0 ? 1 : 0); }
     v.rp_chunk = num("SHARP_RP_CHUNK", 0);
@@ -321,40 +348,21 @@ static Knobs read_knobs() {
     v.rp_cp_wgs = std::max(1, num("SHARP_RP_CP_WGS", 8));
     v.rp_ap_wgs = std::max(1, num("SHARP_RP_AP_WGS", 4));
     v.rp_shape = num("SHARP_RP_SHAPE", 0);
-    if (const char *kv = env("SHARP_RP_KERNEL")) v.rp_kernel = !strcmp(kv, "fused") ? 1 : !strcmp(kv, "dense") ? 2 : !strcmp(kv, "sparse") ? 3 : !strcmp(kv, "pc") ? 4 : !strcmp(kv, "split") ? 5 : 0;
-    v.rp_pc_wgs = std::max(1, num("SHARP_RP_PC_WGS", 2));
     if (const char *ps = env("SHARP_RP_PC_SHAPE")) v.rp_pc_shape = (*ps == 'a' || *ps == 'A') ? 1 : (*ps == 'b' || *ps == 'B') ? 2 : 0;
-    if (const char *xs = env("SHARP_X_STORAGE")) v.x_storage = !strcmp(xs, "fp32") ? 32 : !strcmp(xs, "fp64") ? 64 : 0;
-    v.block_prefetch = num("SHARP_NO_BLOCK_PREFETCH", 0) == 0;
-    v.unlimited_batch = num("SHARP_UNLIMITED_BATCH", 1) != 0;
-    v.unlimited_window_mb = num("SHARP_UNLIMITED_WINDOW_MB", 0);
-    v.ml_min_levels = num("SHARP_ML_MIN_LEVELS", 0);
-    v.hc_mono = num("SHARP_HC_MONO", 0) == 1;
-    v.hc_seq = num("SHARP_HC_SEQ", 0) == 1;
-    v.hc_split = num("SHARP_HC_SPLIT", -1);
-    v.hc_ranges = num("SHARP_HC_RANGES", 0);
     v.hc_wpt = num("SHARP_HC_WPT", 0);
     v.hc_finish_at = num("SHARP_HC_FINISH_AT", 15);
-    v.hc_chunk = num("SHARP_HC_CHUNK", 0);
-    v.hc_pipe = num("SHARP_HC_PIPE", 1) != 0;
     v.mean_early = num("SHARP_MEAN_EARLY", 0) != 0;
     v.hc_prep_early = num("SHARP_HC_PREP_EARLY", 1) != 0;
     v.hc_tri = num("SHARP_HC_TRI", 0) != 0;
-    v.stats_sums = num("SHARP_STATS_SUMS", 1) != 0;
-    v.stats_lane = num("SHARP_STATS_LANE", 1) != 0;
-    v.dist_i8 = num("SHARP_DIST_I8", 0) != 0;
-    v.tail_threads = num("SHARP_TAIL_THREADS", 4);
-    v.host_threads = num("SHARP_HOST_THREADS", 0);
+    v.hc_front = num("SHARP_HC_FRONT", 0);
     v.hc_half = num("SHARP_HC_HALF", 0) != 0;
-    v.step_marks = num("SHARP_STEP_MARKS", 0) != 0;
+    v.stats_sums = num("SHARP_STATS_SUMS", 1) != 0;
+    v.dist_i8 = num("SHARP_DIST_I8", 0) != 0;
     v.free_later = num("SHARP_FREE_LATER", 1) != 0;
     v.front_overlap = num("SHARP_FRONT_OVERLAP", 0);
-    v.hc_first_chunk = num("SHARP_HC_FIRST_CHUNK", 0);
-    v.hc_front = num("SHARP_HC_FRONT", 0);
     v.tail_priority = num("SHARP_TAIL_PRIORITY", 1) != 0;
     v.gemm_slice = num("SHARP_GEMM_SLICE", 8);
-    v.proj_host = num("SHARP_PROJ_HOST", 0) == 1;
-    v.upload_threads = num("SHARP_UPLOAD_THREADS", 0);
+#endif
     if (const char *dl = env("SHARP_DEVICES")) {
         for (const char *q = dl; *q;) {
             char *end = nullptr;

@@ -6,7 +6,7 @@
         sMetaC, R/sMetaC.R:110-119), checked against the oracle's merge on the same centroid tables
   cfg5  10 M cells x 20 000 genes, 200 streamed blocks of 50 000 (25 per GPU in the 8-GPU run), p = 582 -- all 200 generated
         on the fly into one buffer, then the merge at ncells = 1e7 (k = 200 .. 2000: 1801 candidate levels) against the oracle
-  one full-size block (50 000 x 20 000, K = 5, cfg3's reduced dimension) label for label against the oracle
+  cfg2  50 000 x 20 000, K = 15 WHOLE, label for label and decision for decision against the oracle
   sharp_sMetaC at n = 1.2 M cells against the oracle; clustering tasks beyond the LDS-resident limits (> 4096, > 7168 rows)
 
 The oracle is the CPU restatement of the reference (oracle/); where it would need hours (whole configs) the checks are the
@@ -201,44 +201,41 @@ def test_cfg5_two_hundred_streamed_blocks_and_merge_at_1e7_cells(env, oracle):
     assert min(adjusted_rand_score(truth[b], preds[b]) for b in range(0, B, 20)) > 0.9
 
 
-def test_full_size_block_matches_oracle(env, oracle):
-    """One 50 000 x 20 000 block, ensize.K = 5, p = 474 (a block of cfg3), SHARP_large: labels identical to the oracle's."""
-    sa, dev, torch = env
-    n, m, K, p = 50000, 20000, 5, 474
-    dX = torch.empty((n, m), dtype=torch.float32, device="cuda")
-    dev.synth_fill(dX, SEED, 0)
-    pred, info = dev.SHARP_dev(dX, ensize_K=K, reduced_ndim=p, rN_seed=RN)
-    assert info["path"] == "SHARP_large"
-    X = dX.cpu().numpy().T.astype(np.float64)                             # (genes, cells), column-major: 8 GB
-    del dX
-    torch.cuda.empty_cache()
-    cores = min(os.cpu_count() or 1, 32)                                  # 125 tasks; every thread holds a 320 MB fold copy (32 threads beat 64: memory-bound)
-    t0 = time.perf_counter()
-    ref = oracle.SHARP(X, K=K, reduced_ndim=p, rN_seed=RN, nthreads=cores, want_view=False)
-    print("oracle: %.1f s on %d threads (%.0f cells/s)" % (time.perf_counter() - t0, cores, n / (time.perf_counter() - t0)))
-    assert ref["rc"] in (0, 16)
-    assert np.array_equal(pred, ref["pred_clusters"])
-
-
 def test_cfg2_full_size_matches_oracle(env, oracle):
     """BASELINE.json configs[1] whole: 50 000 x 20 000, ensize.K = 15, p = 391 (the reduced dimension SHARP() derives from 50 000 cells),
-    SHARP_large with 375 base tasks: labels identical to the oracle's, cell for cell (R/SHARP.R:478-851)."""
+    SHARP_large with 375 base tasks: labels identical to the oracle's, cell for cell (R/SHARP.R:478-851) -- and the two decision logs
+     agree decision for decision: 375 base tasks, 25 per-fold wMetaC, the sMetaC across the folds.  (One block of
+    cfg3 -- K = 5, p = 474 -- against the oracle: tools/parity_fullsize.py cfg3_block, profiles/r06_cfg3_block_parity.txt.)"""
+    from test_decisions_gpu import compare_logs
+
     sa, dev, torch = env
     n, m, K = 50000, 20000, 15
     dX = torch.empty((n, m), dtype=torch.float32, device="cuda")
     dev.synth_fill(dX, SEED, 0)
-    pred, info = dev.SHARP_dev(dX, ensize_K=K, rN_seed=RN)
+    sa.decision_log(True)
+    try:
+        pred, info = dev.SHARP_dev(dX, ensize_K=K, rN_seed=RN)
+        got = sa.last_decisions()
+    finally:
+        sa.decision_log(False)
     assert info["path"] == "SHARP_large" and info["reduced.dim"] == 391
     X = dX.cpu().numpy().T.astype(np.float64)                             # (genes, cells), column-major: 8 GB
     del dX
     torch.cuda.empty_cache()
     cores = min(len(os.sched_getaffinity(0)), 32)                         # 375 tasks; every thread holds a 320 MB fold copy; the oracle is memory-bound: 32 threads beat 64 (bench.py cpu_baseline)
     t0 = time.perf_counter()
-    ref = oracle.SHARP(X, K=K, rN_seed=RN, nthreads=cores, want_view=False)
+    oracle.decision_log(True)
+    try:
+        ref = oracle.SHARP(X, K=K, rN_seed=RN, nthreads=cores, want_view=False)
+        want = oracle.last_decisions()
+    finally:
+        oracle.decision_log(False)
     print("oracle: %.1f s on %d threads (%.0f cells/s)" % (time.perf_counter() - t0, cores, n / (time.perf_counter() - t0)))
     assert ref["rc"] in (0, 16)
     assert info["N.pred_cluster"] == ref["pred_clusters"].max()
     assert np.array_equal(pred, ref["pred_clusters"])
+    assert got.shape[0] == 375 + 25 + 1
+    compare_logs(sa, got, want, "cfg2 whole")
 
 
 def test_block_of_1e5_cells_no_reshuffle_branch_matches_oracle(env, oracle):
@@ -315,27 +312,6 @@ def test_cfg1_shaped_call_matches_oracle(env, oracle):
         assert rp[k]["N.cluster"] == len(set(rp[k]["rowColor"]))
 
 
-def test_upper_triangle_agglomeration_at_cfg2_size(env, monkeypatch):
-    """BASELINE.json configs[1] (50 000 x 20 000, ensize.K = 15: 375 base tasks of 2000 cells in two chunks of one task per CU) with the
-    upper-triangle agglomeration kernel (SHARP_HC_TRI=1) and with the default full-matrix one: every task done by the bulk-synchronous
-    kernel either way, identical labels."""
-    sa, dev, torch = env
-    n, m, K = 50000, 20000, 15
-    dX = torch.empty((n, m), dtype=torch.float32, device="cuda")
-    dev.synth_fill(dX, SEED, 0)
-    dev.profile(True)
-    pred, info = dev.SHARP_dev(dX, ensize_K=K, rN_seed=RN)
-    tab = dev.profile_table()
-    assert tab.get("host:hclust_tasks_sequential", (0, 0))[1] <= 25 + 1        # (the 25 wMetaC similarity tasks and the sMetaC one have exact ties)
-    monkeypatch.setenv("SHARP_HC_TRI", "1")
-    dev.profile(True)
-    pred_tri, info_tri = dev.SHARP_dev(dX, ensize_K=K, rN_seed=RN)
-    tab_tri = dev.profile_table()
-    dev.profile(False)
-    assert tab_tri.get("host:hclust_tasks_bulk_synchronous", (0, 0))[1] >= 375
-    assert np.array_equal(pred, pred_tri) and info["N.pred_cluster"] == info_tri["N.pred_cluster"]
-
-
 def test_smetac_at_1p2M_cells_matches_oracle(env, oracle):
     """sharp_sMetaC with n >= 1e6 (R/sMetaC.R:110-119: maxN = max(maxN, n/5000), minN = max(minN, n/50000))."""
     sa, dev, torch = env
@@ -385,10 +361,11 @@ def test_similarity_task_beyond_the_lds_limits(env, oracle, n, monkeypatch):
 
 
 def test_unlimited_merge_beyond_7168_rows(env, oracle):
-    """sharp_unlimited_merge on 9000 (block, cluster) rows -- cfg5's 200 blocks x 40 clusters would be 8000 (R/SHARP_unlimited.R:163)."""
+    """sharp_unlimited_merge on 7400 (block, cluster) rows, beyond the 7168 the agglomeration keeps in LDS -- cfg5's 200 blocks x 40 clusters
+    would be 8000 (R/SHARP_unlimited.R:163); test_cfg5_* runs that merge at its true size."""
     sa, dev, torch = env
     rng = np.random.default_rng(5)
-    nC, p, G = 9000, 64, 40
+    nC, p, G = 7400, 64, 40
     cen = rng.standard_normal((G, p))
     M = cen[rng.integers(0, G, nC)] + 0.3 * rng.standard_normal((nC, p))
     Cn = rng.integers(5, 200, nC).astype(np.int64)          # < 1e6 cells in all: the k range stays 10 .. 40
@@ -444,10 +421,8 @@ def test_unlimited_batched_base_clustering_equals_block_by_block(env, monkeypatc
         ph, nh, _ = run()
         monkeypatch.delenv("SHARP_TAIL_THREADS")
         assert nh == n1 and np.array_equal(ph, p1), h
-    # the schedule switches of the window: the blocks' fronts (shuffle, RP kernel) enqueued just in time, two chunks ahead of the base
-    # tasks that read them (SHARP_FRONT_OVERLAP=1; =2: the later blocks' RP kernels with one workgroup per CU), and the first chunk's
-    # size (equal chunks / a short first chunk): the same tasks on the same inputs, whatever the order they are enqueued in
-    for var, val in (("SHARP_FRONT_OVERLAP", "1"), ("SHARP_FRONT_OVERLAP", "2"), ("SHARP_HC_FIRST_CHUNK", "-1"), ("SHARP_HC_FIRST_CHUNK", "150")):
+    # the first chunk's size (equal chunks / a short first chunk): the same tasks on the same inputs, whatever the order they are enqueued in
+    for var, val in (("SHARP_HC_FIRST_CHUNK", "-1"), ("SHARP_HC_FIRST_CHUNK", "150")):
         monkeypatch.setenv(var, val)
         ps, ns_, _ = run()
         monkeypatch.delenv(var)

@@ -54,27 +54,3 @@ def test_symmetric_correlation_epilogues(lib, fast, n, K):
     np.fill_diagonal(ref2, 1.0)
     np.testing.assert_allclose(sres, ref2, rtol=0, atol=1e-13 * K)
     assert np.array_equal(sres, sres.T) and np.all(np.diag(sres) == 1.0) and sres.max() <= 1.0
-
-
-@pytest.mark.parametrize("n,p", [(3, 2), (64, 8), (129, 33), (300, 50), (1000, 223), (2000, 391), (1999, 474)])
-def test_distance_matrix_on_the_integer_matrix_cores(lib, n, p):
-    """gemm_i8.hip (SHARP_DIST_I8=1): D = 1 - U U^T of centred unit rows through seven 7-bit digits per entry and exact int8 products.
-    Against a long-double product: the digits truncate a row below 2^-49 of its largest entry, so |D - ref| stays below 5e-14 (seven
-    digits: 1-2e-14 measured; the fp64 MFMA kernel has 2e-15); symmetric, zero diagonal, ragged n and p (n not a multiple of the 32-row
-    blocks, p not a multiple of the 32-deep k step), rows of very different scale (their powers of two differ)."""
-    rng = np.random.default_rng(n * 7 + p)
-    X = rng.standard_normal((n, p)) * np.exp(2 * rng.standard_normal((n, 1)))
-    X[: n // 3] += 3 * rng.standard_normal((1, p))
-    X[n // 2, :] = 0.0
-    X[n // 2, p // 2] = 5.0                                   # one entry dominates its row
-    Xc = X - X.mean(1, keepdims=True)
-    U = np.ascontiguousarray(Xc / np.sqrt((Xc * Xc).sum(1, keepdims=True)))
-    D = np.full((n, n), np.nan)
-    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-    rc = lib.sharp_dist_i8(dp(U), n, p, dp(D))
-    assert rc == 0, lib.sharp_last_error()
-    Ul = U.astype(np.longdouble)
-    ref = 1 - np.clip(Ul @ Ul.T, -1, 1)
-    np.fill_diagonal(ref, 0)
-    assert np.abs(D - ref.astype(np.float64)).max() < 5e-14
-    assert np.array_equal(D, D.T) and not D.diagonal().any()

@@ -1,5 +1,6 @@
-"""The RP matmul as ONE producer / consumer kernel (rp3.hip, SHARP_RP_KERNEL=pc) against the two-kernel form (rp2.hip,
-SHARP_RP_KERNEL=split) bit for bit, and against the oracle: R/RPmat.R:32, R/SHARP.R:343-345,569-585."""
+"""The RP matmul as ONE producer / consumer kernel (rp3.hip, the default) against the library's other sparse form (rp.hip, the single
+scatter kernel that takes unaligned blocks; SHARP_RP_KERNEL=fused) bit for bit -- both add the same fixed-point terms, in any order --
+and against the oracle: R/RPmat.R:32, R/SHARP.R:343-345,569-585.  (The two-kernel form of rounds 2-3 is lab code: tools/lab/rp2.hip.)"""
 import ctypes as C
 
 import numpy as np
@@ -19,7 +20,7 @@ def sa():
 
 
 def both(sa, monkeypatch, pr, X, logflag):
-    monkeypatch.setenv("SHARP_RP_KERNEL", "split")
+    monkeypatch.setenv("SHARP_RP_KERNEL", "fused")
     E2 = pr.project(X, logflag=logflag)
     monkeypatch.setenv("SHARP_RP_KERNEL", "pc")
     E3 = pr.project(X, logflag=logflag)
@@ -29,7 +30,7 @@ def both(sa, monkeypatch, pr, X, logflag):
 
 @pytest.mark.parametrize("m,n,K,logflag", [(1500, 96, 3, True), (1500, 96, 3, False), (2003, 130, 1, True), (6000, 700, 15, True),
                                             (4097, 1033, 5, True), (20000, 600, 5, True), (27000, 300, 5, True), (1024, 64, 5, True)])
-def test_pc_kernel_equals_two_kernel_form_and_oracle(sa, oracle, monkeypatch, m, n, K, logflag):
+def test_pc_kernel_equals_scatter_form_and_oracle(sa, oracle, monkeypatch, m, n, K, logflag):
     X = oracle.synth_fill(SEED, m, 0, n, 4, max(1, m // 8))
     p = int(np.ceil(np.log2(max(n, 2)) / 0.04)) if m < 20000 else 474
     seeds = [50 + 2103 + k for k in range(1, K + 1)]
@@ -99,7 +100,7 @@ def test_pc_kernel_resident_block_bit_identical_at_cfg3_shape(sa):
     assert lib.sharp_synth_fill_dev(C.c_uint(SEED), m, C.c_longlong(0), n, 12, 1000, C.c_void_p(dX.data_ptr()), C.c_longlong(m)) == 0
     outs = {}
     import os
-    for kern in ("split", "pc", "pc"):
+    for kern in ("fused", "pc", "pc"):
         os.environ["SHARP_RP_KERNEL"] = kern
         sa.reload_options()
         dE = torch.zeros((n, K * p), dtype=torch.float64, device="cuda")
@@ -110,7 +111,7 @@ def test_pc_kernel_resident_block_bit_identical_at_cfg3_shape(sa):
         outs.setdefault(kern, []).append(dE)
     del os.environ["SHARP_RP_KERNEL"]
     sa.reload_options()
-    assert torch.equal(outs["split"][0], outs["pc"][0]) and torch.equal(outs["pc"][0], outs["pc"][1])
+    assert torch.equal(outs["fused"][0], outs["pc"][0]) and torch.equal(outs["pc"][0], outs["pc"][1])
 
 
 def test_dense_cells_and_non_table_values_are_bit_identical_across_kernel_forms(sa, oracle, monkeypatch):
@@ -127,7 +128,7 @@ def test_dense_cells_and_non_table_values_are_bit_identical_across_kernel_forms(
     pr = sa.Projector(m, p, seeds)
     E1 = pr.project(X, logflag=True)
     E1raw = pr.project(X, logflag=False)
-    monkeypatch.setenv("SHARP_RP_KERNEL", "split")
+    monkeypatch.setenv("SHARP_RP_KERNEL", "fused")
     E2 = pr.project(X, logflag=True)
     monkeypatch.delenv("SHARP_RP_KERNEL")
     assert np.array_equal(E1, E2)

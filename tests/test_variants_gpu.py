@@ -151,13 +151,16 @@ def test_unseeded_view_reduction_uses_one_z0_for_the_whole_run(sa, oracle):
     _, _, _, v2 = dev.unlimited_dev([dX, dX], ensize_K=3, viewflag=True, view_dim=50)
     np.testing.assert_array_equal(v2[:n], v2[n:])
     assert not np.array_equal(v1, v2)                                                  # (another run: other projectors, another z0)
-    check(lib().sharp_unlimited_view_dim(50))                                           # two logical devices on the one GPU
-    _, _, _, vm = dev.unlimited_multi_dev([dX, dX], [0, 1], [0, 0], ensize_K=3, viewflag=True)
+    # two logical devices on the one GPU (several devices need a seed: unseeded projectors would differ between them): the thread-local arm,
+    # one z0 on every device, and the arm spent by the call that took it
+    check(lib().sharp_unlimited_view_dim(50))
+    _, _, _, vm = dev.unlimited_multi_dev([dX, dX], [0, 1], [0, 0], ensize_K=3, rN_seed=2103, viewflag=True)
     vm = vm.reshape(-1)[: 2 * n * 50].reshape(2 * n, 50)
     np.testing.assert_array_equal(vm[:n], vm[n:])
-    # the arm is spent by the call that took it: the next call returns E1 itself
-    _, _, _, again = dev.unlimited_multi_dev([dX, dX], [0, 1], [0, 0], ensize_K=3, viewflag=True)
+    _, _, _, again = dev.unlimited_multi_dev([dX, dX], [0, 1], [0, 0], ensize_K=3, rN_seed=2103, viewflag=True)
     assert np.abs(again[:, 50:]).max() > 0
+    with pytest.raises(sa.SharpError):
+        dev.unlimited_multi_dev([dX, dX], [0, 1], [0, 0], ensize_K=3, viewflag=True)            # unseeded on two devices: refused
     # block by block an unseeded run must name the seed of its z0
     proj = sa.Projector(1500, p, [0.5] * 3)
     with pytest.raises(sa.SharpError):
