@@ -4,7 +4,23 @@ the product's kernel and the oracle.  Run on a GPU box: python -m pytest tools/l
 import numpy as np
 import pytest
 
-SEED = 20261003
+SEED, RN = 20261003, 2103
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    import sharp_amd
+    from sharp_amd import device
+
+    sharp_amd.init(0)
+    return sharp_amd, device, torch
+
+
+def _hc_counts(dev):
+    tab = dev.profile_table()
+    return tab.get("host:hclust_tasks_bulk_synchronous", (0, 0))[1], tab.get("host:hclust_tasks_sequential", (0, 0))[1]
 
 
 @pytest.fixture(scope="module")
