@@ -188,6 +188,11 @@ int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K,
  * over X); 64 = fp64 (TPM / CPM-like doubles), so that log2(X + 1) and the projection see the numbers the reference computes with
  * (R/SHARP.R:110-117,343-345).  0: nothing uploaded yet.  The environment variable SHARP_X_STORAGE = fp32 | fp64 forces the choice. */
 int sharp_x_storage(void);
+/* what a value of the most recently uploaded host block was on PCIe: 16 (counts: every value an integer in 0 .. 65535, sent as unsigned
+ * 16-bit integers and stored as fp32), 32 (other fp32-exact values), 64 (doubles).  A sparse block also sends 16-bit row indices when it has
+ * at most 65 536 genes: 4 bytes per non-zero for count data against the 12 of R's dgCMatrix slots (R/SHARP_unlimited.R:125-143 hands the
+ * blocks over as they are). */
+int sharp_x_wire(void);
 
 /* allrpinfo of the most recent call that took the SHARP_small path (R/SHARP.R:350-387,446: per random projection k its tag, the
  * rowColor of every cell, N.cluster and indE = the projected matrix): enrp n x K column-major colour indices (1..40, the index into the

@@ -1100,6 +1100,7 @@ int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K,
 /* 32 or 64: how the most recent host-matrix entry point (sharp_SHARP, sharp_SHARP_csc, sharp_SHARP_unlimited*, sharp_project) stored
  * its block in HBM -- fp32 when every value survives the round trip through float, else fp64 (0: no upload yet). */
 int sharp_x_storage(void) { return upload_last_storage(); }
+int sharp_x_wire(void) { return upload_last_wire(); }
 
 /* allrpinfo of the most recent SHARP_small run (R/SHARP.R:350-387: per random projection k the rowColor of every cell and the projected
  * matrix indE = tmp$mat).  enrp: n x K column-major colour indices; indE: n x (K p) row-major, projection k in columns [k p, (k+1) p). */
@@ -1130,7 +1131,7 @@ int sharp_trim(void) {
         SHARP_HIP_CHECK(hipDeviceSynchronize());
         drop_pending_front();
         host_block().release();
-        { HostBlockPair &hp = per_slot<HostBlockPair>(); hp.hb[0].release(); hp.hb[1].release(); }
+        { HostBlockPair &hp = per_slot<HostBlockPair>(); for (HostBlock &h : hp.hb) h.release(); }
         upload_release_staging();
         dws().Ebatch.release();                          // a batched SHARP_unlimited window's projections (up to 16 GB)
         dws().posbatch.release();
@@ -1281,7 +1282,8 @@ static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, c
                                   double rN_seed, double *const *viE_of,   // NULL, or per block where its E1 rows go (NULL: not wanted)
                                   const ViewCall &view,
                                   const std::function<void(int, std::vector<int> &, std::vector<double> &, std::vector<long long> &)> &take,
-                                  const int *gids = nullptr) {   // (decision log: the blocks' indices in the caller's list; NULL: 0, 1, ...)
+                                  const int *gids = nullptr,     // (decision log: the blocks' indices in the caller's list; NULL: 0, 1, ...)
+                                  bool small_windows = false) {  // a batch also for a few blocks whose tasks merely fill the chip (host blocks taken as they arrive)
     {
         int b = 0;
         while (b < nblocks) {                                                                                  // :125-149
@@ -1299,7 +1301,7 @@ static void unlimited_blocks_loop(const XRef *dX_blocks, const long long *ncb, c
                     ++e;
                 }
             }
-            if (e - b >= 2 && ntasks > 2LL * ctx().num_cu) {
+            if (e - b >= 2 && ntasks > (small_windows ? 3LL * ctx().num_cu / 4 : 2LL * ctx().num_cu)) {
                 struct Got { std::vector<int> pb; std::vector<double> mb; std::vector<long long> cb; };
                 std::vector<Got> got(e - b);                                    // (the window's tails finish on helper threads, in any order)
                 unlimited_batch_window(dX_blocks, ncb, ldb, b, e, m, p, proj, K, rN_seed, [&](int bb, const SharpOut &o) {
@@ -1596,6 +1598,12 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
         feed.ld.assign(my.size(), 0);
         std::vector<int> hostpos;                         // positions in `my` that hold host blocks
         for (size_t i = 0; i < my.size(); ++i) if (blocks[my[i]].on_host()) hostpos.push_back(static_cast<int>(i));
+        // resident copies the upload rotates through: four (the compute thread then takes up to three blocks that arrived while it was busy as ONE
+        // pipelined batch), two for blocks above 8 GB or when SHARP_HOST_GROUP=1 asks for block after block
+        long long big = 0;
+        for (int i : hostpos) big = std::max<long long>(big, blocks[my[i]].n);
+        const int group_max = std::max(1, std::min(knobs().host_group, kHostRing - 1));
+        const int ring = (static_cast<double>(big) * m * 4.0 > 8e9 || group_max == 1) ? 2 : kHostRing;
         std::thread up;
         if (!hostpos.empty())
             up = std::thread([&] {
@@ -1603,14 +1611,14 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
                     init_slot(acquire_slot(devices[w], occ[w], 1), devices[w]);
                     HostBlockPair &P = host_block_pair();
                     for (size_t h = 0; h < hostpos.size(); ++h) {
-                        {   // copy h % 2 is free once the compute thread is done with host block h - 2
+                        {   // copy h % ring is free once the compute thread is done with host block h - ring
                             std::unique_lock<std::mutex> lk(feed.mu);
-                            feed.cv.wait(lk, [&] { return feed.stop || feed.consumed + 2 > static_cast<int>(h); });
+                            feed.cv.wait(lk, [&] { return feed.stop || feed.consumed + ring > static_cast<int>(h); });
                             if (feed.stop) return;
                         }
                         const int i = hostpos[h], b = my[i];
                         const BlockSrc &s = blocks[b];
-                        HostBlock &hb = P.hb[h & 1];
+                        HostBlock &hb = P.hb[h % ring];
                         tl[static_cast<size_t>(b) * 6 + 2] = wall_s() - t_begin;
                         if (s.kind == BlockSrc::HostDense) upload_block(s.host, m, s.n, m, hb);
                         else upload_block_csc(s.colptr, s.rowidx, s.val, m, s.n, hb);
@@ -1674,6 +1682,37 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
                     XRef ref, nref;
                     long long ld = 0, nld = 0;
                     block_ref(i, true, ref, ld);
+                    // The blocks that arrived while the previous ones were clustered go TOGETHER: one block's 125 base tasks leave half of the
+                    // CUs idle during its agglomeration; two or three blocks' tasks are one pipelined batch (unlimited_batch_window) with their
+                    // tails on helper threads.  Whatever the grouping, every block is the same SHARP() call: same labels.
+                    if (ring > 2 && blocks[b].on_host()) {
+                        std::vector<XRef> refs{ref};
+                        std::vector<long long> nn{blocks[b].n}, ll{ld};
+                        size_t j = i + 1;
+                        while (j < my.size() && static_cast<int>(j - i) < std::min(group_max, ring - 1) && blocks[my[j]].on_host() && block_ref(j, false, nref, nld)) {
+                            refs.push_back(nref); nn.push_back(blocks[my[j]].n); ll.push_back(nld);
+                            ++j;
+                        }
+                        if (j - i >= 2) {
+                            std::vector<double *> vo(j - i, nullptr);
+                            for (size_t q = i; q < j; ++q) if (viE) vo[q - i] = viE + static_cast<size_t>(cell0[my[q]]) * view.cols(p);
+                            const double t_go = wall_s() - t_begin;
+                            unlimited_blocks_loop(refs.data(), nn.data(), ll.data(), static_cast<int>(j - i), m, p, proj, K, rN_seed, viE ? vo.data() : nullptr, view,
+                                                  [&](int q, std::vector<int> &a, std::vector<double> &c, std::vector<long long> &d) {
+                                const int bb = my[i + q];
+                                pb[bb].swap(a); mb[bb].swap(c); cb[bb].swap(d);
+                                tl[static_cast<size_t>(bb) * 6 + 0] = w; tl[static_cast<size_t>(bb) * 6 + 1] = bb;
+                                tl[static_cast<size_t>(bb) * 6 + 4] = t_go; tl[static_cast<size_t>(bb) * 6 + 5] = wall_s() - t_begin;
+                            }, my.data() + i, true);
+                            {
+                                std::lock_guard<std::mutex> lk(feed.mu);
+                                feed.consumed += static_cast<int>(j - i);
+                                feed.cv.notify_all();
+                            }
+                            i = j - 1;
+                            continue;
+                        }
+                    }
                     // the next block's front goes under this block's tail if that block is on the GPU by now (a resident block always is)
                     const bool more = i + 1 < my.size() && block_ref(i + 1, false, nref, nld);
                     tl[static_cast<size_t>(b) * 6 + 4] = wall_s() - t_begin;
@@ -1823,13 +1862,16 @@ int sharp_SHARP_unlimited_dev(const float *const *dX_blocks, const long long *nc
 
 int sharp_SHARP_unlimited_view(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,
                                int minN, int maxN, double rN_seed, int *pred, int *n_pred, int *p_used, double *viE) {
-    const std::vector<int> &dv = knobs().devices;        // SHARP_DEVICES=0,1,2,...: the blocks dealt to these GPUs (one host thread each)
-    if (dv.size() >= 2 && rN_seed != 0.5)                // (an unseeded call stays on the caller's GPU: every device would draw its own projectors)
-        return unlimited_run_multi(dense_sources(X_blocks, ncb, nblocks), m, ensize_K, N_cluster, minN, maxN, rN_seed, dv.data(),
-                                   static_cast<int>(dv.size()), pred, n_pred, p_used, viE);
-    HostBlocks H;
-    if (const int rc = H.upload(X_blocks, ncb, nblocks, m)) return rc;
-    return unlimited_run(H.refs.data(), ncb, H.lds.data(), nblocks, m, ensize_K, N_cluster, minN, maxN, rN_seed, pred, n_pred, p_used, viE);
+    // A list of host matrices never sits in HBM as a whole: the blocks cross PCIe one after the other into a ring of resident copies while the
+    // earlier ones are clustered (unlimited_run_multi), on the caller's GPU or dealt to the GPUs of SHARP_DEVICES=0,1,2,... (one host thread
+    // each; an unseeded call stays on the caller's GPU: every device would draw its own projectors).
+    if (!X_blocks || !ncb || nblocks < 1) { sharp::set_error("No expression data is provided!"); return SHARP_ERR_ARG; }
+    std::vector<int> dv;
+    try { dv = call_devices(nullptr, 0); }
+    catch (const sharp::Error &e) { sharp::set_error(e.what()); return e.code; }
+    if (rN_seed == 0.5 && dv.size() > 1) dv.resize(1);
+    return unlimited_run_multi(dense_sources(X_blocks, ncb, nblocks), m, ensize_K, N_cluster, minN, maxN, rN_seed, dv.data(),
+                               static_cast<int>(dv.size()), pred, n_pred, p_used, viE);
 }
 
 int sharp_SHARP_unlimited_multi(const double *const *X_blocks, const long long *ncb, int nblocks, int m, int ensize_K, int N_cluster,

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 
 namespace sharp {
 
@@ -29,6 +30,7 @@ struct UploadStage {
 };
 UploadStage &upload_stage() { return per_slot<UploadStage>(); }
 int &last_storage() { static int s = 0; return s; }
+int &last_wire() { static int s = 0; return s; }
 
 int upload_threads() {
     unsigned hw = static_cast<unsigned>(host_cores());
@@ -49,47 +51,77 @@ void run_threads(int nthr, long long items, F fn) {
 // value beyond FLT_MAX becomes inf and is not)
 inline bool f32_exact(double x) { return !(static_cast<double>(static_cast<float>(x)) != x) || x != x; }
 
-// One pass over the matrix as elements of T (float: narrowed, with the exactness test when `check`; double: copied).  Returns false
-// as soon as a slab held a value that fp32 cannot represent (check only); the device block is then incomplete.
-template <typename T>
-bool upload_as(const double *X, int m, long long n, long long ld, T *dX, long long ldd, bool check, double *max_abs) {
+// What crosses PCIe.  A block is sent in the NARROWEST type that holds every one of its values exactly, decided while it is packed (no
+// scan of its own): unsigned 16-bit integers (counts, UMI data: every value an integer in 0 .. 65535), else float, else double.  The
+// attempt at a type stops at the first slab that holds a value outside it and the block starts over one type wider -- for TPM-like data
+// that is the first slab, a few milliseconds.  u16 and float blocks are STORED as fp32 (the RP kernel's table covers the counts), double
+// blocks as fp64.
+template <typename Wt> inline bool wire_holds(double x);
+template <> inline bool wire_holds<uint16_t>(double x) { return x >= 0.0 && x <= 65535.0 && static_cast<double>(static_cast<uint16_t>(x)) == x; }
+template <> inline bool wire_holds<float>(double x) { return f32_exact(x); }
+template <> inline bool wire_holds<double>(double) { return true; }
+
+template <typename Wt, typename Dt>
+__global__ void widen_kernel(const Wt *__restrict__ src, Dt *__restrict__ dst, long long count) {
+    for (long long q = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; q < count; q += static_cast<long long>(gridDim.x) * blockDim.x)
+        dst[q] = static_cast<Dt>(src[q]);
+}
+
+struct WireStage { DevBuf<unsigned char> slab[2]; };       // device side of a wire type narrower than the stored one
+WireStage &wire_stage() { return per_slot<WireStage>(); }
+
+// One pass over a dense matrix sent as Wt and stored as Dt.  Returns false as soon as a slab held a value Wt cannot represent (check
+// only); the device block is then incomplete.
+template <typename Wt, typename Dt>
+bool upload_as(const double *X, int m, long long n, long long ld, Dt *dX, long long ldd, bool check, double *max_abs) {
+    constexpr bool direct = std::is_same<Wt, Dt>::value;                              // the DMA writes the block itself
     const size_t slab_bytes = static_cast<size_t>(128) << 20;                         // 128 MB per staging buffer
-    const long long slab = std::max<long long>(1, std::min<long long>(n, static_cast<long long>(slab_bytes / (sizeof(T) * ldd))));
+    const long long slab = std::max<long long>(1, std::min<long long>(n, static_cast<long long>(slab_bytes / (sizeof(Wt) * ldd))));
     UploadStage &U = upload_stage();
-    U.ensure(static_cast<size_t>(slab) * ldd * sizeof(T));
+    U.ensure(static_cast<size_t>(slab) * ldd * sizeof(Wt));
+    WireStage &WS = wire_stage();
+    if (!direct) for (int k = 0; k < 2; ++k) WS.slab[k].ensure(static_cast<size_t>(slab) * ldd * sizeof(Wt));
     const int nthr = upload_threads();
-    hipStream_t s = ctx().stream;
+    Ctx &cx = ctx();
+    hipStream_t s = cx.stream;
     int q = 0;
     bool used[2] = {false, false};
-    std::atomic<int> inexact{0}, nonfinite{0};
+    std::atomic<int> inexact{0};
     std::vector<double> tmax(static_cast<size_t>(nthr), 0.0);
     for (long long c0 = 0; c0 < n; c0 += slab, q ^= 1) {
         const long long nc = std::min(slab, n - c0);
-        if (used[q]) SHARP_HIP_CHECK(hipEventSynchronize(U.done[q]));                  // the DMA that last read this buffer
-        T *dst = static_cast<T *>(U.pinned[q]);
+        if (used[q]) SHARP_HIP_CHECK(hipEventSynchronize(U.done[q]));                  // the DMA (and the widening) that last read this buffer
+        Wt *dst = static_cast<Wt *>(U.pinned[q]);
         run_threads(nthr, nc, [&](int t) {
             const long long a = nc * t / nthr, b = nc * (t + 1) / nthr;
             int bad = 0;
             double mx = tmax[t];
             for (long long c = a; c < b; ++c) {
                 const double *src = X + (c0 + c) * ld;
-                T *d = dst + c * ldd;
-                if (check) for (int g = 0; g < m; ++g) { const double x = src[g]; d[g] = static_cast<T>(x); bad |= !f32_exact(x); mx = std::fabs(x) > mx ? std::fabs(x) : mx; if (x != x) mx = HUGE_VAL; }
-                else for (int g = 0; g < m; ++g) { const double x = src[g]; d[g] = static_cast<T>(x); mx = std::fabs(x) > mx ? std::fabs(x) : mx; if (x != x) mx = HUGE_VAL; }
-                for (long long g = m; g < ldd; ++g) d[g] = T(0);
+                Wt *d = dst + c * ldd;
+                if (check) for (int g = 0; g < m; ++g) { const double x = src[g]; d[g] = static_cast<Wt>(x); bad |= !wire_holds<Wt>(x); mx = std::fabs(x) > mx ? std::fabs(x) : mx; if (x != x) mx = HUGE_VAL; }
+                else for (int g = 0; g < m; ++g) { const double x = src[g]; d[g] = static_cast<Wt>(x); mx = std::fabs(x) > mx ? std::fabs(x) : mx; if (x != x) mx = HUGE_VAL; }
+                for (long long g = m; g < ldd; ++g) d[g] = Wt(0);
             }
             tmax[t] = mx;
             if (bad) inexact.store(1, std::memory_order_relaxed);
         });
         if (check && inexact.load()) { SHARP_HIP_CHECK(hipStreamSynchronize(s)); return false; }
-        SHARP_HIP_CHECK(hipMemcpyAsync(dX + c0 * ldd, dst, static_cast<size_t>(nc) * ldd * sizeof(T), hipMemcpyHostToDevice, s));
+        const size_t cnt = static_cast<size_t>(nc) * ldd;
+        if constexpr (direct) {
+            SHARP_HIP_CHECK(hipMemcpyAsync(dX + c0 * ldd, dst, cnt * sizeof(Wt), hipMemcpyHostToDevice, s));
+        } else {
+            Wt *dw = reinterpret_cast<Wt *>(WS.slab[q].p);
+            SHARP_HIP_CHECK(hipMemcpyAsync(dw, dst, cnt * sizeof(Wt), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL((widen_kernel<Wt, Dt>), dim3(cx.num_cu * 8), dim3(256), 0, s, dw, dX + c0 * ldd, static_cast<long long>(cnt));
+            launch_check("widen_kernel");
+        }
         SHARP_HIP_CHECK(hipEventRecord(U.done[q], s));
         used[q] = true;
     }
     stream_sync();
     double mx = 0;
     for (double v : tmax) mx = v > mx ? v : mx;
-    (void)nonfinite;
     // the reference would carry NA / NaN / Inf into cor() and stop in hclust ("NA/NaN/Inf in foreign function call")
     if (!(mx <= 1.7976931348623157e308)) throw Error(SHARP_ERR_ARG, "NA/NaN/Inf in the expression matrix");
     if (max_abs) *max_abs = mx;
@@ -98,76 +130,105 @@ bool upload_as(const double *X, int m, long long n, long long ld, T *dX, long lo
 
 // dgCMatrix slab -> dense block: one wave per cell scatters the cell's (row index, value) pairs into its zeroed column.
 // Out-of-range row indices are counted, never written.
-template <typename T>
-__global__ void csc_expand_kernel(const long long *__restrict__ colptr, const int *__restrict__ rowidx, const T *__restrict__ val,
-                                  long long e_base, long long ncell, int m, T *__restrict__ dX, long long ld, int *__restrict__ bad) {
+template <typename It, typename Vt, typename Dt>
+__global__ void csc_expand_kernel(const long long *__restrict__ colptr, const It *__restrict__ rowidx, const Vt *__restrict__ val,
+                                  long long e_base, long long ncell, int m, Dt *__restrict__ dX, long long ld, int *__restrict__ bad) {
     const int lane = threadIdx.x & 63;
     const long long wave = (blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x) >> 6;
     const long long nwave = (static_cast<long long>(gridDim.x) * blockDim.x) >> 6;
     for (long long c = wave; c < ncell; c += nwave) {
         const long long e0 = colptr[c] - e_base, e1 = colptr[c + 1] - e_base;
-        T *col = dX + c * ld;
+        Dt *col = dX + c * ld;
         for (long long e = e0 + lane; e < e1; e += 64) {
-            const int g = rowidx[e];
-            if (g >= 0 && g < m) col[g] = val[e];
+            const long long g = static_cast<long long>(rowidx[e]);
+            if (g >= 0 && g < m) col[g] = static_cast<Dt>(val[e]);
             else atomicAdd(bad, 1);
         }
     }
 }
 
-// Only the non-zeros cross PCIe (int32 index + value of T), slab by slab through the pinned staging buffers.
-template <typename T>
-void upload_csc_as(const int *colptr, const int *rowidx, const double *val, int m, long long n, T *dX, long long ldd) {
-    if (n <= 0) return;
+// Only the non-zeros cross PCIe, slab by slab through the pinned staging buffers: per entry a row index of It (uint16_t when the block has
+// at most 65 536 genes, else int32) and a value of Vt (see wire_holds): 4 bytes per non-zero for counts over 20 000 genes, 12 as R holds
+// them.  Returns 0 when the block is complete; at the first slab with a value Vt cannot hold (check only) 1, with a row index It cannot 2.
+template <typename It, typename Vt, typename Dt>
+int upload_csc_as(const int *colptr, const int *rowidx, const double *val, int m, long long n, Dt *dX, long long ldd, bool check, double *max_abs) {
+    if (n <= 0) return 0;
     HostTimer ht("upload_csc");
     Ctx &cx = ctx();
     hipStream_t s = cx.stream;
-    SHARP_HIP_CHECK(hipMemsetAsync(dX, 0, static_cast<size_t>(ldd) * n * sizeof(T), s));
+    SHARP_HIP_CHECK(hipMemsetAsync(dX, 0, static_cast<size_t>(ldd) * n * sizeof(Dt), s));
     std::vector<long long> cp(static_cast<size_t>(n) + 1);
     for (long long c = 0; c <= n; ++c) cp[c] = colptr[c];
-    DevBuf<long long> dcp(cp.size());
+    DevBuf<long long> dcp;
+    dcp.alloc_pooled(cp.size());
     dcp.upload(cp.data(), cp.size());
-    DevBuf<int> dbad(1);
+    DevBuf<int> dbad;
+    dbad.alloc_pooled(1);
     dbad.zero();
     const long long slab_e = 16LL << 20;                                   // entries per slab
-    const size_t esz = sizeof(int) + sizeof(T);
+    const size_t esz = sizeof(It) + sizeof(Vt);
     UploadStage &U = upload_stage();
-    U.ensure(static_cast<size_t>(slab_e) * esz);                           // [values | indices] share one staging buffer
-    DevBuf<int> didx[2];
-    DevBuf<T> dval[2];
-    for (int k = 0; k < 2; ++k) { const size_t cap = static_cast<size_t>(std::max<long long>(1, std::min<long long>(slab_e, cp[n] - cp[0]))); didx[k].alloc(cap); dval[k].alloc(cap); }
+    U.ensure(static_cast<size_t>(slab_e) * esz + 16);                      // [values | indices] share one staging buffer
+    WireStage &WS = wire_stage();                                          // ... and one device slab per staging buffer
+    for (int k = 0; k < 2; ++k) WS.slab[k].ensure(static_cast<size_t>(std::max<long long>(1, std::min<long long>(slab_e, cp[n] - cp[0]))) * esz + 16);
     const int nthr = upload_threads();
     int q = 0;
     bool used[2] = {false, false};
     long long c0 = 0;
+    std::atomic<int> inexact{0}, badidx{0};
+    std::vector<double> tmax(static_cast<size_t>(nthr), 0.0);
     while (c0 < n) {
         // whole cells per slab; a single cell never exceeds m <= 2^31 entries but may exceed the slab: grow the slab for it
         long long c1 = c0;
         const long long e0 = cp[c0];
         while (c1 < n && cp[c1 + 1] - e0 <= slab_e) ++c1;
-        if (c1 == c0) { c1 = c0 + 1; SHARP_HIP_CHECK(hipStreamSynchronize(s)); U.ensure(static_cast<size_t>(cp[c1] - e0) * esz); for (int k = 0; k < 2; ++k) used[k] = false; }
+        if (c1 == c0) {
+            c1 = c0 + 1;
+            SHARP_HIP_CHECK(hipStreamSynchronize(s));
+            U.ensure(static_cast<size_t>(cp[c1] - e0) * esz + 16);
+            for (int k = 0; k < 2; ++k) { WS.slab[k].ensure(static_cast<size_t>(cp[c1] - e0) * esz + 16); used[k] = false; }
+        }
         const long long ne = cp[c1] - e0;
         if (ne > 0) {
             if (used[q]) SHARP_HIP_CHECK(hipEventSynchronize(U.done[q]));
-            T *hv = static_cast<T *>(U.pinned[q]);                          // values first: 8-byte alignment for doubles
-            int *hi = reinterpret_cast<int *>(hv + ne);
+            // [values | indices] or [indices | values]: the wider type first, so that both runs are aligned
+            constexpr bool vfirst = sizeof(Vt) >= sizeof(It);
+            Vt *hv = vfirst ? static_cast<Vt *>(U.pinned[q]) : reinterpret_cast<Vt *>(static_cast<It *>(U.pinned[q]) + ne);
+            It *hi = vfirst ? reinterpret_cast<It *>(static_cast<Vt *>(U.pinned[q]) + ne) : static_cast<It *>(U.pinned[q]);
             auto pack = [&](int t) {
                 const long long a = ne * t / nthr, b = ne * (t + 1) / nthr;
-                std::memcpy(hi + a, rowidx + e0 + a, static_cast<size_t>(b - a) * sizeof(int));
-                for (long long e = a; e < b; ++e) hv[e] = static_cast<T>(val[e0 + e]);
+                int bad = 0, bi = 0;
+                double mx = tmax[t];
+                if (std::is_same<It, int>::value) std::memcpy(hi + a, rowidx + e0 + a, static_cast<size_t>(b - a) * sizeof(int));
+                else for (long long e = a; e < b; ++e) { const int g = rowidx[e0 + e]; hi[e] = static_cast<It>(g); bi |= static_cast<int>(static_cast<It>(g)) != g; }
+                for (long long e = a; e < b; ++e) {
+                    const double x = val[e0 + e];
+                    hv[e] = static_cast<Vt>(x);
+                    if (check) bad |= !wire_holds<Vt>(x);
+                    mx = std::fabs(x) > mx ? std::fabs(x) : mx;
+                    if (x != x) mx = HUGE_VAL;
+                }
+                tmax[t] = mx;
+                if (bad) inexact.store(1, std::memory_order_relaxed);
+                if (bi) badidx.store(1, std::memory_order_relaxed);
             };
             if (ne < (1 << 16)) { for (int t = 0; t < nthr; ++t) pack(t); }
             else run_threads(nthr, ne, pack);
-            didx[q].ensure(static_cast<size_t>(ne)); dval[q].ensure(static_cast<size_t>(ne));
-            SHARP_HIP_CHECK(hipMemcpyAsync(didx[q].p, hi, static_cast<size_t>(ne) * sizeof(int), hipMemcpyHostToDevice, s));
-            SHARP_HIP_CHECK(hipMemcpyAsync(dval[q].p, hv, static_cast<size_t>(ne) * sizeof(T), hipMemcpyHostToDevice, s));
-            SHARP_HIP_CHECK(hipEventRecord(U.done[q], s));
-            used[q] = true;
+            if (inexact.load() || badidx.load()) {
+                // a row index It cannot hold can only be an index outside [0, genes): the int32 attempt reports it; a value Vt cannot hold: one type wider
+                SHARP_HIP_CHECK(hipStreamSynchronize(s));
+                return badidx.load() ? 2 : 1;
+            }
+            Vt *dv = vfirst ? reinterpret_cast<Vt *>(WS.slab[q].p) : reinterpret_cast<Vt *>(reinterpret_cast<It *>(WS.slab[q].p) + ne);
+            It *di = vfirst ? reinterpret_cast<It *>(reinterpret_cast<Vt *>(WS.slab[q].p) + ne) : reinterpret_cast<It *>(WS.slab[q].p);
+            SHARP_HIP_CHECK(hipMemcpyAsync(WS.slab[q].p, U.pinned[q], static_cast<size_t>(ne) * esz, hipMemcpyHostToDevice, s));   // values and indices in one transfer
             const long long ncell = c1 - c0;
             const int blocks = static_cast<int>(std::min<long long>((ncell + 3) / 4, static_cast<long long>(cx.num_cu) * 16));
-            hipLaunchKernelGGL(csc_expand_kernel<T>, dim3(blocks), dim3(256), 0, s, dcp.p + c0, didx[q].p, dval[q].p, e0, ncell, m,
+            hipLaunchKernelGGL((csc_expand_kernel<It, Vt, Dt>), dim3(blocks), dim3(256), 0, s, dcp.p + c0, di, dv, e0, ncell, m,
                                dX + c0 * ldd, ldd, dbad.p);
             launch_check("csc_expand_kernel");
+            SHARP_HIP_CHECK(hipEventRecord(U.done[q], s));                  // (behind the expansion: the device slab is free with the staging buffer)
+            used[q] = true;
             q ^= 1;
         }
         c0 = c1;
@@ -175,6 +236,26 @@ void upload_csc_as(const int *colptr, const int *rowidx, const double *val, int 
     int bad = 0;
     dbad.download(&bad, 1);                                                 // also drains the stream: staging and slabs are free again
     if (bad) throw Error(SHARP_ERR_ARG, "sparse input: row index outside [0, genes)");
+    double mx = 0;
+    for (double v : tmax) mx = v > mx ? v : mx;
+    if (!(mx <= 1.7976931348623157e308)) throw Error(SHARP_ERR_ARG, "NA/NaN/Inf in the expression matrix");
+    if (max_abs) *max_abs = mx;
+    return 0;
+}
+
+// the attempts in order (narrowest first), into an fp32 block; false: a value needs fp64
+bool upload_csc_f32(const int *colptr, const int *rowidx, const double *val, int m, long long n, float *dX, long long ldd, bool check, double *max_abs) {
+    bool narrow_idx = m <= 65536;      // (a row index beyond 65 535 in such a block is outside [0, genes): the int32 attempt reports it)
+    int r = 1;
+    if (check) {
+        if (narrow_idx) { r = upload_csc_as<uint16_t, uint16_t, float>(colptr, rowidx, val, m, n, dX, ldd, true, max_abs); if (r == 2) narrow_idx = false; }
+        if (!narrow_idx) r = upload_csc_as<int, uint16_t, float>(colptr, rowidx, val, m, n, dX, ldd, true, max_abs);
+        if (r == 0) { last_wire() = 16; return true; }
+    }
+    if (narrow_idx) { r = upload_csc_as<uint16_t, float, float>(colptr, rowidx, val, m, n, dX, ldd, check, max_abs); if (r == 2) narrow_idx = false; }
+    if (!narrow_idx) r = upload_csc_as<int, float, float>(colptr, rowidx, val, m, n, dX, ldd, check, max_abs);
+    if (r == 0) { last_wire() = 32; return true; }
+    return false;
 }
 
 void check_csc(const int *colptr, const int *rowidx, const double *val, long long n) {
@@ -193,7 +274,11 @@ void upload_block(const double *X, int m, long long n, long long ld, HostBlock &
     if (policy != 64) {
         const long long ldd = (static_cast<long long>(m) + 3) / 4 * 4;
         { HostTimer ha("upload_alloc"); hb.f.ensure(static_cast<size_t>(ldd) * n); }
-        if (upload_as<float>(X, m, n, ld, hb.f.p, ldd, policy == 0, &hb.max_abs)) {
+        // counts cross PCIe as 16-bit integers (a quarter of the doubles R holds), other fp32-exact values as floats
+        bool ok = policy == 0 && upload_as<uint16_t, float>(X, m, n, ld, hb.f.p, ldd, true, &hb.max_abs);
+        if (ok) last_wire() = 16;
+        else { ok = upload_as<float, float>(X, m, n, ld, hb.f.p, ldd, policy == 0, &hb.max_abs); if (ok) last_wire() = 32; }
+        if (ok) {
             hb.d.release();                               // (an fp64 copy left by an earlier block of another kind)
             hb.f64 = false; hb.ld = ldd; last_storage() = 32; return;
         }
@@ -202,59 +287,45 @@ void upload_block(const double *X, int m, long long n, long long ld, HostBlock &
     // a value fp32 cannot hold exactly (or fp64 forced): the block stays in double
     const long long ldd = (static_cast<long long>(m) + 1) / 2 * 2;
     { HostTimer ha("upload_alloc"); hb.d.ensure(static_cast<size_t>(ldd) * n); }
-    upload_as<double>(X, m, n, ld, hb.d.p, ldd, false, &hb.max_abs);
-    hb.f64 = true; hb.ld = ldd; last_storage() = 64;
+    upload_as<double, double>(X, m, n, ld, hb.d.p, ldd, false, &hb.max_abs);
+    hb.f64 = true; hb.ld = ldd; last_storage() = 64; last_wire() = 64;
 }
 
 void upload_block_csc(const int *colptr, const int *rowidx, const double *val, int m, long long n, HostBlock &hb) {
     if (n <= 0) return;
     check_csc(colptr, rowidx, val, n);
     const int policy = storage_policy();
-    bool f64 = policy == 64;
-    {                                                                       // one threaded scan of the stored values decides
-        const long long ne = static_cast<long long>(colptr[n]) - colptr[0];
-        const int nt = ne < (1 << 16) ? 1 : upload_threads();
-        std::atomic<int> inexact{0};
-        std::vector<double> tmax(static_cast<size_t>(nt), 0.0);
-        run_threads(nt, ne, [&](int t) {
-            const long long a = ne * t / nt, b = ne * (t + 1) / nt;
-            int bad = 0;
-            double mx = 0;
-            for (long long e = a; e < b; ++e) { const double x = val[colptr[0] + e]; bad |= !f32_exact(x); mx = std::fabs(x) > mx ? std::fabs(x) : mx; if (x != x) mx = HUGE_VAL; }
-            tmax[t] = mx;
-            if (bad) inexact.store(1, std::memory_order_relaxed);
-        });
-        double mx = 0;
-        for (double v : tmax) mx = v > mx ? v : mx;
-        if (!(mx <= 1.7976931348623157e308)) throw Error(SHARP_ERR_ARG, "NA/NaN/Inf in the expression matrix");
-        hb.max_abs = mx;
-        if (policy == 0) f64 = inexact.load() != 0;
-    }
-    if (f64) {
-        hb.ld = (static_cast<long long>(m) + 1) / 2 * 2;
-        hb.d.ensure(static_cast<size_t>(hb.ld) * n);
-        upload_csc_as<double>(colptr, rowidx, val, m, n, hb.d.p, hb.ld);
-    } else {
+    if (policy != 64) {
         hb.ld = (static_cast<long long>(m) + 3) / 4 * 4;
         hb.f.ensure(static_cast<size_t>(hb.ld) * n);
-        upload_csc_as<float>(colptr, rowidx, val, m, n, hb.f.p, hb.ld);
+        if (upload_csc_f32(colptr, rowidx, val, m, n, hb.f.p, hb.ld, policy == 0, &hb.max_abs)) {
+            hb.d.release();
+            hb.f64 = false; last_storage() = 32; return;
+        }
+        hb.f.release();
     }
-    hb.f64 = f64;
-    last_storage() = f64 ? 64 : 32;
+    hb.ld = (static_cast<long long>(m) + 1) / 2 * 2;
+    hb.d.ensure(static_cast<size_t>(hb.ld) * n);
+    upload_csc_as<int, double, double>(colptr, rowidx, val, m, n, hb.d.p, hb.ld, false, &hb.max_abs);
+    hb.f64 = true;
+    last_storage() = 64; last_wire() = 64;
 }
 
 void upload_csc_into_f32(const int *colptr, const int *rowidx, const double *val, int m, long long n, float *dX, long long ld) {
     if (n <= 0) return;
     check_csc(colptr, rowidx, val, n);
-    upload_csc_as<float>(colptr, rowidx, val, m, n, dX, ld);
+    upload_csc_f32(colptr, rowidx, val, m, n, dX, ld, false, nullptr);      // (values are narrowed: the caller's block is fp32)
 }
 
 void upload_release_staging() {
     UploadStage &U = upload_stage();
     for (int q = 0; q < 2; ++q) if (U.pinned[q]) { (void)hipHostFree(U.pinned[q]); U.pinned[q] = nullptr; }
     U.cap = 0;
+    WireStage &WS = wire_stage();
+    for (int k = 0; k < 2; ++k) WS.slab[k].release();
 }
 
 int upload_last_storage() { return last_storage(); }
+int upload_last_wire() { return last_wire(); }
 
 }  // namespace sharp

@@ -21,17 +21,23 @@ struct HostBlock {               // the resident copy of a host matrix; kept bet
     void release() { f.release(); d.release(); }
 };
 
-// the two resident copies an upload slot rotates through (sharp_SHARP_unlimited_multi: block i + W is uploaded while block i is clustered)
-struct HostBlockPair { HostBlock hb[2]; };
+// the resident copies an upload slot rotates through (sharp_SHARP_unlimited_multi: later blocks are uploaded while earlier ones are clustered;
+// four copies so that the compute thread can take the blocks that arrived meanwhile TOGETHER, as one pipelined batch, and the upload still
+// has a copy to fill; blocks above 8 GB rotate through two)
+constexpr int kHostRing = 4;
+struct HostBlockPair { HostBlock hb[kHostRing]; };
 
 // X: m x n column-major doubles, column stride ld >= m (pageable memory).  Threaded narrowing / copying into pinned slabs, DMA'd
-// while the next slab is prepared.
+// while the next slab is prepared.  The wire carries the narrowest type that holds every value exactly: unsigned 16-bit integers (counts),
+// else floats (both stored as fp32), else doubles.
 void upload_block(const double *X, int m, long long n, long long ld, HostBlock &hb);
-// canonical CSC (colptr n + 1 entries, 0-based row indices): only the non-zeros cross PCIe, the dense block is built on the device
+// canonical CSC (colptr n + 1 entries, 0-based row indices): only the non-zeros cross PCIe -- a u16 / int32 row index and a u16 / float /
+// double value each: 4 bytes per non-zero for counts over at most 65 536 genes, against the 12 R holds -- the dense block is built on the device
 void upload_block_csc(const int *colptr, const int *rowidx, const double *val, int m, long long n, HostBlock &hb);
 // the same into a caller-owned fp32 device block (sharp_csc_to_dense_dev: the *_dev entry points take fp32): values are narrowed
 void upload_csc_into_f32(const int *colptr, const int *rowidx, const double *val, int m, long long n, float *dX, long long ld);
 void upload_release_staging();   // the pinned staging buffers (sharp_trim)
 int upload_last_storage();       // 32 or 64: what the most recent upload_block / upload_block_csc chose (0: none yet)
+int upload_last_wire();          // 16, 32 or 64: the width of a value of that block on PCIe (u16 counts / float / double)
 
 }  // namespace sharp

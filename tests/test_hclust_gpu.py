@@ -268,9 +268,12 @@ def test_lane_program_statistics_equal_the_per_cell_walk(sa, oracle, kind, n, ma
     # the correlations from Gram sums and gets W ~ 1e-31, CH ~ 1e+30.  clues::get_CH is unverifiable here, so which of the
     # two R itself would print is unknown: DESIGN.md 9 lists it; the levels below are told apart from every real one all the same.
     assert np.all((b["CHind"][~fin] > 1e20) | np.isinf(b["CHind"][~fin]))
-    assert b["branch"] == ref["branch"] and np.array_equal(b["v"], ref["v"])            # the same tree, the same cut at every level
-    if fin.all() or ref["branch"] == 0:                                                   # (which.max over Inf's: the first one; over 1e+30's: the largest)
-        assert np.array_equal(b["f"], ref["f"])
+    assert b["branch"] == ref["branch"]
+    # Duplicated rows are at distance 0 or 1.1e-16 of each other, whichever way 1 - cor() happens to round (R's cov.c divides by a product of
+    # two square roots; the GPU takes the product of two unit rows): the ORDER in which the duplicate pairs merge is that rounding's, and a cut
+    # through that part of the tree -- more clusters than distinct rows, i.e. n < 2 maxN here -- may group them differently.
+    if kind != "duplicates" or n >= 2 * maxN:
+        assert np.array_equal(b["v"], ref["v"]) and np.array_equal(b["f"], ref["f"])
     # the CH rule (every median below the threshold) on the same statistics
     c = sa.get_opt_hclust(mat, maxN_cluster=maxN, sil_thre=2.0)
     refc = oracle.get_opt_hclust(mat, maxN=maxN, sil_thre=2.0)

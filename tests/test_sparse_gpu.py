@@ -82,3 +82,75 @@ def test_sparse_input_errors(sa):
     cp2 = np.array([0, 2, 1, 3], np.int32)
     rc = lib.sharp_csc_to_dense_dev(ip(cp2), ip(ri), dp(xv), 8, C.c_longlong(3), C.c_void_p(dX.data_ptr()), C.c_longlong(8))
     assert rc != 0 and b"non-decreasing" in lib.sharp_last_error()
+
+
+def test_wire_formats_of_host_blocks(sa, oracle):
+    """What crosses PCIe (sharp_x_wire): counts as unsigned 16-bit integers, other fp32-exact values as floats, anything else as doubles --
+    decided while the block is packed -- and 16-bit row indices for a sparse block of at most 65 536 genes.  Whatever the wire, the block
+    in HBM is the same, so every result equals the dense fp64 reference path: labels and projections against the oracle."""
+    lib = sa.lib()
+    X = _counts(oracle, 640, 1500)
+    kinds = []
+    for scale, wire, storage in ((1.0, 16, 32), (0.5, 32, 32), (1.0 / 3.0, 64, 64)):
+        for fmt in (np.asfortranarray, sp.csc_matrix):
+            Xs = X * scale
+            if scale == 1.0:
+                Xs = Xs.copy(); Xs[3, 5] = 65535.0                       # the largest value the 16-bit wire holds
+            res = sa.SHARP(fmt(Xs), ensize_K=3, rN_seed=11, logflag=False, prep=False)
+            assert (lib.sharp_x_wire(), lib.sharp_x_storage()) == (wire, storage), (scale, fmt)
+            r2 = oracle.SHARP(Xs, K=3, rN_seed=11, nthreads=4, want_view=True)
+            assert np.array_equal(res["pred_clusters"], r2["pred_clusters"])
+            np.testing.assert_allclose(res["viE"], r2["viE"], rtol=0, atol=2e-12 * np.abs(r2["viE"]).max())
+            kinds.append(res["viE"])
+    np.testing.assert_array_equal(kinds[0], kinds[1])                    # dense and sparse wire: the same block in HBM
+    np.testing.assert_array_equal(kinds[2], kinds[3])
+    # one value beyond 65 535, one non-integer: the block starts over as floats
+    for bad in (65536.0, 2.5):
+        Xb = X.copy(); Xb[7, 600] = bad
+        sa.SHARP(sp.csc_matrix(Xb), ensize_K=2, rN_seed=11, logflag=False, prep=False)
+        assert lib.sharp_x_wire() == 32
+        sa.SHARP(np.asfortranarray(Xb), ensize_K=2, rN_seed=11, logflag=False, prep=False)
+        assert lib.sharp_x_wire() == 32
+
+
+def test_sparse_block_with_more_than_65536_genes_takes_int32_row_indices(sa, oracle):
+    import torch
+    from sharp_amd import device as dev
+
+    m, n = 70001, 40
+    rng = np.random.default_rng(5)
+    X = np.zeros((m, n))
+    for c in range(n):
+        g = rng.choice(m, size=300, replace=False)
+        X[g, c] = rng.integers(1, 30, size=300)
+    X[m - 1, 0] = 9.0; X[65536, 1] = 4.0; X[65535, 2] = 3.0
+    dX = dev.csc_to_dev(sp.csc_matrix(X))
+    assert np.array_equal(dX.cpu().numpy(), X.T.astype(np.float32))
+    pr = sa.Projector(m, 60, [2154])
+    E = pr.project(X, logflag=True)                                       # (the dense host path of the same block: 16-bit values on the wire)
+    assert sa.lib().sharp_x_wire() == 16
+    refE = oracle.project(X, oracle.ranM(m, 60, 2154), True)
+    np.testing.assert_allclose(E, refE, rtol=0, atol=2e-12 * np.abs(refE).max())
+    del torch
+
+
+def test_host_blocks_taken_in_groups_equal_block_after_block(sa, oracle, monkeypatch):
+    """SHARP_unlimited on a list of host blocks (R/SHARP_unlimited.R:125-143): the blocks cross PCIe into a ring of resident copies and the
+    compute thread takes those that arrived meanwhile TOGETHER as one pipelined batch (SHARP_HOST_GROUP, default 3); block after block
+    (SHARP_HOST_GROUP=1) is the same call: labels and E1 rows identical, both equal to the oracle; dense and sparse lists alike."""
+    sizes = [5200, 5100, 640, 5300, 5050, 5400, 5150]
+    c0, blocks = 0, []
+    for nb in sizes:
+        blocks.append(oracle.synth_fill(77, 1400, c0, nb, 5, 140)); c0 += nb
+    ref = oracle.SHARP_unlimited(blocks, K=3, rN_seed=2103, nthreads=8, want_view=True)
+    out = {}
+    for group in ("3", "2", "1"):
+        monkeypatch.setenv("SHARP_HOST_GROUP", group)
+        for name, lst in (("dense", blocks), ("sparse", [sp.csc_matrix(b) for b in blocks])):
+            res = sa.SHARP_unlimited(lst, ensize_K=3, rN_seed=2103)
+            assert np.array_equal(res["pred_clusters"], ref["pred_clusters"]), (group, name)
+            np.testing.assert_allclose(res["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
+            out[(group, name)] = res["viE"]
+    monkeypatch.delenv("SHARP_HOST_GROUP")
+    for k, v in out.items():
+        np.testing.assert_array_equal(v, out[("1", "dense")], err_msg=str(k))

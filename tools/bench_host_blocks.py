@@ -1,6 +1,8 @@
 """Host-inclusive SHARP_unlimited on a LIST of host blocks (what an R session holds): cfg3-shaped data (B blocks of 50 000 cells x 20 000
 genes), dense fp64 matrices against dgCMatrix-like sparse blocks, on one device and on several device slots.  Prints seconds per call,
-cells/s and the per-worker timeline (upload hidden under clustering).  usage: bench_host_blocks.py [blocks=4] [cells_per_block=50000]"""
+cells/s, the bytes that crossed PCIe and their rate, and the per-worker timeline (upload hidden under clustering).
+usage: bench_host_blocks.py [blocks=10] [cells_per_block=50000] [dense_blocks=blocks]     (dense_blocks: how many of the blocks the dense runs
+use -- ten dense fp64 blocks are 80 GB of host memory; fewer are taken when the box has less than twice that free)"""
 import os
 import sys
 import time
@@ -13,22 +15,31 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sharp_amd
 from sharp_amd import device as dev
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 m, K = 20000, 5
+BD = int(sys.argv[3]) if len(sys.argv) > 3 else B
+avail = 0
+for ln in open("/proc/meminfo"):
+    if ln.startswith("MemAvailable"):
+        avail = int(ln.split()[1]) * 1024
+while BD > 2 and BD * nb * m * 8 * 2 > avail:
+    BD -= 1
+print("host memory available %.0f GB: dense runs on %d of %d blocks" % (avail / 1e9, BD, B), flush=True)
 sharp_amd.init(0)
 dense, sparse, dblocks = [], [], []
 for b in range(B):
     dX = torch.empty((nb, m), dtype=torch.float32, device="cuda")
     dev.synth_fill(dX, 20261003, b * nb, 12, 1000)
     X = np.asfortranarray(dX.cpu().numpy().T.astype(np.float64))
-    dense.append(X)
+    if b < BD:
+        dense.append(X)
     sparse.append(sp.csc_matrix(X))
     dblocks.append(dX)
 torch.cuda.synchronize()
-n = B * nb
-print("%d blocks of %d cells x %d genes: dense %.1f GB fp64 on the host, sparse %.2f GB (nnz %.1f %%)"
-      % (B, nb, m, sum(x.nbytes for x in dense) / 1e9, sum(s.nnz for s in sparse) * 12 / 1e9, 100.0 * sparse[0].nnz / dense[0].size), flush=True)
+print("%d blocks of %d cells x %d genes: dense %.1f GB fp64 on the host (%d blocks), sparse %.2f GB as R holds it (12 B per non-zero; nnz %.1f %%)"
+      % (B, nb, m, sum(x.nbytes for x in dense) / 1e9, BD, sum(s.nnz for s in sparse) * 12 / 1e9, 100.0 * sparse[0].nnz / dense[0].size), flush=True)
+nnz = sum(s.nnz for s in sparse)
 
 
 def timeline(tag):
@@ -43,20 +54,36 @@ def timeline(tag):
 
 
 ref = None
-for name, blocks, devices in (("resident (sharp_SHARP_unlimited_multi_dev, 1 slot)", None, [0]),
-                              ("dense host, 1 slot, pipelined upload", dense, [0]),
-                              ("sparse host, 1 slot, pipelined upload", sparse, [0]),
-                              ("sparse host, 2 slots on GPU 0", sparse, [0, 0]),
-                              ("dense host, upload-all-then-cluster (sharp_SHARP_unlimited_view)", dense, None)):
-    for it in range(2):
+for name, blocks, devices, group in (("resident (sharp_SHARP_unlimited_multi_dev, 1 slot)", None, [0], None),
+                                     ("sparse host, blocks taken in groups of up to 3 (default)", sparse, None, None),
+                                     ("sparse host, block after block (SHARP_HOST_GROUP=1)", sparse, None, "1"),
+                                     ("sparse host, groups of up to 2", sparse, None, "2"),
+                                     ("dense host, groups of up to 3 (default)", dense, None, None),
+                                     ("dense host, block after block (SHARP_HOST_GROUP=1)", dense, None, "1"),
+                                     ("sparse host, 2 slots on GPU 0", sparse, [0, 0], None)):
+    if group is None:
+        os.environ.pop("SHARP_HOST_GROUP", None)
+    else:
+        os.environ["SHARP_HOST_GROUP"] = group
+    sharp_amd.reload_options()
+    nblk = B if blocks is None or blocks is sparse else BD
+    n = nblk * nb
+    ts = []
+    for it in range(3):
         t0 = time.perf_counter()
         if blocks is None:
             pred, npred, p, _ = dev.unlimited_multi_dev(dblocks, [0] * B, devices, ensize_K=K, rN_seed=2103)
         else:
             res = sharp_amd.SHARP_unlimited(blocks, ensize_K=K, rN_seed=2103, viewflag=False, devices=devices)
             pred = res["pred_clusters"]
-        t = time.perf_counter() - t0
-    ref = pred if ref is None else ref
-    print("%-70s %.3f s = %.0f cells/s; labels identical to the resident run: %s" % (name, t, n / t, np.array_equal(pred, ref)), flush=True)
-    if devices is not None:
-        timeline(name)
+        ts.append(time.perf_counter() - t0)
+    t = min(ts[1:])
+    if ref is None:
+        ref = pred
+    same = np.array_equal(pred, ref) if nblk == B else "n/a (fewer blocks: another p)"
+    wire = sharp_amd.lib().sharp_x_wire()
+    sent = 0 if blocks is None else (nnz * (wire // 8 + 2) if blocks is sparse else n * m * (wire // 8))
+    print("%-62s %.3f s = %.0f cells/s (calls: %s); wire %d-bit values, %.2f GB over PCIe = %.1f GB/s of the call; labels identical to the resident run: %s"
+          % (name, t, n / t, " ".join("%.3f" % x for x in ts), wire, sent / 1e9, sent / 1e9 / t, same), flush=True)
+    timeline(name)
+os.environ.pop("SHARP_HOST_GROUP", None)

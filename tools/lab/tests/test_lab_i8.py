@@ -15,6 +15,11 @@ def sa():
     return sharp_amd
 
 
+@pytest.fixture(scope="module")
+def lib(sa):
+    return sa.lib()
+
+
 @pytest.mark.parametrize("n,p", [(3, 2), (64, 8), (129, 33), (300, 50), (1000, 223), (2000, 391), (1999, 474)])
 def test_distance_matrix_on_the_integer_matrix_cores(lib, n, p):
     """gemm_i8.hip (SHARP_DIST_I8=1): D = 1 - U U^T of centred unit rows through seven 7-bit digits per entry and exact int8 products.
