@@ -401,6 +401,8 @@ def main():
                        "x_storage": "fp32 in HBM (synthetic counts are fp32-exact)",
                        "parallelism": ("%d blocks, block b on GPU b mod %d; one all-gather of the per-block centroid tables" % (len(ncb), world)) if sharded else "single GPU"},
             "consistency": {"ms_per_step_x_steps_s": round(ms_per_step * args.steps / 1e3, 3), "timed_region_s": round(dt, 3)},
+            # one process per GPU on ONE host: the host cores a rank sizes its upload pool, host loops and tail helpers from (SHARP_HOST_THREADS)
+            "host_threads_per_rank": int(os.environ["SHARP_HOST_THREADS"]) if os.environ.get("SHARP_HOST_THREADS") else host_cores_available(),
             "roofline": roof,
             "kernel_ms_per_step": stages,
             "kernel_ms_note": attribution_note,
@@ -443,6 +445,13 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_cores_available():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
 def level_rules(prof, steps):
@@ -695,35 +704,173 @@ def extra_configs(Bn, headline_tag):
     guarded(out, "cfg4_one_gpu", run_cfg4)
     torch.cuda.empty_cache()
 
+    # ---- cfg5 as the reference's documented workflow runs it (R/SHARP_unlimited3.R: a directory of partitions): block FILES streamed into HBM
+    guarded(out, "cfg5_streamed", lambda: cfg5_streamed(Bn))
+    torch.cuda.empty_cache()
+
     # ---- host-inclusive: the blocks start on the HOST as an R session holds them (dense fp64 matrices / dgCMatrix-like sparse blocks); never `value`
     guarded(out, "host_inclusive", lambda: host_inclusive(Bn))
     torch.cuda.empty_cache()
     return out, by_cfg
 
 
-def host_inclusive(Bn, B=2):
-    """SHARP_unlimited on a LIST OF HOST BLOCKS (PCIe inside the time; tools/bench_host_blocks.py is the longer form): B blocks of cfg3's shape as
-    dense fp64 matrices and as CSC blocks (what Matrix::dgCMatrix holds), block b + 1 uploaded while block b is clustered."""
+def write_packed_block_from_device(path, x, B):
+    """a packed (version 2) block file straight from a resident block of counts: column pointers, 16-bit row indices, 16-bit values"""
+    import numpy as np
+    import torch
+
+    n, m = x.shape
+    nz = x.nonzero()                                                  # (cell, gene), sorted by cell then gene
+    cp = np.concatenate([[0], np.cumsum(torch.bincount(nz[:, 0], minlength=n).cpu().numpy())]).astype(np.int64)
+    idx = nz[:, 1].to(torch.int32).cpu().numpy().astype(np.uint16)
+    val = x[nz[:, 0], nz[:, 1]].to(torch.int32).cpu().numpy().astype(np.uint16)
+    nnz = int(idx.size)
+    o_idx, o_val, total = B._packed_layout(n, nnz, 16, 16)
+    with open(path, "wb") as fh:
+        fh.write(B._HDR2.pack(B.MAGIC, 2, 1, m, n, nnz, 16, 16))
+        fh.write(cp.tobytes()); fh.write(b"\0" * (o_idx - cp.nbytes))
+        fh.write(idx.tobytes()); fh.write(b"\0" * (o_val - o_idx - idx.nbytes))
+        fh.write(val.tobytes()); fh.write(b"\0" * (total - o_val - val.nbytes))
+    return total
+
+
+def cfg5_streamed(Bn, nfiles=20, ndense=3):
+    """BASELINE.json configs[4] the way the reference's README runs its 1.3 M-cell example (R/SHARP_unlimited3.R:59-62,103-105: a DIRECTORY of
+    partitions): `nfiles` of cfg5's 200 blocks of 50 000 cells x 20 000 genes as block files (the packed format: 4 bytes per non-zero),
+    p = 582 as for the whole 10 M cells, read -> pinned memory -> HBM through a ring of buffers while earlier blocks are clustered; the
+    blocks that have arrived go together as one pipelined batch.  Reports blocks/s, the file bytes and how much of the reading was hidden under
+    the clustering; and the same through dense float32 files (4 GB each: `ndense` of them) for comparison.  Never `value`."""
+    import shutil
+    import tempfile
+
+    from sharp_amd import blocks as B
+
+    np, torch, sa, dev = Bn.np, Bn.torch, Bn.sa, Bn.dev
+    nb, m, K = 50000, CFG3["genes"], 5
+    root = None
+    for cand in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            st = os.statvfs(cand)
+            if st.f_bavail * st.f_frsize > (nfiles * 0.6 + ndense * 4.2) * 1e9:
+                root = cand
+                break
+        except OSError:
+            pass
+    if root is None:
+        return {"skipped": "no directory with room for the block files"}
+    # (the reference orders the partitions by the first number in their FULL path, R/SHARP_unlimited3.R:59-61: no digit in the directory's name)
+    import random
+    import string
+    d = os.path.join(root, "sharpblk_" + "".join(random.choice(string.ascii_lowercase) for _ in range(12)))
+    os.mkdir(d)
+    out = {"workload": "SHARP_unlimited3 on %d block files of %d cells x %d genes in %s (cfg5 = BASELINE.json configs[4]: 200 such blocks; p = 582 from the 10 M "
+                       "cells of the whole), ensize.K=%d, viewflag=FALSE; file reads and PCIe inside the time, never `value`" % (nfiles, nb, m, root, K)}
+    try:
+        x = torch.empty((nb, m), dtype=torch.float32, device="cuda")
+        truth = []
+        total = 0
+        for b in range(nfiles):
+            dev.synth_fill(x, DATA_SEED, b * nb, G_TRUE, N_MARK)
+            total += write_packed_block_from_device(os.path.join(d, "part_%d.blk" % (b + 1)), x, B)
+            truth.append(Bn.labels(b * nb, nb))
+        nd = {"dir": d, "ncells": 10000000, "ngenes": m}
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = sa.SHARP_unlimited3(nd, rN_seed=RN_SEED, viewflag=False)
+            ts.append(time.perf_counter() - t0)
+        t = min(ts[1:])
+        out["packed_files"] = {"files": nfiles, "file_gb": round(total / 1e9, 2), "seconds_per_call": round(t, 3), "calls_s": [round(v, 3) for v in ts], "steps": 2, "warmup": 1,
+                               "blocks_per_s": round(nfiles / t, 1), "cells_per_s": round(nfiles * nb / t, 1), "file_gbps_of_the_call": round(total / 1e9 / t, 2),
+                               "read_seconds": round(res["read_seconds"], 3), "consumer_wait_seconds": round(res["wait_seconds"], 3),
+                               "read_hidden_fraction": round(1.0 - res["wait_seconds"] / max(res["read_seconds"], 1e-9), 3),
+                               "clusters_found": int(res["N.pred_clusters"]),
+                               "ari_vs_planted_truth": round(float(Bn.ARI(np.concatenate(truth), res["pred_clusters"])["HA"]), 4)}
+        for b in range(nfiles):
+            os.remove(os.path.join(d, "part_%d.blk" % (b + 1)))
+        hdr = B._HDR.pack(B.MAGIC, 1, 0, m, nb, m)
+        for b in range(ndense):
+            dev.synth_fill(x, DATA_SEED, b * nb, G_TRUE, N_MARK)
+            with open(os.path.join(d, "part_%d.blk" % (b + 1)), "wb") as fh:
+                fh.write(hdr)
+                x.cpu().numpy().tofile(fh)
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            res = sa.SHARP_unlimited3(nd, rN_seed=RN_SEED, viewflag=False)
+            ts.append(time.perf_counter() - t0)
+        t = ts[-1]
+        out["dense_files"] = {"files": ndense, "file_gb": round(ndense * nb * m * 4 / 1e9, 2), "seconds_per_call": round(t, 3), "blocks_per_s": round(ndense / t, 2),
+                              "cells_per_s": round(ndense * nb / t, 1), "file_gbps_of_the_call": round(ndense * nb * m * 4 / 1e9 / t, 2),
+                              "read_seconds": round(res["read_seconds"], 3), "consumer_wait_seconds": round(res["wait_seconds"], 3)}
+        del x
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+def pcie_h2d_gbps(torch, nbytes=1 << 30):
+    """pinned host -> device copy rate of this box, measured (what bounds a host-inclusive call from below)"""
+    h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    d = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    d.copy_(h, non_blocking=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        d.copy_(h, non_blocking=True)
+    e1.record()
+    torch.cuda.synchronize()
+    return 3 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def host_inclusive(Bn, B=CFG3["blocks"]):
+    """SHARP_unlimited on a LIST OF HOST BLOCKS, cfg3 whole (R/SHARP_unlimited.R:125-143: the data starts in R's memory): the ten blocks as
+    dgCMatrix-like CSC blocks and as dense fp64 matrices (as many of the ten as the host's free memory holds twice over: 8 GB each), under a
+    warm-up + timed-calls contract; PCIe inside the time, never `value`.  The blocks cross PCIe in the narrowest exact type (counts: 16-bit
+    values, 16-bit row indices) into a ring of resident copies while earlier blocks are clustered; those that arrived meanwhile go together as
+    one pipelined batch.  tools/bench_host_blocks.py is the longer form (timelines, block after block for comparison)."""
     np, torch, sa = Bn.np, Bn.torch, Bn.sa
     import scipy.sparse as sps
 
     nb, m, K, _ = SHAPES["cfg3"]
+    avail = 0
+    for ln in open("/proc/meminfo"):
+        if ln.startswith("MemAvailable"):
+            avail = int(ln.split()[1]) * 1024
+    BD = B
+    while BD > 2 and (BD * nb * m * 8 + B * nb * m * 0.13 * 12) * 2 > avail:
+        BD -= 1
     dense, sparse = [], []
     for b in range(B):
         x = Bn.synth_block(b * nb, nb, m)
         nz = x.nonzero()                                              # (cell, gene), sorted by cell then gene = CSC order of genes x cells
         indptr = np.concatenate([[0], np.cumsum(torch.bincount(nz[:, 0], minlength=nb).cpu().numpy())]).astype(np.int32)
         sparse.append(sps.csc_matrix((x[nz[:, 0], nz[:, 1]].double().cpu().numpy(), nz[:, 1].int().cpu().numpy(), indptr), shape=(m, nb)))
-        dense.append(x.double().cpu().numpy().T)                      # (genes, cells) column-major view: R's layout, no copy
+        if b < BD:
+            dense.append(x.double().cpu().numpy().T)                  # (genes, cells) column-major view: R's layout, no copy
         del x, nz
     torch.cuda.empty_cache()
-    out = {"workload": "SHARP_unlimited on %d host blocks of %d cells x %d genes, ensize.K=%d, viewflag=FALSE; PCIe-inclusive, never `value`" % (B, nb, m, K),
-           "dense_host_gb": round(sum(d.nbytes for d in dense) / 1e9, 2), "sparse_host_gb": round(sum(s.data.nbytes + s.indices.nbytes + s.indptr.nbytes for s in sparse) / 1e9, 3)}
+    bw = pcie_h2d_gbps(torch)
+    nnz = sum(int(s_.nnz) for s_ in sparse)
+    out = {"workload": "SHARP_unlimited on host blocks of %d cells x %d genes (BASELINE.json configs[2] from the caller's memory), ensize.K=%d, viewflag=FALSE; "
+                       "PCIe-inclusive, never `value`" % (nb, m, K),
+           "dense_host_gb": round(sum(d.nbytes for d in dense) / 1e9, 2), "sparse_host_gb": round(sum(s_.data.nbytes + s_.indices.nbytes + s_.indptr.nbytes for s_ in sparse) / 1e9, 3),
+           "pcie_h2d_pinned_gbps_measured": round(bw, 1), "host_memory_available_gb": round(avail / 1e9, 1)}
     ref = None
-    for name, blocks in (("dense_fp64", dense), ("sparse_csc", sparse)):
-        dt, res = timed_calls(Bn, lambda: sa.SHARP_unlimited(blocks, ensize_K=K, rN_seed=RN_SEED, viewflag=False, devices=[0]), 2)
-        ref = res["pred_clusters"] if ref is None else ref
-        out[name] = {"seconds_per_call": round(dt, 4), "cells_per_s": round(B * nb / dt, 1), "labels_equal_dense": bool(np.array_equal(ref, res["pred_clusters"]))}
+    for name, blocks in (("sparse_csc", sparse), ("dense_fp64", dense)):
+        nblk = len(blocks)
+        dt, res = timed_calls(Bn, lambda: sa.SHARP_unlimited(blocks, ensize_K=K, rN_seed=RN_SEED, viewflag=False), 3)
+        wire = Bn.lib.sharp_x_wire()
+        sent = nnz * (wire // 8 + 2) if blocks is sparse else nblk * nb * m * (wire // 8)
+        if nblk == B:
+            ref = res["pred_clusters"] if ref is None else ref
+        out[name] = {"blocks": nblk, "cells": nblk * nb, "seconds_per_call": round(dt, 4), "cells_per_s": round(nblk * nb / dt, 1), "steps": 3, "warmup": 1,
+                     "wire_value_bits": wire, "bytes_over_pcie": int(sent), "pcie_gbps_of_the_call": round(sent / dt / 1e9, 1),
+                     "pcie_bound_s": round(sent / (bw * 1e9), 4),
+                     "labels_equal_sparse_run": bool(np.array_equal(ref, res["pred_clusters"])) if nblk == B and ref is not None else None}
+    out["note"] = ("pcie_bound_s = bytes_over_pcie / the measured pinned copy rate: what the call could not beat on this box; the dense path also "
+                   "reads 8 B per value from pageable host memory, which bounds it before PCIe does")
     return out
 
 
@@ -743,44 +890,72 @@ def cpu_baseline(Bn, tag):
     # threads are not always faster (round 3: 672 cells/s on 120 threads, 947 on 30).
     threads = max(1, min(avail, 32))
 
-    def unlimited_sample(m, K, nblk, ncell, nmark=N_MARK):
+    sa = Bn.sa
+    margins = {}
+
+    def decisions(tag_, got, want):
+        """the two decision logs of a sample: do they agree decision for decision, and how close did any decision come"""
+        exact = [0, 1, 2, 3, 4, 5, 6, 7, 12, 13]        # call, rule, chosen k, exact ties, override, levels
+        agree = got.shape == want.shape and bool((got[:, exact] == want[:, exact]).all())
+        margins[tag_] = {"decisions": int(len(got)), "logs_agree_decision_for_decision": agree, "per_level": sa.decision_margins(got)}
+
+    def unlimited_sample(m, K, nblk, ncell, nmark=N_MARK, tag_=None):
         xs = [Bn.synth_block(b * 50000, ncell, m, nmark) for b in range(nblk)]     # the first cells of the configuration's first blocks
         hs = [x.cpu().numpy().T.astype(np.float64) for x in xs]
         orc.stage_seconds()
+        orc.decision_log(True)
         t0 = time.perf_counter()
         ref = orc.SHARP_unlimited(hs, K=K, rN_seed=RN_SEED, nthreads=threads)
         t = time.perf_counter() - t0
+        want = orc.last_decisions()
+        orc.decision_log(False)
         stages = orc.stage_seconds()
+        sa.decision_log(True)
         pred, npred, p, _ = Bn.unlimited_call(xs, K)
+        got = sa.last_decisions()
+        sa.decision_log(False)
+        decisions(tag_, got, want)
         return t, stages, float(ARI(ref["pred_clusters"], pred)["HA"]), bool(np.array_equal(ref["pred_clusters"], pred)), p
 
-    def large_sample(m, K, ncell, nmark):
+    def large_sample(m, K, ncell, nmark, tag_=None):
         x = Bn.synth_block(0, ncell, m, nmark)
         h = x.cpu().numpy().T.astype(np.float64)
         orc.stage_seconds()
+        orc.decision_log(True)
         t0 = time.perf_counter()
         ref = orc.SHARP(h, K=K, base_ncells=1, rN_seed=RN_SEED, nthreads=threads, want_view=False)
         t = time.perf_counter() - t0
+        want = orc.last_decisions()
+        orc.decision_log(False)
         stages = orc.stage_seconds()
+        sa.decision_log(True)
         pred, _ = dev.SHARP_dev(x, ensize_K=K, base_ncells=1, rN_seed=RN_SEED)
+        got = sa.last_decisions()
+        sa.decision_log(False)
+        decisions(tag_, got, want)
         return t, stages, float(ARI(ref["pred_clusters"], pred)["HA"]), bool(np.array_equal(ref["pred_clusters"], pred))
 
     parity = {}
     # cfg3: two blocks of 16 000 cells (8 folds x 5 RPs = 40 tasks per block): 10-15 s of oracle time
-    t3, st3, ari3, eq3, p3 = unlimited_sample(CFG3["genes"], CFG3["K"], 2, 16000)
+    t3, st3, ari3, eq3, p3 = unlimited_sample(CFG3["genes"], CFG3["K"], 2, 16000, tag_="cfg3")
     parity["cfg3"] = {"ari_gpu_vs_oracle_on_sample": round(ari3, 4), "labels_identical": eq3, "sample": "2 blocks x 16000 cells x 20000 genes, K = 5"}
     # cfg2: 8000 cells, K = 15 (60 tasks); and the same on the CH-decided data set
-    t2, st2, ari2, eq2 = large_sample(CFG2["genes"], CFG2["K"], 8000, N_MARK)
+    t2, st2, ari2, eq2 = large_sample(CFG2["genes"], CFG2["K"], 8000, N_MARK, tag_="cfg2")
     parity["cfg2"] = {"ari_gpu_vs_oracle_on_sample": round(ari2, 4), "labels_identical": eq2, "sample": "8000 cells x 20000 genes, K = 15"}
-    t2c, st2c, ari2c, eq2c = large_sample(CFG2["genes"], CFG2["K"], 8000, N_MARK_CH)
+    t2c, st2c, ari2c, eq2c = large_sample(CFG2["genes"], CFG2["K"], 8000, N_MARK_CH, tag_="cfg2_ch")
     parity["cfg2_ch"] = {"ari_gpu_vs_oracle_on_sample": round(ari2c, 4), "labels_identical": eq2c, "sample": "8000 cells x 20000 genes, K = 15, %d marker genes" % N_MARK_CH}
     # cfg4: two blocks of 6000 cells x 27000 genes
-    t4, st4, ari4, eq4, _ = unlimited_sample(CFG4["genes"], CFG4["K"], 2, 6000)
+    t4, st4, ari4, eq4, _ = unlimited_sample(CFG4["genes"], CFG4["K"], 2, 6000, tag_="cfg4")
     parity["cfg4"] = {"ari_gpu_vs_oracle_on_sample": round(ari4, 4), "labels_identical": eq4, "sample": "2 blocks x 6000 cells x 27000 genes, K = 5"}
+    for k_, v_ in margins.items():
+        # how close the sample's decisions came to going the other way, per level (SURVEY.md 7 / App. D.2; sharp_last_decisions): for a decision
+        # by the median silhouette with ONE maximum, best - runner-up; exact ties are counted (the reference picks the middle one by `==`);
+        # CH decisions: the relative margin; every decision: its distance to the sil.thre switch.  profiles/r06_margins.txt: full-size runs.
+        parity[k_]["min_margin"] = v_
     parity["ari_gpu_vs_oracle_on_sample"] = parity[{"cfg2": "cfg2", "cfg2_ch": "cfg2_ch", "cfg3": "cfg3", "cfg4": "cfg4"}[tag]]["ari_gpu_vs_oracle_on_sample"]
-    parity["full_size"] = ("tests/test_configs_gpu.py: ::test_cfg2_full_size_matches_oracle (50 000 x 20 000, K = 15, 375 base tasks), ::test_full_size_block_matches_oracle "
-                           "(a cfg3 block, K = 5), ::test_block_of_1e5_cells_no_reshuffle_branch_matches_oracle (cfg4's n >= 1e5 branch): labels identical to the oracle's; "
-                           "profiles/r05_cfg4_share_parity.txt, r05_cfg2_ch_parity.txt: one true cfg4 share and the CH-decided data set at full size")
+    parity["full_size"] = ("tests/test_configs_gpu.py: ::test_cfg2_full_size_matches_oracle (50 000 x 20 000, K = 15, 375 base tasks: labels AND the two decision logs), "
+                           "::test_block_of_1e5_cells_no_reshuffle_branch_matches_oracle (cfg4's n >= 1e5 branch): labels identical to the oracle's; "
+                           "tools/parity_fullsize.py -> profiles/r06_*_parity.txt: a cfg3 block, one true cfg4 share and the CH-decided data set at full size, with margins")
     per = {"cfg3": (32000, t3, st3), "cfg2": (8000, t2, st2), "cfg2_ch": (8000, t2c, st2c), "cfg4": (12000, t4, st4)}
     ns, t, st = per[tag]
     base = {"value": round(ns / t, 2), "unit": "cells/s", "cores": threads, "cores_available": avail, "cores_present": present, "kind": "port",

@@ -213,6 +213,12 @@ int sharp_trim(void);
  * sharp_csc_to_dense_dev fills a caller-owned device block (m x n fp32, column stride ld >= m; values narrowed to fp32) for the
  * *_dev entry points. */
 int sharp_csc_to_dense_dev(const int *colptr, const int *rowidx, const double *val, int m, long long n, float *dX, long long ld);
+/* The same for a block that is ALREADY PACKED and ALREADY IN DEVICE MEMORY: d_colptr n + 1 int64, d_idx row indices of idx_bits (16 or 32),
+ * d_val values of val_bits (16: unsigned integers, 32: float, 64: double) -- what a block file of the compact format holds
+ * (sharp_amd/blocks.py; the directory-of-partitions input of R/SHARP_unlimited3.R:59-62,103-105), DMA'd as it is.  dX: m x n, column stride
+ * ld, fp32 or (dx_is_f64) fp64; zeroed and filled on the library's stream. */
+int sharp_csc_packed_expand_dev(const long long *d_colptr, const void *d_idx, int idx_bits, const void *d_val, int val_bits, int m,
+                                long long n, void *dX, long long ld, int dx_is_f64);
 int sharp_SHARP_csc(const int *colptr, const int *rowidx, const double *val, int m, long long n, int ensize_K, int reduced_ndim,
                     int base_ncells, int partition_ncells, int hmethod, int N_cluster, int enpN_cluster, int indN_cluster,
                     int minN, int maxN, double sil_thre, double height_Ntimes, int log_flag, int projector, double rN_seed,

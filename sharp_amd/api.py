@@ -595,8 +595,9 @@ def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed
     """R/SHARP_unlimited3.R:29-235: SHARP_unlimited over a DIRECTORY of partitions.
 
     ndinfo: dict(dir=..., ncells=..., ngenes=...) like the reference's list; the partitions are block files written by
-    sharp_amd.blocks.write_block (the reference's .rds needs R to be read), taken in the order of the first number in
-    their path (:59-61) and streamed disk -> pinned memory -> HBM one block ahead of the clustering.
+    sharp_amd.blocks.write_block (the reference's .rds needs R to be read; dense float32 or the packed sparse format: 4 bytes per
+    non-zero for counts), taken in the order of the first number in their path (:59-61) and streamed disk -> pinned memory -> HBM
+    through a ring of buffers ahead of the clustering, which takes the blocks that have arrived together.
     logflag: False = log2 always on, as SHARP_unlimited passes it; True = leave it to testlog() per block, which is
     what unlimited3's SHARP() call does (:122; unseeded sample -> not reproducible unless testlog_cells is given)."""
     import time as _t
@@ -626,11 +627,20 @@ def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed
     _lib.ensure_init()
     proj = Projector(ngenes, p, [0.5 if rN_seed == 0.5 else 50 + rN_seed + k for k in range(1, K + 1)])   # :84-90
     preds, means, counts, views, nnc = [], [], [], [], []
+    stream = None
     try:
         stream = _blocks.BlockStreamer(files)
-        for i, hdr, dX in stream:
-            if hdr["genes"] != ngenes:
-                raise SharpError("%s has %d genes, ndinfo$ngenes is %d" % (files[i], hdr["genes"], ngenes))
+        # The blocks that have arrived when the clustering asks for more go TOGETHER (up to three: one pipelined batch of base-clustering tasks,
+        # sharp_unlimited_blocks_dev) -- unless their E1 rows are wanted or testlog has to look at each block, which the per-block entry serves.
+        for grp in stream.groups(1 if (viewflag or logflag) else 3):
+            for i, hdr, dX in grp:
+                if hdr["genes"] != ngenes:
+                    raise SharpError("%s has %d genes, ndinfo$ngenes is %d" % (files[i], hdr["genes"], ngenes))
+            if len(grp) >= 2:
+                for (i, hdr, dX), (pr, mn, cn) in zip(grp, _device.unlimited_blocks_dev([g[2] for g in grp], p, proj.handle, K, rN_seed)):
+                    preds.append(pr); means.append(mn); counts.append(cn); views.append(None); nnc.append(hdr["cells"])
+                continue
+            i, hdr, dX = grp[0]
             nb = hdr["cells"]
             flag = True
             if logflag:                                                            # the block's SHARP() runs testlog (R/SHARP.R:205-222)
@@ -643,6 +653,8 @@ def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed
             preds.append(pr); means.append(mn); counts.append(cn); views.append(vi); nnc.append(nb)
     finally:
         proj.close()
+        if stream is not None:
+            stream.close()
     n = int(sum(nnc))
     first = np.concatenate([[0], np.cumsum([m_.shape[0] for m_ in means])])
     fid, nf = _device.unlimited_merge(np.concatenate(means, 0), np.concatenate(counts, 0), n, int(N_cluster or 0),
@@ -654,6 +666,8 @@ def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed
         out["viE"] = _view_reduce(E1, rN_seed, K) if n > 1e5 else E1
         out["x0"] = _one_hot(pred, nf)
     out["bytes_streamed"] = stream.bytes_streamed
+    out["read_seconds"] = stream.read_seconds              # the reader thread's file reads (wall), hidden under the clustering except for ...
+    out["wait_seconds"] = stream.wait_seconds              # ... what the clustering waited for blocks that had not arrived
     return out
 
 

@@ -317,6 +317,41 @@ void upload_csc_into_f32(const int *colptr, const int *rowidx, const double *val
     upload_csc_f32(colptr, rowidx, val, m, n, dX, ld, false, nullptr);      // (values are narrowed: the caller's block is fp32)
 }
 
+// A packed CSC block ALREADY IN DEVICE MEMORY (a block file of the compact format, DMA'd as it is: sharp_amd/blocks.py) -> the dense block.
+void expand_packed_csc_dev(const long long *d_colptr, const void *d_idx, int idx_bits, const void *d_val, int val_bits, int m, long long n,
+                           void *dX, long long ld, bool dx_f64) {
+    if (n <= 0) return;
+    Ctx &cx = ctx();
+    hipStream_t s = cx.stream;
+    SHARP_HIP_CHECK(hipMemsetAsync(dX, 0, static_cast<size_t>(ld) * n * (dx_f64 ? 8 : 4), s));
+    DevBuf<int> dbad;
+    dbad.alloc_pooled(1);
+    dbad.zero();
+    const int blocks = static_cast<int>(std::min<long long>((n + 3) / 4, static_cast<long long>(cx.num_cu) * 16));
+#define SHARP_EXPAND(IT, VT, DT)                                                                                                         \
+    hipLaunchKernelGGL((csc_expand_kernel<IT, VT, DT>), dim3(blocks), dim3(256), 0, s, d_colptr, static_cast<const IT *>(d_idx),         \
+                       static_cast<const VT *>(d_val), 0LL, n, m, static_cast<DT *>(dX), ld, dbad.p)
+    const int key = (idx_bits == 16 ? 0 : 1) * 8 + (val_bits == 16 ? 0 : val_bits == 32 ? 1 : 2) * 2 + (dx_f64 ? 1 : 0);
+    switch (key) {
+        case 0: SHARP_EXPAND(uint16_t, uint16_t, float); break;
+        case 1: SHARP_EXPAND(uint16_t, uint16_t, double); break;
+        case 2: SHARP_EXPAND(uint16_t, float, float); break;
+        case 3: SHARP_EXPAND(uint16_t, float, double); break;
+        case 5: SHARP_EXPAND(uint16_t, double, double); break;
+        case 8: SHARP_EXPAND(int, uint16_t, float); break;
+        case 9: SHARP_EXPAND(int, uint16_t, double); break;
+        case 10: SHARP_EXPAND(int, float, float); break;
+        case 11: SHARP_EXPAND(int, float, double); break;
+        case 13: SHARP_EXPAND(int, double, double); break;
+        default: throw Error(SHARP_ERR_ARG, "packed sparse block: 64-bit values need an fp64 block");
+    }
+#undef SHARP_EXPAND
+    launch_check("csc_expand_kernel");
+    int bad = 0;
+    dbad.download(&bad, 1);
+    if (bad) throw Error(SHARP_ERR_ARG, "sparse input: row index outside [0, genes)");
+}
+
 void upload_release_staging() {
     UploadStage &U = upload_stage();
     for (int q = 0; q < 2; ++q) if (U.pinned[q]) { (void)hipHostFree(U.pinned[q]); U.pinned[q] = nullptr; }

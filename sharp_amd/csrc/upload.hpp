@@ -36,6 +36,10 @@ void upload_block(const double *X, int m, long long n, long long ld, HostBlock &
 void upload_block_csc(const int *colptr, const int *rowidx, const double *val, int m, long long n, HostBlock &hb);
 // the same into a caller-owned fp32 device block (sharp_csc_to_dense_dev: the *_dev entry points take fp32): values are narrowed
 void upload_csc_into_f32(const int *colptr, const int *rowidx, const double *val, int m, long long n, float *dX, long long ld);
+// a packed CSC block already in device memory (colptr: n + 1 int64; row indices of 16 or 32 bits; values u16 / float / double) -> the dense
+// block dX (fp32, or fp64 when dx_f64): what a block file of the compact format holds, expanded where it lands
+void expand_packed_csc_dev(const long long *d_colptr, const void *d_idx, int idx_bits, const void *d_val, int val_bits, int m, long long n,
+                           void *dX, long long ld, bool dx_f64);
 void upload_release_staging();   // the pinned staging buffers (sharp_trim)
 int upload_last_storage();       // 32 or 64: what the most recent upload_block / upload_block_csc chose (0: none yet)
 int upload_last_wire();          // 16, 32 or 64: the width of a value of that block on PCIe (u16 counts / float / double)

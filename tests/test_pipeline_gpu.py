@@ -207,50 +207,6 @@ def test_sharp_unlimited2_matches_oracle(sa, oracle):
     assert oracle.round1([0.25, 0.35, 0.15, 2.5, -0.25]).tolist() == [0.2, 0.3, 0.1, 2.5, -0.2]
 
 
-@pytest.fixture
-def digit_free_dir():
-    """The reference orders partitions by the first number in the FULL path (R/SHARP_unlimited3.R:60), so a digit in a
-    parent directory (pytest's tmp_path has one) makes every key equal; use a path without digits."""
-    import shutil
-    import string
-    import tempfile
-
-    rng = np.random.default_rng()
-    name = "sharpblk_" + "".join(rng.choice(list(string.ascii_lowercase), 12))
-    d = os.path.join(tempfile.gettempdir(), name)
-    if any(ch.isdigit() for ch in d):
-        pytest.skip("temporary directory path contains digits")
-    os.mkdir(d)
-    yield d
-    shutil.rmtree(d, ignore_errors=True)
-
-
-def test_sharp_unlimited3_streams_a_directory_of_blocks(sa, oracle, digit_free_dir):
-    """R/SHARP_unlimited3.R: same result as SHARP_unlimited on the same partitions, read from block files in the order of
-    the number in their name (part_10 after part_2), one block ahead of the clustering."""
-    from sharp_amd import blocks as B
-
-    m, G, nm = 3000, 6, 300
-    sizes = [6000, 6000, 5200]
-    offs = np.concatenate([[0], np.cumsum(sizes)])
-    parts = [oracle.synth_fill(SEED, m, int(offs[i]), sizes[i], G, nm) for i in range(3)]
-    d = digit_free_dir
-    for name, X in zip(["part_1.blk", "part_2.blk", "part_10.blk"], parts):      # alphabetical order would put part_10 second
-        B.write_block(os.path.join(d, name), X)
-    assert [os.path.basename(f) for f in B.list_block_files(d + "/")] == ["part_1.blk", "part_2.blk", "part_10.blk"]
-    assert B.read_header(os.path.join(d, "part_10.blk")) == {"genes": m, "cells": 5200, "ld": m}
-    res3 = sa.SHARP_unlimited3({"dir": d, "ncells": int(offs[-1]), "ngenes": m}, rN_seed=2103)
-    res = sa.SHARP_unlimited(parts, rN_seed=2103)
-    assert np.array_equal(res3["pred_clusters"], res["pred_clusters"])
-    assert np.array_equal(res3["viE"], res["viE"])
-    ref = oracle.SHARP_unlimited(parts, rN_seed=2103, nthreads=8, want_view=True)      # and both equal the oracle on these partitions
-    assert np.array_equal(res3["pred_clusters"], ref["pred_clusters"])
-    np.testing.assert_allclose(res3["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
-    assert res3["bytes_streamed"] == sum(sizes) * m * 4
-    with pytest.raises(sa.SharpError, match="should be a folder"):
-        sa.SHARP_unlimited3({"dir": os.path.join(d, "missing"), "ncells": 10, "ngenes": m})
-
-
 def test_view_reduction_above_1e5_cells(sa, oracle):
     """R/SHARP_unlimited.R:217-225: viE = 1/sqrt(50) * E1 %*% ranM2(p, 50, seed) (the branch itself needs > 1e5 cells;
     the reduction is checked on a small E1).  E1 is not fp32-exact, so the block is stored as fp64 (upload.hip) and the
