@@ -150,11 +150,11 @@ def test_sharp_large_pipelined_chunks_match_oracle(sa, oracle, monkeypatch, chun
 
 def test_sharp_large_with_two_launch_groups_of_projectors(sa, oracle):
     # K * reduced.ndim = 9000 components: two launch groups (13 + 2 projectors) of the RP kernel over the same block
-    m, n, G, nm = 2000, 4500, 5, 200
+    m, n, G, nm = 2000, 2400, 5, 200
     X = oracle.synth_fill(SEED, m, 0, n, G, nm)
-    kw = dict(ensize_K=15, reduced_ndim=600, base_ncells=300, partition_ncells=2300, rN_seed=2103, logflag=False, prep=False)
+    kw = dict(ensize_K=15, reduced_ndim=600, base_ncells=300, partition_ncells=1200, rN_seed=2103, logflag=False, prep=False)
     res = sa.SHARP(X, **kw)
-    ref = oracle.SHARP(X, K=15, reduced_ndim=600, base_ncells=300, partition_ncells=2300, rN_seed=2103, nthreads=8, want_view=True)
+    ref = oracle.SHARP(X, K=15, reduced_ndim=600, base_ncells=300, partition_ncells=1200, rN_seed=2103, nthreads=8, want_view=True)
     assert res["path"] == "SHARP_large" and res["reduced.dim"] == 600
     assert np.array_equal(res["pred_clusters"], ref["pred_clusters"])
     np.testing.assert_allclose(res["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())

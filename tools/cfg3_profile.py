@@ -1,7 +1,11 @@
 import sys, time, ctypes as C
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import os
 import sharp_amd
+from sharp_amd import _lib as _L
+if os.environ.get('SHARP_VARIANT'):
+    _L._SO = os.path.join(os.path.dirname(_L._SO), 'variants', 'libsharp_hip_%s.so' % os.environ['SHARP_VARIANT'])
 from sharp_amd import device as dev
 sharp_amd.init(0); lib = sharp_amd.lib()
 B, nb, m, K = 10, 50000, 20000, 5
