@@ -35,17 +35,17 @@ int &last_wire() { static int s = 0; return s; }
 int upload_threads() {
     unsigned hw = static_cast<unsigned>(host_cores());
     if (knobs().upload_threads > 0) hw = static_cast<unsigned>(knobs().upload_threads);
-    return static_cast<int>(std::max(1u, std::min(hw ? hw : 4u, 32u)));
+    return static_cast<int>(std::max(1u, std::min(hw ? hw : 4u, 48u)));
 }
 // 0 auto, 32, 64
 int storage_policy() { return knobs().x_storage; }       // SHARP_X_STORAGE=fp32 / fp64
+// the slot's persistent worker pool (a block is packed slab by slab: seven rounds of threads per 50 000-cell sparse block -- spawning them anew
+// per slab cost a third of a block's upload)
 template <typename F>
 void run_threads(int nthr, long long items, F fn) {
     if (nthr == 1 || items < nthr) { for (int t = 0; t < nthr; ++t) fn(t); return; }
-    std::vector<std::thread> th;
-    for (int t = 1; t < nthr; ++t) th.emplace_back(fn, t);
-    fn(0);
-    for (auto &x : th) x.join();
+    host_pool_threads_hint(nthr - 1);                    // (takes effect if this slot's pool does not exist yet: an upload slot's first block)
+    host_parallel_for(nthr, nthr, [&](int t) { fn(t); });
 }
 // does the double survive the round trip through float?  (NaN counts as exact: it is NaN either way; +-inf is exact; a finite
 // value beyond FLT_MAX becomes inf and is not)
