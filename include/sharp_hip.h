@@ -332,6 +332,10 @@ int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long lo
 int sharp_unlimited_block_viewk_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
                                     double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
                                     long long *counts, int view_dim, double view_seed, double *viE);
+/* ... and for a resident fp64 block (values fp32 cannot hold: 16-byte aligned, even leading dimension) */
+int sharp_unlimited_block_viewk_dev64(const double *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
+                                      double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
+                                      long long *counts, int view_dim, double view_seed, double *viE);
 int sharp_unlimited_merge(const double *means, const long long *counts, int nC, int p, long long ncells, int N_cluster,
                           int minN, int maxN, int *final_id, int *n_final);
 /* One-shot hint for a caller that runs its blocks one call at a time (a rank of the sharded run with several blocks per GPU): the block

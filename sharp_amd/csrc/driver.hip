@@ -1194,7 +1194,7 @@ int sharp_unlimited_next_block_dev(const float *dX_next, long long nb_next, long
     return SHARP_OK;
 }
 
-static int unlimited_block_view_entry(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
+static int unlimited_block_view_entry(const void *dXv, bool f64, int m, long long nb, long long ld, int p, int projector, int ensize_K,
                                       double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
                                       long long *counts, double *viE, const ViewCall *view_in) {
     SHARP_API_BEGIN
@@ -1208,6 +1208,7 @@ static int unlimited_block_view_entry(const float *dX, int m, long long nb, long
     std::vector<long long> cn;
     const NextHint h = next_hint();
     next_hint() = NextHint();
+    const XRef dX = f64 ? dev64_ref(static_cast<const double *>(dXv), m, nb, ld) : XRef(static_cast<const float *>(dXv));
     unlimited_block_dev(dX, m, nb, ld, p, projector, ensize_K > 0 ? ensize_K : 5, rN_seed, pr, mn, cn, viE, view, flag != 0, nullptr,
                         h.dX ? XRef(h.dX) : XRef(), h.nb, h.ld);
     SHARP_REQUIRE(static_cast<int>(cn.size()) <= cap_rows, "sharp_unlimited_block_view_dev: centroid buffer too small");
@@ -1221,7 +1222,7 @@ static int unlimited_block_view_entry(const float *dX, int m, long long nb, long
 int sharp_unlimited_block_view_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
                                    double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
                                    long long *counts, double *viE) {
-    return unlimited_block_view_entry(dX, m, nb, ld, p, projector, ensize_K, rN_seed, flag, pred, n_clusters, means, cap_rows, counts, viE, nullptr);
+    return unlimited_block_view_entry(dX, false, m, nb, ld, p, projector, ensize_K, rN_seed, flag, pred, n_clusters, means, cap_rows, counts, viE, nullptr);
 }
 
 int sharp_unlimited_block_viewk_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
@@ -1234,7 +1235,21 @@ int sharp_unlimited_block_viewk_dev(const float *dX, int m, long long nb, long l
     ViewCall v;
     v.kdim = viE ? view_dim : 0;
     v.seed = view_seed;
-    return unlimited_block_view_entry(dX, m, nb, ld, p, projector, ensize_K, rN_seed, flag, pred, n_clusters, means, cap_rows, counts, viE, &v);
+    return unlimited_block_view_entry(dX, false, m, nb, ld, p, projector, ensize_K, rN_seed, flag, pred, n_clusters, means, cap_rows, counts, viE, &v);
+}
+
+/* the same for a resident fp64 block (TPM / CPM-like values: 16-byte aligned, even leading dimension) */
+int sharp_unlimited_block_viewk_dev64(const double *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K,
+                                      double rN_seed, int flag, int *pred, int *n_clusters, double *means, int cap_rows,
+                                      long long *counts, int view_dim, double view_seed, double *viE) {
+    if (view_dim < 0 || view_dim > 4096 || (view_dim > 0 && std::fmod(view_seed, 1.0) != 0.0)) {
+        sharp::set_error("sharp_unlimited_block_viewk_dev64: view_dim must lie in 0 .. 4096 and view_seed must be an integer (the seed of the run's z0)");
+        return SHARP_ERR_ARG;
+    }
+    ViewCall v;
+    v.kdim = viE ? view_dim : 0;
+    v.seed = view_seed;
+    return unlimited_block_view_entry(dX, true, m, nb, ld, p, projector, ensize_K, rN_seed, flag, pred, n_clusters, means, cap_rows, counts, viE, &v);
 }
 
 int sharp_unlimited_block_dev(const float *dX, int m, long long nb, long long ld, int p, int projector, int ensize_K, double rN_seed,

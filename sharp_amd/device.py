@@ -102,7 +102,8 @@ def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag
     (sharp_unlimited_next_block_dev)."""
     _lib.ensure_init()
     nb, m = dX.shape
-    if next_block is not None:
+    f64 = str(dX.dtype) == "torch.float64"
+    if next_block is not None and not f64 and str(next_block.dtype) == "torch.float32":
         check(lib().sharp_unlimited_next_block_dev(C.c_void_p(next_block.data_ptr()), C.c_longlong(next_block.shape[0]),
                                                    C.c_longlong(next_block.stride(0))))
     if viE is not None and view_dim > 0 and view_seed is None:
@@ -113,7 +114,8 @@ def unlimited_block_dev(dX, p, projector, ensize_K, rN_seed, cap_rows=4096, flag
     means = np.empty((cap_rows, p))                 # only the first G rows are written and returned
     counts = np.empty(cap_rows, np.int64)
     G = C.c_int()
-    check(lib().sharp_unlimited_block_viewk_dev(C.c_void_p(dX.data_ptr()), m, C.c_longlong(nb), C.c_longlong(dX.stride(0)), p,
+    entry = lib().sharp_unlimited_block_viewk_dev64 if f64 else lib().sharp_unlimited_block_viewk_dev      # (a float64 block: TPM / CPM-like values)
+    check(entry(C.c_void_p(dX.data_ptr()), m, C.c_longlong(nb), C.c_longlong(dX.stride(0)), p,
                                                 projector, ensize_K, C.c_double(rN_seed), int(bool(flag)), _ip(pred), C.byref(G),
                                                 _dp(means), cap_rows, counts.ctypes.data_as(C.POINTER(C.c_longlong)),
                                                 int(view_dim) if viE is not None else 0, C.c_double(view_seed or 0.0), _dp(viE)))
