@@ -715,7 +715,7 @@ def extra_configs(Bn, headline_tag):
 
 
 def write_packed_block_from_device(path, x, B):
-    """a packed (version 2) block file straight from a resident block of counts: column pointers, 16-bit row indices, 16-bit values"""
+    """a packed (version 2) block file straight from a resident block of counts below 256: column pointers, 16-bit row indices, 8-bit values"""
     import numpy as np
     import torch
 
@@ -723,11 +723,13 @@ def write_packed_block_from_device(path, x, B):
     nz = x.nonzero()                                                  # (cell, gene), sorted by cell then gene
     cp = np.concatenate([[0], np.cumsum(torch.bincount(nz[:, 0], minlength=n).cpu().numpy())]).astype(np.int64)
     idx = nz[:, 1].to(torch.int32).cpu().numpy().astype(np.uint16)
-    val = x[nz[:, 0], nz[:, 1]].to(torch.int32).cpu().numpy().astype(np.uint16)
+    vi = x[nz[:, 0], nz[:, 1]].to(torch.int32).cpu().numpy()
+    vb = 8 if int(vi.max(initial=0)) <= 255 else 16
+    val = vi.astype(np.uint8 if vb == 8 else np.uint16)
     nnz = int(idx.size)
-    o_idx, o_val, total = B._packed_layout(n, nnz, 16, 16)
+    o_idx, o_val, total = B._packed_layout(n, nnz, 16, vb)
     with open(path, "wb") as fh:
-        fh.write(B._HDR2.pack(B.MAGIC, 2, 1, m, n, nnz, 16, 16))
+        fh.write(B._HDR2.pack(B.MAGIC, 2, 1, m, n, nnz, 16, vb))
         fh.write(cp.tobytes()); fh.write(b"\0" * (o_idx - cp.nbytes))
         fh.write(idx.tobytes()); fh.write(b"\0" * (o_val - o_idx - idx.nbytes))
         fh.write(val.tobytes()); fh.write(b"\0" * (total - o_val - val.nbytes))

@@ -188,10 +188,10 @@ int sharp_SHARP(const double *X, int m, long long n, long long ld, int ensize_K,
  * over X); 64 = fp64 (TPM / CPM-like doubles), so that log2(X + 1) and the projection see the numbers the reference computes with
  * (R/SHARP.R:110-117,343-345).  0: nothing uploaded yet.  The environment variable SHARP_X_STORAGE = fp32 | fp64 forces the choice. */
 int sharp_x_storage(void);
-/* what a value of the most recently uploaded host block was on PCIe: 16 (counts: every value an integer in 0 .. 65535, sent as unsigned
- * 16-bit integers and stored as fp32), 32 (other fp32-exact values), 64 (doubles).  A sparse block also sends 16-bit row indices when it has
- * at most 65 536 genes: 4 bytes per non-zero for count data against the 12 of R's dgCMatrix slots (R/SHARP_unlimited.R:125-143 hands the
- * blocks over as they are). */
+/* what a value of the most recently uploaded host block was on PCIe: 8 or 16 (counts: every value an integer in 0 .. 255 / 0 .. 65535, sent
+ * as unsigned integers of that width and stored as fp32), 32 (other fp32-exact values), 64 (doubles).  A sparse block also sends 16-bit row
+ * indices when it has at most 65 536 genes: 3 bytes per non-zero for typical count data against the 12 of R's dgCMatrix slots
+ * (R/SHARP_unlimited.R:125-143 hands the blocks over as they are). */
 int sharp_x_wire(void);
 
 /* allrpinfo of the most recent call that took the SHARP_small path (R/SHARP.R:350-387,446: per random projection k its tag, the
@@ -214,7 +214,7 @@ int sharp_trim(void);
  * *_dev entry points. */
 int sharp_csc_to_dense_dev(const int *colptr, const int *rowidx, const double *val, int m, long long n, float *dX, long long ld);
 /* The same for a block that is ALREADY PACKED and ALREADY IN DEVICE MEMORY: d_colptr n + 1 int64, d_idx row indices of idx_bits (16 or 32),
- * d_val values of val_bits (16: unsigned integers, 32: float, 64: double) -- what a block file of the compact format holds
+ * d_val values of val_bits (8 / 16: unsigned integers, 32: float, 64: double) -- what a block file of the compact format holds
  * (sharp_amd/blocks.py; the directory-of-partitions input of R/SHARP_unlimited3.R:59-62,103-105), DMA'd as it is.  dX: m x n, column stride
  * ld, fp32 or (dx_is_f64) fp64; zeroed and filled on the library's stream. */
 int sharp_csc_packed_expand_dev(const long long *d_colptr, const void *d_idx, int idx_bits, const void *d_val, int val_bits, int m,

@@ -6,8 +6,8 @@ formats used here (an R maintainer writes them with `writeBin`, INTEGRATION.md);
   version 1, dense:  the block exactly as it lives in HBM -- cells x ld float32, one cell per row (genes x cells column-major in R's
              terms), ld = genes rounded up to 4 -- so a file goes page-locked buffer -> DMA with no conversion: 4 GB per 50 000 x 20 000 block;
   version 2, packed: the block as the three slots of a dgCMatrix in their narrowest exact types -- column pointers (cells + 1 int64), row
-             indices (16 bits up to 65 536 genes, else 32), values (unsigned 16-bit integers for counts, else float, else double) --
-             4 bytes per non-zero for count data: 0.4 GB for the same block.  The bytes go page-locked buffer -> DMA as they are and
+             indices (16 bits up to 65 536 genes, else 32), values (unsigned 8- or 16-bit integers for counts, else float, else double) --
+             3 bytes per non-zero for typical count data: 0.35 GB for the same block.  The bytes go page-locked buffer -> DMA as they are and
              the dense block is built on the device (sharp_csc_packed_expand_dev); values that fp32 cannot hold give an fp64 block.
 
 While earlier blocks are clustered a reader thread brings the next files into a ring of pinned buffers and enqueues their copies on a
@@ -74,7 +74,9 @@ def write_block(path, X, fmt="auto"):
         Xc.sort_indices()
         vals = np.asarray(Xc.data, np.float64)
     idx_bits = 16 if m <= 65536 else 32
-    if vals.size == 0 or (np.all(vals >= 0) and np.all(vals <= 65535) and np.all(vals == np.floor(vals))):
+    if vals.size == 0 or (np.all(vals >= 0) and np.all(vals <= 255) and np.all(vals == np.floor(vals))):
+        val_bits, v = 8, vals.astype(np.uint8)
+    elif np.all(vals >= 0) and np.all(vals <= 65535) and np.all(vals == np.floor(vals)):
         val_bits, v = 16, vals.astype(np.uint16)
     elif np.all(vals.astype(np.float32).astype(np.float64) == vals):
         val_bits, v = 32, vals.astype(np.float32)
@@ -108,7 +110,7 @@ def read_header(path):
         return {"version": 1, "genes": int(m), "cells": int(n), "ld": int(ld), "f64": False, "payload": int(n * ld * 4)}
     if ver == 2:
         _, _, _, m, n, nnz, idx_bits, val_bits = _HDR2.unpack(raw)
-        if dtype != 1 or idx_bits not in (16, 32) or val_bits not in (16, 32, 64) or (idx_bits == 16 and m > 65536):
+        if dtype != 1 or idx_bits not in (16, 32) or val_bits not in (8, 16, 32, 64) or (idx_bits == 16 and m > 65536):
             raise ValueError("%s: not a SHARP block file (bad header)" % path)
         o_idx, o_val, total = _packed_layout(n, nnz, idx_bits, val_bits)
         if os.path.getsize(path) != HEADER_BYTES + total:
@@ -129,7 +131,7 @@ def read_block(path):
     n, nnz = h["cells"], h["nnz"]
     cp = raw[: (n + 1) * 8].view(np.int64)
     idx = raw[h["o_idx"]: h["o_idx"] + nnz * h["idx_bits"] // 8].view(np.uint16 if h["idx_bits"] == 16 else np.int32)
-    val = raw[h["o_val"]: h["o_val"] + nnz * h["val_bits"] // 8].view({16: np.uint16, 32: np.float32, 64: np.float64}[h["val_bits"]])
+    val = raw[h["o_val"]: h["o_val"] + nnz * h["val_bits"] // 8].view({8: np.uint8, 16: np.uint16, 32: np.float32, 64: np.float64}[h["val_bits"]])
     out = np.zeros((h["genes"], n), np.float64 if h["f64"] else np.float32)
     cols = np.repeat(np.arange(n), np.diff(cp))
     out[idx.astype(np.int64), cols] = val

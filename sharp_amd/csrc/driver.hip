@@ -1162,7 +1162,7 @@ int sharp_csc_packed_expand_dev(const long long *d_colptr, const void *d_idx, in
     ctx();
     SHARP_REQUIRE(d_colptr && dX && m > 0 && n >= 0 && ld >= m, "sharp_csc_packed_expand_dev: bad block");
     SHARP_REQUIRE((idx_bits == 16 && m <= 65536) || idx_bits == 32, "sharp_csc_packed_expand_dev: row indices of 16 (at most 65 536 genes) or 32 bits");
-    SHARP_REQUIRE(val_bits == 16 || val_bits == 32 || val_bits == 64, "sharp_csc_packed_expand_dev: values of 16 (unsigned integers), 32 (float) or 64 (double) bits");
+    SHARP_REQUIRE(val_bits == 8 || val_bits == 16 || val_bits == 32 || val_bits == 64, "sharp_csc_packed_expand_dev: values of 8 or 16 (unsigned integers), 32 (float) or 64 (double) bits");
     SHARP_REQUIRE(val_bits != 64 || dx_is_f64, "sharp_csc_packed_expand_dev: 64-bit values need an fp64 block");
     expand_packed_csc_dev(d_colptr, d_idx, idx_bits, d_val, val_bits, m, n, dX, ld, dx_is_f64 != 0);
     SHARP_API_END

@@ -52,11 +52,12 @@ void run_threads(int nthr, long long items, F fn) {
 inline bool f32_exact(double x) { return !(static_cast<double>(static_cast<float>(x)) != x) || x != x; }
 
 // What crosses PCIe.  A block is sent in the NARROWEST type that holds every one of its values exactly, decided while it is packed (no
-// scan of its own): unsigned 16-bit integers (counts, UMI data: every value an integer in 0 .. 65535), else float, else double.  The
+// scan of its own): unsigned 8-bit integers (counts up to 255: most UMI data), unsigned 16-bit integers (counts up to 65535), else float, else double.  The
 // attempt at a type stops at the first slab that holds a value outside it and the block starts over one type wider -- for TPM-like data
 // that is the first slab, a few milliseconds.  u16 and float blocks are STORED as fp32 (the RP kernel's table covers the counts), double
 // blocks as fp64.
 template <typename Wt> inline bool wire_holds(double x);
+template <> inline bool wire_holds<uint8_t>(double x) { return x >= 0.0 && x <= 255.0 && static_cast<double>(static_cast<uint8_t>(x)) == x; }
 template <> inline bool wire_holds<uint16_t>(double x) { return x >= 0.0 && x <= 65535.0 && static_cast<double>(static_cast<uint16_t>(x)) == x; }
 template <> inline bool wire_holds<float>(double x) { return f32_exact(x); }
 template <> inline bool wire_holds<double>(double) { return true; }
@@ -248,6 +249,9 @@ bool upload_csc_f32(const int *colptr, const int *rowidx, const double *val, int
     bool narrow_idx = m <= 65536;      // (a row index beyond 65 535 in such a block is outside [0, genes): the int32 attempt reports it)
     int r = 1;
     if (check) {
+        if (narrow_idx) { r = upload_csc_as<uint16_t, uint8_t, float>(colptr, rowidx, val, m, n, dX, ldd, true, max_abs); if (r == 2) narrow_idx = false; }
+        if (!narrow_idx) r = upload_csc_as<int, uint8_t, float>(colptr, rowidx, val, m, n, dX, ldd, true, max_abs);
+        if (r == 0) { last_wire() = 8; return true; }
         if (narrow_idx) { r = upload_csc_as<uint16_t, uint16_t, float>(colptr, rowidx, val, m, n, dX, ldd, true, max_abs); if (r == 2) narrow_idx = false; }
         if (!narrow_idx) r = upload_csc_as<int, uint16_t, float>(colptr, rowidx, val, m, n, dX, ldd, true, max_abs);
         if (r == 0) { last_wire() = 16; return true; }
@@ -275,8 +279,9 @@ void upload_block(const double *X, int m, long long n, long long ld, HostBlock &
         const long long ldd = (static_cast<long long>(m) + 3) / 4 * 4;
         { HostTimer ha("upload_alloc"); hb.f.ensure(static_cast<size_t>(ldd) * n); }
         // counts cross PCIe as 16-bit integers (a quarter of the doubles R holds), other fp32-exact values as floats
-        bool ok = policy == 0 && upload_as<uint16_t, float>(X, m, n, ld, hb.f.p, ldd, true, &hb.max_abs);
-        if (ok) last_wire() = 16;
+        bool ok = policy == 0 && upload_as<uint8_t, float>(X, m, n, ld, hb.f.p, ldd, true, &hb.max_abs);
+        if (ok) last_wire() = 8;
+        else if (policy == 0 && (ok = upload_as<uint16_t, float>(X, m, n, ld, hb.f.p, ldd, true, &hb.max_abs))) last_wire() = 16;
         else { ok = upload_as<float, float>(X, m, n, ld, hb.f.p, ldd, policy == 0, &hb.max_abs); if (ok) last_wire() = 32; }
         if (ok) {
             hb.d.release();                               // (an fp64 copy left by an earlier block of another kind)
@@ -331,8 +336,13 @@ void expand_packed_csc_dev(const long long *d_colptr, const void *d_idx, int idx
 #define SHARP_EXPAND(IT, VT, DT)                                                                                                         \
     hipLaunchKernelGGL((csc_expand_kernel<IT, VT, DT>), dim3(blocks), dim3(256), 0, s, d_colptr, static_cast<const IT *>(d_idx),         \
                        static_cast<const VT *>(d_val), 0LL, n, m, static_cast<DT *>(dX), ld, dbad.p)
-    const int key = (idx_bits == 16 ? 0 : 1) * 8 + (val_bits == 16 ? 0 : val_bits == 32 ? 1 : 2) * 2 + (dx_f64 ? 1 : 0);
+    const int key = val_bits == 8 ? 100 + (idx_bits == 16 ? 0 : 2) + (dx_f64 ? 1 : 0)
+                                  : (idx_bits == 16 ? 0 : 1) * 8 + (val_bits == 16 ? 0 : val_bits == 32 ? 1 : 2) * 2 + (dx_f64 ? 1 : 0);
     switch (key) {
+        case 100: SHARP_EXPAND(uint16_t, uint8_t, float); break;
+        case 101: SHARP_EXPAND(uint16_t, uint8_t, double); break;
+        case 102: SHARP_EXPAND(int, uint8_t, float); break;
+        case 103: SHARP_EXPAND(int, uint8_t, double); break;
         case 0: SHARP_EXPAND(uint16_t, uint16_t, float); break;
         case 1: SHARP_EXPAND(uint16_t, uint16_t, double); break;
         case 2: SHARP_EXPAND(uint16_t, float, float); break;

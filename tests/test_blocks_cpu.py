@@ -28,8 +28,8 @@ def test_block_file_round_trip(tmp_path):
 
 
 def test_packed_block_file_takes_the_narrowest_exact_types(tmp_path):
-    """Version 2 (the three slots of a dgCMatrix): counts -> 16-bit values, 16-bit row indices up to 65 536 genes: 4 bytes per non-zero; other
-    fp32-exact values -> float; anything else -> double (an fp64 block on the device); more genes -> 32-bit indices.  Round trips are exact."""
+    """Version 2 (the three slots of a dgCMatrix): counts -> 8- or 16-bit values, 16-bit row indices up to 65 536 genes: 3-4 bytes per non-zero;
+    other fp32-exact values -> float; anything else -> double (an fp64 block on the device); more genes -> 32-bit indices.  Round trips are exact."""
     import scipy.sparse as sp
 
     rng = np.random.default_rng(4)
@@ -48,6 +48,10 @@ def test_packed_block_file_takes_the_narrowest_exact_types(tmp_path):
         h = B.read_header(f)
         assert (h["val_bits"], h["f64"], h["ld"]) == (bits, f64, 1004)
         assert np.array_equal(B.read_block(f), X * scale)
+    Xs = np.minimum(X, 255)                                           # typical UMI counts: 8-bit values, 3 bytes per non-zero
+    B.write_block(f, Xs)
+    h = B.read_header(f)
+    assert h["val_bits"] == 8 and os.path.getsize(f) <= B.HEADER_BYTES + 41 * 8 + 3 * int(np.count_nonzero(Xs)) + 48 and np.array_equal(B.read_block(f), Xs)
     Xb = X.copy(); Xb[7, 7] = 65536                                 # one count too large for 16 bits
     B.write_block(f, Xb)
     assert B.read_header(f)["val_bits"] == 32 and np.array_equal(B.read_block(f), Xb)

@@ -85,25 +85,27 @@ def test_sparse_input_errors(sa):
 
 
 def test_wire_formats_of_host_blocks(sa, oracle):
-    """What crosses PCIe (sharp_x_wire): counts as unsigned 16-bit integers, other fp32-exact values as floats, anything else as doubles --
-    decided while the block is packed -- and 16-bit row indices for a sparse block of at most 65 536 genes.  Whatever the wire, the block
+    """What crosses PCIe (sharp_x_wire): counts as unsigned 8- or 16-bit integers, other fp32-exact values as floats, anything else as doubles
+    -- decided while the block is packed -- and 16-bit row indices for a sparse block of at most 65 536 genes.  Whatever the wire, the block
     in HBM is the same, so every result equals the dense fp64 reference path: labels and projections against the oracle."""
     lib = sa.lib()
     X = _counts(oracle, 640, 1500)
     kinds = []
-    for scale, wire, storage in ((1.0, 16, 32), (0.5, 32, 32), (1.0 / 3.0, 64, 64)):
+    for scale, wire, storage in ((1.0, 16, 32), (-1.0, 8, 32), (0.5, 32, 32), (1.0 / 3.0, 64, 64)):
         for fmt in (np.asfortranarray, sp.csc_matrix):
-            Xs = X * scale
+            Xs = X * abs(scale)
             if scale == 1.0:
                 Xs = Xs.copy(); Xs[3, 5] = 65535.0                       # the largest value the 16-bit wire holds
+            if scale == -1.0:
+                Xs = np.minimum(Xs, 255.0)                               # counts up to 255: 8-bit values
             res = sa.SHARP(fmt(Xs), ensize_K=3, rN_seed=11, logflag=False, prep=False)
             assert (lib.sharp_x_wire(), lib.sharp_x_storage()) == (wire, storage), (scale, fmt)
             r2 = oracle.SHARP(Xs, K=3, rN_seed=11, nthreads=4, want_view=True)
             assert np.array_equal(res["pred_clusters"], r2["pred_clusters"])
             np.testing.assert_allclose(res["viE"], r2["viE"], rtol=0, atol=2e-12 * np.abs(r2["viE"]).max())
             kinds.append(res["viE"])
-    np.testing.assert_array_equal(kinds[0], kinds[1])                    # dense and sparse wire: the same block in HBM
-    np.testing.assert_array_equal(kinds[2], kinds[3])
+    for q in range(0, len(kinds), 2):
+        np.testing.assert_array_equal(kinds[q], kinds[q + 1])            # dense and sparse wire: the same block in HBM
     # one value beyond 65 535, one non-integer: the block starts over as floats
     for bad in (65536.0, 2.5):
         Xb = X.copy(); Xb[7, 600] = bad
@@ -127,8 +129,8 @@ def test_sparse_block_with_more_than_65536_genes_takes_int32_row_indices(sa, ora
     dX = dev.csc_to_dev(sp.csc_matrix(X))
     assert np.array_equal(dX.cpu().numpy(), X.T.astype(np.float32))
     pr = sa.Projector(m, 60, [2154])
-    E = pr.project(X, logflag=True)                                       # (the dense host path of the same block: 16-bit values on the wire)
-    assert sa.lib().sharp_x_wire() == 16
+    E = pr.project(X, logflag=True)                                       # (the dense host path of the same block: 8-bit values on the wire)
+    assert sa.lib().sharp_x_wire() == 8
     refE = oracle.project(X, oracle.ranM(m, 60, 2154), True)
     np.testing.assert_allclose(E, refE, rtol=0, atol=2e-12 * np.abs(refE).max())
     del torch
