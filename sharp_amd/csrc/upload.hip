@@ -148,6 +148,54 @@ __global__ void csc_expand_kernel(const long long *__restrict__ colptr, const It
     }
 }
 
+// The same without the zero-fill pass and without scattered 4-byte writes to HBM: one workgroup builds a cell's column tile by tile in LDS
+// (zero, place the cell's entries that fall into the tile, stream the tile out with 16-byte stores), so the dense block is WRITTEN ONCE,
+// coalesced -- 4 GB per 50 000 x 20 000 block instead of a 4 GB memset plus 1e8 partial-line writes -- and the expansion of a block that
+// arrives while other blocks are being clustered does not fight their kernels for the memory system (round 6: a block's upload took 13 ms
+// on an idle GPU and 31 ms beside the clustering).  Entries need not be sorted.  Out-of-range row indices are counted, never written.
+constexpr int kExpandTileBytes = 64 * 1024;
+template <typename It, typename Vt, typename Dt>
+__global__ __launch_bounds__(256) void csc_expand_rows_kernel(const long long *__restrict__ colptr, const It *__restrict__ rowidx, const Vt *__restrict__ val,
+                                                             long long e_base, long long ncell, int m, Dt *__restrict__ dX, long long ld, int *__restrict__ bad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+    Dt *tile = reinterpret_cast<Dt *>(tile_raw);
+    constexpr int TILE = kExpandTileBytes / static_cast<int>(sizeof(Dt));          // elements per tile
+    constexpr int V = 16 / static_cast<int>(sizeof(Dt));                           // elements per 16-byte store
+    typedef Dt vec_t __attribute__((ext_vector_type(V)));
+    const int tid = threadIdx.x;
+    int nbad = 0;
+    const bool vec = ld % V == 0 && (reinterpret_cast<uintptr_t>(dX) & 15u) == 0;  // the library's own blocks; a caller's block may have any stride
+    for (long long c = blockIdx.x; c < ncell; c += gridDim.x) {
+        const long long e0 = colptr[c] - e_base, e1 = colptr[c + 1] - e_base;
+        Dt *col = dX + c * ld;
+        for (long long t0 = 0; t0 < ld; t0 += TILE) {
+            const int len = static_cast<int>(ld - t0 < TILE ? ld - t0 : TILE);
+            for (int q = tid * V; q < len; q += 256 * V) *reinterpret_cast<vec_t *>(tile + q) = vec_t(0);     // (TILE is a multiple of V: a ragged end stays inside the tile)
+            __syncthreads();
+            for (long long e = e0 + tid; e < e1; e += 256) {
+                const long long g = static_cast<long long>(rowidx[e]);
+                if (g >= t0 && g < t0 + len && g < m) tile[g - t0] = static_cast<Dt>(val[e]);
+                else if (t0 == 0 && (g < 0 || g >= m)) ++nbad;
+            }
+            __syncthreads();
+            if (vec) for (int q = tid * V; q < len; q += 256 * V) __builtin_nontemporal_store(*reinterpret_cast<const vec_t *>(tile + q), reinterpret_cast<vec_t *>(col + t0 + q));
+            else for (int q = tid; q < len; q += 256) col[t0 + q] = tile[q];
+            __syncthreads();
+        }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+template <typename It, typename Vt, typename Dt>
+void launch_csc_expand(const long long *d_colptr, const It *d_idx, const Vt *d_val, long long e_base, long long ncell, int m, Dt *dX, long long ld, int *d_bad,
+                       hipStream_t s) {
+    Ctx &cx = ctx();
+    auto kern = csc_expand_rows_kernel<It, Vt, Dt>;
+    SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kExpandTileBytes));
+    const int blocks = static_cast<int>(std::min<long long>(ncell, static_cast<long long>(cx.num_cu) * 2));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), kExpandTileBytes, s, d_colptr, d_idx, d_val, e_base, ncell, m, dX, ld, d_bad);
+    launch_check("csc_expand_rows_kernel");
+}
+
 // Only the non-zeros cross PCIe, slab by slab through the pinned staging buffers: per entry a row index of It (uint16_t when the block has
 // at most 65 536 genes, else int32) and a value of Vt (see wire_holds): 4 bytes per non-zero for counts over 20 000 genes, 12 as R holds
 // them.  Returns 0 when the block is complete; at the first slab with a value Vt cannot hold (check only) 1, with a row index It cannot 2.
@@ -157,7 +205,6 @@ int upload_csc_as(const int *colptr, const int *rowidx, const double *val, int m
     HostTimer ht("upload_csc");
     Ctx &cx = ctx();
     hipStream_t s = cx.stream;
-    SHARP_HIP_CHECK(hipMemsetAsync(dX, 0, static_cast<size_t>(ldd) * n * sizeof(Dt), s));
     std::vector<long long> cp(static_cast<size_t>(n) + 1);
     for (long long c = 0; c <= n; ++c) cp[c] = colptr[c];
     DevBuf<long long> dcp;
@@ -190,8 +237,11 @@ int upload_csc_as(const int *colptr, const int *rowidx, const double *val, int m
             for (int k = 0; k < 2; ++k) { WS.slab[k].ensure(static_cast<size_t>(cp[c1] - e0) * esz + 16); used[k] = false; }
         }
         const long long ne = cp[c1] - e0;
+        if (ne == 0) {                                                      // cells without a single non-zero: their columns are zeros
+            SHARP_HIP_CHECK(hipMemsetAsync(dX + c0 * ldd, 0, static_cast<size_t>(ldd) * (c1 - c0) * sizeof(Dt), s));
+        }
         if (ne > 0) {
-            if (used[q]) SHARP_HIP_CHECK(hipEventSynchronize(U.done[q]));
+            if (used[q]) { HostTimer hw("upload_csc_wait_staging"); SHARP_HIP_CHECK(hipEventSynchronize(U.done[q])); }
             // [values | indices] or [indices | values]: the wider type first, so that both runs are aligned
             constexpr bool vfirst = sizeof(Vt) >= sizeof(It);
             Vt *hv = vfirst ? static_cast<Vt *>(U.pinned[q]) : reinterpret_cast<Vt *>(static_cast<It *>(U.pinned[q]) + ne);
@@ -213,8 +263,11 @@ int upload_csc_as(const int *colptr, const int *rowidx, const double *val, int m
                 if (bad) inexact.store(1, std::memory_order_relaxed);
                 if (bi) badidx.store(1, std::memory_order_relaxed);
             };
-            if (ne < (1 << 16)) { for (int t = 0; t < nthr; ++t) pack(t); }
-            else run_threads(nthr, ne, pack);
+            {
+                HostTimer hp("upload_csc_pack");
+                if (ne < (1 << 16)) { for (int t = 0; t < nthr; ++t) pack(t); }
+                else run_threads(nthr, ne, pack);
+            }
             if (inexact.load() || badidx.load()) {
                 // a row index It cannot hold can only be an index outside [0, genes): the int32 attempt reports it; a value Vt cannot hold: one type wider
                 SHARP_HIP_CHECK(hipStreamSynchronize(s));
@@ -223,11 +276,7 @@ int upload_csc_as(const int *colptr, const int *rowidx, const double *val, int m
             Vt *dv = vfirst ? reinterpret_cast<Vt *>(WS.slab[q].p) : reinterpret_cast<Vt *>(reinterpret_cast<It *>(WS.slab[q].p) + ne);
             It *di = vfirst ? reinterpret_cast<It *>(reinterpret_cast<Vt *>(WS.slab[q].p) + ne) : reinterpret_cast<It *>(WS.slab[q].p);
             SHARP_HIP_CHECK(hipMemcpyAsync(WS.slab[q].p, U.pinned[q], static_cast<size_t>(ne) * esz, hipMemcpyHostToDevice, s));   // values and indices in one transfer
-            const long long ncell = c1 - c0;
-            const int blocks = static_cast<int>(std::min<long long>((ncell + 3) / 4, static_cast<long long>(cx.num_cu) * 16));
-            hipLaunchKernelGGL((csc_expand_kernel<It, Vt, Dt>), dim3(blocks), dim3(256), 0, s, dcp.p + c0, di, dv, e0, ncell, m,
-                               dX + c0 * ldd, ldd, dbad.p);
-            launch_check("csc_expand_kernel");
+            launch_csc_expand<It, Vt, Dt>(dcp.p + c0, di, dv, e0, c1 - c0, m, dX + c0 * ldd, ldd, dbad.p, s);   // (writes every cell of the slab whole: no zero-fill pass)
             SHARP_HIP_CHECK(hipEventRecord(U.done[q], s));                  // (behind the expansion: the device slab is free with the staging buffer)
             used[q] = true;
             q ^= 1;
@@ -235,7 +284,7 @@ int upload_csc_as(const int *colptr, const int *rowidx, const double *val, int m
         c0 = c1;
     }
     int bad = 0;
-    dbad.download(&bad, 1);                                                 // also drains the stream: staging and slabs are free again
+    { HostTimer hd("upload_csc_drain"); dbad.download(&bad, 1); }           // also drains the stream: staging and slabs are free again
     if (bad) throw Error(SHARP_ERR_ARG, "sparse input: row index outside [0, genes)");
     double mx = 0;
     for (double v : tmax) mx = v > mx ? v : mx;
@@ -326,16 +375,12 @@ void upload_csc_into_f32(const int *colptr, const int *rowidx, const double *val
 void expand_packed_csc_dev(const long long *d_colptr, const void *d_idx, int idx_bits, const void *d_val, int val_bits, int m, long long n,
                            void *dX, long long ld, bool dx_f64) {
     if (n <= 0) return;
-    Ctx &cx = ctx();
-    hipStream_t s = cx.stream;
-    SHARP_HIP_CHECK(hipMemsetAsync(dX, 0, static_cast<size_t>(ld) * n * (dx_f64 ? 8 : 4), s));
+    hipStream_t s = ctx().stream;
     DevBuf<int> dbad;
     dbad.alloc_pooled(1);
     dbad.zero();
-    const int blocks = static_cast<int>(std::min<long long>((n + 3) / 4, static_cast<long long>(cx.num_cu) * 16));
 #define SHARP_EXPAND(IT, VT, DT)                                                                                                         \
-    hipLaunchKernelGGL((csc_expand_kernel<IT, VT, DT>), dim3(blocks), dim3(256), 0, s, d_colptr, static_cast<const IT *>(d_idx),         \
-                       static_cast<const VT *>(d_val), 0LL, n, m, static_cast<DT *>(dX), ld, dbad.p)
+    launch_csc_expand<IT, VT, DT>(d_colptr, static_cast<const IT *>(d_idx), static_cast<const VT *>(d_val), 0LL, n, m, static_cast<DT *>(dX), ld, dbad.p, s)
     const int key = val_bits == 8 ? 100 + (idx_bits == 16 ? 0 : 2) + (dx_f64 ? 1 : 0)
                                   : (idx_bits == 16 ? 0 : 1) * 8 + (val_bits == 16 ? 0 : val_bits == 32 ? 1 : 2) * 2 + (dx_f64 ? 1 : 0);
     switch (key) {
@@ -356,7 +401,6 @@ void expand_packed_csc_dev(const long long *d_colptr, const void *d_idx, int idx
         default: throw Error(SHARP_ERR_ARG, "packed sparse block: 64-bit values need an fp64 block");
     }
 #undef SHARP_EXPAND
-    launch_check("csc_expand_kernel");
     int bad = 0;
     dbad.download(&bad, 1);
     if (bad) throw Error(SHARP_ERR_ARG, "sparse input: row index outside [0, genes)");
