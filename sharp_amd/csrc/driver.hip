@@ -1797,6 +1797,7 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
         std::lock_guard<std::mutex> lk(T.mu);
         T.rows = tl;
     }
+    step_marks_dump();
     for (int w = 0; w < W; ++w)
         if (rcs[w] != SHARP_OK) throw sharp::Error(rcs[w], "device " + std::to_string(devices[w]) + ": " + err[w]);
     long long off = 0;

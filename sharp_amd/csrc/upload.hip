@@ -151,9 +151,12 @@ __global__ void csc_expand_kernel(const long long *__restrict__ colptr, const It
 // The same without the zero-fill pass and without scattered 4-byte writes to HBM: one workgroup builds a cell's column tile by tile in LDS
 // (zero, place the cell's entries that fall into the tile, stream the tile out with 16-byte stores), so the dense block is WRITTEN ONCE,
 // coalesced -- 4 GB per 50 000 x 20 000 block instead of a 4 GB memset plus 1e8 partial-line writes -- and the expansion of a block that
-// arrives while other blocks are being clustered does not fight their kernels for the memory system (round 6: a block's upload took 13 ms
-// on an idle GPU and 31 ms beside the clustering).  Entries need not be sorted.  Out-of-range row indices are counted, never written.
-constexpr int kExpandTileBytes = 64 * 1024;
+// arrives while other blocks are being clustered does not fight their kernels for the memory system (round 6: with the memset + scatter form
+// a block's upload took 13 ms on an idle GPU and 29-31 ms beside the clustering, exactly the clustering's own pace; with this form 13-15 ms).
+// The tile is small (16 KB): the agglomeration's workgroups hold a whole CU's LDS each, and a 64 KB tile waited up to 32 ms for a CU without
+// one; a cell's entries are re-scanned per tile (five tiles at 20 000 genes: from the L2).  Entries need not be sorted.  Out-of-range row
+// indices are counted, never written.
+constexpr int kExpandTileBytes = 16 * 1024;
 template <typename It, typename Vt, typename Dt>
 __global__ __launch_bounds__(256) void csc_expand_rows_kernel(const long long *__restrict__ colptr, const It *__restrict__ rowidx, const Vt *__restrict__ val,
                                                              long long e_base, long long ncell, int m, Dt *__restrict__ dX, long long ld, int *__restrict__ bad) {
@@ -191,7 +194,7 @@ void launch_csc_expand(const long long *d_colptr, const It *d_idx, const Vt *d_v
     Ctx &cx = ctx();
     auto kern = csc_expand_rows_kernel<It, Vt, Dt>;
     SHARP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kExpandTileBytes));
-    const int blocks = static_cast<int>(std::min<long long>(ncell, static_cast<long long>(cx.num_cu) * 2));
+    const int blocks = static_cast<int>(std::min<long long>(ncell, static_cast<long long>(cx.num_cu) * 4));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), kExpandTileBytes, s, d_colptr, d_idx, d_val, e_base, ncell, m, dX, ld, d_bad);
     launch_check("csc_expand_rows_kernel");
 }
