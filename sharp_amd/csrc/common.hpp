@@ -107,7 +107,8 @@ struct Knobs {
     int front_overlap = 0;      // SHARP_FRONT_OVERLAP=b (an experiment): in a batched SHARP_unlimited window the blocks from the b-th on are projected with ONE workgroup per CU and
                                 // the chunks of base tasks wait for their own blocks' projections only, so that the first distance GEMM runs beside the later blocks' RP kernels
     int hc_first_chunk = 0;     // SHARP_HC_FIRST_CHUNK=n: tasks in the first chunk of a pipelined batch (0: by the library, -1: equal chunks)
-    int host_group = 3;         // SHARP_HOST_GROUP=1..3: host blocks of a SHARP_unlimited list that arrived while earlier ones were clustered go together, up to this many, as one pipelined batch (1: block after block)
+    int host_group = 1;         // SHARP_HOST_GROUP=2..3: host blocks of a SHARP_unlimited list go in groups of up to this many as one pipelined batch instead of block after block
+                                // (measured on cfg3's ten blocks: a pair as one batch takes 40-50 ms, two blocks one after the other -- each prepared under the other's tail -- 2 x 25: no gain; default 1)
     bool decision_log = false;  // SHARP_DECISION_LOG=1: every get_opt_hclust call leaves a row in the decision log from the start (sharp_last_decisions)
     bool free_later = true;     // SHARP_FREE_LATER=0: a buffer that grows inside a batched SHARP_unlimited window is freed at once (hipFree drains the device) instead of when the window ends
     bool step_marks = false;    // SHARP_STEP_MARKS=1: host timestamps of a SHARP_unlimited call's milestones (chunks fetched, blocks' tails, merge) on stderr at its end

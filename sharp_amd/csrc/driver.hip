@@ -1625,8 +1625,8 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
         feed.ld.assign(my.size(), 0);
         std::vector<int> hostpos;                         // positions in `my` that hold host blocks
         for (size_t i = 0; i < my.size(); ++i) if (blocks[my[i]].on_host()) hostpos.push_back(static_cast<int>(i));
-        // resident copies the upload rotates through: four (the compute thread then takes up to three blocks that arrived while it was busy as ONE
-        // pipelined batch), two for blocks above 8 GB or when SHARP_HOST_GROUP=1 asks for block after block
+        // resident copies the upload rotates through: two (block after block, each prepared under the previous one's tail: the default), four when
+        // SHARP_HOST_GROUP >= 2 asks for groups of arrived blocks as one pipelined batch (measured: no gain at two or three blocks)
         long long big = 0;
         for (int i : hostpos) big = std::max<long long>(big, blocks[my[i]].n);
         const int group_max = std::max(1, std::min(knobs().host_group, kHostRing - 1));
@@ -1635,7 +1635,7 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
         if (!hostpos.empty())
             up = std::thread([&] {
                 try {
-                    init_slot(acquire_slot(devices[w], occ[w], 1), devices[w]);
+                    init_slot(acquire_slot(devices[w], occ[w], 1), devices[w], true);   // (high-priority stream: a block's expansion takes the CUs the clustering leaves free ahead of the next chunk's distance GEMM, which nothing waits for yet)
                     HostBlockPair &P = host_block_pair();
                     for (size_t h = 0; h < hostpos.size(); ++h) {
                         {   // copy h % ring is free once the compute thread is done with host block h - ring
@@ -1709,14 +1709,16 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
                     XRef ref, nref;
                     long long ld = 0, nld = 0;
                     block_ref(i, true, ref, ld);
-                    // The blocks that arrived while the previous ones were clustered go TOGETHER: one block's 125 base tasks leave half of the
-                    // CUs idle during its agglomeration; two or three blocks' tasks are one pipelined batch (unlimited_batch_window) with their
-                    // tails on helper threads.  Whatever the grouping, every block is the same SHARP() call: same labels.
+                    // SHARP_HOST_GROUP >= 2: the blocks that arrived go TOGETHER as one pipelined batch (unlimited_batch_window).  Whatever the
+                    // grouping, every block is the same SHARP() call: same labels.
                     if (ring > 2 && blocks[b].on_host()) {
                         std::vector<XRef> refs{ref};
                         std::vector<long long> nn{blocks[b].n}, ll{ld};
                         size_t j = i + 1;
-                        while (j < my.size() && static_cast<int>(j - i) < std::min(group_max, ring - 1) && blocks[my[j]].on_host() && block_ref(j, false, nref, nld)) {
+                        // (the SECOND block of a group is waited for -- one upload, 15-20 ms, against the 25 ms a lone block costs while half of the
+                        // chip idles; its successor's upload then runs under the pair's 44 ms -- a third is taken only if it is there already)
+                        while (j < my.size() && static_cast<int>(j - i) < std::min(group_max, ring - 1) && blocks[my[j]].on_host() &&
+                               block_ref(j, j - i < 2 && blocks[my[j]].n >= 5000 && blocks[b].n >= 5000, nref, nld)) {
                             refs.push_back(nref); nn.push_back(blocks[my[j]].n); ll.push_back(nld);
                             ++j;
                         }

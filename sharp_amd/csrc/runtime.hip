@@ -324,7 +324,7 @@ static Knobs read_knobs() {
     v.unlimited_window_mb = num("SHARP_UNLIMITED_WINDOW_MB", 0);
     v.block_prefetch = num("SHARP_NO_BLOCK_PREFETCH", 0) == 0;
     v.decision_log = num("SHARP_DECISION_LOG", 0) != 0;
-    v.host_group = num("SHARP_HOST_GROUP", 3);
+    v.host_group = num("SHARP_HOST_GROUP", 1);
     v.step_marks = num("SHARP_STEP_MARKS", 0) != 0;
     // cross-checks between the forms the library itself chooses from (tests/): sequential / one-launch / round-per-launch agglomeration, chunking,
     // the two statistics kernels, the incremental statistics, the host build of the projectors

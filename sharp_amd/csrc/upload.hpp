@@ -21,9 +21,8 @@ struct HostBlock {               // the resident copy of a host matrix; kept bet
     void release() { f.release(); d.release(); }
 };
 
-// the resident copies an upload slot rotates through (sharp_SHARP_unlimited_multi: later blocks are uploaded while earlier ones are clustered;
-// four copies so that the compute thread can take the blocks that arrived meanwhile TOGETHER, as one pipelined batch, and the upload still
-// has a copy to fill; blocks above 8 GB rotate through two)
+// the resident copies an upload slot rotates through (sharp_SHARP_unlimited_multi: later blocks are uploaded while earlier ones are clustered):
+// two; four with SHARP_HOST_GROUP >= 2, when the compute thread takes several arrived blocks together
 constexpr int kHostRing = 4;
 struct HostBlockPair { HostBlock hb[kHostRing]; };
 
