@@ -370,8 +370,8 @@ def test_unlimited_merge_beyond_7168_rows(env, oracle):
     M = cen[rng.integers(0, G, nC)] + 0.3 * rng.standard_normal((nC, p))
     Cn = rng.integers(5, 200, nC).astype(np.int64)          # < 1e6 cells in all: the k range stays 10 .. 40
     ncells = int(Cn.sum())
-    fid, nf = dev.unlimited_merge(M, Cn, ncells)
-    ref = oracle.unlimited_merge(M, Cn, ncells)
+    fid, nf = dev.unlimited_merge(M, Cn, ncells, maxN_cluster=16)          # k = 10 .. 16 (seven levels: the oracle's cost is per level)
+    ref = oracle.unlimited_merge(M, Cn, ncells, maxN=16)
     assert nf == ref["n_final"] and np.array_equal(fid, ref["final_id"])
 
 

@@ -33,7 +33,10 @@ def _compare(res, ref, n, label_exact=True):
         assert np.array_equal(res["f"], ref["f"])
 
 
-@pytest.mark.parametrize("m,n,G,nm", [(2000, 300, 6, 200), (3000, 97, 3, 500), (6000, 700, 8, 500)])
+@pytest.mark.parametrize("m,n,G,nm", [(2000, 300, 6, 200), (3000, 97, 3, 500), (6000, 700, 8, 500),
+                                      (2000, 41, 2, 300),      # n - 1 = maxN.cluster: the last level is all but one singleton
+                                      (1500, 1025, 12, 100),   # one observation beyond 1024
+                                      (4000, 513, 5, 40)])     # weak structure: the CH / height rules decide
 def test_get_opt_hclust_features_matches_oracle(sa, oracle, m, n, G, nm):
     E = _projected(oracle, m, n, G, nm)
     ref = oracle.get_opt_hclust(E)

@@ -29,7 +29,10 @@ def _noisy_ensemble(rng, N, C, G, flip):
     return base, np.stack(cols, 1)
 
 
-@pytest.mark.parametrize("N,C,G,flip", [(400, 5, 6, 0.05), (1200, 15, 9, 0.15), (300, 3, 4, 0.0)])
+@pytest.mark.parametrize("N,C,G,flip", [(400, 5, 6, 0.05), (1200, 15, 9, 0.15), (300, 3, 4, 0.0),
+                                        (2000, 5, 12, 0.02),    # a cfg3 fold: 2000 cells, K = 5, nearly consistent labelings (the saturating case)
+                                        (2000, 15, 12, 0.3),    # a cfg2 fold with noisy labelings
+                                        (97, 2, 3, 0.1)])       # two labelings only
 def test_wmetac_stages_match_oracle(sa, oracle, N, C, G, flip):
     rng = np.random.default_rng(N + C)
     base, nC = _noisy_ensemble(rng, N, C, G, flip)
@@ -306,7 +309,7 @@ def test_reference_error_behaviour(sa, oracle):
         sa.SHARP_unlimited("nope")
 
 
-@pytest.mark.parametrize("trial", range(6))
+@pytest.mark.parametrize("trial", range(8))
 def test_randomised_sharp_parity(sa, oracle, trial):
     """Randomised end-to-end sweep (tools/parity_sweep.py in miniature): random data seed, size class (SHARP_small,
     SHARP_large, SHARP_large + small-cluster merge), ensemble size, linkage and projector seed; labels bit-identical."""

@@ -45,7 +45,12 @@ def test_projector_device_build_equals_host_build(sa, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("m,n,K,logflag", [(1500, 96, 3, True), (1500, 96, 3, False), (2003, 130, 1, True),
-                                            (6000, 70, 15, True), (4097, 33, 5, True)])
+                                            (6000, 70, 15, True), (4097, 33, 5, True),
+                                            (17, 40, 2, True),         # the smallest block the sparse kernels take (m <= 16: the dense form)
+                                            (1024, 64, 5, False),      # exactly one unit of genes, raw values
+                                            (20000, 66, 5, True),      # cfg3's gene count: twenty units, the last one ragged
+                                            (27000, 48, 5, True),      # cfg4's gene count
+                                            (3001, 257, 7, True)])     # odd gene count, more cells than one pass of the grid
 def test_rp_matmul_matches_oracle(sa, oracle, m, n, K, logflag):
     X = oracle.synth_fill(SEED, m, 0, n, 4, max(1, m // 8))
     p = int(np.ceil(np.log2(max(n, 2)) / 0.04))

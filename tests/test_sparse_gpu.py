@@ -140,13 +140,13 @@ def test_host_blocks_taken_in_groups_equal_block_after_block(sa, oracle, monkeyp
     """SHARP_unlimited on a list of host blocks (R/SHARP_unlimited.R:125-143): the blocks cross PCIe into a ring of resident copies and the
     compute thread takes those that arrived meanwhile TOGETHER as one pipelined batch (SHARP_HOST_GROUP, default 3); block after block
     (SHARP_HOST_GROUP=1) is the same call: labels and E1 rows identical, both equal to the oracle; dense and sparse lists alike."""
-    sizes = [5200, 5100, 640, 5300, 5050, 5400, 5150]
+    sizes = [5200, 5100, 640, 5300, 5050]
     c0, blocks = 0, []
     for nb in sizes:
         blocks.append(oracle.synth_fill(77, 1400, c0, nb, 5, 140)); c0 += nb
     ref = oracle.SHARP_unlimited(blocks, K=3, rN_seed=2103, nthreads=8, want_view=True)
     out = {}
-    for group in ("3", "2", "1"):
+    for group in ("3", "1"):
         monkeypatch.setenv("SHARP_HOST_GROUP", group)
         for name, lst in (("dense", blocks), ("sparse", [sp.csc_matrix(b) for b in blocks])):
             res = sa.SHARP_unlimited(lst, ensize_K=3, rN_seed=2103)
