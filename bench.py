@@ -782,6 +782,13 @@ def cfg5_streamed(Bn, nfiles=20, ndense=3):
             res = sa.SHARP_unlimited3(nd, rN_seed=RN_SEED, viewflag=False)
             ts.append(time.perf_counter() - t0)
         t = min(ts[1:])
+        t1s = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            res1 = sa.SHARP_unlimited3(nd, rN_seed=RN_SEED, viewflag=False, group=1)
+            t1s.append(time.perf_counter() - t0)
+        out["packed_files_block_after_block"] = {"seconds_per_call": round(min(t1s), 3), "blocks_per_s": round(nfiles / min(t1s), 1),
+                                                 "labels_equal_grouped_run": bool(np.array_equal(res1["pred_clusters"], res["pred_clusters"]))}
         out["packed_files"] = {"files": nfiles, "file_gb": round(total / 1e9, 2), "seconds_per_call": round(t, 3), "calls_s": [round(v, 3) for v in ts], "steps": 2, "warmup": 1,
                                "blocks_per_s": round(nfiles / t, 1), "cells_per_s": round(nfiles * nb / t, 1), "file_gbps_of_the_call": round(total / 1e9 / t, 2),
                                "read_seconds": round(res["read_seconds"], 3), "consumer_wait_seconds": round(res["wait_seconds"], 3),

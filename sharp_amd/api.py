@@ -591,7 +591,7 @@ def SHARP_unlimited2(scExp, ensize_K=None, reduced_ndim=None, partition_ncells=N
 
 
 def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed=None, N_cluster=None, minN_cluster=None,
-                     maxN_cluster=None, logflag=False, testlog_cells=None):
+                     maxN_cluster=None, logflag=False, testlog_cells=None, group=3):
     """R/SHARP_unlimited3.R:29-235: SHARP_unlimited over a DIRECTORY of partitions.
 
     ndinfo: dict(dir=..., ncells=..., ngenes=...) like the reference's list; the partitions are block files written by
@@ -599,7 +599,8 @@ def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed
     non-zero for counts), taken in the order of the first number in their path (:59-61) and streamed disk -> pinned memory -> HBM
     through a ring of buffers ahead of the clustering, which takes the blocks that have arrived together.
     logflag: False = log2 always on, as SHARP_unlimited passes it; True = leave it to testlog() per block, which is
-    what unlimited3's SHARP() call does (:122; unseeded sample -> not reproducible unless testlog_cells is given)."""
+    what unlimited3's SHARP() call does (:122; unseeded sample -> not reproducible unless testlog_cells is given).
+    group (no reference counterpart): how many ARRIVED blocks the clustering takes together as one pipelined batch (1: block after block)."""
     import time as _t
 
     import torch
@@ -632,7 +633,7 @@ def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed
         stream = _blocks.BlockStreamer(files)
         # The blocks that have arrived when the clustering asks for more go TOGETHER (up to three: one pipelined batch of base-clustering tasks,
         # sharp_unlimited_blocks_dev) -- unless their E1 rows are wanted or testlog has to look at each block, which the per-block entry serves.
-        for grp in stream.groups(1 if (viewflag or logflag) else 3):
+        for grp in stream.groups(1 if (viewflag or logflag) else group):
             for i, hdr, dX in grp:
                 if hdr["genes"] != ngenes:
                     raise SharpError("%s has %d genes, ndinfo$ngenes is %d" % (files[i], hdr["genes"], ngenes))
