@@ -591,7 +591,7 @@ def SHARP_unlimited2(scExp, ensize_K=None, reduced_ndim=None, partition_ncells=N
 
 
 def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed=None, N_cluster=None, minN_cluster=None,
-                     maxN_cluster=None, logflag=False, testlog_cells=None, group=3):
+                     maxN_cluster=None, logflag=False, testlog_cells=None, group=6):
     """R/SHARP_unlimited3.R:29-235: SHARP_unlimited over a DIRECTORY of partitions.
 
     ndinfo: dict(dir=..., ncells=..., ngenes=...) like the reference's list; the partitions are block files written by
@@ -631,7 +631,7 @@ def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed
     stream = None
     try:
         stream = _blocks.BlockStreamer(files)
-        # The blocks that have arrived when the clustering asks for more go TOGETHER (up to three: one pipelined batch of base-clustering tasks,
+        # The blocks that have arrived when the clustering asks for more go TOGETHER (up to `group`: one pipelined batch of base-clustering tasks,
         # sharp_unlimited_blocks_dev) -- unless their E1 rows are wanted or testlog has to look at each block, which the per-block entry serves.
         for grp in stream.groups(1 if (viewflag or logflag) else group):
             for i, hdr, dX in grp:

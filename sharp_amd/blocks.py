@@ -162,7 +162,7 @@ class BlockStreamer:
     the copy's event only; a packed block is expanded into its dense block on the library's stream (sharp_csc_packed_expand_dev) when the
     consumer takes it.  `for i, hdr, dX in streamer` yields one block at a time; `streamer.groups(g)` yields lists of up to g blocks: those
     that have ARRIVED when the consumer asks (at least one: it waits for the first).  A block's buffers are reused once the consumer has
-    asked for what comes after it.  Ring: four buffers (files up to 1 GB), two for larger files."""
+    asked for what comes after it.  Ring: eight buffers (files up to 1 GB), two for larger files."""
 
     def __init__(self, files, device="cuda", read_threads=8, ring=None):
         import torch
@@ -171,7 +171,7 @@ class BlockStreamer:
         self.files = list(files)
         self.hdrs = [read_header(f) for f in self.files]
         pay = max((h["payload"] for h in self.hdrs), default=0)
-        self.ring = int(ring) if ring else (4 if pay <= (1 << 30) else 2)
+        self.ring = int(ring) if ring else (8 if pay <= (1 << 30) else 2)
         dense_bytes = max((h["cells"] * h["ld"] * (8 if h["f64"] else 4) for h in self.hdrs), default=0)
         any_packed = any(h["version"] == 2 for h in self.hdrs)
         self.pinned = [torch.empty(max(pay, 16), dtype=torch.uint8).pin_memory() for _ in range(self.ring)]
