@@ -260,3 +260,20 @@ sMetaC <- function(rerowColor, sE1, folds, hmethod, finalN.cluster, minN.cluster
     r$view.dim <- kdim                                                        # > 0: r$viE IS enresults$viE (ncells x 50); 0: r$viE is E1
     r                                                                         # finalrowColor = r$pred (ids by decreasing size)
 }
+
+# ---- the decision log (include/sharp_hip.h: sharp_decision_log / sharp_last_decisions; SURVEY.md 7, App. D.2) -------------------------
+# sharp_decision_log(TRUE); res <- SHARP(...); d <- sharp_last_decisions(); sharp_decision_log(FALSE)
+# One row per get_opt_hclust call of the run: which rule of R/get_opt_hclust.R:162-229 chose the number of clusters, how many levels tied
+# exactly at the maximum (the reference takes the middle one), the maximum and the runner-up.  To attribute a label difference between this
+# library and the reference to ONE decision, print the same quantities from the reference's own get_opt_hclust and compare row by row.
+sharp_decision_log <- function(enable = TRUE) invisible(.sharp_check(.C("sharp_C_decision_log", as.integer(enable), status = integer(1))$status))
+sharp_last_decisions <- function(cap = 65536L) {
+    r <- .C("sharp_C_last_decisions", rows = double(14L * cap), as.integer(cap), n = integer(1), status = integer(1))
+    .sharp_check(r$status)
+    d <- as.data.frame(t(matrix(r$rows[seq_len(14L * min(r$n, cap))], nrow = 14L)))
+    names(d) <- c("level", "block", "k", "fold", "n", "branch", "chosen.k", "ties", "best", "runner.up", "sil.minus.thre", "height.ratio",
+                  "smetac.override.k", "levels")
+    d$level <- c("direct", "base", "wMetaC", "sMetaC", "merge")[d$level + 2L]
+    d$branch <- c("silhouette", "CH", "height", "N.cluster")[d$branch + 1L]
+    d
+}
