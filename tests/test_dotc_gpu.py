@@ -181,3 +181,35 @@ def test_dotc_unlimited_and_merge(lib, oracle):
     dotc(lib, "sharp_C_unlimited_merge", np.ascontiguousarray(M), cnt, I(60), I(16), D(cnt.sum()), I(0), I(0), I(0), fid, nf, st)
     refm = oracle.unlimited_merge(M, cnt.astype(np.int64), int(cnt.sum()))
     assert st[0] in (0, 16) and nf[0] == refm["n_final"] and np.array_equal(fid, refm["final_id"])
+
+
+def test_dotc_decision_log(lib, oracle):
+    """sharp_C_decision_log / sharp_C_last_decisions as r/sharp_hip.R calls them (sharp_decision_log(), sharp_last_decisions()): the rows of a
+    SHARP_small call against the oracle's log."""
+    m, n, K = 1500, 400, 3
+    X = oracle.synth_fill(SEED, m, 0, n, 4, 200)
+    p = int(np.ceil(np.log2(n) / 0.04))
+    pred, viE, x0 = np.zeros(n, np.int32), np.zeros(n * p), np.zeros(n * 42)
+    info, st = np.zeros(5, np.int32), I(-1)
+    dotc(lib, "sharp_C_decision_log", I(1), st)
+    assert st[0] == 0
+    dotc(lib, "sharp_C_SHARP", X, I(m), D(n), I(K), I(0), I(0), I(0), I(1), I(0), I(0), I(0), I(0), I(0), D(-1.0), D(0.0), I(0), I(1),
+         I(0), D(2103.0), pred, viE, x0, I(42), info, I(3), st)
+    assert st[0] in (0, 16, 32, 48), last_error(lib)
+    rows, cnt = np.zeros(14 * 64), I(0)
+    dotc(lib, "sharp_C_last_decisions", rows, I(64), cnt, st)
+    assert st[0] == 0 and cnt[0] == K + 1
+    got = rows[: 14 * cnt[0]].reshape(-1, 14)
+    dotc(lib, "sharp_C_decision_log", I(0), st)
+    dotc(lib, "sharp_C_last_decisions", rows, I(64), cnt, st)
+    assert cnt[0] == 0
+    oracle.decision_log(True)
+    try:
+        ref = oracle.SHARP(X, K=K, rN_seed=2103)
+        want = oracle.last_decisions()
+    finally:
+        oracle.decision_log(False)
+    assert np.array_equal(pred, ref["pred_clusters"])
+    exact = [0, 1, 2, 3, 4, 5, 6, 7, 12, 13]
+    assert got.shape == want.shape and np.array_equal(got[:, exact], want[:, exact])
+    np.testing.assert_allclose(got[:, 8], want[:, 8], rtol=1e-8, atol=1e-10)
