@@ -26,17 +26,17 @@ def _blocks(oracle, sizes, m=2500, G=6, nm=250):
     return out
 
 
-@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
-def test_unlimited_on_several_slots_equals_one_device_and_the_oracle(sa, oracle, devices):
+def test_unlimited_on_several_slots_equals_one_device_and_the_oracle(sa, oracle):
     blocks = _blocks(oracle, [5200, 5600, 5100, 5300, 5050])          # SHARP_large blocks (>= 5000 cells), ragged
     ref = oracle.SHARP_unlimited(blocks, K=3, rN_seed=2103, nthreads=8, want_view=True)
     one = sa.SHARP_unlimited(blocks, ensize_K=3, rN_seed=2103, viewflag=True)
-    multi = sa.SHARP_unlimited(blocks, ensize_K=3, rN_seed=2103, viewflag=True, devices=devices)
     assert np.array_equal(one["pred_clusters"], ref["pred_clusters"])
-    assert np.array_equal(multi["pred_clusters"], one["pred_clusters"])
-    assert multi["N.pred_clusters"] == one["N.pred_clusters"]
-    np.testing.assert_array_equal(multi["viE"], one["viE"])            # same kernels, same order: bit for bit
-    np.testing.assert_allclose(multi["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
+    np.testing.assert_allclose(one["viE"], ref["viE"], rtol=0, atol=2e-12 * np.abs(ref["viE"]).max())
+    for devices in ([0, 0], [0, 0, 0]):                               # two and three logical devices on the one GPU
+        multi = sa.SHARP_unlimited(blocks, ensize_K=3, rN_seed=2103, viewflag=True, devices=devices)
+        assert np.array_equal(multi["pred_clusters"], one["pred_clusters"])
+        assert multi["N.pred_clusters"] == one["N.pred_clusters"]
+        np.testing.assert_array_equal(multi["viE"], one["viE"])        # same kernels, same order: bit for bit
 
 
 def test_unlimited_multi_through_the_dotC_convention_and_the_environment(sa, oracle, monkeypatch):
