@@ -17,7 +17,10 @@ def sa():
     return sharp_amd
 
 
-@pytest.mark.parametrize("m,p,seed", [(500, 40, 2154), (4000, 246, 2155), (20000, 391, 2168)])
+@pytest.mark.parametrize("m,p,seed", [(500, 40, 2154), (4000, 246, 2155), (20000, 391, 2168),
+                                      (20000, 474, 2158),      # cfg3's projectors (50 + 2103 + 5)
+                                      (27000, 508, 2154),      # cfg4's
+                                      (20000, 582, 2156)])     # cfg5's
 def test_projector_matches_r_stream(sa, oracle, m, p, seed):
     pr = sa.ranM2(m, p, seed)
     g, c, s = pr.triplets(0)
