@@ -55,11 +55,11 @@ def timeline(tag):
 
 ref = None
 for name, blocks, devices, group in (("resident (sharp_SHARP_unlimited_multi_dev, 1 slot)", None, [0], None),
-                                     ("sparse host, blocks taken in groups of up to 3 (default)", sparse, None, None),
-                                     ("sparse host, block after block (SHARP_HOST_GROUP=1)", sparse, None, "1"),
-                                     ("sparse host, groups of up to 2", sparse, None, "2"),
-                                     ("dense host, groups of up to 3 (default)", dense, None, None),
-                                     ("dense host, block after block (SHARP_HOST_GROUP=1)", dense, None, "1"),
+                                     ("sparse host, block after block (the default)", sparse, None, None),
+                                     ("sparse host, groups of up to 3 (SHARP_HOST_GROUP=3)", sparse, None, "3"),
+                                     ("sparse host, groups of up to 2 (SHARP_HOST_GROUP=2)", sparse, None, "2"),
+                                     ("dense host, block after block (the default)", dense, None, None),
+                                     ("dense host, groups of up to 3 (SHARP_HOST_GROUP=3)", dense, None, "3"),
                                      ("sparse host, 2 slots on GPU 0", sparse, [0, 0], None)):
     if group is None:
         os.environ.pop("SHARP_HOST_GROUP", None)
