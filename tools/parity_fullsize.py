@@ -8,11 +8,12 @@
               R/get_opt_hclust.R:194-210) through sharp_SHARP_dev, vs oracle.SHARP
   cfg3_block_ch  one cfg3 block (50 000 x 20 000, K = 5, p = 474) of the CH-decided data set
   cfg3_block  the same block of the bench's own data set (1 000 marker genes: the silhouette rule decides)
+  cfg2        BASELINE.json configs[1] whole on the bench's data set: 50 000 x 20 000, K = 15 (what tests/test_configs_gpu.py::test_cfg2_full_size_matches_oracle runs)
 
 Every mode also compares the two decision logs (sharp_last_decisions against the oracle's) decision for decision and
 prints the smallest margins per level.
 
-usage: python tools/parity_fullsize.py cfg4_share|cfg2_ch|cfg3_block_ch|cfg3_block [threads]      (prints a report; kept as profiles/r0N_*_parity.txt)"""
+usage: python tools/parity_fullsize.py cfg4_share|cfg2|cfg2_ch|cfg3_block_ch|cfg3_block [threads]      (prints a report; kept as profiles/r0N_*_parity.txt)"""
 import os
 import sys
 import time
@@ -33,7 +34,7 @@ threads = int(sys.argv[2]) if len(sys.argv) > 2 else min(len(os.sched_getaffinit
 sharp_amd.init(0)
 orc.build()
 n, m, K, p, nmark = {"cfg4_share": (162500, 27000, 5, 508, 1000), "cfg2_ch": (50000, 20000, 15, 0, 400),
-                     "cfg3_block_ch": (50000, 20000, 5, 474, 400), "cfg3_block": (50000, 20000, 5, 474, 1000)}[what]
+                     "cfg3_block_ch": (50000, 20000, 5, 474, 400), "cfg3_block": (50000, 20000, 5, 474, 1000), "cfg2": (50000, 20000, 15, 0, 1000)}[what]
 dX = torch.empty((n, m), dtype=torch.float32, device="cuda")
 dev.synth_fill(dX, SEED, 0, 12, nmark)
 truth = dev.synth_labels(SEED, 0, n, 12)
