@@ -629,6 +629,7 @@ def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed
     proj = Projector(ngenes, p, [0.5 if rN_seed == 0.5 else 50 + rN_seed + k for k in range(1, K + 1)])   # :84-90
     preds, means, counts, views, nnc = [], [], [], [], []
     stream = None
+    t_cluster = 0.0
     try:
         stream = _blocks.BlockStreamer(files)
         # The blocks that have arrived when the clustering asks for more go TOGETHER (up to `group`: one pipelined batch of base-clustering tasks,
@@ -637,9 +638,11 @@ def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed
             for i, hdr, dX in grp:
                 if hdr["genes"] != ngenes:
                     raise SharpError("%s has %d genes, ndinfo$ngenes is %d" % (files[i], hdr["genes"], ngenes))
+            t_c0 = _t.perf_counter()
             if len(grp) >= 2:
                 for (i, hdr, dX), (pr, mn, cn) in zip(grp, _device.unlimited_blocks_dev([g[2] for g in grp], p, proj.handle, K, rN_seed)):
                     preds.append(pr); means.append(mn); counts.append(cn); views.append(None); nnc.append(hdr["cells"])
+                t_cluster += _t.perf_counter() - t_c0
                 continue
             i, hdr, dX = grp[0]
             nb = hdr["cells"]
@@ -652,6 +655,7 @@ def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed
             vi = np.zeros((nb, p)) if viewflag else None
             pr, mn, cn = _device.unlimited_block_dev(dX, p, proj.handle, K, rN_seed, flag=flag, viE=vi)
             preds.append(pr); means.append(mn); counts.append(cn); views.append(vi); nnc.append(nb)
+            t_cluster += _t.perf_counter() - t_c0
     finally:
         proj.close()
         if stream is not None:
@@ -669,6 +673,8 @@ def SHARP_unlimited3(ndinfo, viewflag=True, n_cores=None, ensize_K=None, rN_seed
     out["bytes_streamed"] = stream.bytes_streamed
     out["read_seconds"] = stream.read_seconds              # the reader thread's file reads (wall), hidden under the clustering except for ...
     out["wait_seconds"] = stream.wait_seconds              # ... what the clustering waited for blocks that had not arrived
+    out["expand_seconds"] = stream.expand_seconds          # packed blocks -> dense blocks on the device (before their clustering)
+    out["cluster_seconds"] = t_cluster                     # the per-block / per-group library calls
     return out
 
 

@@ -183,6 +183,7 @@ class BlockStreamer:
         self.read_threads = int(read_threads)
         self.read_seconds = 0.0                       # wall time the reader thread spent reading files (hidden under the clustering or not)
         self.wait_seconds = 0.0                       # wall time the CONSUMER waited for a block that had not arrived
+        self.expand_seconds = 0.0                     # wall time the consumer spent turning packed blocks into dense ones (its own stream, before the clustering)
         self._mu = threading.Condition()
         self._ready = 0                               # files [0, _ready) are on their way to the device (event recorded)
         self._consumed = 0                            # blocks [0, _consumed) are finished with
@@ -271,9 +272,12 @@ class BlockStreamer:
         """block i as a device tensor (its copy has been enqueued); a packed block is expanded now, on the library's stream"""
         from ._lib import check, lib
 
+        import time
+
         torch = self.torch
         h = self.hdrs[i]
         slot = i % self.ring
+        t_ex = time.perf_counter()
         self.events[i].synchronize()
         dt = torch.float64 if h["f64"] else torch.float32
         n, ld, m = h["cells"], h["ld"], h["genes"]
@@ -282,6 +286,7 @@ class BlockStreamer:
             base = self.stage[slot].data_ptr()
             check(lib().sharp_csc_packed_expand_dev(C.c_void_p(base), C.c_void_p(base + h["o_idx"]), h["idx_bits"], C.c_void_p(base + h["o_val"]),
                                                     h["val_bits"], m, C.c_longlong(n), C.c_void_p(dX.data_ptr()), C.c_longlong(ld), int(h["f64"])))
+        self.expand_seconds += time.perf_counter() - t_ex
         return dX[:, :m]
 
     def groups(self, max_group=3):

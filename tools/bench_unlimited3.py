@@ -43,9 +43,9 @@ try:
         dt = time.perf_counter() - t0
         ref = res["pred_clusters"] if ref is None else ref
         print("%-44s %d cells in %.3f s = %.0f cells/s = %.1f blocks/s; files %.2f GB/s; reader %.2f s of reads, the clustering waited %.3f s for blocks (%.0f %% of the "
-              "reading hidden); p = %d, %d clusters, ARI vs planted truth %.4f; labels equal to the first run: %s"
+              "reading hidden), expansion %.2f s, clustering calls %.2f s; p = %d, %d clusters, ARI vs planted truth %.4f; labels equal to the first run: %s"
               % (name, nblk * nb, dt, nblk * nb / dt, nblk / dt, total / 1e9 / dt, res["read_seconds"], res["wait_seconds"],
-                 100.0 * (1.0 - res["wait_seconds"] / max(res["read_seconds"], 1e-9)), res["reduced.dim"], res["N.pred_clusters"],
+                 100.0 * (1.0 - res["wait_seconds"] / max(res["read_seconds"], 1e-9)), res["expand_seconds"], res["cluster_seconds"], res["reduced.dim"], res["N.pred_clusters"],
                  float(sharp_amd.ARI(np.concatenate(truth), res["pred_clusters"])["HA"]), bool(np.array_equal(ref, res["pred_clusters"]))), flush=True)
 finally:
     shutil.rmtree(d, ignore_errors=True)
