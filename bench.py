@@ -792,6 +792,7 @@ def cfg5_streamed(Bn, nfiles=20, ndense=3):
         out["packed_files"] = {"files": nfiles, "file_gb": round(total / 1e9, 2), "seconds_per_call": round(t, 3), "calls_s": [round(v, 3) for v in ts], "steps": 2, "warmup": 1,
                                "blocks_per_s": round(nfiles / t, 1), "cells_per_s": round(nfiles * nb / t, 1), "file_gbps_of_the_call": round(total / 1e9 / t, 2),
                                "read_seconds": round(res["read_seconds"], 3), "consumer_wait_seconds": round(res["wait_seconds"], 3),
+                               "expand_seconds": round(res["expand_seconds"], 3), "clustering_calls_seconds": round(res["cluster_seconds"], 3),
                                "read_hidden_fraction": round(1.0 - res["wait_seconds"] / max(res["read_seconds"], 1e-9), 3),
                                "clusters_found": int(res["N.pred_clusters"]),
                                "ari_vs_planted_truth": round(float(Bn.ARI(np.concatenate(truth), res["pred_clusters"])["HA"]), 4)}
