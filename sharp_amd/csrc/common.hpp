@@ -100,6 +100,7 @@ struct Knobs {
     int gemm_slice = 8;         // SHARP_GEMM_SLICE: workgroups per CU per slice of a distance GEMM prepared under another block's tail
     bool proj_host = false;     // SHARP_PROJ_HOST=1 (cross-check): the host build of the projectors
     int hc_front = 0;           // SHARP_HC_FRONT=c: the first c agglomeration rounds without rewriting the matrix (hclust_front.inc; an experiment)
+    bool hc_nn_gemm = true;     // SHARP_HC_NN_GEMM=0: the agglomeration's first round scans the distance matrix instead of reading the GEMM's per-tile partials
     bool hc_half = false;       // SHARP_HC_HALF=1: the eight-wave agglomeration kernel (half a CU per task) also when there is at most one task per CU
     int host_threads = 0;       // SHARP_HOST_THREADS: cap on the host cores this process sizes its pools from (0: its affinity mask); host_cores()
     int upload_threads = 0;     // SHARP_UPLOAD_THREADS: host threads narrowing / copying an uploaded block (0: up to 32)

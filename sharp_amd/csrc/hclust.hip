@@ -29,6 +29,7 @@ struct HcMeta {
     long long oH, oT, oG;     // n * kpad doubles each
     long long oCSt, oQ;       // p * kpad, kpad * kpad
     long long oOut;           // msil[nk] then CH[nk]
+    const double *nn;         // row minima per 128-column tile written by the distance GEMM ([nld / 128 slots][nld rows], at most 16 slots); nullptr: scan D
 };
 
 constexpr int HC_THREADS = 512;
@@ -278,6 +279,27 @@ __device__ __forceinline__ HrBest hr_wave(HrBest x) {
     return r;
 }
 
+// the same over the 16 lanes of a DPP row: every lane of the row ends with the row's result
+__device__ __forceinline__ HrBest hr_row16(HrBest x) {
+    x = hr_dpp_step<0xB1, 0xf>(x);
+    x = hr_dpp_step<0x4E, 0xf>(x);
+    x = hr_dpp_step<0x141, 0xf>(x);
+    x = hr_dpp_step<0x140, 0xf>(x);
+    return x;
+}
+template <int CTRL>
+__device__ __forceinline__ double hr_min_step(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    return fmin(x, __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false)));
+}
+__device__ __forceinline__ double hr_min16(double x) {
+    x = hr_min_step<0xB1>(x);
+    x = hr_min_step<0x4E>(x);
+    x = hr_min_step<0x141>(x);
+    x = hr_min_step<0x140>(x);
+    return x;
+}
+
 // HR_THREADS = 512: two tasks per CU (LDS state 37 B per observation, <= 128 VGPRs) when there are more tasks than CUs;
 // 1024: one task per CU with twice the loads in flight when there are not (a task streams ~300 MB through ONE workgroup).
 // MODE 0: the whole agglomeration in one launch, one workgroup per task.
@@ -355,7 +377,41 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     for (int i = tid; i < n; i += HR_THREADS) { cidA[i] = static_cast<uint16_t>(i); cszA[i] = 1; }
     if (tid == 0) { for (int q = 0; q < 16; ++q) ctl[q] = 0; }
     __syncthreads();
-    // round 0 nearest neighbours from the pristine matrix (squared for ward.D2)
+    // round 0 nearest neighbours.  With the row minima the distance GEMM left per 128-column tile (HcMeta::nn, already squared for ward.D2): a row's
+    // minimum is the smallest of its tiles' minima, and only the tile(s) that hold it are scanned for the lowest column and a second one (tie) --
+    // 1 KB per row instead of 16 KB.  Sixteen lanes per row, four rows per wave.
+    if (M.nn) {
+        const int slots = nld / 128;                            // <= 16 (setup_chunk)
+        const int g = lane >> 4, l = lane & 15;
+        for (int a0 = wave * 4; a0 < n; a0 += nwave * 4) {
+            const int a = a0 + g < n ? a0 + g : n - 1;          // (a group beyond the last row repeats it and stores nothing)
+            const double pm = l < slots ? M.nn[static_cast<long long>(l) * nld + a] : HC_INF;
+            const double m = hr_min16(pm);
+            unsigned cand = static_cast<unsigned>(__ballot(l < slots && pm == m) >> (16 * g)) & 0xffffu;   // this row's tiles that hold its minimum
+            const double *row = D + static_cast<long long>(a) * nld;
+            HrBest b; b.v = HC_INF; b.i = 0x7fffffff; b.tie = 0;
+            while (__any(cand != 0u)) {
+                if (cand) {
+                    const int j0 = (__ffs(cand) - 1) * 128 + l;
+                    cand &= cand - 1;
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int j = j0 + 16 * u; v[u] = row[j < n ? j : n - 1]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + 16 * u;
+                        if (j < n && j != a) {
+                            const double x = method == 8 ? v[u] * v[u] : v[u];
+                            if (x < b.v) { b.v = x; b.i = j; b.tie = 0; } else if (x == b.v) b.tie = 1;
+                        }
+                    }
+                }
+            }
+            b = hr_row16(b);
+            if (l == 0 && a0 + g < n) { nn[a] = static_cast<uint16_t>(b.i < n ? b.i : 0); dnnA[a] = b.v; tie[a] = static_cast<unsigned char>(b.tie); }
+        }
+    } else
+    // ... or from the pristine matrix (squared for ward.D2)
     for (int a = wave; a < n; a += nwave) {
         const double *row = D + static_cast<long long>(a) * nld;
         HrBest b; b.v = HC_INF; b.i = 0x7fffffff; b.tie = 0;
@@ -1542,6 +1598,7 @@ struct Workspace {
     DevBuf<double> D, D0, S0, S1, Cr, Ct, nrm, height, H, T, G, CSt, Q, out;
     DevBuf<int> ia, ib, lab, chosen, packed, status, remaining;
     DevBuf<unsigned char> img;          // LDS state images of the round-per-launch agglomeration
+    DevBuf<double> nnp;                 // per-tile row minima of the distance matrices (HcMeta::nn)
     DevBuf<unsigned char> seqstate;     // nearest-neighbour state of the sequential kernel for tasks beyond kHcLdsMaxN observations
     // many-levels statistics (ml_*_kernel)
     DevBuf<MlMeta> mlmeta;
@@ -1570,7 +1627,7 @@ static void release_workspaces_of_slot() {
         for (DevBuf<double> *b : {&W.D, &W.D0, &W.S0, &W.S1, &W.Cr, &W.Ct, &W.nrm, &W.height, &W.H, &W.T, &W.G, &W.CSt, &W.Q, &W.out,
                                   &W.mlS, &W.mlcn2m, &W.mlB, &W.mlcn2F, &W.mltot2, &W.slscale}) b->release();
         for (DevBuf<int> *b : {&W.ia, &W.ib, &W.lab, &W.chosen, &W.packed, &W.status, &W.remaining, &W.mlr1, &W.mlr2, &W.mlcntF}) b->release();
-        W.img.release(); W.seqstate.release(); W.sl.release();
+        W.img.release(); W.seqstate.release(); W.sl.release(); W.nnp.release();
     }
 }
 
@@ -1806,6 +1863,21 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
     W.H.ensure(oK); W.T.ensure(oK); W.G.ensure(oK); W.CSt.ensure(oCS); W.Q.ensure(oQ); W.out.ensure(oOut); }
     { HostTimer ht("hc_workspace_alloc");
     W.meta.ensure(T); W.prep.ensure(T); W.gemm.ensure(5 * static_cast<size_t>(T)); W.status.ensure(T); }
+    // feature tasks of at most 2048 observations: the distance GEMM also leaves every row's minimum per column tile (SHARP_HC_NN_GEMM=0: the
+    // agglomeration's first round scans D)
+    {
+        bool parts = knobs().hc_nn_gemm;
+#ifdef SHARP_LAB
+        if (knobs().dist_i8 && max_p <= 8192) parts = false;   // (the sliced-integer GEMM of the lab build writes none)
+#endif
+        long long oNN = 0;
+        if (parts) for (int t = 0; t < T; ++t) if (!metas[t].symmetric && metas[t].nld <= 2048) oNN += static_cast<long long>(metas[t].nld / 128) * metas[t].nld;
+        if (oNN > 0) {
+            W.nnp.ensure(oNN);
+            oNN = 0;
+            for (int t = 0; t < T; ++t) if (!metas[t].symmetric && metas[t].nld <= 2048) { metas[t].nn = W.nnp.p + oNN; oNN += static_cast<long long>(metas[t].nld / 128) * metas[t].nld; }
+        }
+    }
     W.meta.upload(metas.data(), T);
 
     // Every descriptor of the chunk goes up once; the device work is then enqueued per RANGE of tasks, each range on its
@@ -1852,7 +1924,8 @@ void setup_chunk(const std::vector<HcTask> &tasks, ChunkJob &J) {
                 R.any_sym |= M.symmetric != 0; R.any_feat |= M.symmetric == 0;
                 switch (kind) {
                     case 0:   // D = 1 - U U^T (feature tasks)
-                        if (!M.symmetric) g.push_back(GemmTask{W.Ct.p + M.oCt, W.Ct.p + M.oCt, W.D.p + M.oD, M.n, M.n, M.p, M.nld, M.nld, M.nld, 1, 1, 1});
+                        if (!M.symmetric) g.push_back(GemmTask{W.Ct.p + M.oCt, W.Ct.p + M.oCt, W.D.p + M.oD, M.n, M.n, M.p, M.nld, M.nld, M.nld, 1, 1, 1,
+                                                               const_cast<double *>(M.nn), M.method == 8});
                         break;
                     case 1:   // finest-level sums on the MFMA:  CSt = Cr^T H
                         g.push_back(GemmTask{W.Cr.p + M.oCr, W.H.p + M.oH, W.CSt.p + M.oCSt, M.p, M.kpad, M.n, M.p, M.kpad, M.kpad, 0, 0, 0});

@@ -113,6 +113,21 @@ __global__ __launch_bounds__(256) void gemm_tn_f64_kernel(const GemmTask *__rest
 // VGPRs); no bounds checks in the K loop, 16-byte loads, next K tile fetched into registers while the MFMAs run.
 constexpr int FT = 128, FLD = 144;   // 144 doubles per k row: two k rows of a half-wave land 32 banks apart
 
+constexpr double NN_INF = 1.0e300;   // (hclust.hip: HC_INF)
+template <int CTRL>
+__device__ __forceinline__ double min_dpp_step(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    return fmin(x, __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false)));
+}
+// minimum over the 16 lanes of a DPP row (quad swaps, then the two mirrors): every lane of the row ends with it
+__device__ __forceinline__ double min_row16(double x) {
+    x = min_dpp_step<0xB1>(x);
+    x = min_dpp_step<0x4E>(x);
+    x = min_dpp_step<0x141>(x);
+    x = min_dpp_step<0x140>(x);
+    return x;
+}
+
 // Block -> (task, tile).  Only live tiles are launched (a workgroup that exits at once still costs a full dispatch: with
 // the lower-triangle tiles of a symmetric product in the grid the kernel ran at 43 TF/s instead of 76, see
 // tools/micro/mfma_f64_loop.hip), and the linear id is dealt so that the eight tasks of a group sit on the eight XCDs
@@ -240,9 +255,63 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
                     }
                     ((gdp)t.C)[static_cast<long long>(row) * t.ldc + col] = v;
                     if (mirror) ((gdp)t.C)[static_cast<long long>(col) * t.ldc + row] = v;
+                    acc[i][j][r] = v;
                 }
             }
         }
+    if (t.nn == nullptr) return;
+    // Row minima of the tile (GemmTask::nn): every row's smallest off-diagonal entry over the tile's columns and, for the mirrored entries, every
+    // column's smallest entry over the tile's rows.  The first round of the agglomeration takes a row's nearest neighbour from the one tile that
+    // holds the row's minimum (1 KB) instead of scanning the row (16 KB): one of the ~10.7 passes over n^2 that hclust_rnn_kernel makes.  Values
+    // only -- a (value, index, tie) reduction across lanes cost the GEMM 18 % (the K loop is only 30 tiles long), this one 3 %.
+    double *rows_s = &As[0][0][0];          // [4 column blocks][128 rows]   (the k loop ended on a barrier: the tiles are free)
+    double *cols_s = rows_s + 4 * FT;       // [2 row blocks][128 columns]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double b = NN_INF;
+            const int row = m0 + wr + i * 16 + (lane >> 4) + 4 * r;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wc + j * 16 + (lane & 15);
+                if (i < ni && j < nj && row < t.M && col < t.N && row != col) {
+                    const double v = acc[i][j][r];
+                    b = fmin(b, t.nn_square ? v * v : v);
+                }
+            }
+            b = min_row16(b);
+            if ((lane & 15) == 0) rows_s[wn * FT + wr + i * 16 + (lane >> 4) + 4 * r] = b;
+        }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        double b = NN_INF;
+        const int col = n0 + wc + j * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool mirror = t.symmetric && (n0 > m0 || wn * 2 + j > wm * 4 + i);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr + i * 16 + (lane >> 4) + 4 * r;
+                if (i < ni && j < nj && mirror && row < t.M && col < t.N) {
+                    const double v = acc[i][j][r];
+                    b = fmin(b, t.nn_square ? v * v : v);
+                }
+            }
+        }
+        b = fmin(b, __shfl_xor(b, 16));
+        b = fmin(b, __shfl_xor(b, 32));
+        if (lane < 16) cols_s[wm * FT + wc + j * 16 + lane] = b;
+    }
+    __syncthreads();
+    if (tid < FT) {
+        double b = fmin(fmin(rows_s[tid], rows_s[FT + tid]), fmin(rows_s[2 * FT + tid], rows_s[3 * FT + tid]));
+        if (ti == tj) b = fmin(b, fmin(cols_s[tid], cols_s[FT + tid]));
+        if (m0 + tid < t.M) t.nn[static_cast<long long>(tj) * t.ldc + m0 + tid] = b;
+    } else if (tid < 2 * FT && ti != tj) {
+        const int cc = tid - FT;
+        if (n0 + cc < t.N) t.nn[static_cast<long long>(ti) * t.ldc + n0 + cc] = fmin(cols_s[cc], cols_s[FT + cc]);
+    }
 }
 
 void gemm_tn_f64_batched(const GemmTask *d_tasks, int count, int max_M, int max_N, const char *timer_name, bool fast, bool symmetric) {

@@ -19,6 +19,10 @@ struct GemmTask {
     int symmetric;
     int fast;   // 1: operands are zero-padded to tile multiples (K rows to a multiple of 16, M/N to 128, lda/ldb % 4 == 0): unchecked 16-byte loads,
                 //    register-prefetched K tiles
+    double *nn = nullptr;   // fast symmetric distance tasks: nn[slot * ldc + row] = the smallest off-diagonal entry of the row over column tile `slot`
+                            // (128 columns; every slot of every row is written exactly once: by the tile's row reduction or, below the diagonal,
+                            // by the mirrored tile's column reduction)
+    int nn_square = 0;      // the minima are of v * v (ward.D2 agglomerates squared distances)
 };
 
 // Launch over a device-resident array of `count` GemmTask (max_M/max_N size the grid).

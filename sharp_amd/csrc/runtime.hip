@@ -335,6 +335,7 @@ static Knobs read_knobs() {
     v.hc_chunk = num("SHARP_HC_CHUNK", 0);
     v.hc_first_chunk = num("SHARP_HC_FIRST_CHUNK", 0);
     v.hc_ranges = num("SHARP_HC_RANGES", 0);
+    v.hc_nn_gemm = num("SHARP_HC_NN_GEMM", 1) != 0;
     v.stats_lane = num("SHARP_STATS_LANE", 1) != 0;
     v.ml_min_levels = num("SHARP_ML_MIN_LEVELS", 0);
     v.proj_host = num("SHARP_PROJ_HOST", 0) == 1;

@@ -170,6 +170,40 @@ def test_bulk_synchronous_and_sequential_agglomeration_agree(sa, oracle, monkeyp
     dev.profile(False)
 
 
+@pytest.mark.parametrize("n", [5, 127, 129, 350, 2000, 2048, 2300])
+def test_first_round_neighbours_from_the_distance_gemm_equal_the_matrix_scan(sa, oracle, n, monkeypatch):
+    """The distance GEMM leaves every row's minimum per 128-column tile and the agglomeration's first round scans only the tile(s) that hold
+    a row's minimum for its nearest neighbour (lowest column, tie flag); SHARP_HC_NN_GEMM=0 scans the whole matrix.  Same merges, heights
+    and labels bit for bit, for sizes below / across / well beyond a tile, at the 16-tile limit and beyond it (2300: no minima, the scan
+    either way); duplicated observations in different tiles (exact ties) are abandoned to the sequential kernel by both."""
+    from sharp_amd import device as dev
+
+    rng = np.random.default_rng(100 + n)
+    G = max(1, min(8, n // 3))
+    E = rng.standard_normal((n, 30)) + rng.standard_normal((G, 30))[rng.integers(0, G, n)] * 2.0
+    kmax = min(10, n - 1)
+    for hm in ["ward.D2", "average", "complete"]:
+        dev.profile(True)
+        a = sa.get_opt_hclust(E, hmethod=hm, maxN_cluster=kmax)
+        counts = _hc_counts(dev)
+        monkeypatch.setenv("SHARP_HC_NN_GEMM", "0")
+        dev.profile(True)
+        b = sa.get_opt_hclust(E, hmethod=hm, maxN_cluster=kmax)
+        assert _hc_counts(dev) == counts == (1, 0)
+        monkeypatch.delenv("SHARP_HC_NN_GEMM")
+        for key in ("v", "f", "height", "msil", "CHind"):
+            assert np.array_equal(a[key], b[key]), (hm, key)
+    if n >= 300:
+        T = E.copy()
+        T[n - 40:] = T[:40]                                    # 40 duplicates, first against last tile
+        dev.profile(True)
+        a = sa.get_opt_hclust(T, maxN_cluster=kmax)
+        assert _hc_counts(dev) == (0, 1)
+        if n <= 2300:
+            assert np.array_equal(a["f"], oracle.get_opt_hclust(T, maxN=kmax)["f"])
+    dev.profile(False)
+
+
 @pytest.mark.parametrize("n", [3900, 4200])
 def test_agglomeration_large_tasks(sa, oracle, n, monkeypatch):
     """One clustering task around the LDS limit of the bulk-synchronous kernel (4096 observations: 39 B of LDS state each): below it
