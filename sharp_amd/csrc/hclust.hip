@@ -313,6 +313,8 @@ __device__ __forceinline__ double hr_min16(double x) {
 // 2000-observation task took 3.3 ms as 66 launches.
 // GS (MODE 1 / 2 / 3 only): tasks beyond HR_MAXN observations, whose state does not fit a CU's LDS -- the state arrays ARE the global
 // image (no copy in or out; the same code addresses them), only the stage of the rebuild stays in LDS.
+typedef __attribute__((address_space(1))) const double *hr_gcd;   // the distance matrices, in the global address space
+typedef __attribute__((address_space(1))) double *hr_gd;
 template <int HR_THREADS, int MODE, bool GS = false>
 __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__restrict__ metas, const double *__restrict__ Dall,
                                                                 double *__restrict__ S0all, double *__restrict__ S1all,
@@ -322,8 +324,10 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                                                                 int lds_bytes, int round, int *__restrict__ remaining, int lds_launch) {
     const HcMeta M = metas[blockIdx.x];
     const int n = M.n, nld = M.nld, method = M.method;
-    const double *D = Dall + M.oD;
-    double *Sb[2] = {S0all + M.oD, S1all + M.oD};
+    // (global address space spelled out: left generic, every access of the matrices compiled to a FLAT instruction, which takes an LDS issue slot
+    // as well and counts on lgkmcnt -- each wait for the column map in LDS then also waited for the 16 row loads in flight)
+    const hr_gcd D = (hr_gcd)(Dall + M.oD);
+    const hr_gd Sb[2] = {(hr_gd)(S0all + M.oD), (hr_gd)(S1all + M.oD)};
     int *ia = ia_all + M.oM, *ib = ib_all + M.oM;
     double *crit = h_all + M.oM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = HR_THREADS / 64;
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
             const double pm = l < slots ? M.nn[static_cast<long long>(l) * nld + a] : HC_INF;
             const double m = hr_min16(pm);
             unsigned cand = static_cast<unsigned>(__ballot(l < slots && pm == m) >> (16 * g)) & 0xffffu;   // this row's tiles that hold its minimum
-            const double *row = D + static_cast<long long>(a) * nld;
+            const hr_gcd row = D + static_cast<long long>(a) * nld;
             HrBest b; b.v = HC_INF; b.i = 0x7fffffff; b.tie = 0;
             while (__any(cand != 0u)) {
                 if (cand) {
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
     } else
     // ... or from the pristine matrix (squared for ward.D2)
     for (int a = wave; a < n; a += nwave) {
-        const double *row = D + static_cast<long long>(a) * nld;
+        const hr_gcd row = D + static_cast<long long>(a) * nld;
         HrBest b; b.v = HC_INF; b.i = 0x7fffffff; b.tie = 0;
         for (int j0 = lane; j0 < n; j0 += 64 * 8) {
             double v[8];
@@ -550,15 +554,15 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         // (4) next matrix, one wave per new row; nearest neighbour of the new row on the fly.
         // Rows of unmerged clusters (~90 %) are a gathered copy of the old row (eight loads in flight per lane) plus one
         // Lance-Williams value per merged column; rows of merged clusters take the general path.
-        const double *Dsrc = src < 0 ? D : Sb[src];
-        double *Ddst = Sb[src < 0 ? 0 : (src ^ 1)];
+        const hr_gcd Dsrc = src < 0 ? D : (hr_gcd)Sb[src];
+        const hr_gd Ddst = Sb[src < 0 ? 0 : (src ^ 1)];
         const bool sq = (src < 0 && method == 8);
         auto do_row = [&](int A) {
             const int a = oldidx[A] & 0x7fff;
             const int pa = partner[a];                          // NONE or j > a
             const bool am = pa != HR_NONE;
-            const double *ra = Dsrc + static_cast<long long>(a) * nld;
-            double *wr = Ddst + static_cast<long long>(A) * nld;
+            const hr_gcd ra = Dsrc + static_cast<long long>(a) * nld;
+            const hr_gd wr = Ddst + static_cast<long long>(A) * nld;
             const double na_ = csz[a];
             HrBest best; best.v = HC_INF; best.i = 0x7fffffff; best.tie = 0;
             auto consider = [&](double v, int B) {
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
                     consider(v, B);
                 }
             } else {
-                const double *rj = Dsrc + static_cast<long long>(pa) * nld;
+                const hr_gcd rj = Dsrc + static_cast<long long>(pa) * nld;
                 const double hP = dnn[a];
                 const double nj_ = csz[pa];
                 const int seqP = pseq[a];
@@ -671,8 +675,9 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         auto staged = [&](auto NR_, auto FIRST_, int A0) {
             constexpr int NR = decltype(NR_)::value;
             constexpr bool FIRST = decltype(FIRST_)::value;
-            const double *r[NR];
-            double *w[NR], *stg[NR];
+            hr_gcd r[NR];
+            hr_gd w[NR];
+            double *stg[NR];
             double mn[NR], sc[NR];
             int ix[NR], ao[NR];
 #pragma unroll
@@ -760,8 +765,8 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
         auto staged_merged = [&](int A) {
             const int a = __builtin_amdgcn_readfirstlane(oldidx[A] & 0x7fff);
             const int pa = __builtin_amdgcn_readfirstlane(partner[a]);
-            const double *ra = Dsrc + static_cast<long long>(a) * nld, *rj = Dsrc + static_cast<long long>(pa) * nld;
-            double *wr = Ddst + static_cast<long long>(A) * nld;
+            const hr_gcd ra = Dsrc + static_cast<long long>(a) * nld, rj = Dsrc + static_cast<long long>(pa) * nld;
+            const hr_gd wr = Ddst + static_cast<long long>(A) * nld;
             const double na_ = csz[a], nj_ = csz[pa], hP = dnn[a];
             const int seqP = pseq[a];
             double *sa = stage + static_cast<size_t>(wave) * 4 * np, *sj = sa + 2 * np;
@@ -876,8 +881,8 @@ __global__ __launch_bounds__(HR_THREADS) void hclust_rnn_kernel(const HcMeta *__
 #ifdef HR_TIMING
             const long long q1 = __builtin_readcyclecounter();
 #endif
-            const double *r1 = Dsrc + static_cast<long long>(a1) * nld, *r2 = Dsrc + static_cast<long long>(a2) * nld;
-            double *w1 = Ddst + static_cast<long long>(A) * nld, *w2 = Ddst + static_cast<long long>(A2) * nld;
+            const hr_gcd r1 = Dsrc + static_cast<long long>(a1) * nld, r2 = Dsrc + static_cast<long long>(a2) * nld;
+            const hr_gd w1 = Ddst + static_cast<long long>(A) * nld, w2 = Ddst + static_cast<long long>(A2) * nld;
             if (src >= 0) {
                 // Later rounds (the bulk of the work): the source is a scratch matrix whose diagonal holds +inf, so a plain
                 // gathered copy needs no diagonal test; per element: one LDS read (old column | merged flag), two loads, two
