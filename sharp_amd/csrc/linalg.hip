@@ -307,10 +307,10 @@ __global__ __launch_bounds__(512) void gemm_tn_f64_fast_kernel(const GemmTask *_
     if (tid < FT) {
         double b = fmin(fmin(rows_s[tid], rows_s[FT + tid]), fmin(rows_s[2 * FT + tid], rows_s[3 * FT + tid]));
         if (ti == tj) b = fmin(b, fmin(cols_s[tid], cols_s[FT + tid]));
-        if (m0 + tid < t.M) t.nn[static_cast<long long>(tj) * t.ldc + m0 + tid] = b;
+        if (m0 + tid < t.M) ((gdp)t.nn)[static_cast<long long>(tj) * t.ldc + m0 + tid] = b;
     } else if (tid < 2 * FT && ti != tj) {
         const int cc = tid - FT;
-        if (n0 + cc < t.N) t.nn[static_cast<long long>(ti) * t.ldc + n0 + cc] = fmin(cols_s[cc], cols_s[FT + cc]);
+        if (n0 + cc < t.N) ((gdp)t.nn)[static_cast<long long>(ti) * t.ldc + n0 + cc] = fmin(cols_s[cc], cols_s[FT + cc]);
     }
 }
 
