@@ -1554,7 +1554,7 @@ double wall_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv
 // bound to a device slot of its own (context, streams, workspaces, projector handles: common.hpp): it builds the K projectors on its GPU
 // (a pure function of m, p and the seeds, :97-104; p from the GLOBAL cell count, :65-66) and clusters its blocks one after the other, each
 // prepared under the previous one's tail when it is already resident.  Host blocks -- dense or sparse -- reach the GPU through a second
-// thread per worker with a slot of its own (own stream, pinned staging, two resident copies in rotation): block i + W crosses PCIe while
+// thread per worker with a slot of its own (own stream, pinned staging, three resident copies in rotation): block i + W crosses PCIe while
 // block i is clustered.  Per block the worker keeps the labels and the per-cluster centroid means and sizes -- all the final sMetaC uses
 // of E1 (R/sMetaC.R:58-63); the tables (a few hundred rows x p doubles per block) meet in host memory, worker 0 runs the merge (:163-183)
 // once the others are done, and every block's labels are mapped through it.  No other data crosses between devices.
@@ -1607,7 +1607,7 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
     std::vector<long long> counts;
 
     auto worker = [&](int w) {
-        // ---- the upload thread of this worker: host blocks into the two resident copies of its own slot, in block order
+        // ---- the upload thread of this worker: host blocks into the resident copies of its own slot, in block order
         struct Feed {
             std::mutex mu;
             std::condition_variable cv;
@@ -1625,12 +1625,14 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
         feed.ld.assign(my.size(), 0);
         std::vector<int> hostpos;                         // positions in `my` that hold host blocks
         for (size_t i = 0; i < my.size(); ++i) if (blocks[my[i]].on_host()) hostpos.push_back(static_cast<int>(i));
-        // resident copies the upload rotates through: two (block after block, each prepared under the previous one's tail: the default), four when
+        // resident copies the upload rotates through: three (block after block, each prepared under the previous one's tail: the default), four when
         // SHARP_HOST_GROUP >= 2 asks for groups of arrived blocks as one pipelined batch (measured: no gain at two or three blocks)
         long long big = 0;
         for (int i : hostpos) big = std::max<long long>(big, blocks[my[i]].n);
         const int group_max = std::max(1, std::min(knobs().host_group, kHostRing - 1));
-        const int ring = (static_cast<double>(big) * m * 4.0 > 8e9 || group_max == 1) ? 2 : kHostRing;
+        // (three when block follows block: with two, block i + 2 could only start its upload when block i was done, i.e. when block i + 1 began -- so
+        // no block was ever on the GPU in time to have its front prepared under its predecessor's tail, and a cfg3 block cost 26 ms instead of 20)
+        const int ring = static_cast<double>(big) * m * 4.0 > 8e9 ? 2 : (group_max == 1 ? 3 : kHostRing);
         std::thread up;
         if (!hostpos.empty())
             up = std::thread([&] {
@@ -1711,7 +1713,7 @@ int unlimited_run_multi(const std::vector<BlockSrc> &blocks, int m, int ensize_K
                     block_ref(i, true, ref, ld);
                     // SHARP_HOST_GROUP >= 2: the blocks that arrived go TOGETHER as one pipelined batch (unlimited_batch_window).  Whatever the
                     // grouping, every block is the same SHARP() call: same labels.
-                    if (ring > 2 && blocks[b].on_host()) {
+                    if (group_max > 1 && ring > 2 && blocks[b].on_host()) {
                         std::vector<XRef> refs{ref};
                         std::vector<long long> nn{blocks[b].n}, ll{ld};
                         size_t j = i + 1;

@@ -22,7 +22,7 @@ struct HostBlock {               // the resident copy of a host matrix; kept bet
 };
 
 // the resident copies an upload slot rotates through (sharp_SHARP_unlimited_multi: later blocks are uploaded while earlier ones are clustered):
-// two; four with SHARP_HOST_GROUP >= 2, when the compute thread takes several arrived blocks together
+// three (two for blocks beyond 8 GB); four with SHARP_HOST_GROUP >= 2, when the compute thread takes several arrived blocks together
 constexpr int kHostRing = 4;
 struct HostBlockPair { HostBlock hb[kHostRing]; };
 
